@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (build container only).
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Imports /root/reference (Python sources in place, C++ ext compiled unmodified into
+oracle/_ref) through oracle/ref_import.py and records inputs (or their seeds, see
+tests/datagen.py) and the reference's outputs.  Fixtures are data only: no reference source
+text is stored.  G-numbers follow SURVEY.md section 8(c).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import datagen  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+torch.set_num_threads(4)
+ref = ref_import.load()
+T = torch.from_numpy
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, keys={len(arrays)}")
+
+
+# --------------------------------------------------------------------------- G1  S1 assign
+def g1_assign():
+    L, bs, D, M = 196, 2, 192, 128
+    cb = datagen.bellish((M, D), 101, 1.0)
+    cb[7] = cb[3]                                   # exact duplicate -> first index must win
+    mid = datagen.bellish((L + 1, bs, D), 102, 1.0)
+    # tokens drawn near codewords so margins look like k-means data
+    near = datagen.integers((L, bs), 103, M)
+    mid[1:] = cb[near] + 0.35 * mid[1:]
+    mid[1 + 5, 0] = cb[3]                           # exact tie between words 3 and 7
+    mid[1 + 6, 1] = cb[7] + np.float32(1e-3) * mid[1 + 6, 1]
+    a, b = cb[20], cb[21]                           # near tie: 1e-4 relative off the bisector
+    mid[1 + 9, 0] = 0.5 * (a + b) + np.float32(1e-4) * (b - a)
+    mid[1 + 9, 1] = 0.5 * (a + b) - np.float32(1e-4) * (b - a)
+
+    disc = ref.discretization.Discretization(size=M, dim=D)
+    with torch.no_grad():
+        disc.vocabulary.weight.copy_(T(cb))
+    adapter = ref.discretization.Adapter()
+    out = {}
+    for act in (True, False):
+        disc.activate() if act else disc.deactivate()
+        seq = adapter.adapt(T(mid))
+        seq, match = disc(seq)
+        seq, match = adapter.reconstruct(seq, match)
+        out[act] = (seq.detach().numpy(), match.numpy())
+    assert np.array_equal(out[True][1], out[False][1])
+    save("assign.npz", codebook=cb, mid_feat=mid, ingredients=out[True][1],
+         seq_active=out[True][0], seq_inactive_equals_input=np.array_equal(out[False][0], mid))
+
+
+# --------------------------------------------------------------------------- ext level, small L
+def ext_small():
+    """The four pybind functions on a 6x6 grid (L=36): bit-exact targets for the C oracle and
+    the HIP kernels (inputs are stored already soft-maxed, so no transcendental is involved)."""
+    B, L, M, K, n_max = 5, 36, 24, 3, 10
+    ing = datagen.integers((B, L), 201, M)
+    ing[1, :] = 4
+    ing[2, :] = np.arange(L)[::-1] % M
+    attn_cls = torch.softmax(T(datagen.bellish((B, L), 202, 1.5)), -1).numpy()
+    attn = torch.softmax(T(datagen.bellish((B, L, L), 203, 1.5)), -1).numpy()
+    attn[3, 2, :] = np.nan                          # what a fully clamped row looks like
+    attn_cls[4, :] = 0.0                            # nan_to_num'ed fully clamped cls row
+    geo = ref.graph_utils.pair_wise_point_sim(6, 6, 1.0, 2.0).numpy()
+    w_v = np.asarray([[0.3], [0.7]], np.float32)
+    w_e = np.asarray([[0.6], [0.4]], np.float32)
+    cx = ref.cpp_extension
+
+    ids, wts, num_v = cx.cpp_feat_to_instance_v(T(ing), T(attn_cls), T(w_v), mean=True)
+    ids_s, wts_s, _ = cx.cpp_feat_to_instance_v(T(ing), T(attn_cls), T(w_v), mean=False)
+    inst = torch.split_with_sizes(ids, num_v.tolist())
+    dicts = [{v: k for k, v in enumerate(i.tolist())} for i in inst]
+    e = {}
+    out = cx.cpp_feat_to_instance_e(T(ing), T(attn), T(geo), dicts, T(w_e), mean=True, remove_self_loop=False)
+    e[False] = np.concatenate([o.numpy().reshape(-1) for o in out])
+    # remove_self_loop=True: the reference calls diagonal(0, 1) == diagonal(offset=0, dim1=1,
+    # dim2=1) (large_scale_feat_to_e.cpp:138) which raises on every torch version that has
+    # this overload; record that fact instead of an output.
+    try:
+        cx.cpp_feat_to_instance_e(T(ing), T(attn), T(geo), dicts, T(w_e), mean=True, remove_self_loop=True)
+        rsl_raises = False
+    except RuntimeError as err:
+        rsl_raises = "diagonal" in str(err)
+    out = cx.cpp_feat_to_instance_e(T(ing), T(attn), T(geo), dicts, T(w_e), mean=False, remove_self_loop=False)
+    e_sum = np.concatenate([o.numpy().reshape(-1) for o in out])
+    # a non-canonical dictionary: permuted rows, one extra key, one missing word (-> slot 0)
+    d0 = dict(dicts[0])
+    perm = list(reversed(sorted(d0)))
+    odd = {w: r for r, w in enumerate(perm)}
+    missing = perm[0]
+    del odd[missing]
+    odd[M + 5] = len(odd)                           # key that never occurs
+    odd_list = [odd] + dicts[1:]
+    out = cx.cpp_feat_to_instance_e(T(ing), T(attn), T(geo), odd_list, T(w_e), mean=True, remove_self_loop=False)
+    e_odd0 = out[0].numpy()
+
+    v_attr = cx.cpp_feat_to_v_attr(T(ing), T(attn_cls), M, mean=True).numpy()
+    v_attr_sum = cx.cpp_feat_to_v_attr(T(ing), T(attn_cls), M, mean=False).numpy()
+    v_attr_io = cx.cpp_feat_to_v_attr(T(ing), T(attn_cls), M, mean=True, ingredients_only=True).numpy()
+    cls_ing = np.stack([np.random.RandomState(s).permutation(M)[:n_max] for s in range(K)]).astype(np.int64)
+    cdict = [{int(k): v for v, k in enumerate(row)} for row in cls_ing]
+    label = np.asarray([0, 1, 2, 1, 0], np.int64)
+    fe = cx.cpp_feat_to_e(T(ing), T(attn), T(geo), cdict, label.tolist(), n_max, mean=True).numpy()
+    save("ext_small.npz", ing=ing, attn_cls=attn_cls, attn=attn, geo=geo, w_v=w_v, w_e=w_e,
+         ids=ids.numpy(), weights=wts.numpy(), weights_sum=wts_s.numpy(), num_v=num_v.numpy(),
+         edges=e[False], rsl_raises=rsl_raises, edges_sum=e_sum,
+         odd_keys=np.asarray(sorted(odd), np.int64), odd_vals=np.asarray([odd[k] for k in sorted(odd)], np.int64),
+         edges_odd0=e_odd0, v_attr=v_attr, v_attr_sum=v_attr_sum, v_attr_io=v_attr_io,
+         class_ingredients=cls_ing, label=label, feat_to_e=fe)
+
+
+# --------------------------------------------------------------------------- G2 G3 G4 G7 graph
+def make_schema_net(M, K, n_max=None, remove_self_loop=False, seed=4):
+    torch.manual_seed(seed)
+    return ref.graph.SchemaNet(
+        num_vertices=M, num_classes=K, class_max_vertices=n_max, clamp_vertex_attn=-1.0,
+        clamp_edge_attn=-1.0, remove_self_loop=remove_self_loop, prune_node_threshold=0.001)
+
+
+def graph():
+    B, L, M, K = 4, 196, 256, 5
+    ing, attn, attn_cls = datagen.graph_case(B, L, M, seed=11)
+    rec = {"case": np.asarray([B, L, M, 11])}
+    for rsl in (False,):     # True raises inside the reference ext, see ext_small()
+        sn = make_schema_net(M, K, remove_self_loop=rsl)
+        with torch.no_grad():
+            sn.vertex_attribute_weights.tensor.copy_(torch.tensor([[0.35], [0.65]]))
+            sn.edge_attribute_weights.tensor.copy_(torch.tensor([[0.55], [0.45]]))
+        a_cls, a = T(attn_cls.copy()), T(attn.copy())
+        with torch.no_grad():
+            out = sn(T(ing), a, a_cls)
+        tag = "_rsl" if rsl else ""
+        rec["num_v"] = np.asarray([len(x) for x in out["instance_ingredients"]], np.int64)
+        rec["ids"] = torch.cat(out["instance_ingredients"]).numpy()
+        rec["vertices"] = torch.cat(out["instance_vertices"]).numpy()
+        rec["edges" + tag] = torch.cat([e.reshape(-1) for e in out["instance_edges"]]).numpy()
+        rec["attn_cls_after"] = a_cls.numpy()       # in-place masked_fill_ side effect
+        rec["attn_after_row17_isinf"] = np.isinf(a.numpy()[0, 17]).all()
+    rec["w_v"] = np.asarray([[0.35], [0.65]], np.float32)
+    rec["w_e"] = np.asarray([[0.55], [0.45]], np.float32)
+
+    # G4 + G7: initialisation path, M=128 words, n_max=64 < M (class restriction), 8 images
+    B2, M2, K2, n_max = 8, 128, 5, 64
+    ing2, attn2, attn_cls2 = datagen.graph_case(B2, L, M2, seed=23)
+    label = np.asarray([0, 3, 1, 3, 4, 0, 3, 1], np.int64)   # class 2 never occurs -> 0/0
+    sn = make_schema_net(M2, K2, n_max=n_max)
+    with torch.no_grad():
+        fv = sn.feat_to_full_vertices(T(ing2), T(attn_cls2.copy()))          # [8,128]
+        cv = torch.zeros(K2, M2)
+        nt = torch.zeros(K2)
+        for c, v in zip(label.tolist(), fv):
+            cv[c] += v
+            nt[c] += 1
+        cv_mean = cv / nt[:, None]
+        cv_norm = cv_mean / cv_mean.sum(-1, keepdim=True)
+        cv_for_topk = torch.nan_to_num(cv_norm, 0.0)   # class 2 is NaN; keep topk defined
+        init_w, valid = cv_for_topk.topk(n_max, dim=1)
+        sn.register_class_vertices(valid)
+        sn.vertex_weights.copy_(init_w)
+        fe = sn.feat_to_limited_edges(T(ing2), T(attn2.copy()), T(label))   # [8,64,64]
+        es = torch.zeros(K2, n_max, n_max)
+        for c, e in zip(label.tolist(), fe):
+            es[c] += e
+        e_mean = es / nt[:, None, None]
+    rec.update(init_case=np.asarray([B2, L, M2, 23, K2, n_max]), init_label=label,
+               full_vertices=fv.numpy(), class_vertex_sums=cv.numpy(), n_tracked=nt.numpy(),
+               class_vertices_norm=cv_norm.numpy(), topk_values=init_w.numpy(), topk_index=valid.numpy(),
+               limited_edges=fe.numpy(), class_edge_sums=es.numpy(), class_edge_mean=e_mean.numpy())
+    save("graph.npz", **rec)
+
+
+# --------------------------------------------------------------------------- G5 G6 atlas + matcher
+def matcher():
+    B, L, M, K, n_max, E = 4, 196, 256, 5, 64, 48
+    ing, attn, attn_cls = datagen.graph_case(B, L, M, seed=11)
+    sn = make_schema_net(M, K, n_max=n_max, seed=7)
+    torch.manual_seed(8)
+    cls_ing = torch.stack([torch.randperm(M)[:n_max] for _ in range(K)])
+    sn.register_class_vertices(cls_ing)
+    with torch.no_grad():
+        sn.vertex_weights.tensor[:, ::7] = 1.0e-7          # -> normalised below 0.001: pruned
+        sn.vertex_weights.tensor[1, 3] = -0.5              # negative raw weight (clamp_min path)
+        sn.edge_weights.tensor[2, 5, :] = -0.1             # row that clamps to all-zero -> 0/0
+    raw_vw = sn.vertex_weights.tensor.detach().clone().numpy()
+    raw_ew = sn.edge_weights.tensor.detach().clone().numpy()
+    rec = dict(case=np.asarray([B, L, M, 11, K, n_max, E]), class_ingredients=cls_ing.numpy(),
+               vertex_weights=raw_vw, edge_weights=raw_ew)
+    gnn_cfg = dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu")
+    state = None
+    for sim in ("inner_product", "cosine", "euclidean"):
+        torch.manual_seed(5)
+        m = ref.graph.Matcher(similarity=sim, num_codes=M, gnn_cfg=gnn_cfg)
+        if state is None:
+            with torch.no_grad():                          # non-trivial LayerNorm affine
+                for lyr in m.gnn.layers:
+                    lyr.norm.weight.uniform_(0.5, 1.5)
+                    lyr.norm.bias.uniform_(-0.3, 0.3)
+            state = {k: v.clone() for k, v in m.state_dict().items()}
+        m.load_state_dict(state)
+        with torch.no_grad():
+            inst = sn(T(ing), T(attn.copy()), T(attn_cls.copy()))
+            atlas = sn.get_atlas()
+            pred = m(inst, atlas)
+        rec["pred_" + sim] = pred.numpy()
+    rec["class_vertices"] = atlas["class_vertices"].numpy()
+    rec["class_edges"] = atlas["class_edges"].numpy()
+    rec["edge_weights_after"] = sn.edge_weights.tensor.detach().numpy()   # in-place prune (:164)
+    for k, v in state.items():
+        rec["param:" + k] = v.numpy()
+    # single-image batches: pins the padded-length pooling (gnn.py:96) per image
+    m = ref.graph.Matcher(similarity="inner_product", num_codes=M, gnn_cfg=gnn_cfg)
+    m.load_state_dict(state)
+    solo = []
+    with torch.no_grad():
+        for b in range(B):
+            inst = sn(T(ing[b:b + 1]), T(attn[b:b + 1].copy()), T(attn_cls[b:b + 1].copy()))
+            solo.append(m(inst, sn.get_atlas()).numpy()[0])
+    rec["pred_inner_product_solo"] = np.stack(solo)
+    save("matcher.npz", **rec)
+
+
+# --------------------------------------------------------------------------- G8 wrapper
+def wrapper():
+    bs, H, L = 2, 3, 196
+    extracted = datagen.bellish((bs * H, L + 1, L + 1), 301, 2.0)
+
+    class _Disc(torch.nn.Module):        # the two attributes / call contract the wrapper reads
+        def __init__(self):
+            super().__init__()
+            self.discretization = ref.discretization.Discretization(size=16, dim=8)
+            self.adapter = ref.discretization.Adapter()
+
+        def forward(self, x):
+            seq, match = self.discretization(self.adapter.adapt(x))
+            return self.adapter.reconstruct(seq, match)
+
+    class _Backbone(torch.nn.Module):
+        def forward(self, x):
+            return {"mid_feat": T(datagen.bellish((L + 1, bs, 8), 302, 1.0)), "extracted": T(extracted)}
+
+    w = ref.IngredientModelWrapper(_Backbone(), _Disc())
+    with torch.no_grad():
+        out = w(torch.zeros(bs, 3, 4, 4))
+    save("wrapper.npz", case=np.asarray([bs, H, L, 301]), attn=out["attn"].numpy(),
+         attn_cls=out["attn_cls"].numpy())
+
+
+if __name__ == "__main__":
+    g1_assign()
+    ext_small()
+    graph()
+    matcher()
+    wrapper()
