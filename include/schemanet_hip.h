@@ -1,0 +1,229 @@
+/*
+ * schemanet_hip.h -- C ABI of libschemanet_hip.so: the MI355X (gfx950) implementation of
+ * SchemaNet's schema-inference hot path.
+ *
+ * This library REPLACES the reference's pybind11 module `cpp_extension.extension`
+ * (reference cpp_extension/src/extension.cpp:6-11, four at::Tensor functions, CPU only) and the
+ * torch.cdist/argmin inside Discretization.encode (discretization/discretization.py:58-70).
+ *
+ * Conventions
+ *  - plain C: device pointers + sizes + a hipStream_t passed as void*; no torch types.
+ *  - every pointer is DEVICE memory unless the name ends in _host.
+ *  - nothing here allocates, synchronises or throws: outputs and workspaces are supplied by the
+ *    caller, kernels are enqueued on `stream` and the call returns immediately.
+ *  - return value: 0 = enqueued; <0 = rejected (nothing enqueued), message via sn_last_error().
+ *  - int64 for word ids / labels (torch.long in the reference), float32 for attributes.
+ *  - "words"/"ingredients" = visual-word ids, "vertices"/"edges" = IR-graph attributes,
+ *    "atlas" = the per-class IR-Atlas, following the reference's vocabulary.
+ */
+#ifndef SCHEMANET_HIP_H
+#define SCHEMANET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_OK 0
+#define SN_ERR_BAD_ARG (-1)      /* null pointer, negative size, unsupported shape */
+#define SN_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels are built for   */
+#define SN_ERR_LAUNCH (-3)       /* hipLaunchKernel reported an error              */
+#define SN_ERR_WORKSPACE (-4)    /* workspace too small                            */
+
+#define SN_MAX_TOKENS 196        /* L: 14x14 patch tokens; the graph kernels keep one image in LDS */
+
+/* ABI version, bumped on any signature change. */
+int sn_abi_version(void);
+/* Thread-local, NUL-terminated description of the last non-zero return on this thread. */
+const char *sn_last_error(void);
+/* 1 when a gfx950 device is visible to this process (hipGetDeviceProperties), else 0. */
+int sn_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline figure; off by default, zero cost when off).
+ * kernel ids: 0 = assignment screen (fp16 MFMA), 1 = assignment re-rank (fp64),
+ *             2 = instance graph (S2+S3), 3 = atlas normalise
+ * ------------------------------------------------------------------------------------------ */
+#define SN_PROF_KERNELS 4
+/* max_samples > 0: (re)start recording up to that many launches per kernel; 0: stop + free. */
+int sn_profile_enable(int max_samples);
+/* Number of launches recorded so far for kernel_id. */
+int sn_profile_count(int kernel_id);
+/* Waits for the recorded launches and writes their durations (ms) to out_ms_host[0..n). */
+int sn_profile_elapsed_ms(int kernel_id, float *out_ms_host, int n);
+
+/* ------------------------------------------------------------------------------------------
+ * S1  visual-word assignment
+ * replaces: torch.cdist(seq, vocabulary.weight).argmin(dim=1)  discretization/discretization.py:65
+ *
+ * Result contract: out[t] = index of the codeword nearest to token t in (near-)exact
+ * arithmetic (fp64 re-rank of every candidate the fp16-MFMA screening cannot separate with a
+ * rigorous error bound), lowest index on exact ties -- bit-identical to oracle sno_assign_words.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bytes of the packed codebook image for (M, D).  M <= 65536, D % 32 == 0, D <= 1024. */
+size_t sn_codebook_pack_bytes(int M, int D);
+
+/* Packs codebook [M, D] f32 into `packed` (fp16 MFMA fragments, per-word fp64 norms, scale
+ * factors).  Call once per codebook version; the packed image is read-only afterwards. */
+int sn_codebook_prepare(const float *codebook, int M, int D, void *packed, void *stream);
+
+/* Bytes of scratch sn_assign_words needs for n_tokens tokens. */
+size_t sn_assign_workspace_bytes(int64_t n_tokens);
+
+/* Tokens form an [n_outer, n_inner] grid of D-vectors: token (o, i) starts at
+ * x + o*x_stride_outer + i*x_stride_inner (strides in floats, rows contiguous in D);
+ * its word id is written to out[o*out_stride_outer + i*out_stride_inner].
+ *   reference layout  (seq-first mid_feat[1:], [L, bs, D]): n_outer=L, n_inner=bs,
+ *                      x strides (bs*D, D), out strides (bs, 1)  -> ingredients [L, bs]
+ *   batch-first tokens ([B, 197, D], cls row skipped by passing x + D): n_outer=B, n_inner=196,
+ *                      x strides (197*D, D), out strides (196, 1) -> ingredients [B, 196]
+ * mode: 0 = fp16-MFMA screening + fp64 re-rank (fast path), 1 = fp64 full scan (slow, exact by
+ * construction; used as fallback and cross-check).  Both give identical indices. */
+int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
+                    int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
+                    int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
+                    void *workspace, size_t workspace_bytes, int mode, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * attention taps of the wrapper
+ * replaces: IngredientModelWrapper.forward  schema_inference/utils/ingredient_model_wrapper.py:58-68
+ * extracted [B*H, L+1, L+1] raw logits -> attn [B, L, L] (head mean, cls row/col dropped) and
+ * attn_cls [B, L] (cls row, cls col dropped).
+ * ------------------------------------------------------------------------------------------ */
+int sn_head_mean_attention(const float *extracted, int B, int H, int L, float *attn,
+                           float *attn_cls, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * S2 + S3  instance IR-graph
+ * replaces: ext::feat_to_instance_v  cpp_extension/src/large_scale_feat_to_v.cpp:41-143
+ *           ext::feat_to_instance_e  cpp_extension/src/large_scale_feat_to_e.cpp:33-150
+ *           and, when *_is_logits, the clamp / softmax / nan_to_num in front of them
+ *           (schema_inference/graph/schema_net.py:295-297, 334-336).
+ *
+ * One workgroup per image.  Outputs are PADDED to n_pad vertices per image (pad id = pad_id,
+ * pad weights / edges = 0): the layout Matcher.forward builds with F.pad (match.py:48-54).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sn_graph_args {
+    /* inputs */
+    const int64_t *ingredients;   /* word of token (b, l) at [b*ing_stride_b + l*ing_stride_l] */
+    int64_t ing_stride_b, ing_stride_l;
+    const float *attn_cls;        /* element (b, l) of head h at
+                                     [b*acls_stride_b + h*acls_stride_h + l]; NULL = skip vertices */
+    const float *attn;            /* element (b, p, q) of head h at [b*attn_stride_b +
+                                     h*attn_stride_h + p*attn_stride_r + q]; NULL = skip edges   */
+    int64_t acls_stride_b, acls_stride_h;              /* 0, 0 = contiguous [B, L]              */
+    int64_t attn_stride_b, attn_stride_r, attn_stride_h; /* 0, 0, 0 = contiguous [B, L, L]      */
+    int acls_heads, attn_heads;   /* >1: the kernel averages that many heads first (the
+                                     wrapper's torch.mean over heads, ingredient_model_wrapper.py
+                                     :58-62), so `extracted` [B*H, L+1, L+1] can be consumed in
+                                     place: pass a pointer to element (1,1) resp. (0,1), row
+                                     stride L+1, head stride (L+1)^2, batch stride H*(L+1)^2.
+                                     0 or 1 = single (already averaged) map                      */
+    int B, L;
+    int attn_cls_is_logits;       /* 1: apply clamp_v / softmax / nan_to_num(0) first           */
+    int attn_is_logits;           /* 1: apply clamp_e / row softmax (no nan_to_num) first       */
+    int use_clamp_v, use_clamp_e; /* reference: clamp_*_attn is not None                        */
+    float clamp_v, clamp_e;
+    const float *geo;             /* [L, L] table, or NULL = grid similarity computed in-kernel */
+    int feat_h, feat_w;           /* grid (feat_h*feat_w == L) when geo == NULL                 */
+    float dist_alpha, dist_pow;   /* graph/utils.py:72-81                                       */
+    const float *w_v, *w_e;       /* [2] each, device (vertex_/edge_attribute_weights)          */
+    int mean;                     /* reference `mean` flag (all callers pass 1)                 */
+    int remove_self_loop;
+    /* optional non-canonical word->row dictionaries (batch_ingredient_dict of the reference):
+     * image b owns dict_keys/vals[dict_off[b] .. +dict_len[b]), keys ascending.  NULL = the
+     * canonical mapping (rank among the image's sorted distinct words). */
+    const int64_t *dict_keys, *dict_vals, *dict_off, *dict_len;
+    /* outputs (any may be NULL) */
+    int n_pad;                    /* padded vertex count, >= every image's vertex count         */
+    int64_t pad_id;               /* id written to padded slots (Matcher: num_codes)            */
+    int64_t *out_ids;             /* [B, n_pad]                                                 */
+    float *out_v2;                /* [B, n_pad, 2] (count, mean attn) / col max, nan_to_num     */
+    float *out_v;                 /* [B, n_pad]     out_v2 @ w_v                                */
+    float *out_e2;                /* [B, n_pad, n_pad, 2] means / row sum, nan_to_num, [diag 0] */
+    float *out_e;                 /* [B, n_pad, n_pad]     out_e2 @ w_e                         */
+    int32_t *out_n;               /* [B] vertices per image                                     */
+    int32_t *out_n_max;           /* [1] max over images (atomicMax; caller zeroes it)          */
+    float *attn_cls_masked;       /* [B, L] logits after the clamp (the reference's in-place
+                                     masked_fill_ side effect, schema_net.py:296); may alias
+                                     attn_cls                                                   */
+} sn_graph_args;
+
+int sn_instance_graph(const sn_graph_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * atlas-initialisation statistics ("per-class schema statistics")
+ * replaces: ext::feat_to_v_attr  cpp_extension/src/feat_to_v_attr.cpp:19-63, 74-148
+ *           ext::feat_to_e       cpp_extension/src/feat_to_e.cpp:31-127
+ *           + their epilogues in SchemaNet.feat_to_full_vertices / feat_to_limited_edges
+ *             (schema_net.py:188-207, 222-254)
+ *           + the per-class sums of scripts/init_schema_net.py:33-35, 59-61
+ * ------------------------------------------------------------------------------------------ */
+
+/* out_attr2 [B, M, 2]: (count, sum-or-mean attn) scattered at the word id, zeros elsewhere
+ * (== cpp_feat_to_v_attr).  out_v [B, M]: normalize_max_(dim=1) then @ w_v.  Either may be NULL.
+ * is_logits: clamp / softmax WITHOUT nan_to_num first (schema_net.py:200-202). */
+int sn_full_vertices(const int64_t *ingredients, int64_t ing_stride_b, int64_t ing_stride_l,
+                     const float *attn_cls, int B, int L, int M, int is_logits, int use_clamp,
+                     float clamp, int mean, int ingredients_only, const float *w_v,
+                     float *out_attr2, float *out_v, void *stream);
+
+/* class_slot [K, Mtab] i32: slot of a word in class k's graph or -1 (dense form of
+ * class_ingredient_dict, schema_net.py:121-126).  label [B] i64.
+ * out_attr2 [B, n_max, n_max, 2]: raw means at (slot_i, slot_j), zeros elsewhere
+ * (== cpp_feat_to_e).  out_e [B, n_max, n_max]: normalize_sum_(dim=2), [diag 0], @ w_e. */
+int sn_limited_edges(const int64_t *ingredients, int64_t ing_stride_b, int64_t ing_stride_l,
+                     const float *attn, int B, int L, int is_logits, int use_clamp, float clamp,
+                     const float *geo, int feat_h, int feat_w, float dist_alpha, float dist_pow,
+                     const int32_t *class_slot, int K, int Mtab, const int64_t *label, int n_max,
+                     int mean, int remove_self_loop, const float *w_e, float *out_attr2,
+                     float *out_e, void *stream);
+
+/* class_sum[label[b], :] += feat[b, :] for b = 0..B-1 IN IMAGE ORDER (deterministic, same order
+ * as the reference's python loop); n_tracked[label[b]] += 1.  feat [B, F]. */
+int sn_stats_accumulate(const float *feat, const int64_t *label, int B, int64_t F, int K,
+                        float *class_sum, float *n_tracked, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * IR-Atlas normalisation
+ * replaces: SchemaNet.get_class_vertices / get_class_edges  schema_net.py:144-175
+ * vertex_weights [K, n], edge_weights [K, n, n].  With use_prune the edges touching a vertex
+ * whose normalised weight is <= prune_threshold are zeroed IN PLACE in edge_weights (the
+ * reference's masked_fill_ on the Parameter, :164) before normalisation.
+ * ------------------------------------------------------------------------------------------ */
+int sn_atlas_normalize(const float *vertex_weights, float *edge_weights, int K, int n,
+                       int use_prune, float prune_threshold, int remove_self_loop,
+                       float *class_vertices, float *class_edges, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * S4  graph matching
+ * replaces pieces of Matcher.forward / GNN.forward  schema_inference/graph/match.py:33-76,
+ * gnn.py:20-31, 78-98.  (The dense Linear / bmm GEMMs run on rocBLAS through torch.)
+ * ------------------------------------------------------------------------------------------ */
+
+/* adj[g] = (edges[g] + edges[g]^T) / 2 + I      gnn.py:27-30.   edges, adj: [G, n, n] */
+int sn_gcn_adjacency(const float *edges, int G, int n, float *adj, void *stream);
+
+/* x [G, n, E] in place: rows r >= n_valid[g] are zeroed (feat_mask, gnn.py:44-45), then
+ * LayerNorm(E) with gamma/beta/eps, then ReLU (relu != 0).  n_valid NULL = no mask. */
+int sn_mask_layernorm_act(float *x, int G, int n, int E, const int32_t *n_valid,
+                          const float *gamma, const float *beta, float eps, int relu, void *stream);
+
+/* out[g, :] = (sum_r feat[g, r, :] * nodes[g, r]) / divisor      gnn.py:94-96
+ * divisor = *divisor_dev if non-NULL (device int32: the batch's max vertex count) else n. */
+int sn_weighted_pool(const float *feat, const float *nodes, int G, int n, int E,
+                     const int32_t *divisor_dev, float *out, void *stream);
+
+/* pred [B, K] from feat_inst [B, E], feat_kg [K, E]        match.py:21-31
+ * similarity: 0 inner_product, 1 cosine ((cos+1)/2), 2 euclidean (1/(1+dist)). */
+int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, int E,
+                    int similarity, float *pred, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCHEMANET_HIP_H */

@@ -1,0 +1,168 @@
+"""Drop-in replacement of the reference's `cpp_extension` package, backed by HIP kernels.
+
+The reference package (reference cpp_extension/__init__.py:20-76) exposes four functions that
+forward to a CPU-only pybind module.  The same four names, argument lists and return shapes are
+kept here so `from cpp_extension import cpp_feat_to_...` inside SchemaNet (reference
+schema_inference/graph/schema_net.py:214, 264, 312, 365) keeps working, but the work runs on the
+MI355X through lib/libschemanet_hip.so (C ABI: include/schemanet_hip.h).
+
+Device contract: inputs may live on the CPU (what the reference's callers pass) or on the GPU.
+Outputs follow the reference: `cpp_feat_to_v_attr` / `cpp_feat_to_e` return on the device of
+`ingredients`; the `instance_*` variants return on the device of the weight tensor and carry a
+grad_fn to it (the reference runs the `@ w` matmul inside C++; here it is a torch op on the
+kernel's 2-channel output).  Inputs are never mutated.  No GPU / no library => RuntimeError.
+"""
+from typing import Dict, List
+
+import torch
+
+from . import _native, ops
+from ._native import build, load  # noqa: F401  (used by __graft_entry__.build and tests)
+
+__all__ = [
+    "cpp_feat_to_v_attr",
+    "cpp_feat_to_instance_v",
+    "cpp_feat_to_e",
+    "cpp_feat_to_instance_e",
+]
+
+
+def _check_inputs(ingredients, *others):
+    if ingredients.dtype != torch.int64 or ingredients.dim() != 2:
+        # the reference's accessor<long, 2> raises the same way (large_scale_feat_to_v.cpp:64)
+        raise RuntimeError(f"expected ingredients to be a 2-d int64 tensor, got {ingredients.dtype} {tuple(ingredients.shape)}")
+    for t in others:
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+
+
+def cpp_feat_to_v_attr(
+    ingredients: torch.LongTensor,
+    attn_cls: torch.Tensor,
+    n_vertices: int,
+    mean: bool = False,
+    ingredients_only: bool = False
+) -> torch.Tensor:
+    """[bs, L] words + [bs, L] attention -> dense [bs, n_vertices, 2] (count, sum|mean attn).
+    Replaces ext::feat_to_v_attr (reference cpp_extension/src/feat_to_v_attr.cpp:74-148)."""
+    _check_inputs(ingredients, attn_cls)
+    dev = _native.compute_device(ingredients, attn_cls)
+    ing = _native.to_device(ingredients, dev)
+    acls = _native.to_device(attn_cls, dev)
+    attr2, _ = ops.full_vertices(ing, acls, n_vertices, is_logits=False, mean=mean,
+                                 ingredients_only=ingredients_only, want_attr2=True, want_weighted=False)
+    return attr2.to(ingredients.device)
+
+
+def cpp_feat_to_instance_v(
+    ingredients: torch.LongTensor,
+    attn_cls: torch.Tensor,
+    vertex_attribute_weights: torch.Tensor,
+    mean: bool = False
+) -> List[torch.Tensor]:
+    """-> [cat instance ingredients i64, cat instance vertex weights f32, num_vertices i64 (CPU)].
+    Replaces ext::feat_to_instance_v (reference cpp_extension/src/large_scale_feat_to_v.cpp:41-143)."""
+    _check_inputs(ingredients, attn_cls)
+    w = vertex_attribute_weights
+    dev = _native.compute_device(w, ingredients, attn_cls)
+    ing = _native.to_device(ingredients, dev)
+    acls = _native.to_device(attn_cls, dev)
+    w_dev = _native.to_device(w, dev)
+    B, L = ing.shape
+    g = ops.instance_graph(ing, None, acls, w_v=w_dev, n_pad=L, pad_id=-1, attn_cls_is_logits=False,
+                           mean=mean, want_attr2=True, want_weighted=False)
+    num_v = g["n"].to(torch.int64).cpu()                       # the API returns it on the host
+    mask = torch.arange(L, device=dev)[None, :] < g["n"][:, None]
+    ids = g["ids"][mask]
+    weights = (g["v2"][mask] @ w_dev).squeeze(-1)              # autograd reaches w (survey 3.3)
+    return [ids.to(w.device), weights.to(w.device), num_v]
+
+
+def _slot_table(class_ingredient_dict: List[Dict[int, int]], device) -> torch.Tensor:
+    """K python dicts word -> slot  =>  dense int32 [K, Mtab] (-1 = not an ingredient of k)."""
+    m_tab = 1
+    for d in class_ingredient_dict:
+        if d:
+            m_tab = max(m_tab, max(d.keys()) + 1)
+    tab = torch.full((len(class_ingredient_dict), m_tab), -1, dtype=torch.int32)
+    for k, d in enumerate(class_ingredient_dict):
+        if d:
+            ks = torch.tensor(list(d.keys()), dtype=torch.int64)
+            vs = torch.tensor(list(d.values()), dtype=torch.int32)
+            ok = ks >= 0
+            tab[k, ks[ok]] = vs[ok]
+    return tab.to(device)
+
+
+def cpp_feat_to_e(
+    ingredients: torch.LongTensor,
+    attn: torch.Tensor,
+    geo_sim: torch.Tensor,
+    class_ingredient_dict: List[Dict[int, int]],
+    label: List[int],
+    n_max: int,
+    mean: bool = False
+) -> torch.Tensor:
+    """-> dense [bs, n_max, n_max, 2] (geo, attn) over the words registered for label[b].
+    Replaces ext::feat_to_e (reference cpp_extension/src/feat_to_e.cpp:31-127)."""
+    _check_inputs(ingredients, attn, geo_sim)
+    dev = _native.compute_device(ingredients, attn)
+    ing = _native.to_device(ingredients, dev)
+    at = _native.to_device(attn, dev)
+    geo = _native.to_device(geo_sim, dev)
+    if isinstance(class_ingredient_dict, torch.Tensor):        # already a dense slot table
+        tab = _native.to_device(class_ingredient_dict, dev, torch.int32).contiguous()
+    else:
+        tab = _slot_table(class_ingredient_dict, dev)
+    lab = torch.as_tensor(label, dtype=torch.int64).to(dev)
+    if lab.numel() != ing.shape[0]:
+        raise RuntimeError("Batch size is not compat with `label`")
+    attr2, _ = ops.limited_edges(ing, at, tab, lab, n_max, is_logits=False, geo=geo, mean=mean,
+                                 want_attr2=True, want_weighted=False)
+    return attr2.to(ingredients.device)
+
+
+def cpp_feat_to_instance_e(
+    ingredients: torch.LongTensor,
+    attn: torch.Tensor,
+    geo_sim: torch.Tensor,
+    batch_ingredient_dict: List[Dict[int, int]],
+    edge_attribute_weights: torch.Tensor,
+    mean: bool = False,
+    remove_self_loop: bool = False
+) -> List[torch.Tensor]:
+    """-> list of bs tensors [n_i, n_i] on edge_attribute_weights.device.
+    Replaces ext::feat_to_instance_e (reference cpp_extension/src/large_scale_feat_to_e.cpp:33-150).
+    remove_self_loop=True raises inside the reference (diagonal(0, 1)); here it zeroes the
+    diagonal, which is what the reference's own comment (:127-133) says it intends."""
+    _check_inputs(ingredients, attn, geo_sim)
+    w = edge_attribute_weights
+    B, L = ingredients.shape
+    if len(batch_ingredient_dict) != B:
+        raise RuntimeError("Batch size is not compat with `batch_ingredient_dict`")   # :53-56
+    dev = _native.compute_device(w, ingredients, attn)
+    ing = _native.to_device(ingredients, dev)
+    at = _native.to_device(attn, dev)
+    geo = _native.to_device(geo_sim, dev)
+    w_dev = _native.to_device(w, dev)
+    keys, vals, off, ln = [], [], [], []
+    o = 0
+    for d in batch_ingredient_dict:
+        ks = sorted(d)
+        keys += ks
+        vals += [d[k] for k in ks]
+        off.append(o)
+        ln.append(len(ks))
+        o += len(ks)
+    n_out = max(ln) if ln else 0
+    if n_out > 256:
+        raise RuntimeError(f"dictionary with {n_out} > 256 entries is not supported")
+    i64 = dict(dtype=torch.int64, device=dev)
+    dicts = (torch.tensor(keys + [0], **i64), torch.tensor(vals + [0], **i64),
+             torch.tensor(off, **i64), torch.tensor(ln, **i64))
+    n_pad = max(n_out, 1)
+    g = ops.instance_graph(ing, at, None, w_e=w_dev, n_pad=n_pad, pad_id=-1, attn_is_logits=False,
+                           geo=geo, mean=mean, remove_self_loop=remove_self_loop, dicts=dicts,
+                           want_attr2=True, want_weighted=False)
+    e = (g["e2"] @ w_dev).squeeze(-1)                          # [B, n_pad, n_pad], grad -> w
+    return [e[b, :n, :n].to(w.device) for b, n in enumerate(ln)]

@@ -1,0 +1,318 @@
+"""Tensor-level wrappers of the C ABI: allocate outputs, pass data_ptr()s + the current HIP
+stream, raise RuntimeError on a non-zero status.  All tensors are CUDA tensors here; the
+reference-compatible shims (CPU tensors in, lists out) live in cpp_extension/__init__.py.
+"""
+from ctypes import byref, c_void_p
+
+import torch
+
+from . import _native as N
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
+def _check_dev(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("expected CUDA tensors (the HIP path has no CPU fallback)")
+        dev = dev or t.device
+        if t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {t.device} vs {dev}")
+    return dev
+
+
+# ------------------------------------------------------------------------------- S1
+class PackedCodebook:
+    """fp16 MFMA-fragment image + fp64 norms of a codebook (sn_codebook_prepare).  Rebuilt when
+    the codebook tensor changes (data_ptr / _version / device)."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+        self.codebook = None
+
+    def get(self, codebook):
+        cb = _f32c(codebook.detach())
+        key = (cb.data_ptr(), codebook._version, cb.device, tuple(cb.shape))
+        if key != self.key:
+            lib = N.require_gpu()
+            M, D = cb.shape
+            nbytes = lib.sn_codebook_pack_bytes(M, D)
+            if nbytes == 0:
+                raise RuntimeError(f"unsupported codebook shape M={M}, D={D} (need D % 32 == 0, D <= 1024, M <= 65536)")
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=cb.device)
+            with torch.cuda.device(cb.device):
+                N.check(lib.sn_codebook_prepare(N.ptr(cb), M, D, N.ptr(buf), N.stream_ptr(cb.device)), "sn_codebook_prepare")
+            self.key, self.buf, self.codebook = key, buf, cb
+        return self.codebook, self.buf
+
+
+def assign_words(tokens, codebook, packed, out=None, mode=0):
+    """tokens: [n_outer, n_inner, D] view (last dim contiguous, any outer strides);
+    returns int64 [n_outer, n_inner] word ids (or fills `out`, any strides)."""
+    lib = N.require_gpu()
+    dev = _check_dev(tokens, codebook, packed, out)
+    if tokens.dtype != torch.float32 or tokens.stride(-1) != 1:
+        tokens = tokens.to(torch.float32).contiguous()
+    assert tokens.dim() == 3
+    n_outer, n_inner, D = tokens.shape
+    M = codebook.shape[0]
+    assert codebook.shape[1] == D and codebook.is_contiguous() and codebook.dtype == torch.float32
+    if out is None:
+        out = torch.empty((n_outer, n_inner), dtype=torch.int64, device=dev)
+    assert out.dtype == torch.int64 and tuple(out.shape) == (n_outer, n_inner)
+    n_tok = n_outer * n_inner
+    ws_bytes = lib.sn_assign_workspace_bytes(n_tok)
+    ws = torch.empty(max(ws_bytes, 32), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_assign_words(
+            N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(codebook), N.ptr(packed), M, D,
+            N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws_bytes, int(mode), N.stream_ptr(dev)), "sn_assign_words")
+    return out
+
+
+# ------------------------------------------------------------------------------- wrapper taps
+def head_mean_attention(extracted, bs):
+    """extracted [bs*H, L+1, L+1] -> (attn [bs, L, L], attn_cls [bs, L])."""
+    lib = N.require_gpu()
+    dev = _check_dev(extracted)
+    ext = _f32c(extracted)
+    H = ext.shape[0] // bs
+    L = ext.shape[1] - 1
+    attn = torch.empty((bs, L, L), dtype=torch.float32, device=dev)
+    attn_cls = torch.empty((bs, L), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_head_mean_attention(N.ptr(ext), bs, H, L, N.ptr(attn), N.ptr(attn_cls), N.stream_ptr(dev)),
+                "sn_head_mean_attention")
+    return attn, attn_cls
+
+
+# ------------------------------------------------------------------------------- S2 + S3
+def _attn_view(t, L, what):
+    """Accept [B, L, L] / [B, H, L, L] (any batch/head/row strides, unit column stride)."""
+    if t.dtype != torch.float32 or t.stride(-1) != 1:
+        t = t.to(torch.float32).contiguous()
+    if t.dim() == 3:
+        return t, 1, t.stride(0), t.stride(1), 0
+    if t.dim() == 4:
+        return t, t.shape[1], t.stride(0), t.stride(2), t.stride(1)
+    raise RuntimeError(f"{what}: expected 3 or 4 dims, got {tuple(t.shape)}")
+
+
+def _acls_view(t, L, what):
+    if t.dtype != torch.float32 or t.stride(-1) != 1:
+        t = t.to(torch.float32).contiguous()
+    if t.dim() == 2:
+        return t, 1, t.stride(0), 0
+    if t.dim() == 3:
+        return t, t.shape[1], t.stride(0), t.stride(1)
+    raise RuntimeError(f"{what}: expected 2 or 3 dims, got {tuple(t.shape)}")
+
+
+def instance_graph(ingredients, attn=None, attn_cls=None, *, w_v=None, w_e=None, n_pad, pad_id,
+                   attn_is_logits=True, attn_cls_is_logits=True, clamp_v=None, clamp_e=None,
+                   geo=None, feat_h=14, feat_w=14, dist_alpha=1.0, dist_pow=2.0, mean=True,
+                   remove_self_loop=False, dicts=None, want_attr2=False, want_weighted=True,
+                   attn_cls_masked_out=None):
+    """One launch of sn_instance_graph.  Returns a dict of padded tensors:
+    ids [B,n_pad] i64, n [B] i32, n_max [1] i32, and (when the inputs are given)
+    v / v2 ([B,n_pad] / [B,n_pad,2]) and e / e2 ([B,n_pad,n_pad] / [...,2])."""
+    lib = N.require_gpu()
+    dev = _check_dev(ingredients, attn, attn_cls, w_v, w_e, geo)
+    assert ingredients.dtype == torch.int64 and ingredients.dim() == 2
+    B, L = ingredients.shape
+    a = N.GraphArgs()
+    a.ingredients = ingredients.data_ptr()
+    a.ing_stride_b, a.ing_stride_l = ingredients.stride(0), ingredients.stride(1)
+    a.B, a.L = B, L
+    keep = [ingredients]
+    out = {}
+    f32 = dict(dtype=torch.float32, device=dev)
+    if attn_cls is not None:
+        t, heads, sb, sh = _acls_view(attn_cls, L, "attn_cls")
+        assert t.shape[0] == B and t.shape[-1] == L
+        keep.append(t)
+        a.attn_cls, a.acls_heads, a.acls_stride_b, a.acls_stride_h = t.data_ptr(), heads, sb, sh
+        a.attn_cls_is_logits = int(attn_cls_is_logits)
+        a.use_clamp_v, a.clamp_v = int(clamp_v is not None), float(clamp_v or 0.0)
+        wv = _f32c(w_v.detach()).reshape(-1)
+        keep.append(wv)
+        a.w_v = wv.data_ptr()
+        if want_weighted:
+            out["v"] = torch.empty((B, n_pad), **f32)
+            a.out_v = out["v"].data_ptr()
+        if want_attr2:
+            out["v2"] = torch.empty((B, n_pad, 2), **f32)
+            a.out_v2 = out["v2"].data_ptr()
+        if attn_cls_masked_out is not None:
+            assert attn_cls_masked_out.is_contiguous() and tuple(attn_cls_masked_out.shape) == (B, L)
+            a.attn_cls_masked = attn_cls_masked_out.data_ptr()
+    if attn is not None:
+        t, heads, sb, sr, sh = _attn_view(attn, L, "attn")
+        assert t.shape[0] == B and t.shape[-1] == L and t.shape[-2] == L
+        keep.append(t)
+        a.attn, a.attn_heads = t.data_ptr(), heads
+        a.attn_stride_b, a.attn_stride_r, a.attn_stride_h = sb, sr, sh
+        a.attn_is_logits = int(attn_is_logits)
+        a.use_clamp_e, a.clamp_e = int(clamp_e is not None), float(clamp_e or 0.0)
+        we = _f32c(w_e.detach()).reshape(-1)
+        keep.append(we)
+        a.w_e = we.data_ptr()
+        if geo is not None:
+            g = _f32c(geo)
+            assert tuple(g.shape) == (L, L)
+            keep.append(g)
+            a.geo = g.data_ptr()
+        a.feat_h, a.feat_w, a.dist_alpha, a.dist_pow = feat_h, feat_w, float(dist_alpha), float(dist_pow)
+        if want_weighted:
+            out["e"] = torch.empty((B, n_pad, n_pad), **f32)
+            a.out_e = out["e"].data_ptr()
+        if want_attr2:
+            out["e2"] = torch.empty((B, n_pad, n_pad, 2), **f32)
+            a.out_e2 = out["e2"].data_ptr()
+        if dicts is not None:
+            keys, vals, off, ln = dicts
+            keep += [keys, vals, off, ln]
+            a.dict_keys, a.dict_vals, a.dict_off, a.dict_len = (keys.data_ptr(), vals.data_ptr(),
+                                                                off.data_ptr(), ln.data_ptr())
+    a.mean, a.remove_self_loop = int(mean), int(remove_self_loop)
+    a.n_pad, a.pad_id = int(n_pad), int(pad_id)
+    out["ids"] = torch.empty((B, n_pad), dtype=torch.int64, device=dev)
+    out["n"] = torch.empty((B,), dtype=torch.int32, device=dev)
+    out["n_max"] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    a.out_ids, a.out_n, a.out_n_max = out["ids"].data_ptr(), out["n"].data_ptr(), out["n_max"].data_ptr()
+    with torch.cuda.device(dev):
+        N.check(lib.sn_instance_graph(byref(a), N.stream_ptr(dev)), "sn_instance_graph")
+    del keep
+    return out
+
+
+# ------------------------------------------------------------------------------- init statistics
+def full_vertices(ingredients, attn_cls, M, *, w_v=None, is_logits=True, clamp=None, mean=True,
+                  ingredients_only=False, want_attr2=False, want_weighted=True):
+    lib = N.require_gpu()
+    dev = _check_dev(ingredients, attn_cls, w_v)
+    B, L = ingredients.shape
+    ac = _f32c(attn_cls) if attn_cls is not None else None
+    wv = _f32c(w_v.detach()).reshape(-1) if w_v is not None else None
+    attr2 = torch.empty((B, M, 2), dtype=torch.float32, device=dev) if want_attr2 else None
+    v = torch.empty((B, M), dtype=torch.float32, device=dev) if want_weighted else None
+    with torch.cuda.device(dev):
+        N.check(lib.sn_full_vertices(
+            N.ptr(ingredients), ingredients.stride(0), ingredients.stride(1), N.ptr(ac), B, L, int(M), int(is_logits),
+            int(clamp is not None), float(clamp or 0.0), int(mean), int(ingredients_only), N.ptr(wv),
+            N.ptr(attr2), N.ptr(v), N.stream_ptr(dev)), "sn_full_vertices")
+    return attr2, v
+
+
+def limited_edges(ingredients, attn, class_slot, label, n_max, *, w_e=None, is_logits=True, clamp=None,
+                  geo=None, feat_h=14, feat_w=14, dist_alpha=1.0, dist_pow=2.0, mean=True,
+                  remove_self_loop=False, want_attr2=False, want_weighted=True):
+    lib = N.require_gpu()
+    dev = _check_dev(ingredients, attn, class_slot, label, w_e, geo)
+    B, L = ingredients.shape
+    at = _f32c(attn)
+    assert tuple(at.shape) == (B, L, L)
+    assert class_slot.dtype == torch.int32 and class_slot.is_contiguous()
+    lab = label.to(torch.int64).contiguous()
+    K, Mtab = class_slot.shape
+    we = _f32c(w_e.detach()).reshape(-1) if w_e is not None else None
+    g = _f32c(geo) if geo is not None else None
+    attr2 = torch.empty((B, n_max, n_max, 2), dtype=torch.float32, device=dev) if want_attr2 else None
+    e = torch.empty((B, n_max, n_max), dtype=torch.float32, device=dev) if want_weighted else None
+    with torch.cuda.device(dev):
+        N.check(lib.sn_limited_edges(
+            N.ptr(ingredients), ingredients.stride(0), ingredients.stride(1), N.ptr(at), B, L, int(is_logits),
+            int(clamp is not None), float(clamp or 0.0), N.ptr(g), feat_h, feat_w, float(dist_alpha), float(dist_pow),
+            N.ptr(class_slot), K, Mtab, N.ptr(lab), int(n_max), int(mean), int(remove_self_loop), N.ptr(we),
+            N.ptr(attr2), N.ptr(e), N.stream_ptr(dev)), "sn_limited_edges")
+    return attr2, e
+
+
+def stats_accumulate(feat, label, class_sum, n_tracked=None):
+    """class_sum[label[b]] += feat[b] in image order (in place); n_tracked[label[b]] += 1."""
+    lib = N.require_gpu()
+    dev = _check_dev(feat, label, class_sum, n_tracked)
+    B = feat.shape[0]
+    f = _f32c(feat).reshape(B, -1)
+    K = class_sum.shape[0]
+    assert class_sum.is_contiguous() and class_sum.dtype == torch.float32 and class_sum.numel() == K * f.shape[1]
+    lab = label.to(torch.int64).contiguous()
+    with torch.cuda.device(dev):
+        N.check(lib.sn_stats_accumulate(N.ptr(f), N.ptr(lab), B, f.shape[1], K, N.ptr(class_sum), N.ptr(n_tracked),
+                                        N.stream_ptr(dev)), "sn_stats_accumulate")
+    return class_sum
+
+
+# ------------------------------------------------------------------------------- atlas
+def atlas_normalize(vertex_weights, edge_weights, prune_threshold=None, remove_self_loop=False):
+    """-> (class_vertices [K,n], class_edges [K,n,n]); edge_weights is pruned IN PLACE."""
+    lib = N.require_gpu()
+    dev = _check_dev(vertex_weights, edge_weights)
+    K, n = vertex_weights.shape
+    assert vertex_weights.is_contiguous() and edge_weights.is_contiguous()
+    cv = torch.empty((K, n), dtype=torch.float32, device=dev)
+    ce = torch.empty((K, n, n), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_atlas_normalize(N.ptr(vertex_weights), N.ptr(edge_weights), K, n, int(prune_threshold is not None),
+                                       float(prune_threshold or 0.0), int(remove_self_loop), N.ptr(cv), N.ptr(ce),
+                                       N.stream_ptr(dev)), "sn_atlas_normalize")
+    return cv, ce
+
+
+# ------------------------------------------------------------------------------- S4
+def gcn_adjacency(edges):
+    lib = N.require_gpu()
+    dev = _check_dev(edges)
+    e = _f32c(edges)
+    G, n, _ = e.shape
+    adj = torch.empty_like(e)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_gcn_adjacency(N.ptr(e), G, n, N.ptr(adj), N.stream_ptr(dev)), "sn_gcn_adjacency")
+    return adj
+
+
+def mask_layernorm_act_(x, gamma, beta, eps, n_valid=None, relu=True):
+    """In place on x [G, n, E]."""
+    lib = N.require_gpu()
+    dev = _check_dev(x, gamma, beta, n_valid)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    G, n, E = x.shape
+    with torch.cuda.device(dev):
+        N.check(lib.sn_mask_layernorm_act(N.ptr(x), G, n, E, N.ptr(n_valid), N.ptr(_f32c(gamma.detach())),
+                                          N.ptr(_f32c(beta.detach())), float(eps), int(relu), N.stream_ptr(dev)),
+                "sn_mask_layernorm_act")
+    return x
+
+
+def weighted_pool(feat, nodes, divisor_dev=None):
+    lib = N.require_gpu()
+    dev = _check_dev(feat, nodes, divisor_dev)
+    f, w = _f32c(feat), _f32c(nodes)
+    G, n, E = f.shape
+    out = torch.empty((G, E), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_weighted_pool(N.ptr(f), N.ptr(w), G, n, E, N.ptr(divisor_dev), N.ptr(out), N.stream_ptr(dev)),
+                "sn_weighted_pool")
+    return out
+
+
+SIMILARITY = {"inner_product": 0, "cosine": 1, "euclidean": 2}
+
+
+def match_scores(feat_inst, feat_kg, similarity="inner_product"):
+    lib = N.require_gpu()
+    dev = _check_dev(feat_inst, feat_kg)
+    a, b = _f32c(feat_inst), _f32c(feat_kg)
+    B, E = a.shape
+    K = b.shape[0]
+    pred = torch.empty((B, K), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_match_scores(N.ptr(a), N.ptr(b), B, K, E, SIMILARITY[similarity], N.ptr(pred), N.stream_ptr(dev)),
+                "sn_match_scores")
+    return pred

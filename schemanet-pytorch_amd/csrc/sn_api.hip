@@ -1,0 +1,107 @@
+// ABI housekeeping: version, thread-local error string, device probe.
+#include "sn_common.h"
+
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void sn_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int sn_abi_version(void) { return 1; }
+
+extern "C" const char *sn_last_error(void) { return g_err; }
+
+extern "C" int sn_device_ok(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-kernel event timing (bench.py roofline): events are recorded on the SAME stream as the
+// kernel, immediately before / after its launch.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Prof {
+    int cap = 0;
+    int n_start[SN_PROF_KERNELS] = {0};
+    int n_stop[SN_PROF_KERNELS] = {0};
+    hipEvent_t *ev[SN_PROF_KERNELS][2] = {{nullptr}};
+} g_prof;
+}  // namespace
+
+void sn_prof_start(int k, hipStream_t st)
+{
+    if (g_prof.cap == 0 || g_prof.n_start[k] >= g_prof.cap) return;
+    (void)hipEventRecord(g_prof.ev[k][0][g_prof.n_start[k]++], st);
+}
+
+void sn_prof_stop(int k, hipStream_t st)
+{
+    if (g_prof.cap == 0 || g_prof.n_stop[k] >= g_prof.cap) return;
+    (void)hipEventRecord(g_prof.ev[k][1][g_prof.n_stop[k]++], st);
+}
+
+extern "C" int sn_profile_enable(int max_samples)
+{
+    SN_REQUIRE(max_samples >= 0 && max_samples <= (1 << 20), SN_ERR_BAD_ARG, "sn_profile_enable: max_samples=%d", max_samples);
+    for (int k = 0; k < SN_PROF_KERNELS; ++k) {
+        for (int s = 0; s < 2; ++s) {
+            if (g_prof.ev[k][s]) {
+                for (int i = 0; i < g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[k][s][i]);
+                delete[] g_prof.ev[k][s];
+                g_prof.ev[k][s] = nullptr;
+            }
+        }
+        g_prof.n_start[k] = g_prof.n_stop[k] = 0;
+    }
+    g_prof.cap = 0;
+    if (max_samples == 0) return SN_OK;
+    for (int k = 0; k < SN_PROF_KERNELS; ++k)
+        for (int s = 0; s < 2; ++s) {
+            g_prof.ev[k][s] = new hipEvent_t[max_samples];
+            for (int i = 0; i < max_samples; ++i)
+                if (hipEventCreate(&g_prof.ev[k][s][i]) != hipSuccess) {
+                    sn_set_error("sn_profile_enable: hipEventCreate failed");
+                    return SN_ERR_LAUNCH;
+                }
+        }
+    g_prof.cap = max_samples;
+    return SN_OK;
+}
+
+extern "C" int sn_profile_count(int kernel_id)
+{
+    if (kernel_id < 0 || kernel_id >= SN_PROF_KERNELS) return 0;
+    return g_prof.n_stop[kernel_id];
+}
+
+extern "C" int sn_profile_elapsed_ms(int kernel_id, float *out_ms_host, int n)
+{
+    SN_REQUIRE(kernel_id >= 0 && kernel_id < SN_PROF_KERNELS && out_ms_host, SN_ERR_BAD_ARG, "sn_profile_elapsed_ms: bad argument");
+    SN_REQUIRE(n >= 0 && n <= g_prof.n_stop[kernel_id], SN_ERR_BAD_ARG, "sn_profile_elapsed_ms: only %d samples", g_prof.n_stop[kernel_id]);
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(g_prof.ev[kernel_id][1][i]) != hipSuccess ||
+            hipEventElapsedTime(&out_ms_host[i], g_prof.ev[kernel_id][0][i], g_prof.ev[kernel_id][1][i]) != hipSuccess) {
+            sn_set_error("sn_profile_elapsed_ms: event query failed");
+            return SN_ERR_LAUNCH;
+        }
+    }
+    return SN_OK;
+}

@@ -1,0 +1,722 @@
+// Instance IR-graph construction and the atlas-initialisation statistics, one workgroup per
+// image.  HBM-bound gather/scatter work: the image's attention map is streamed once with
+// coalesced row loads into LDS (153.7 KB of the CU's 160 KB at L = 196), soft-maxed per row by
+// one wave with shuffle reductions, and every (word_i, word_j) cell is then summed out of LDS
+// in exactly the reference's order (positions of word_i ascending x positions of word_j
+// ascending, fp32 sequential from 0).  No MFMA: there is no contraction here.
+//
+// Reference being replaced (paths relative to /root/reference):
+//   cpp_extension/src/large_scale_feat_to_v.cpp:41-143   ext::feat_to_instance_v
+//   cpp_extension/src/large_scale_feat_to_e.cpp:33-150   ext::feat_to_instance_e
+//   cpp_extension/src/feat_to_v_attr.cpp:19-148          ext::feat_to_v_attr
+//   cpp_extension/src/feat_to_e.cpp:31-127               ext::feat_to_e
+//   schema_inference/graph/schema_net.py:188-254, 278-356 (clamp / softmax / normalise / @ w)
+//   schema_inference/utils/ingredient_model_wrapper.py:58-68 (head mean + slicing)
+//   scripts/init_schema_net.py:33-35, 59-61 (per-class sums)
+#include "sn_common.h"
+
+namespace {
+
+constexpr int kCellsPerLane = 4;               // 4 x 64 lanes = 256 output columns per row
+constexpr int kMaxCols = kCellsPerLane * SN_WAVE;
+
+__host__ __device__ inline size_t up16(size_t x) { return (x + 15) & ~size_t(15); }
+
+// ------------------------------------------------------------------------------------------
+// LDS carve shared by the three graph kernels
+// ------------------------------------------------------------------------------------------
+struct Lds {
+    float *A;                  // [L, L] soft-maxed attention of this image (edges only)
+    int64_t *words;            // [L]
+    float *acls;               // [L] soft-maxed attention to the cls token
+    float *T;                  // [L] grid similarity by (|drow|, |dcol|)
+    int *rev;                  // [256] output row/col -> group (or -1)
+    unsigned short *gstart;    // [L+1] group g owns pos_sorted[gstart[g] .. gstart[g+1])
+    unsigned short *prc;       // [L] (row << 8) | col of each position on the feature grid
+    unsigned char *pos_sorted; // [L] positions grouped by word (ascending), ascending inside
+    unsigned char *flag;       // [L] first-occurrence flag / keep flag
+    float *red;                // [64] reduction scratch
+    int *misc;                 // [16]
+};
+
+__host__ __device__ inline size_t lds_bytes(int L, bool with_attn)
+{
+    size_t n = 0;
+    if (with_attn) n += up16((size_t)L * L * 4);
+    n += up16((size_t)L * 8) + up16((size_t)L * 4) * 2 + up16(kMaxCols * 4);
+    n += up16((size_t)(L + 1) * 2) + up16((size_t)L * 2) + up16(L) * 2 + up16(64 * 4) + up16(16 * 4);
+    return n;
+}
+
+__device__ inline Lds carve(unsigned char *p, int L, bool with_attn)
+{
+    Lds s;
+    s.A = (float *)p;                 if (with_attn) p += up16((size_t)L * L * 4);
+    s.words = (int64_t *)p;           p += up16((size_t)L * 8);
+    s.acls = (float *)p;              p += up16((size_t)L * 4);
+    s.T = (float *)p;                 p += up16((size_t)L * 4);
+    s.rev = (int *)p;                 p += up16(kMaxCols * 4);
+    s.gstart = (unsigned short *)p;   p += up16((size_t)(L + 1) * 2);
+    s.prc = (unsigned short *)p;      p += up16((size_t)L * 2);
+    s.pos_sorted = p;                 p += up16(L);
+    s.flag = p;                       p += up16(L);
+    s.red = (float *)p;               p += up16(64 * 4);
+    s.misc = (int *)p;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// attention rows -> LDS.  One wave per row, 4 elements per lane (L <= 256), optional head mean
+// (ingredient_model_wrapper.py:58-62), optional clamp + softmax (schema_net.py:334-336; an
+// all-clamped row becomes NaN exactly like torch: (-inf) - (-inf)).
+// src points at element (row 0, col 0) of head 0; rows are `stride_r` floats apart.
+// ------------------------------------------------------------------------------------------
+__device__ inline void load_row4(const float *row, int L, int lane, bool vec, float x[4])
+{
+    if (vec) {                      // L % 4 == 0 and 16-byte aligned rows: one dwordx4 per lane
+        if (lane * 4 < L) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + lane * 4);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else {
+            x[0] = x[1] = x[2] = x[3] = 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + SN_WAVE * k;
+            x[k] = c < L ? row[c] : 0.0f;
+        }
+    }
+}
+
+__device__ inline int col_of(int lane, int k, bool vec) { return vec ? lane * 4 + k : lane + SN_WAVE * k; }
+
+__device__ inline void softmax_row4(float x[4], int L, int lane, bool vec, bool use_clamp, float clamp)
+{
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok = col_of(lane, k, vec) < L;
+        if (ok && use_clamp && x[k] < clamp) x[k] = -INFINITY;
+        if (ok) m = fmaxf(m, x[k]);
+    }
+    m = sn_wave_max(m);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok = col_of(lane, k, vec) < L;
+        x[k] = ok ? expf(x[k] - m) : 0.0f;
+        s += x[k];
+    }
+    s = sn_wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = x[k] / s;
+}
+
+__device__ inline void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
+                                        int64_t stride_h, int L, bool is_logits, bool use_clamp,
+                                        float clamp, int wid, int nw, int lane)
+{
+    const bool vec = (L % 4 == 0) && (stride_r % 4 == 0) && (stride_h % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    for (int r = wid; r < L; r += nw) {
+        float x[4];
+        load_row4(src + (int64_t)r * stride_r, L, lane, vec, x);
+        if (heads > 1) {
+            for (int h = 1; h < heads; ++h) {
+                float y[4];
+                load_row4(src + h * stride_h + (int64_t)r * stride_r, L, lane, vec, y);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] += y[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = x[k] / (float)heads;
+        }
+        if (is_logits) softmax_row4(x, L, lane, vec, use_clamp, clamp);
+        if (vec) {
+            if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[0], x[1], x[2], x[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = col_of(lane, k, vec);
+                if (c < L) A[r * L + c] = x[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grid similarity table (graph/utils.py:55-81): geo[p,q] = 1 / (1 + |grid_p - grid_q|_pow / alpha)
+// depends only on (|drow|, |dcol|).  pow == 2 uses sqrt: integer inputs, correctly rounded
+// sqrt / div => bit-identical to the reference's torch.cdist based table.
+// ------------------------------------------------------------------------------------------
+__device__ inline void build_grid_table(const Lds &s, int L, int feat_w, float alpha, float pw, int tid)
+{
+    if (tid < L) {
+        const int dr = tid / feat_w, dc = tid % feat_w;
+        float d;
+        if (pw == 2.0f) d = sqrtf((float)(dr * dr + dc * dc));
+        else d = powf(powf((float)dr, pw) + powf((float)dc, pw), 1.0f / pw);
+        d = d / alpha;
+        s.T[tid] = 1.0f / (1.0f + d);
+        s.prc[tid] = (unsigned short)((dr << 8) | dc);
+    }
+}
+
+__device__ inline float geo_at(const Lds &s, const float *geo, int L, int feat_w, int p, int q)
+{
+    if (geo) return geo[p * L + q];
+    const int a = s.prc[p], b = s.prc[q];
+    const int dr = abs((a >> 8) - (b >> 8)), dc = abs((a & 255) - (b & 255));
+    return s.T[dr * feat_w + dc];
+}
+
+// ------------------------------------------------------------------------------------------
+// grouping: positions -> sorted distinct words ("groups", std::map order of the reference)
+// thread p < L owns position p; kept == false positions are ignored (class restriction).
+// Fills pos_sorted, gstart, misc[0] = number of groups.  Returns this position's group, its
+// count, and whether it is the word's first occurrence.  attn-sum (position order) optional.
+// ------------------------------------------------------------------------------------------
+struct PosInfo { int group, cnt, first; float attn_sum; };
+
+__device__ inline PosInfo group_positions(const Lds &s, int L, int tid, bool kept, bool want_sum)
+{
+    PosInfo r = {0, 0, 0, 0.0f};
+    if (tid == 0) s.misc[0] = 0;
+    if (tid < L) s.flag[tid] = kept ? 1 : 0;
+    __syncthreads();
+    int rank = 0, less = 0;
+    int64_t w = 0;
+    if (tid < L && kept) {
+        w = s.words[tid];
+        for (int q = 0; q < L; ++q) {
+            if (!s.flag[q]) continue;
+            const int64_t wq = s.words[q];
+            const int same = (wq == w);
+            r.cnt += same;
+            rank += same & (q < tid);
+            less += (wq < w);
+            if (want_sum && same) r.attn_sum = r.attn_sum + s.acls[q];   // utils.cpp:9 order
+        }
+        r.first = (rank == 0);
+    }
+    __syncthreads();
+    if (tid < L) s.flag[tid] = (unsigned char)((kept ? 1 : 0) | (r.first ? 2 : 0));
+    __syncthreads();
+    if (tid < L && kept) {
+        int g = 0;
+        for (int q = 0; q < L; ++q) g += ((s.flag[q] & 2) != 0) & (s.words[q] < w);
+        r.group = g;
+        s.pos_sorted[less + rank] = (unsigned char)tid;
+        if (r.first) {
+            s.gstart[g] = (unsigned short)less;
+            atomicMax(&s.misc[0], g + 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+        for (int q = 0; q < L; ++q) total += (s.flag[q] & 1);
+        s.gstart[s.misc[0]] = (unsigned short)total;
+    }
+    __syncthreads();
+    return r;
+}
+
+// block-wide max over first-occurrence values; NaN propagates like at::max (large_scale_feat_to_v.cpp:124)
+__device__ inline float block_max_nan(const Lds &s, float v, bool valid, int tid, int wid, int nw, int lane)
+{
+    float m = valid && !(v != v) ? v : -INFINITY;
+    const int has_nan = __any(valid && (v != v));
+    m = sn_wave_max(m);
+    __syncthreads();
+    if (lane == 0) { s.red[wid] = m; s.red[32 + wid] = has_nan ? 1.0f : 0.0f; }
+    __syncthreads();
+    float out = -INFINITY, nanf_ = 0.0f;
+    for (int i = 0; i < nw; ++i) { out = fmaxf(out, s.red[i]); nanf_ += s.red[32 + i]; }
+    return nanf_ > 0.0f ? NAN : out;
+}
+
+// one cell: sequential fp32 sums over (p in group gi) x (q in group gj), p-major
+__device__ inline void cell_sums(const Lds &s, const float *geo, int L, int feat_w, int gi, int gj,
+                                 int mean, float &out_geo, float &out_attn)
+{
+    const int ia = s.gstart[gi], ib = s.gstart[gi + 1];
+    const int ja = s.gstart[gj], jb = s.gstart[gj + 1];
+    float sa = 0.0f, sg = 0.0f;
+    for (int x = ia; x < ib; ++x) {
+        const int p = s.pos_sorted[x];
+        for (int y = ja; y < jb; ++y) {
+            const int q = s.pos_sorted[y];
+            sa = sa + s.A[p * L + q];
+            sg = sg + geo_at(s, geo, L, feat_w, p, q);
+        }
+    }
+    if (mean) {
+        const float n = (float)((ib - ia) * (jb - ja));
+        sa = sa / n;
+        sg = sg / n;
+    }
+    out_geo = sg;
+    out_attn = sa;
+}
+
+// ------------------------------------------------------------------------------------------
+// S2 + S3 kernel
+// ------------------------------------------------------------------------------------------
+template <bool kEdges>
+__global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int L = a.L, b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    const Lds s = carve(smem, L, kEdges);
+    const bool do_v = a.attn_cls != nullptr;
+
+    // ---- stream this image's attention map into LDS (the only large HBM read)
+    if (kEdges) {
+        attn_rows_to_lds(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
+                         a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e,
+                         wid, nw, lane);
+        if (!a.geo) build_grid_table(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);
+    }
+    if (tid < L) s.words[tid] = a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)tid * a.ing_stride_l];
+    for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;
+
+    // ---- attention to the cls token: clamp / softmax / nan_to_num(0)  (schema_net.py:295-297)
+    if (do_v && wid == nw - 1) {
+        const float *row = a.attn_cls + (int64_t)b * a.acls_stride_b;
+        float x[4];
+        load_row4(row, L, lane, false, x);
+        for (int h = 1; h < a.acls_heads; ++h) {
+            float y[4];
+            load_row4(row + h * a.acls_stride_h, L, lane, false, y);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] += y[k];
+        }
+        if (a.acls_heads > 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = x[k] / (float)a.acls_heads;
+        }
+        if (a.attn_cls_is_logits) {
+            if (a.attn_cls_masked) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = lane + SN_WAVE * k;
+                    if (c < L) a.attn_cls_masked[(int64_t)b * L + c] =
+                        (a.use_clamp_v && x[k] < a.clamp_v) ? -INFINITY : x[k];
+                }
+            }
+            softmax_row4(x, L, lane, false, a.use_clamp_v != 0, a.clamp_v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = sn_nan_to_num(x[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + SN_WAVE * k;
+            if (c < L) s.acls[c] = x[k];
+        }
+    }
+    __syncthreads();
+
+    // ---- group positions by word
+    const PosInfo me = group_positions(s, L, tid, tid < L, do_v);
+    const int n_groups = s.misc[0];
+    const bool owner = tid < L && me.first;
+
+    // ---- vertices  (large_scale_feat_to_v.cpp:100-125)
+    if (a.out_n && tid == 0) a.out_n[b] = n_groups;
+    if (a.out_n_max && tid == 0) atomicMax(a.out_n_max, n_groups);
+    if (do_v) {
+        const float a0 = (float)me.cnt;
+        const float a1 = a.mean ? me.attn_sum / (float)me.cnt : me.attn_sum;
+        const float m0 = block_max_nan(s, a0, owner, tid, wid, nw, lane);
+        const float m1 = block_max_nan(s, a1, owner, tid, wid, nw, lane);
+        if (owner && me.group < a.n_pad) {
+            const float v0 = sn_nan_to_num(a0 / m0), v1 = sn_nan_to_num(a1 / m1);
+            const int64_t o = (int64_t)b * a.n_pad + me.group;
+            if (a.out_v2) { a.out_v2[2 * o] = v0; a.out_v2[2 * o + 1] = v1; }
+            if (a.out_v) {
+                const float t0 = v0 * a.w_v[0], t1 = v1 * a.w_v[1];
+                a.out_v[o] = t0 + t1;
+            }
+        }
+        for (int c = n_groups + tid; c < a.n_pad; c += blockDim.x) {
+            const int64_t o = (int64_t)b * a.n_pad + c;
+            if (a.out_v2) { a.out_v2[2 * o] = 0.0f; a.out_v2[2 * o + 1] = 0.0f; }
+            if (a.out_v) a.out_v[o] = 0.0f;
+        }
+    }
+    if (a.out_ids) {
+        if (owner && me.group < a.n_pad) a.out_ids[(int64_t)b * a.n_pad + me.group] = s.words[tid];
+        for (int c = n_groups + tid; c < a.n_pad; c += blockDim.x) a.out_ids[(int64_t)b * a.n_pad + c] = a.pad_id;
+    }
+    if (!kEdges) return;
+
+    // ---- output row of every group: canonical rank, or the caller's dictionary
+    // (large_scale_feat_to_e.cpp:117-118; missing key -> 0; on collisions the last (gi, gj) in
+    // iteration order wins, i.e. the largest group index)
+    int n_out = n_groups;
+    if (a.dict_keys) {
+        n_out = (int)a.dict_len[b];
+        if (owner) {
+            const int64_t *keys = a.dict_keys + a.dict_off[b], *vals = a.dict_vals + a.dict_off[b];
+            const int64_t w = s.words[tid];
+            int lo = 0, hi = n_out - 1;
+            int64_t row = 0;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const int64_t k = keys[mid];
+                if (k == w) { row = vals[mid]; break; }
+                if (k < w) lo = mid + 1; else hi = mid - 1;
+            }
+            if (row >= 0 && row < n_out && row < kMaxCols) atomicMax(&s.rev[(int)row], me.group);
+        }
+    } else if (owner && me.group < kMaxCols) {
+        s.rev[me.group] = me.group;
+    }
+    __syncthreads();
+
+    // ---- edges: one wave per output row, lanes over output columns
+    // (large_scale_feat_to_e.cpp:90-140)
+    const float w0 = a.w_e[0], w1 = a.w_e[1];
+    for (int r = wid; r < a.n_pad; r += nw) {
+        const int gi = (r < n_out && r < kMaxCols) ? s.rev[r] : -1;
+        float c0[kCellsPerLane], c1[kCellsPerLane];
+        float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kCellsPerLane; ++k) {
+            const int c = lane + SN_WAVE * k;
+            const int gj = (gi >= 0 && c < n_out) ? s.rev[c] : -1;
+            c0[k] = 0.0f; c1[k] = 0.0f;
+            if (gj >= 0) cell_sums(s, a.geo, L, a.feat_w, gi, gj, a.mean, c0[k], c1[k]);
+            t0 += c0[k]; t1 += c1[k];
+        }
+        t0 = sn_wave_sum(t0);     // instance_edges.sum(1, keepdim)  :135
+        t1 = sn_wave_sum(t1);
+        const int64_t rowbase = ((int64_t)b * a.n_pad + r) * a.n_pad;
+#pragma unroll
+        for (int k = 0; k < kCellsPerLane; ++k) {
+            const int c = lane + SN_WAVE * k;
+            if (c >= a.n_pad) continue;
+            float e0 = 0.0f, e1 = 0.0f;
+            if (gi >= 0 && c < n_out) {
+                e0 = sn_nan_to_num(c0[k] / t0);
+                e1 = sn_nan_to_num(c1[k] / t1);
+                if (a.remove_self_loop && c == r) { e0 = 0.0f; e1 = 0.0f; }
+            }
+            if (a.out_e2) { a.out_e2[2 * (rowbase + c)] = e0; a.out_e2[2 * (rowbase + c) + 1] = e1; }
+            if (a.out_e) {
+                const float p0 = e0 * w0, p1 = e1 * w1;
+                a.out_e[rowbase + c] = p0 + p1;
+            }
+        }
+        for (int c = kMaxCols + lane; c < a.n_pad; c += SN_WAVE) {
+            if (a.out_e2) { a.out_e2[2 * (rowbase + c)] = 0.0f; a.out_e2[2 * (rowbase + c) + 1] = 0.0f; }
+            if (a.out_e) a.out_e[rowbase + c] = 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// init: dense vertex attributes  (feat_to_v_attr.cpp:74-148 + schema_net.py:200-207)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void full_vertices_kernel(
+    const int64_t *ing, int64_t sb, int64_t sl, const float *attn_cls, int L, int M, int is_logits,
+    int use_clamp, float clamp, int mean, int ingredients_only, const float *w_v, float *out_attr2,
+    float *out_v)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    const Lds s = carve(smem, L, false);
+    if (tid < L) s.words[tid] = ing[(int64_t)b * sb + (int64_t)tid * sl];
+    const bool want_attn = !ingredients_only && attn_cls != nullptr;
+    if (want_attn && wid == nw - 1) {
+        float x[4];
+        load_row4(attn_cls + (int64_t)b * L, L, lane, false, x);
+        if (is_logits) softmax_row4(x, L, lane, false, use_clamp != 0, clamp);   // no nan_to_num (:202)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = lane + SN_WAVE * k;
+            if (c < L) s.acls[c] = x[k];
+        }
+    }
+    // zero-fill this image's dense outputs while the grouping runs
+    if (out_attr2) for (int i = tid; i < 2 * M; i += blockDim.x) out_attr2[(int64_t)b * 2 * M + i] = 0.0f;
+    if (out_v) for (int i = tid; i < M; i += blockDim.x) out_v[(int64_t)b * M + i] = 0.0f;
+    __syncthreads();
+    const PosInfo me = group_positions(s, L, tid, tid < L, want_attn);
+    const bool owner = tid < L && me.first;
+    const float a0 = (float)me.cnt;
+    const float a1 = want_attn ? (mean ? me.attn_sum / (float)me.cnt : me.attn_sum) : 0.0f;
+    // normalize_max_(dim=1) runs over all M vertices; absent words hold 0 (graph/utils.py:16-22)
+    const bool has_absent = s.misc[0] < M;
+    float m0 = block_max_nan(s, a0, owner, tid, wid, nw, lane);
+    float m1 = block_max_nan(s, a1, owner, tid, wid, nw, lane);
+    if (has_absent) { m0 = (m0 != m0) ? m0 : fmaxf(m0, 0.0f); m1 = (m1 != m1) ? m1 : fmaxf(m1, 0.0f); }
+    if (owner) {
+        const int64_t w = s.words[tid];
+        if (w >= 0 && w < M) {
+            if (out_attr2) { out_attr2[((int64_t)b * M + w) * 2] = a0; out_attr2[((int64_t)b * M + w) * 2 + 1] = a1; }
+            if (out_v) {
+                const float t0 = sn_nan_to_num(a0 / m0) * w_v[0], t1 = sn_nan_to_num(a1 / m1) * w_v[1];
+                out_v[(int64_t)b * M + w] = t0 + t1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// init: class-restricted dense edges  (feat_to_e.cpp:31-127 + schema_net.py:237-254)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void limited_edges_kernel(
+    const int64_t *ing, int64_t sb, int64_t sl, const float *attn, int L, int is_logits, int use_clamp,
+    float clamp, const float *geo, int feat_w, float alpha, float pw, const int32_t *class_slot,
+    int Mtab, const int64_t *label, int n_max, int mean, int remove_self_loop, const float *w_e,
+    float *out_attr2, float *out_e)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    const Lds s = carve(smem, L, true);
+    attn_rows_to_lds(s.A, attn + (int64_t)b * L * L, L, 1, 0, L, is_logits != 0, use_clamp != 0, clamp, wid, nw, lane);
+    if (!geo) build_grid_table(s, L, feat_w, alpha, pw, tid);
+    const int32_t *slot_tab = class_slot + (int64_t)label[b] * Mtab;
+    int my_slot = -1;
+    if (tid < L) {
+        const int64_t w = ing[(int64_t)b * sb + (int64_t)tid * sl];
+        s.words[tid] = w;
+        if (w >= 0 && w < Mtab) my_slot = slot_tab[w];
+        if (my_slot >= n_max) my_slot = -1;
+    }
+    // zero-fill the dense [n_max, n_max] outputs (at::zeros, feat_to_e.cpp:46)
+    const int64_t cells = (int64_t)n_max * n_max;
+    if (out_attr2) for (int64_t i = tid; i < 2 * cells; i += blockDim.x) out_attr2[(int64_t)b * 2 * cells + i] = 0.0f;
+    if (out_e) for (int64_t i = tid; i < cells; i += blockDim.x) out_e[(int64_t)b * cells + i] = 0.0f;
+    __syncthreads();
+    const PosInfo me = group_positions(s, L, tid, my_slot >= 0, false);
+    const int n_groups = s.misc[0];
+    // group -> class slot, kept in rev[] (n_groups <= L <= kMaxCols)
+    if (tid < L && me.first && my_slot >= 0) s.rev[me.group] = my_slot;
+    __syncthreads();
+    const float w0 = w_e ? w_e[0] : 0.0f, w1 = w_e ? w_e[1] : 0.0f;
+    for (int gi = wid; gi < n_groups; gi += nw) {
+        const int si = s.rev[gi];
+        float c0[kCellsPerLane], c1[kCellsPerLane];
+        float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kCellsPerLane; ++k) {
+            const int gj = lane + SN_WAVE * k;
+            c0[k] = 0.0f; c1[k] = 0.0f;
+            if (gj < n_groups) cell_sums(s, geo, L, feat_w, gi, gj, mean, c0[k], c1[k]);
+            t0 += c0[k]; t1 += c1[k];
+        }
+        t0 = sn_wave_sum(t0);     // normalize_sum_(edges_attr, dim=2)  schema_net.py:249
+        t1 = sn_wave_sum(t1);
+#pragma unroll
+        for (int k = 0; k < kCellsPerLane; ++k) {
+            const int gj = lane + SN_WAVE * k;
+            if (gj >= n_groups) continue;
+            const int sj = s.rev[gj];
+            const int64_t o = (int64_t)b * cells + (int64_t)si * n_max + sj;
+            if (out_attr2) { out_attr2[2 * o] = c0[k]; out_attr2[2 * o + 1] = c1[k]; }
+            if (out_e) {
+                float e0 = sn_nan_to_num(c0[k] / t0), e1 = sn_nan_to_num(c1[k] / t1);
+                if (remove_self_loop && si == sj) { e0 = 0.0f; e1 = 0.0f; }
+                const float p0 = e0 * w0, p1 = e1 * w1;
+                out_e[o] = p0 + p1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-class sums in image order (scripts/init_schema_net.py:33-35, 59-61)
+// grid: (ceil(F / 1024), K); each thread owns up to 4 feature columns of one class.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_accumulate_kernel(const float *feat, const int64_t *label,
+                                                               int B, int64_t F, float *class_sum,
+                                                               float *n_tracked)
+{
+    const int k = blockIdx.y;
+    const int64_t c0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t c = c0 + 256 * j;
+        acc[j] = c < F ? class_sum[(int64_t)k * F + c] : 0.0f;
+    }
+    int n = 0;
+    for (int b = 0; b < B; ++b) {
+        if (label[b] != k) continue;     // wave-uniform
+        ++n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t c = c0 + 256 * j;
+            if (c < F) acc[j] = acc[j] + feat[(int64_t)b * F + c];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t c = c0 + 256 * j;
+        if (c < F) class_sum[(int64_t)k * F + c] = acc[j];
+    }
+    if (n_tracked && blockIdx.x == 0 && threadIdx.x == 0) n_tracked[k] = n_tracked[k] + (float)n;
+}
+
+// ------------------------------------------------------------------------------------------
+// wrapper taps: head mean + slicing  (ingredient_model_wrapper.py:58-68)
+// grid (L+1 rows, B); row 0 -> attn_cls, row p+1 -> attn[:, p, :]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_mean_kernel(const float *ext, int H, int L, float *attn, float *attn_cls)
+{
+    const int row = blockIdx.x, b = blockIdx.y, q = threadIdx.x;
+    if (q >= L) return;
+    const int64_t S = (int64_t)(L + 1) * (L + 1);
+    const float *src = ext + (int64_t)b * H * S + (int64_t)row * (L + 1) + 1 + q;
+    float acc = src[0];
+    for (int h = 1; h < H; ++h) acc = acc + src[h * S];
+    acc = acc / (float)H;
+    if (row == 0) attn_cls[(int64_t)b * L + q] = acc;
+    else attn[((int64_t)b * L + (row - 1)) * L + q] = acc;
+}
+
+int ensure_lds(const void *fn, size_t bytes, const char *name)
+{
+    if (bytes > 160 * 1024) {
+        sn_set_error("%s: needs %zu bytes of LDS (> 160 KiB)", name, bytes);
+        return SN_ERR_UNSUPPORTED;
+    }
+    static const void *done[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (const void *d : done) if (d == fn) return SN_OK;
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            sn_set_error("%s: cannot raise dynamic LDS to %zu: %s", name, bytes, hipGetErrorString(e));
+            return SN_ERR_LAUNCH;
+        }
+        for (const void *&d : done) if (!d) { d = fn; break; }
+    }
+    return SN_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
+{
+    SN_REQUIRE(args, SN_ERR_BAD_ARG, "sn_instance_graph: args is NULL");
+    sn_graph_args a = *args;
+    SN_REQUIRE(a.B >= 0 && a.L > 0, SN_ERR_BAD_ARG, "sn_instance_graph: bad B=%d L=%d", a.B, a.L);
+    if (a.B == 0) return SN_OK;
+    SN_REQUIRE(a.ingredients, SN_ERR_BAD_ARG, "sn_instance_graph: ingredients is NULL");
+    SN_REQUIRE(a.attn || a.attn_cls, SN_ERR_BAD_ARG, "sn_instance_graph: nothing to do (attn and attn_cls NULL)");
+    SN_REQUIRE(a.L <= SN_MAX_TOKENS, SN_ERR_UNSUPPORTED, "sn_instance_graph: L=%d > %d tokens", a.L, SN_MAX_TOKENS);
+    SN_REQUIRE(a.n_pad > 0, SN_ERR_BAD_ARG, "sn_instance_graph: n_pad=%d", a.n_pad);
+    SN_REQUIRE(a.B <= 0x7fffffff / 2, SN_ERR_BAD_ARG, "sn_instance_graph: B too large");
+    if (a.attn_cls) SN_REQUIRE(a.w_v || !a.out_v, SN_ERR_BAD_ARG, "sn_instance_graph: out_v needs w_v");
+    if (a.attn) {
+        SN_REQUIRE(a.w_e, SN_ERR_BAD_ARG, "sn_instance_graph: w_e is NULL");
+        SN_REQUIRE(a.geo || (a.feat_h > 0 && a.feat_w > 0 && a.feat_h * a.feat_w == a.L && a.feat_h < 256 && a.feat_w < 256),
+                   SN_ERR_BAD_ARG, "sn_instance_graph: feat_h*feat_w (%d*%d) != L (%d)", a.feat_h, a.feat_w, a.L);
+        SN_REQUIRE(a.geo || a.dist_alpha > 0.0f, SN_ERR_BAD_ARG, "sn_instance_graph: dist_alpha must be > 0");
+    }
+    if (a.dict_keys) SN_REQUIRE(a.dict_vals && a.dict_off && a.dict_len, SN_ERR_BAD_ARG, "sn_instance_graph: incomplete dictionary");
+    // defaults: contiguous single-head maps
+    if (a.attn_heads < 1) a.attn_heads = 1;
+    if (a.acls_heads < 1) a.acls_heads = 1;
+    if (a.attn_stride_r == 0) a.attn_stride_r = a.L;
+    if (a.attn_stride_b == 0) a.attn_stride_b = (int64_t)a.L * a.L * a.attn_heads;
+    if (a.attn_stride_h == 0) a.attn_stride_h = (int64_t)a.L * a.L;
+    if (a.acls_stride_b == 0) a.acls_stride_b = (int64_t)a.L * a.acls_heads;
+    if (a.acls_stride_h == 0) a.acls_stride_h = a.L;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.attn) {
+        const size_t lds = lds_bytes(a.L, true);
+        int rc = ensure_lds((const void *)instance_graph_kernel<true>, lds, "sn_instance_graph");
+        if (rc) return rc;
+        sn_prof_start(2, st);
+        hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a);
+        sn_prof_stop(2, st);
+    } else {
+        const size_t lds = lds_bytes(a.L, false);
+        hipLaunchKernelGGL(instance_graph_kernel<false>, dim3(a.B), dim3(256), lds, st, a);
+    }
+    SN_CHECK_LAUNCH("sn_instance_graph");
+    return SN_OK;
+}
+
+extern "C" int sn_full_vertices(const int64_t *ingredients, int64_t ing_stride_b, int64_t ing_stride_l,
+                                const float *attn_cls, int B, int L, int M, int is_logits, int use_clamp,
+                                float clamp, int mean, int ingredients_only, const float *w_v,
+                                float *out_attr2, float *out_v, void *stream)
+{
+    SN_REQUIRE(B >= 0 && L > 0 && M > 0, SN_ERR_BAD_ARG, "sn_full_vertices: bad B=%d L=%d M=%d", B, L, M);
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(ingredients, SN_ERR_BAD_ARG, "sn_full_vertices: ingredients is NULL");
+    SN_REQUIRE(ingredients_only || attn_cls, SN_ERR_BAD_ARG, "sn_full_vertices: attn_cls is NULL");
+    SN_REQUIRE(L <= SN_MAX_TOKENS, SN_ERR_UNSUPPORTED, "sn_full_vertices: L=%d > %d", L, SN_MAX_TOKENS);
+    SN_REQUIRE(out_attr2 || out_v, SN_ERR_BAD_ARG, "sn_full_vertices: no output");
+    SN_REQUIRE(!out_v || w_v, SN_ERR_BAD_ARG, "sn_full_vertices: out_v needs w_v");
+    hipLaunchKernelGGL(full_vertices_kernel, dim3(B), dim3(256), lds_bytes(L, false), (hipStream_t)stream,
+                       ingredients, ing_stride_b, ing_stride_l, attn_cls, L, M, is_logits, use_clamp, clamp,
+                       mean, ingredients_only, w_v, out_attr2, out_v);
+    SN_CHECK_LAUNCH("sn_full_vertices");
+    return SN_OK;
+}
+
+extern "C" int sn_limited_edges(const int64_t *ingredients, int64_t ing_stride_b, int64_t ing_stride_l,
+                                const float *attn, int B, int L, int is_logits, int use_clamp, float clamp,
+                                const float *geo, int feat_h, int feat_w, float dist_alpha, float dist_pow,
+                                const int32_t *class_slot, int K, int Mtab, const int64_t *label, int n_max,
+                                int mean, int remove_self_loop, const float *w_e, float *out_attr2,
+                                float *out_e, void *stream)
+{
+    SN_REQUIRE(B >= 0 && L > 0 && K > 0 && Mtab > 0 && n_max > 0, SN_ERR_BAD_ARG,
+               "sn_limited_edges: bad B=%d L=%d K=%d Mtab=%d n_max=%d", B, L, K, Mtab, n_max);
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(ingredients && attn && class_slot && label, SN_ERR_BAD_ARG, "sn_limited_edges: NULL input");
+    SN_REQUIRE(L <= SN_MAX_TOKENS, SN_ERR_UNSUPPORTED, "sn_limited_edges: L=%d > %d", L, SN_MAX_TOKENS);
+    SN_REQUIRE(geo || (feat_h > 0 && feat_w > 0 && feat_h * feat_w == L && feat_h < 256 && feat_w < 256 && dist_alpha > 0.0f),
+               SN_ERR_BAD_ARG, "sn_limited_edges: bad grid %dx%d for L=%d", feat_h, feat_w, L);
+    SN_REQUIRE(out_attr2 || out_e, SN_ERR_BAD_ARG, "sn_limited_edges: no output");
+    SN_REQUIRE(!out_e || w_e, SN_ERR_BAD_ARG, "sn_limited_edges: out_e needs w_e");
+    const size_t lds = lds_bytes(L, true);
+    int rc = ensure_lds((const void *)limited_edges_kernel, lds, "sn_limited_edges");
+    if (rc) return rc;
+    hipLaunchKernelGGL(limited_edges_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, ingredients,
+                       ing_stride_b, ing_stride_l, attn, L, is_logits, use_clamp, clamp, geo, feat_w,
+                       dist_alpha, dist_pow, class_slot, Mtab, label, n_max, mean, remove_self_loop, w_e,
+                       out_attr2, out_e);
+    SN_CHECK_LAUNCH("sn_limited_edges");
+    return SN_OK;
+}
+
+extern "C" int sn_stats_accumulate(const float *feat, const int64_t *label, int B, int64_t F, int K,
+                                   float *class_sum, float *n_tracked, void *stream)
+{
+    SN_REQUIRE(B >= 0 && F > 0 && K > 0, SN_ERR_BAD_ARG, "sn_stats_accumulate: bad B=%d F=%lld K=%d", B, (long long)F, K);
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(feat && label && class_sum, SN_ERR_BAD_ARG, "sn_stats_accumulate: NULL pointer");
+    SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_stats_accumulate: K=%d > 65535", K);
+    const dim3 grid((unsigned)((F + 1023) / 1024), (unsigned)K);
+    hipLaunchKernelGGL(stats_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, label, B, F,
+                       class_sum, n_tracked);
+    SN_CHECK_LAUNCH("sn_stats_accumulate");
+    return SN_OK;
+}
+
+extern "C" int sn_head_mean_attention(const float *extracted, int B, int H, int L, float *attn,
+                                      float *attn_cls, void *stream)
+{
+    SN_REQUIRE(B >= 0 && H > 0 && L > 0, SN_ERR_BAD_ARG, "sn_head_mean_attention: bad B=%d H=%d L=%d", B, H, L);
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(extracted && attn && attn_cls, SN_ERR_BAD_ARG, "sn_head_mean_attention: NULL pointer");
+    SN_REQUIRE(L <= 256, SN_ERR_UNSUPPORTED, "sn_head_mean_attention: L=%d > 256", L);
+    SN_REQUIRE(B <= 65535, SN_ERR_UNSUPPORTED, "sn_head_mean_attention: B=%d > 65535", B);
+    hipLaunchKernelGGL(head_mean_kernel, dim3(L + 1, B), dim3(256), 0, (hipStream_t)stream, extracted, H, L,
+                       attn, attn_cls);
+    SN_CHECK_LAUNCH("sn_head_mean_attention");
+    return SN_OK;
+}

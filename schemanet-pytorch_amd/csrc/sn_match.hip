@@ -1,0 +1,184 @@
+// Graph-matching epilogues around the GCN GEMMs (which run on rocBLAS through torch):
+// adjacency symmetrisation, masked LayerNorm + ReLU, node-weighted pooling and the
+// instance-vs-atlas similarity scores.  All HBM-bound elementwise / row-reduction work with
+// wavefront shuffle reductions; no MFMA.
+//
+// Reference being replaced:
+//   schema_inference/graph/gnn.py:27-30    adj = (E + E^T) / 2 + I
+//   schema_inference/graph/gnn.py:41-46    masked_fill_(feat_mask) -> LayerNorm -> activation
+//   schema_inference/graph/gnn.py:93-96    feat * nodes[..., None]; mean(dim=1)  (padded length)
+//   schema_inference/graph/match.py:21-31  cosine / euclidean / inner_product similarity
+#include "sn_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ adjacency
+__global__ __launch_bounds__(256) void gcn_adjacency_kernel(const float *edges, int n, float *adj)
+{
+    __shared__ float tile[32][33];
+    const int g = blockIdx.z, bi = blockIdx.y * 32, bj = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const float *e = edges + (int64_t)g * n * n;
+    // tile of E^T: read block (bj.., bi..) row-major
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bj + r, j = bi + tx;
+        tile[r][tx] = (i < n && j < n) ? e[(int64_t)i * n + j] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bi + r, j = bj + tx;
+        if (i < n && j < n) {
+            const float s = e[(int64_t)i * n + j] + tile[tx][r];
+            float v = s / 2.0f;
+            if (i == j) v = v + 1.0f;
+            adj[(int64_t)g * n * n + (int64_t)i * n + j] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ mask + LayerNorm + ReLU
+// one wave per row; E <= 64 * 16
+constexpr int kLnMax = 16;
+
+__global__ __launch_bounds__(256) void mask_layernorm_act_kernel(float *x, int64_t rows, int n, int E,
+                                                                 const int32_t *n_valid, const float *gamma,
+                                                                 const float *beta, float eps, int relu)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int g = (int)(row / n), r = (int)(row % n);
+    const bool masked = n_valid && r >= n_valid[g];
+    float *p = x + row * E;
+    float v[kLnMax];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLnMax; ++k) {
+        const int c = lane + SN_WAVE * k;
+        v[k] = (c < E && !masked) ? p[c] : 0.0f;
+        s += v[k];
+    }
+    const float mean = sn_wave_sum(s) / (float)E;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLnMax; ++k) {
+        const int c = lane + SN_WAVE * k;
+        const float d = (c < E) ? v[k] - mean : 0.0f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(sn_wave_sum(q) / (float)E + eps);
+#pragma unroll
+    for (int k = 0; k < kLnMax; ++k) {
+        const int c = lane + SN_WAVE * k;
+        if (c < E) {
+            float y = (v[k] - mean) * rstd * gamma[c] + beta[c];
+            if (relu) y = fmaxf(y, 0.0f);
+            p[c] = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weighted pooling
+__global__ __launch_bounds__(256) void weighted_pool_kernel(const float *feat, const float *nodes, int n, int E,
+                                                            const int32_t *divisor_dev, float *out)
+{
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= E) return;
+    const float *f = feat + (int64_t)g * n * E + c;
+    const float *w = nodes + (int64_t)g * n;
+    float acc = 0.0f;
+    for (int r = 0; r < n; ++r) acc = acc + f[(int64_t)r * E] * w[r];
+    const float div = divisor_dev ? (float)(*divisor_dev) : (float)n;
+    out[(int64_t)g * E + c] = acc / div;
+}
+
+// ------------------------------------------------------------------ similarity scores
+// block = 4 waves, one image per block; each wave walks classes k = wid, wid+4, ...
+__global__ __launch_bounds__(256) void match_scores_kernel(const float *fi, const float *fk, int K, int E,
+                                                           int similarity, float *pred)
+{
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float *a = fi + (int64_t)b * E;
+    float na = 0.0f;
+    if (similarity == 1) {
+        for (int c = lane; c < E; c += SN_WAVE) na += a[c] * a[c];
+        na = sqrtf(sn_wave_sum(na));
+    }
+    for (int k = wid; k < K; k += 4) {
+        const float *c_ = fk + (int64_t)k * E;
+        float dot = 0.0f, nb = 0.0f, d2 = 0.0f;
+        for (int c = lane; c < E; c += SN_WAVE) {
+            const float x = a[c], y = c_[c];
+            dot += x * y;
+            nb += y * y;
+            d2 += (x - y) * (x - y);
+        }
+        float r;
+        if (similarity == 0) {
+            r = sn_wave_sum(dot);
+        } else if (similarity == 1) {          // (cosine_similarity + 1) / 2, eps = 1e-8
+            const float den = fmaxf(na, 1.0e-8f) * fmaxf(sqrtf(sn_wave_sum(nb)), 1.0e-8f);
+            r = (sn_wave_sum(dot) / den + 1.0f) / 2.0f;
+        } else {                               // 1 / (1 + |a - b|_2)
+            r = 1.0f / (1.0f + sqrtf(sn_wave_sum(d2)));
+        }
+        if (lane == 0) pred[(int64_t)b * K + k] = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int sn_gcn_adjacency(const float *edges, int G, int n, float *adj, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency: bad G=%d n=%d", G, n);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(edges && adj && edges != adj, SN_ERR_BAD_ARG, "sn_gcn_adjacency: NULL or aliased pointers");
+    SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency: G=%d > 65535", G);
+    const unsigned t = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL(gcn_adjacency_kernel, dim3(t, t, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, adj);
+    SN_CHECK_LAUNCH("sn_gcn_adjacency");
+    return SN_OK;
+}
+
+extern "C" int sn_mask_layernorm_act(float *x, int G, int n, int E, const int32_t *n_valid,
+                                     const float *gamma, const float *beta, float eps, int relu, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0 && E > 0, SN_ERR_BAD_ARG, "sn_mask_layernorm_act: bad G=%d n=%d E=%d", G, n, E);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(x && gamma && beta, SN_ERR_BAD_ARG, "sn_mask_layernorm_act: NULL pointer");
+    SN_REQUIRE(E <= SN_WAVE * kLnMax, SN_ERR_UNSUPPORTED, "sn_mask_layernorm_act: E=%d > %d", E, SN_WAVE * kLnMax);
+    const int64_t rows = (int64_t)G * n;
+    const int64_t blocks = (rows + 3) / 4;
+    SN_REQUIRE(blocks <= 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_mask_layernorm_act: too many rows");
+    hipLaunchKernelGGL(mask_layernorm_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       n, E, n_valid, gamma, beta, eps, relu);
+    SN_CHECK_LAUNCH("sn_mask_layernorm_act");
+    return SN_OK;
+}
+
+extern "C" int sn_weighted_pool(const float *feat, const float *nodes, int G, int n, int E,
+                                const int32_t *divisor_dev, float *out, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0 && E > 0, SN_ERR_BAD_ARG, "sn_weighted_pool: bad G=%d n=%d E=%d", G, n, E);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(feat && nodes && out, SN_ERR_BAD_ARG, "sn_weighted_pool: NULL pointer");
+    SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_weighted_pool: G=%d > 65535", G);
+    hipLaunchKernelGGL(weighted_pool_kernel, dim3((unsigned)((E + 255) / 256), (unsigned)G), dim3(256), 0,
+                       (hipStream_t)stream, feat, nodes, n, E, divisor_dev, out);
+    SN_CHECK_LAUNCH("sn_weighted_pool");
+    return SN_OK;
+}
+
+extern "C" int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, int E,
+                               int similarity, float *pred, void *stream)
+{
+    SN_REQUIRE(B >= 0 && K > 0 && E > 0, SN_ERR_BAD_ARG, "sn_match_scores: bad B=%d K=%d E=%d", B, K, E);
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(feat_inst && feat_kg && pred, SN_ERR_BAD_ARG, "sn_match_scores: NULL pointer");
+    SN_REQUIRE(similarity >= 0 && similarity <= 2, SN_ERR_BAD_ARG, "sn_match_scores: similarity=%d", similarity);
+    hipLaunchKernelGGL(match_scores_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, feat_inst, feat_kg,
+                       K, E, similarity, pred);
+    SN_CHECK_LAUNCH("sn_match_scores");
+    return SN_OK;
+}

@@ -1,0 +1,11 @@
+"""`schema_inference` -- hot-path subset (graph/, utils/ingredient_model_wrapper) of the
+reference package, MI355X-native.
+
+`__path__` is extended so that, when the reference checkout is also on sys.path (after this
+directory), its orchestration sub-packages that are NOT re-implemented here
+(schema_inference.tasks / eval / data / loss) still resolve, while `schema_inference.graph` and
+`schema_inference.utils` resolve to this implementation.  See INTEGRATION.md.
+"""
+from pkgutil import extend_path
+
+__path__ = extend_path(__path__, __name__)

@@ -1,0 +1,115 @@
+"""Shared 2-layer GCN that embeds instance graphs and class graphs
+(reference schema_inference/graph/gnn.py).  Same module tree => same state-dict keys:
+`embedding.weight`, `layers.{i}.g_conv.linear.{weight,bias}`, `layers.{i}.norm.{weight,bias}`,
+`fc.{weight,bias}`.
+
+Inference: adjacency symmetrisation, masked LayerNorm+ReLU and the node-weighted pooling are
+HIP kernels (csrc/sn_match.hip); the dense bmm / Linear GEMMs are plain library GEMMs
+(rocBLAS via torch), fp32 so the scores stay within the 1e-5 budget.
+Training (any input or parameter requires grad): the same maths as differentiable torch ops.
+"""
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from cpp_extension import ops
+
+_ACTIVATIONS = {
+    "relu": nn.ReLU, "gelu": nn.GELU, "glu": nn.GLU, "swish": nn.SiLU, "sigmoid": nn.Sigmoid,
+    "hard_sigmoid": nn.Hardsigmoid, "none": nn.Identity,
+}
+
+
+def get_activation_fn(name: str) -> Callable[[torch.Tensor], torch.Tensor]:
+    """reference models/layers/__init__.py:16-26"""
+    return _ACTIVATIONS[name]()
+
+
+class GraphConv(nn.Module):
+    def __init__(self, in_dim: int, out_dim: int, identity_proj: bool = False):
+        super().__init__()
+        assert not identity_proj or in_dim == out_dim
+        self.linear = nn.Identity() if identity_proj else nn.Linear(in_dim, out_dim)
+        if isinstance(self.linear, nn.Linear):
+            nn.init.xavier_uniform_(self.linear.weight)
+            nn.init.normal_(self.linear.bias)
+
+    @staticmethod
+    def adjacency(edges: torch.Tensor) -> torch.Tensor:
+        """(E + E^T) / 2 + I   (reference gnn.py:27-30), differentiable form."""
+        eye = torch.eye(edges.shape[-1], dtype=edges.dtype, device=edges.device)
+        return (edges + edges.transpose(1, 2)) / 2 + eye
+
+    def forward(self, edges: torch.Tensor, feat: torch.Tensor, adj: torch.Tensor = None) -> torch.Tensor:
+        if adj is None:
+            adj = self.adjacency(edges)
+        return self.linear(torch.bmm(adj, feat))
+
+
+class Layer(nn.Module):
+    def __init__(self, emb_dim: int, activation: str, identity_proj: bool = False):
+        super().__init__()
+        self.g_conv = GraphConv(emb_dim, emb_dim, identity_proj)
+        self.norm = nn.LayerNorm(emb_dim)
+        self.activation = get_activation_fn(activation)
+        self._is_relu = activation == "relu"
+        self._is_none = activation == "none"
+
+    def forward(self, edges: torch.Tensor, feat: torch.Tensor, feat_mask: torch.BoolTensor = None,
+                adj: torch.Tensor = None, n_valid: torch.Tensor = None, fused: bool = False):
+        feat = self.g_conv(edges, feat, adj)
+        if fused and (self._is_relu or self._is_none) and feat.is_contiguous():
+            # pad rows -> 0, LayerNorm, ReLU in one pass (reference gnn.py:43-46)
+            return ops.mask_layernorm_act_(feat, self.norm.weight, self.norm.bias, self.norm.eps,
+                                           n_valid=n_valid, relu=self._is_relu)
+        if feat_mask is not None:
+            feat = feat.masked_fill(feat_mask[..., None], 0)
+        return self.activation(self.norm(feat))
+
+
+class GNN(nn.Module):
+    def __init__(self, num_codes: int, embed_dim: int, num_layers: int, identity_proj: bool = False,
+                 activation: str = "relu"):
+        super().__init__()
+        self.num_codes = num_codes
+        self.embed_dim = embed_dim
+        self.num_layers = num_layers
+        self.embedding = nn.Embedding(num_codes + 1, embed_dim, padding_idx=num_codes)
+        self.layers = nn.ModuleList([Layer(embed_dim, activation, identity_proj) for _ in range(num_layers)])
+        self.fc = nn.Linear(embed_dim, embed_dim)
+        nn.init.normal_(self.fc.weight)
+        nn.init.zeros_(self.fc.bias)
+        with torch.no_grad():
+            nn.init.trunc_normal_(self.embedding.weight[:num_codes])
+
+    def _differentiable(self, *tensors) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return any(t.requires_grad for t in tensors if t is not None) or any(p.requires_grad for p in self.parameters())
+
+    def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
+                feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
+                divisor: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """nodes [G, n], edges [G, n, n], ingredients [G, n] -> graph feature [G, embed_dim].
+
+        feat_mask (bool [G, n], True = padding) is the reference argument (gnn.py:78-98).
+        n_valid (int32 [G]) is its compact device form; `divisor` (int32 [1] device tensor)
+        replaces the padded length in the mean pooling (gnn.py:96) so that graphs padded to a
+        fixed n_pad give the same result as graphs padded to the batch maximum.
+        """
+        fused = nodes.is_cuda and not self._differentiable(nodes, edges)
+        if n_valid is None and feat_mask is not None:
+            n_valid = (~feat_mask).sum(dim=1).to(torch.int32)   # masks are suffix masks (match.py:48-51)
+        if feat_mask is None and n_valid is not None and not fused:
+            feat_mask = torch.arange(nodes.shape[1], device=nodes.device)[None, :] >= n_valid[:, None]
+        feat = self.embedding(ingredients)
+        adj = ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges)
+        for layer in self.layers:
+            feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused)
+        if fused:
+            pooled = ops.weighted_pool(feat, nodes, divisor)
+        else:
+            pooled = (feat * nodes[..., None]).sum(dim=1)
+            pooled = pooled / (divisor.to(pooled.dtype) if divisor is not None else feat.shape[1])
+        return self.fc(pooled)

@@ -1,0 +1,68 @@
+"""Instance-graph vs class-graph matching (reference schema_inference/graph/match.py)."""
+from typing import Any, Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from cpp_extension import ops
+
+from .gnn import GNN
+
+
+class Matcher(nn.Module):
+    """Same constructor and state-dict (`gnn.*`) as the reference.  `forward` keeps the
+    reference's list-based contract; `forward_padded` consumes the padded batch produced by
+    `SchemaNet.instance_graph_padded` without python loops or host syncs."""
+
+    def __init__(self, similarity: str, num_codes: int, gnn_cfg: Dict[str, Any]):
+        super().__init__()
+        if similarity not in ops.SIMILARITY:
+            raise KeyError(similarity)
+        self.similarity_name = similarity
+        self.gnn = GNN(num_codes=num_codes, **gnn_cfg)
+
+    # reference match.py:21-31
+    def similarity(self, feat_inst: torch.Tensor, feat_kg: torch.Tensor) -> torch.Tensor:
+        """feat_inst [bs, E], feat_kg [K, E] -> [bs, K]"""
+        if feat_inst.is_cuda and not (torch.is_grad_enabled() and (feat_inst.requires_grad or feat_kg.requires_grad)):
+            return ops.match_scores(feat_inst, feat_kg, self.similarity_name)
+        a, b = feat_inst[:, None, :], feat_kg[None, :, :]
+        if self.similarity_name == "inner_product":
+            return (a * b).sum(-1)
+        if self.similarity_name == "cosine":
+            return (torch.cosine_similarity(a, b, dim=-1) + 1) / 2
+        return 1 / (1 + torch.linalg.vector_norm(a - b, dim=-1))
+
+    def atlas_features(self, class_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """GNN over the K class graphs -> [K, E]  (reference match.py:66-70)."""
+        return self.gnn(nodes=class_dict["class_vertices"], edges=class_dict["class_edges"],
+                        ingredients=class_dict["class_ingredients"])
+
+    def forward_padded(self, graph: Dict[str, torch.Tensor], class_dict: Dict[str, torch.Tensor],
+                       feat_kg: torch.Tensor = None) -> torch.Tensor:
+        """graph: ids [bs, n_pad], vertices [bs, n_pad], edges [bs, n_pad, n_pad], n [bs] i32,
+        n_max [1] i32 (device).  The pooling divides by n_max, i.e. by the length the reference
+        pads to (max_i n_i, match.py:46; gnn.py:96), so the result does not depend on n_pad."""
+        feat_instance = self.gnn(nodes=graph["vertices"], edges=graph["edges"], ingredients=graph["ids"],
+                                 n_valid=graph["n"], divisor=graph["n_max"])
+        if feat_kg is None:
+            feat_kg = self.atlas_features(class_dict)
+        return self.similarity(feat_instance, feat_kg)
+
+    def forward(self, instance_dict: Dict[str, List[torch.Tensor]], class_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Reference contract (match.py:33-76): ragged python lists in, [bs, K] out.  Like the
+        reference it pads the caller's lists IN PLACE to the batch maximum."""
+        ids, vs, es = (instance_dict["instance_ingredients"], instance_dict["instance_vertices"],
+                       instance_dict["instance_edges"])
+        sizes = [len(x) for x in ids]
+        n = max(sizes)
+        for i, s in enumerate(sizes):
+            ids[i] = F.pad(ids[i], (0, n - s), value=self.gnn.num_codes)
+            vs[i] = F.pad(vs[i], (0, n - s))
+            es[i] = F.pad(es[i], (0, n - s, 0, n - s))
+        dev = ids[0].device
+        n_valid = torch.tensor(sizes, dtype=torch.int32, device=dev)
+        graph = {"ids": torch.stack(ids), "vertices": torch.stack(vs), "edges": torch.stack(es),
+                 "n": n_valid, "n_max": torch.tensor([n], dtype=torch.int32, device=dev)}
+        return self.forward_padded(graph, class_dict)
