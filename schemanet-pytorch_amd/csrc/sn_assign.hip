@@ -31,14 +31,22 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kTokPerBlock = kTokPerWave * kWavesPerBlock;
 constexpr int kRing = 3;               // LDS slots for codebook tiles
 constexpr int kMaxCand = 6;
-constexpr int kOverflow = 255;         // work-list entry: scan every word (a 6-bit mask is < 64)
 constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
+// fp32 accumulate of v_mfma_f32_32x32x16_f16: measured (tools/mfma_probe.hip, MI355X) total error
+// after 24 chained MFMAs <= 12.3 x 2^-24 x max|partial sum| (about 0.5 per instruction).  The
+// window below budgets 8 per instruction (15x the observed total).
+constexpr float kAccUlpPerMfma = 8.0f * 5.9604645e-8f;
 
 // packed codebook image -------------------------------------------------------------------
+//   tiles   [n_tiles][n_steps + 1][1 KiB]   per 32-word tile: n_steps chunks of fp16 MFMA A-fragments
+//                                           holding -c (negated), then one chunk whose first 128 B
+//                                           are |c|^2 / 2 (fp32) in accumulator-row order
+//   cn64    [M_pad] f64  |c|^2 (oracle summation order)     cbT [D][M_pad] f32 (transposed copy)
+//   scal    [0] max |c|_2  [1] max |c|_1  [2] max |c|^2  [3] max |c_mk|   (uint bits of floats)
 struct PackLayout {
-    size_t frag_off, cn32_off, cn64_off, scal_off, total;
-    int n_tiles, n_steps;
+    size_t tiles_off, cn64_off, cbt_off, scal_off, total;
+    int n_tiles, n_steps, tile_bytes, m_pad;
 };
 
 __host__ __device__ inline PackLayout pack_layout(int M, int D)
@@ -46,16 +54,15 @@ __host__ __device__ inline PackLayout pack_layout(int M, int D)
     PackLayout p;
     p.n_tiles = (M + 31) / 32;
     p.n_steps = D / 16;
-    const size_t mp = (size_t)p.n_tiles * 32;
-    p.frag_off = 0;
-    p.cn32_off = mp * D * 2;
-    p.cn64_off = p.cn32_off + ((mp * 4 + 255) & ~size_t(255));
-    p.scal_off = p.cn64_off + ((mp * 8 + 255) & ~size_t(255));
+    p.m_pad = p.n_tiles * 32;
+    p.tile_bytes = (p.n_steps + 1) * 1024;
+    p.tiles_off = 0;
+    p.cn64_off = (size_t)p.n_tiles * p.tile_bytes;
+    p.cbt_off = p.cn64_off + (((size_t)p.m_pad * 8 + 255) & ~size_t(255));
+    p.scal_off = p.cbt_off + (((size_t)p.m_pad * D * 4 + 255) & ~size_t(255));
     p.total = p.scal_off + 256;
     return p;
 }
-// scalars (uint bit patterns of non-negative floats, so atomicMax orders them):
-//   [0] max |c|_2   [1] max |c|_1   [2] max |c|^2   [3] max |c_mk|
 
 // fp64 dot in the oracle's order: lane l accumulates k = l, l+64, ... then xor-butterfly.
 template <int NT>
@@ -73,25 +80,32 @@ __device__ __forceinline__ double dot64(const double (&x)[NT], const float *c, i
 // ------------------------------------------------------------------------------------------
 // codebook_prepare
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_frag_kernel(const float *cb, int M, int D, _Float16 *frag, int n_steps)
+__global__ __launch_bounds__(256) void pack_frag_kernel(const float *cb, int M, int D, unsigned char *tiles,
+                                                        int n_steps, int tile_bytes, float *cbT, int m_pad)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [M_pad, D]
     const int m = (int)(idx / D), k = (int)(idx % D);
     const int w = m >> 5, i = m & 31;
+    // k -> (step s, lane half h, element j): a lane's 16 consecutive floats feed two k-steps
     const int u = k >> 5, rem = k & 31, h = rem >> 4, e = (rem >> 3) & 1, j = rem & 7;
     const int s = 2 * u + e;
     const float v = m < M ? cb[(int64_t)m * D + k] : 0.0f;
-    frag[(((int64_t)w * n_steps + s) * 64 + (i + 32 * h)) * 8 + j] = (_Float16)v;
+    _Float16 *frag = (_Float16 *)(tiles + (size_t)w * tile_bytes + (size_t)s * 1024);
+    frag[(i + 32 * h) * 8 + j] = (_Float16)(-v);
+    cbT[(int64_t)k * m_pad + m] = v;
 }
 
-__global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, int D, int m_pad, float *cn32,
-                                                        double *cn64, unsigned *scal)
+__global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, int D, int m_pad, unsigned char *tiles,
+                                                        int n_steps, int tile_bytes, double *cn64, unsigned *scal)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= m_pad) return;
+    // half-norm slot of word m inside its tile: accumulator row order [g][h][e], row = e + 8g + 4h
+    const int i = m & 31, g = i >> 3, h = (i >> 2) & 1, e = i & 3;
+    float *hc = (float *)(tiles + (size_t)(m >> 5) * tile_bytes + (size_t)n_steps * 1024) + (g * 2 + h) * 4 + e;
     if (m >= M) {                       // padding words can never win
-        if (lane == 0) { cn32[m] = INFINITY; cn64[m] = (double)INFINITY; }
+        if (lane == 0) { *hc = INFINITY; cn64[m] = (double)INFINITY; }
         return;
     }
     const float *c = cb + (int64_t)m * D;
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, 
     mx = sn_wave_max(mx);
     if (lane == 0) {
         cn64[m] = p;
-        cn32[m] = (float)p;
+        *hc = (float)(0.5 * p);
         const float up = 1.0f + 1.0e-6f;
         atomicMax(&scal[0], __float_as_uint(sqrtf((float)p) * up));
         atomicMax(&scal[1], __float_as_uint(l1 * (1.0f + 1.0e-4f)));
@@ -128,9 +142,9 @@ struct AssignArgs {
     int M, D;
     int64_t *out;
     int64_t oso, osi;
-    int *work;          // [0] = entry count, entries start at int 8, 8 ints each
+    int *work;          // [0] #entries, [1] #overflow tokens; entries (8 ints each) from int 8;
+    int *overflow;      // token ids that need a full scan
 };
-
 __device__ __forceinline__ const float *token_row(const AssignArgs &p, int64_t n)
 {
     return p.x + (n / p.n_inner) * p.xso + (n % p.n_inner) * p.xsi;
@@ -184,17 +198,33 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 }
 
 // ------------------------------------------------------------------------------------------
-// mode 0, pass 2: fp64 re-rank of the work list
+// mode 0, pass 2: fp64 re-rank
+//   phase A  one wave per work-list entry: the <= 6 candidates the screen could not separate
+//   phase B  one BLOCK per overflow token: fp32 scan of every word through the transposed
+//            codebook (coalesced, thread = word), survivors inside a rigorous fp32 window are
+//            re-ranked in fp64.  All fp64 scores use the oracle's summation order.
 // ------------------------------------------------------------------------------------------
+constexpr int kMaxSurvivors = 64;
+
 template <int NT>
 __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ float xs[NT * SN_WAVE];
+    __shared__ float red[4];
+    __shared__ int surv[kMaxSurvivors];
+    __shared__ int n_surv;
+    __shared__ double best_s[4];
+    __shared__ int best_i[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const PackLayout lay = pack_layout(p.M, p.D);
     const double *cn64 = (const double *)(p.packed + lay.cn64_off);
+    const float *cbT = (const float *)(p.packed + lay.cbt_off);
+    const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
+
+    // ---- phase A
     const int count = p.work[0];
     const int n_waves = gridDim.x * kWavesPerBlock;
-    for (int e = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); e < count; e += n_waves) {
+    for (int e = blockIdx.x * kWavesPerBlock + wid; e < count; e += n_waves) {
         const int *ent = p.work + 8 + (int64_t)e * 8;
         const int64_t n = ent[0];
         const int cmask = ent[1];
@@ -202,67 +232,142 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
         load_token64<NT>(x, token_row(p, n), p.D, lane);
         double best = (double)INFINITY;
         int bi = 0x7fffffff;
-        if (cmask == kOverflow) {
-            bi = 0;
-            exact_scan<NT>(x, p, cn64, 0, p.M, lane, best, bi);
-        } else {
-            for (int c = 0; c < kMaxCand; ++c) {
-                if (!((cmask >> c) & 1)) continue;
-                const int m = ent[2 + c];
-                const double s = cn64[m] - 2.0 * dot64<NT>(x, p.cb + (int64_t)m * p.D, p.D, lane);
-                if (s < best || (s == best && m < bi)) { best = s; bi = m; }
-            }
-            if (bi == 0x7fffffff) {    // every candidate NaN: fall back to the full scan
-                bi = 0;
-                exact_scan<NT>(x, p, cn64, 0, p.M, lane, best, bi);
+        for (int c = 0; c < kMaxCand; ++c) {
+            if (!((cmask >> c) & 1)) continue;
+            const int m = ent[2 + c];
+            const double s = cn64[m] - 2.0 * dot64<NT>(x, p.cb + (int64_t)m * p.D, p.D, lane);
+            if (s < best || (s == best && m < bi)) { best = s; bi = m; }
+        }
+        if (bi != 0x7fffffff && lane == 0) p.out[out_index(p, n)] = bi;
+        // (all candidates NaN cannot happen: such tokens are routed to the overflow list)
+    }
+
+    // ---- phase B
+    const int n_over = p.work[1];
+    for (int e = blockIdx.x; e < n_over; e += gridDim.x) {
+        const int64_t n = p.overflow[e];
+        const float *row = token_row(p, n);
+        __syncthreads();
+        float sq = 0.0f;
+        for (int k = tid; k < NT * SN_WAVE; k += 256) {
+            const float v = k < p.D ? row[k] : 0.0f;
+            xs[k] = v;
+            sq = fmaf(v, v, sq);
+        }
+        if (tid == 0) n_surv = 0;
+        sq = sn_wave_sum(sq);
+        if (lane == 0) red[wid] = sq;
+        __syncthreads();
+        const float X2 = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * 1.001f;
+        const float C2 = __uint_as_float(scal[0]), CN = __uint_as_float(scal[2]);
+        // |fp32 chain - exact| <= gamma_D * sum|x_k c_k|  (+ the |c|^2/2 rounding)
+        const float e32 = 1.01f * ((float)(p.D + 2) * 5.9604645e-8f * X2 * C2 + 6.0e-8f * CN);
+        const bool finite = e32 < 1.0e30f;        // false for NaN / inf tokens
+        float smin = INFINITY;
+        // pass 1: block minimum of the fp32 scores
+        for (int m = tid; m < p.M; m += 256) {
+            float acc = 0.0f;
+            for (int k = 0; k < p.D; ++k) acc = fmaf(xs[k], cbT[(int64_t)k * lay.m_pad + m], acc);
+            smin = fminf(smin, (float)(0.5 * cn64[m]) - acc);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) smin = fminf(smin, __shfl_xor(smin, off, SN_WAVE));
+        __syncthreads();
+        if (lane == 0) red[wid] = smin;
+        __syncthreads();
+        smin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        // pass 2: survivors inside the window (recomputed: identical arithmetic, identical bits)
+        bool too_many = false;
+        for (int m = tid; m < p.M; m += 256) {
+            float acc = 0.0f;
+            for (int k = 0; k < p.D; ++k) acc = fmaf(xs[k], cbT[(int64_t)k * lay.m_pad + m], acc);
+            const float sc = (float)(0.5 * cn64[m]) - acc;
+            if (finite && sc <= smin + 2.0f * e32) {
+                const int slot = atomicAdd(&n_surv, 1);
+                if (slot < kMaxSurvivors) surv[slot] = m;
             }
         }
-        if (lane == 0) p.out[out_index(p, n)] = bi;
+        __syncthreads();
+        const int ns = n_surv;
+        too_many = !finite || ns > kMaxSurvivors || ns == 0;
+        // fp64 re-rank: wave w takes survivors w, w+4, ... (or every word when the window failed)
+        double x[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = (double)xs[lane + SN_WAVE * t];
+        double best = (double)INFINITY;
+        int bi = 0x7fffffff;
+        const int total = too_many ? p.M : ns;
+        for (int q = wid; q < total; q += 4) {
+            const int m = too_many ? q : surv[q];
+            const double s = cn64[m] - 2.0 * dot64<NT>(x, p.cb + (int64_t)m * p.D, p.D, lane);
+            if (s < best || (s == best && m < bi)) { best = s; bi = m; }
+        }
+        if (lane == 0) { best_s[wid] = best; best_i[wid] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double b = best_s[0];
+            int i0 = best_i[0];
+            for (int w = 1; w < 4; ++w)
+                if (best_s[w] < b || (best_s[w] == b && best_i[w] < i0)) { b = best_s[w]; i0 = best_i[w]; }
+            p.out[out_index(p, n)] = i0 == 0x7fffffff ? 0 : i0;   // all-NaN row -> 0 (oracle)
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // mode 0, pass 1: fp16-MFMA screen
+// Each lane tracks, for its token and its half of the words, the three SMALLEST values of
+//   v[word] = |c|^2/2 + (|x|^2/2 + 2E) - x.c      (= dist^2/2 + 2E  >= 0)
+// as packed keys (float bits with the low 8 mantissa bits replaced by a word code).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void top3_insert(unsigned k, unsigned &m1, unsigned &m2, unsigned &m3)
 {
-    const unsigned lo = min(k, m2);
+    const unsigned hi = max(k, m2);
     m2 = max(min(k, m1), min(max(k, m1), m2));   // v_med3_u32
-    m1 = max(k, m1);
-    m3 = max(m3, lo);
+    m1 = min(k, m1);
+    m3 = min(m3, hi);
 }
 
-struct Cand { float v; int w; };
+// running (value, word) top-3 per lane, ascending by value then word; plain scalars so nothing
+// lands in scratch
+struct Top3 { float v0, v1, v2; int w0, w1, w2; };
 
-__device__ __forceinline__ void cand_insert(Cand (&c)[3], float v, int w)
+__device__ __forceinline__ bool cand_less(float v, int w, float cv, int cw) { return v < cv || (v == cv && w < cw); }
+
+__device__ __forceinline__ void cand_insert(Top3 &c, float v, int w)
 {
-    // descending by value; on equal value the lower word index first
-    if (v > c[0].v || (v == c[0].v && w < c[0].w)) { c[2] = c[1]; c[1] = c[0]; c[0].v = v; c[0].w = w; }
-    else if (v > c[1].v || (v == c[1].v && w < c[1].w)) { c[2] = c[1]; c[1].v = v; c[1].w = w; }
-    else if (v > c[2].v || (v == c[2].v && w < c[2].w)) { c[2].v = v; c[2].w = w; }
+    const bool l0 = cand_less(v, w, c.v0, c.w0), l1 = cand_less(v, w, c.v1, c.w1), l2 = cand_less(v, w, c.v2, c.w2);
+    const float n2v = l1 ? c.v1 : (l2 ? v : c.v2);
+    const int n2w = l1 ? c.w1 : (l2 ? w : c.w2);
+    const float n1v = l0 ? c.v0 : (l1 ? v : c.v1);
+    const int n1w = l0 ? c.w0 : (l1 ? w : c.w1);
+    c.v2 = n2v; c.w2 = n2w; c.v1 = n1v; c.w1 = n1w;
+    if (l0) { c.v0 = v; c.w0 = w; }
 }
 
 template <int NSTEPS>
 __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_kernel(const AssignArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kTileBytes = NSTEPS * 1024;
+    constexpr int kChunks = NSTEPS + 1;
+    constexpr int kTileBytes = kChunks * 1024;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const PackLayout lay = pack_layout(p.M, p.D);
-    const unsigned char *frag = p.packed + lay.frag_off;
-    const float *cn32 = (const float *)(p.packed + lay.cn32_off);
+    const unsigned char *tiles = p.packed + lay.tiles_off;
     const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
     const int n_tiles = lay.n_tiles;
 
     auto issue_tile = [&](int w, int slot) {
 #pragma unroll
-        for (int j = 0; j < NSTEPS / kWavesPerBlock; ++j) {
+        for (int j = 0; j < (kChunks + kWavesPerBlock - 1) / kWavesPerBlock; ++j) {
             const int c = wid + kWavesPerBlock * j;
-            const unsigned char *src = frag + (size_t)w * kTileBytes + c * 1024 + lane * 16;
-            unsigned char *dst = smem + slot * kTileBytes + c * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            if (c < kChunks) {
+                const unsigned char *src = tiles + (size_t)w * kTileBytes + c * 1024 + lane * 16;
+                unsigned char *dst = smem + slot * kTileBytes + c * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            }
         }
     };
     issue_tile(0, 0);
@@ -293,97 +398,125 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     sumabs += __shfl_xor(sumabs, 32, SN_WAVE);
     maxabs = fmaxf(maxabs, __shfl_xor(maxabs, 32, SN_WAVE));
 
-    // ---- per-token constants of the error analysis (see DESIGN.md "S1 error window")
+    // ---- per-token error window (DESIGN.md "S1 error window"): |v_key - v_exact| <= E
     const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
     const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
     const float X2 = sqrtf(sumsq) * 1.001f, X1 = sumabs * 1.001f;
-    const float OFF = 0.5f * CN + 1.02f * X2 * C2;
-    // |acc'_computed - acc'_exact| <= E for every word
-    const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1) +
-                             OFF * (1.2e-7f + (float)(16 * NSTEPS) * 4.8e-7f + 6.2e-5f));
+    const float hx = 0.5f * sumsq;
+    const float vmax = 0.5f * CN + 0.5f * X2 * X2 + X2 * C2;                 // >= any v (before the shift)
+    const float E = 1.01f * (2.01f * kU16 * X2 * C2                           // fp16 rounding of x and c
+                             + 5.96e-8f * (X1 + C1)                           // fp16 subnormal flush
+                             + (float)NSTEPS * kAccUlpPerMfma * X2 * C2       // MFMA fp32 accumulate
+                             + vmax * (3.0f * 5.96e-8f + 3.1e-5f));           // hx/hc/adds rounding + key truncation (2^-15)
+    const float shift = hx + 2.0f * E;                                        // keeps every key non-negative
     const float window = 2.0f * E;
-    const bool bad = !(maxabs <= kHugeIn) || !(CMAX <= kHugeIn) || !(OFF < 1.0e30f);   // NaN-safe
+    const bool bad = !(maxabs <= kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e30f);   // NaN-safe
 
-    unsigned m1 = 0, m2 = 0, m3 = 0;
-    Cand top[3] = {{-1.0f, -1}, {-1.0f, -1}, {-1.0f, -1}};
+    unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu, m3 = 0xFFFFFFFFu;
+    Top3 top = {INFINITY, INFINITY, INFINITY, -1, -1, -1};
 
     for (int w = 0; w < n_tiles; ++w) {
         __syncthreads();                 // tile w landed (vmcnt(0) + barrier); slot (w+2)%3 is free
         if (w + 2 < n_tiles) issue_tile(w + 2, (w + 2) % kRing);
         const unsigned char *slot = smem + (w % kRing) * kTileBytes;
-        f32x16 acc;
+        const unsigned char *frag = slot + lane * 16;
+        // A fragments through a 4-deep register ring so ds_read latency hides behind the MFMAs
+        half8 a0 = *reinterpret_cast<const half8 *>(frag + 0 * 1024);
+        half8 a1 = *reinterpret_cast<const half8 *>(frag + 1 * 1024);
+        half8 a2 = *reinterpret_cast<const half8 *>(frag + 2 * 1024);
+        half8 a3 = *reinterpret_cast<const half8 *>(frag + 3 * 1024);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 DS reads up front
+        f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(cn32 + 32 * w + 8 * g + 4 * h);
-            acc[4 * g + 0] = OFF - 0.5f * c4.x;
-            acc[4 * g + 1] = OFF - 0.5f * c4.y;
-            acc[4 * g + 2] = OFF - 0.5f * c4.z;
-            acc[4 * g + 3] = OFF - 0.5f * c4.w;
+        for (int s = 0; s < NSTEPS; s += 4) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[s + 0], acc, 0, 0, 0);
+            if (s + 4 < NSTEPS) a0 = *reinterpret_cast<const half8 *>(frag + (s + 4) * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA ...
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... then the DS read 4 steps ahead
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[s + 1], acc, 0, 0, 0);
+            if (s + 5 < NSTEPS) a1 = *reinterpret_cast<const half8 *>(frag + (s + 5) * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b[s + 2], acc, 0, 0, 0);
+            if (s + 6 < NSTEPS) a2 = *reinterpret_cast<const half8 *>(frag + (s + 6) * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, b[s + 3], acc, 0, 0, 0);
+            if (s + 7 < NSTEPS) a3 = *reinterpret_cast<const half8 *>(frag + (s + 7) * 1024);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-#pragma unroll
-        for (int s = 0; s < NSTEPS; ++s) {
-            const half8 a = *reinterpret_cast<const half8 *>(slot + s * 1024 + lane * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[s], acc, 0, 0, 0);
-        }
+        // epilogue: v = acc + (|c|^2/2 + shift); keys; running top-3
+        const float *hc = reinterpret_cast<const float *>(slot + NSTEPS * 1024);
         const unsigned tcode = (unsigned)(w & 15) << 4;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const float v = fmaxf(acc[reg], 0.0f);      // also maps NaN / -inf (padding words) to 0
-            const unsigned k = (__float_as_uint(v) & 0xFFFFFF00u) | (tcode | (unsigned)reg);
-            top3_insert(k, m1, m2, m3);
+        for (int g = 0; g < 4; ++g) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(hc + (g * 2 + h) * 4);
+            const float t[4] = {c4.x + shift, c4.y + shift, c4.z + shift, c4.w + shift};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int reg = 4 * g + e;
+                const float v = acc[reg] + t[e];
+                const unsigned k = (__float_as_uint(v) & 0xFFFFFF00u) | (tcode | (unsigned)reg);
+                top3_insert(k, m1, m2, m3);
+            }
         }
         if ((w & 15) == 15 || w == n_tiles - 1) {        // unpack this 16-tile chunk
             const int base = (w & ~15) * 32;
-            const unsigned ks[3] = {m1, m2, m3};
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const unsigned k = ks[q];
+            auto unpack = [&](unsigned k) {
                 const float v = __uint_as_float(k & 0xFFFFFF00u);
                 const int code = (int)(k & 0xFFu), reg = code & 15;
                 const int word = base + (code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (v > 0.0f && word < p.M) cand_insert(top, v, word);
-            }
-            m1 = m2 = m3 = 0;
+                if (k < 0x7F800000u && word < p.M) cand_insert(top, v, word);   // finite, non-negative
+            };
+            unpack(m1); unpack(m2); unpack(m3);
+            m1 = m2 = m3 = 0xFFFFFFFFu;
         }
     }
 
     // ---- merge the two half-lanes that share a token
-    Cand oth[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        oth[q].v = __shfl_xor(top[q].v, 32, SN_WAVE);
-        oth[q].w = __shfl_xor(top[q].w, 32, SN_WAVE);
-    }
-    float vbest = fmaxf(top[0].v, oth[0].v);
-    int best_w = (top[0].v > oth[0].v || (top[0].v == oth[0].v && (unsigned)top[0].w < (unsigned)oth[0].w)) ? top[0].w : oth[0].w;
-    const float cut = vbest - window;
-    // candidate set as a 6-bit mask over {top[0..2], oth[0..2]} (no runtime-indexed arrays)
+    Top3 oth;
+    oth.v0 = __shfl_xor(top.v0, 32, SN_WAVE); oth.w0 = __shfl_xor(top.w0, 32, SN_WAVE);
+    oth.v1 = __shfl_xor(top.v1, 32, SN_WAVE); oth.w1 = __shfl_xor(top.w1, 32, SN_WAVE);
+    oth.v2 = __shfl_xor(top.v2, 32, SN_WAVE); oth.w2 = __shfl_xor(top.w2, 32, SN_WAVE);
+    const float vbest = fminf(top.v0, oth.v0);
+    const int best_w = cand_less(top.v0, (int)((unsigned)top.w0 & 0x7fffffff), oth.v0, (int)((unsigned)oth.w0 & 0x7fffffff)) ? top.w0 : oth.w0;
+    const float cut = vbest + window;
+    // candidate set as a 6-bit mask over {top 0..2, oth 0..2}
     unsigned cmask = 0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        if (top[q].w >= 0 && top[q].v >= cut) cmask |= 1u << q;
-        if (oth[q].w >= 0 && oth[q].v >= cut) cmask |= 8u << q;
-    }
+    if (top.w0 >= 0 && top.v0 <= cut) cmask |= 1u;
+    if (top.w1 >= 0 && top.v1 <= cut) cmask |= 2u;
+    if (top.w2 >= 0 && top.v2 <= cut) cmask |= 4u;
+    if (oth.w0 >= 0 && oth.v0 <= cut) cmask |= 8u;
+    if (oth.w1 >= 0 && oth.v1 <= cut) cmask |= 16u;
+    if (oth.w2 >= 0 && oth.v2 <= cut) cmask |= 32u;
     const int nc = __popc(cmask);
     // a lane whose third-best is still inside the window may hide a fourth
-    const bool overflow = bad || best_w < 0 || (top[2].w >= 0 && top[2].v >= cut) || (oth[2].w >= 0 && oth[2].v >= cut);
+    const bool overflow = bad || best_w < 0 || (cmask & 36u) != 0;
     const bool writer = valid && h == 0;
     if (writer) p.out[out_index(p, n)] = best_w < 0 ? 0 : best_w;
-    const bool need = writer && (overflow || nc > 1);
-    const unsigned long long mask = __ballot(need);
-    if (mask) {
+    const bool need_a = writer && !overflow && nc > 1;
+    const bool need_b = writer && overflow;
+    const unsigned long long mask_a = __ballot(need_a), mask_b = __ballot(need_b);
+    if (mask_a) {
         int base = 0;
-        const int leader = __ffsll((long long)mask) - 1;
-        if (lane == leader) base = atomicAdd(&p.work[0], __popcll(mask));
+        const int leader = __ffsll((long long)mask_a) - 1;
+        if (lane == leader) base = atomicAdd(&p.work[0], __popcll(mask_a));
         base = __shfl(base, leader, SN_WAVE);
-        if (need) {
-            const int slot_i = base + __popcll(mask & ((1ull << lane) - 1ull));
-            int *ent = p.work + 8 + (int64_t)slot_i * 8;
+        if (need_a) {
+            int *ent = p.work + 8 + (int64_t)(base + __popcll(mask_a & ((1ull << lane) - 1ull))) * 8;
             ent[0] = (int)n;
-            ent[1] = overflow ? kOverflow : (int)cmask;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { ent[2 + q] = top[q].w; ent[5 + q] = oth[q].w; }
+            ent[1] = (int)cmask;
+            ent[2] = top.w0; ent[3] = top.w1; ent[4] = top.w2;
+            ent[5] = oth.w0; ent[6] = oth.w1; ent[7] = oth.w2;
         }
+    }
+    if (mask_b) {
+        int base = 0;
+        const int leader = __ffsll((long long)mask_b) - 1;
+        if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
+        base = __shfl(base, leader, SN_WAVE);
+        if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;
     }
 }
 
@@ -399,7 +532,7 @@ int launch_exact(const AssignArgs &a, hipStream_t st)
 template <int NSTEPS>
 int launch_screen(const AssignArgs &a, hipStream_t st)
 {
-    const size_t lds = (size_t)kRing * NSTEPS * 1024;
+    const size_t lds = (size_t)kRing * (NSTEPS + 1) * 1024;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)assign_screen_kernel<NSTEPS>,
@@ -413,7 +546,7 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
-    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(1024), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(2048), dim3(256), 0, st, a);
     sn_prof_stop(1, st);
     return 0;
 }
@@ -442,12 +575,12 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
         sn_set_error("sn_codebook_prepare: memset failed");
         return SN_ERR_LAUNCH;
     }
-    const int m_pad = lay.n_tiles * 32;
-    const int64_t elems = (int64_t)m_pad * D;
+    const int64_t elems = (int64_t)lay.m_pad * D;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)(elems / 256)), dim3(256), 0, st, codebook, M, D,
-                       (_Float16 *)(base + lay.frag_off), lay.n_steps);
-    hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((m_pad + 3) / 4)), dim3(256), 0, st, codebook, M, D, m_pad,
-                       (float *)(base + lay.cn32_off), (double *)(base + lay.cn64_off), (unsigned *)(base + lay.scal_off));
+                       base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (float *)(base + lay.cbt_off), lay.m_pad);
+    hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((lay.m_pad + 3) / 4)), dim3(256), 0, st, codebook, M, D, lay.m_pad,
+                       base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (double *)(base + lay.cn64_off),
+                       (unsigned *)(base + lay.scal_off));
     SN_CHECK_LAUNCH("sn_codebook_prepare");
     return SN_OK;
 }
@@ -455,7 +588,7 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
 extern "C" size_t sn_assign_workspace_bytes(int64_t n_tokens)
 {
     if (n_tokens < 0) return 0;
-    return 32 + (size_t)n_tokens * 32;
+    return 32 + (size_t)n_tokens * 36;      // header + 8-int entries + overflow token ids
 }
 
 extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
@@ -475,6 +608,7 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.x = x; a.n_tokens = n_tokens; a.n_inner = n_inner; a.xso = x_stride_outer; a.xsi = x_stride_inner;
     a.cb = codebook; a.packed = (const unsigned char *)packed; a.M = M; a.D = D;
     a.out = out; a.oso = out_stride_outer; a.osi = out_stride_inner; a.work = (int *)workspace;
+    a.overflow = workspace ? (int *)workspace + 8 + n_tokens * 8 : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
     const bool screen_ok = mode == 0 && aligned && M % 32 == 0 && (D == 192 || D == 384 || D == 768);
