@@ -25,12 +25,15 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTokPerWave = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTokPerBlock = kTokPerWave * kWavesPerBlock;
-constexpr int kRing = 3;               // LDS slots for codebook tiles
-constexpr int kMaxCand = 6;
+constexpr int kRing = 2;               // LDS slots for codebook tiles (register-staged double buffer)
+constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
+constexpr int kEntryInts = 32;          // work-list entry: [0] token, [1] 24-bit candidate mask, [2..25] words
+constexpr int kMaxTilesScreen = 64;     // 6-bit tile code in the keys -> M <= 2048 on the MFMA path
 constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
 // fp32 accumulate of v_mfma_f32_32x32x16_f16: measured (tools/mfma_probe.hip, MI355X) total error
@@ -144,7 +147,15 @@ struct AssignArgs {
     int64_t oso, osi;
     int *work;          // [0] #entries, [1] #overflow tokens; entries (8 ints each) from int 8;
     int *overflow;      // token ids that need a full scan
+    unsigned long long *stamps;   // diagnostics only (sn_debug_set_stamps): 16 u64 slots per wave
 };
+
+__device__ __forceinline__ void stamp(const AssignArgs &p, int slot, int lane, int wave_id)
+{
+    if (p.stamps && lane == 0) p.stamps[(size_t)wave_id * 16 + slot] = __builtin_amdgcn_s_memtime();
+}
+
+static unsigned long long *g_stamps = nullptr;
 __device__ __forceinline__ const float *token_row(const AssignArgs &p, int64_t n)
 {
     return p.x + (n / p.n_inner) * p.xso + (n % p.n_inner) * p.xsi;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
     const int count = p.work[0];
     const int n_waves = gridDim.x * kWavesPerBlock;
     for (int e = blockIdx.x * kWavesPerBlock + wid; e < count; e += n_waves) {
-        const int *ent = p.work + 8 + (int64_t)e * 8;
+        const int *ent = p.work + 8 + (int64_t)e * kEntryInts;
         const int64_t n = ent[0];
         const int cmask = ent[1];
         double x[NT];
@@ -264,11 +275,30 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
         const float e32 = 1.01f * ((float)(p.D + 2) * 5.9604645e-8f * X2 * C2 + 6.0e-8f * CN);
         const bool finite = e32 < 1.0e30f;        // false for NaN / inf tokens
         float smin = INFINITY;
-        // pass 1: block minimum of the fp32 scores
-        for (int m = tid; m < p.M; m += 256) {
-            float acc = 0.0f;
-            for (int k = 0; k < p.D; ++k) acc = fmaf(xs[k], cbT[(int64_t)k * lay.m_pad + m], acc);
-            smin = fminf(smin, (float)(0.5 * cn64[m]) - acc);
+        // pass 1: fp32 score of every word (thread = word, coalesced reads of the transposed
+        // codebook, 8 loads in flight), kept in registers for pass 2 (<= 8 words per thread)
+        float sc[8];
+#pragma unroll
+        for (int j0 = 0; j0 < 8; j0 += 2) {                 // two words per thread at a time: 32 loads in flight
+            const int ma = tid + 256 * j0, mb = ma + 256;
+            sc[j0] = INFINITY; sc[j0 + 1] = INFINITY;
+            if (ma >= p.M) continue;
+            const bool has_b = mb < p.M;
+            const float *ca = cbT + ma, *cbp = cbT + (has_b ? mb : ma);
+            float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+            for (int k = 0; k < p.D; k += 16) {
+                float va[16], vb[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { va[q] = ca[(int64_t)(k + q) * lay.m_pad]; vb[q] = cbp[(int64_t)(k + q) * lay.m_pad]; }
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    a0 = fmaf(xs[k + q], va[q], a0); a1 = fmaf(xs[k + q + 1], va[q + 1], a1);
+                    b0 = fmaf(xs[k + q], vb[q], b0); b1 = fmaf(xs[k + q + 1], vb[q + 1], b1);
+                }
+            }
+            sc[j0] = (float)(0.5 * cn64[ma]) - (a0 + a1);
+            smin = fminf(smin, sc[j0]);
+            if (has_b) { sc[j0 + 1] = (float)(0.5 * cn64[mb]) - (b0 + b1); smin = fminf(smin, sc[j0 + 1]); }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) smin = fminf(smin, __shfl_xor(smin, off, SN_WAVE));
@@ -276,20 +306,19 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
         if (lane == 0) red[wid] = smin;
         __syncthreads();
         smin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-        // pass 2: survivors inside the window (recomputed: identical arithmetic, identical bits)
-        bool too_many = false;
-        for (int m = tid; m < p.M; m += 256) {
-            float acc = 0.0f;
-            for (int k = 0; k < p.D; ++k) acc = fmaf(xs[k], cbT[(int64_t)k * lay.m_pad + m], acc);
-            const float sc = (float)(0.5 * cn64[m]) - acc;
-            if (finite && sc <= smin + 2.0f * e32) {
+        // pass 2: survivors inside the rigorous fp32 window
+        bool too_many = p.M > 2048;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = tid + 256 * j;
+            if (m < p.M && finite && sc[j] <= smin + 2.0f * e32) {
                 const int slot = atomicAdd(&n_surv, 1);
                 if (slot < kMaxSurvivors) surv[slot] = m;
             }
         }
         __syncthreads();
         const int ns = n_surv;
-        too_many = !finite || ns > kMaxSurvivors || ns == 0;
+        too_many = too_many || !finite || ns > kMaxSurvivors || ns == 0;
         // fp64 re-rank: wave w takes survivors w, w+4, ... (or every word when the window failed)
         double x[NT];
 #pragma unroll
@@ -328,23 +357,6 @@ __device__ __forceinline__ void top3_insert(unsigned k, unsigned &m1, unsigned &
     m3 = min(m3, hi);
 }
 
-// running (value, word) top-3 per lane, ascending by value then word; plain scalars so nothing
-// lands in scratch
-struct Top3 { float v0, v1, v2; int w0, w1, w2; };
-
-__device__ __forceinline__ bool cand_less(float v, int w, float cv, int cw) { return v < cv || (v == cv && w < cw); }
-
-__device__ __forceinline__ void cand_insert(Top3 &c, float v, int w)
-{
-    const bool l0 = cand_less(v, w, c.v0, c.w0), l1 = cand_less(v, w, c.v1, c.w1), l2 = cand_less(v, w, c.v2, c.w2);
-    const float n2v = l1 ? c.v1 : (l2 ? v : c.v2);
-    const int n2w = l1 ? c.w1 : (l2 ? w : c.w2);
-    const float n1v = l0 ? c.v0 : (l1 ? v : c.v1);
-    const int n1w = l0 ? c.w0 : (l1 ? w : c.w1);
-    c.v2 = n2v; c.w2 = n2w; c.v1 = n1v; c.w1 = n1w;
-    if (l0) { c.v0 = v; c.w0 = w; }
-}
-
 template <int NSTEPS>
 __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_kernel(const AssignArgs p)
 {
@@ -358,20 +370,28 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
     const int n_tiles = lay.n_tiles;
 
-    auto issue_tile = [&](int w, int slot) {
+    // codebook tiles: global -> registers (issued before the MFMAs of the previous tile) -> LDS
+    // (written after them): plain loads so that hipcc's counted vmcnt keeps them in flight across
+    // the compute phase (an LDS-DMA prefetch is drained by the vmcnt(0) hipcc puts before every
+    // ds_read that follows it).
+    constexpr int kCopies = (kTileBytes + 4095) / 4096;          // 16-B pieces per thread
+    f32x4 stage[kCopies];
+    auto load_tile = [&](int w) {
+        const unsigned char *src = tiles + (size_t)w * kTileBytes + tid * 16;
 #pragma unroll
-        for (int j = 0; j < (kChunks + kWavesPerBlock - 1) / kWavesPerBlock; ++j) {
-            const int c = wid + kWavesPerBlock * j;
-            if (c < kChunks) {
-                const unsigned char *src = tiles + (size_t)w * kTileBytes + c * 1024 + lane * 16;
-                unsigned char *dst = smem + slot * kTileBytes + c * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-            }
-        }
+        for (int j = 0; j < kCopies; ++j)
+            if (j * 4096 + tid * 16 < kTileBytes) stage[j] = *reinterpret_cast<const f32x4 *>(src + j * 4096);
     };
-    issue_tile(0, 0);
-    if (n_tiles > 1) issue_tile(1, 1);
+    auto store_tile = [&](int slot) {
+        unsigned char *dst = smem + slot * kTileBytes + tid * 16;
+#pragma unroll
+        for (int j = 0; j < kCopies; ++j)
+            if (j * 4096 + tid * 16 < kTileBytes) *reinterpret_cast<f32x4 *>(dst + j * 4096) = stage[j];
+    };
+    const int wave_id = blockIdx.x * kWavesPerBlock + wid;
+    stamp(p, 0, lane, wave_id);
+    load_tile(0);
+    store_tile(0);
 
     // ---- this wave's 32 tokens: fp32 -> fp16 B fragments, kept in registers for the whole kernel
     const int64_t n = (int64_t)blockIdx.x * kTokPerBlock + wid * kTokPerWave + r;
@@ -379,20 +399,35 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     const float *row = token_row(p, valid ? n : 0);
     half8 b[NSTEPS];
     float sumsq = 0.0f, sumabs = 0.0f, maxabs = 0.0f;
+    // all loads of a half-row are issued before the first conversion (the MFMA loop's registers are
+    // not live yet, so up to 24 x 16 B per lane can be in flight), in two batches
+    constexpr int kHalf = NSTEPS / 4;                 // u-steps per batch
 #pragma unroll
-    for (int u = 0; u < NSTEPS / 2; ++u) {
-        const float4 *q = reinterpret_cast<const float4 *>(row + 32 * u + 16 * h);
-        const float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
-        const float f[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
-                             v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    for (int batch = 0; batch < 2; ++batch) {
+        f32x4 raw[kHalf][4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            sumsq = fmaf(f[j], f[j], sumsq);
-            sumabs += fabsf(f[j]);
-            maxabs = fmaxf(maxabs, fabsf(f[j]));
+        for (int uu = 0; uu < kHalf; ++uu) {
+            const f32x4 *q = reinterpret_cast<const f32x4 *>(row + 32 * (batch * kHalf + uu) + 16 * h);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) raw[uu][v] = q[v];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { b[2 * u][j] = (_Float16)f[j]; b[2 * u + 1][j] = (_Float16)f[8 + j]; }
+        for (int uu = 0; uu < kHalf; ++uu) {
+            const int u = batch * kHalf + uu;
+            const float f[16] = {raw[uu][0].x, raw[uu][0].y, raw[uu][0].z, raw[uu][0].w, raw[uu][1].x, raw[uu][1].y,
+                                 raw[uu][1].z, raw[uu][1].w, raw[uu][2].x, raw[uu][2].y, raw[uu][2].z, raw[uu][2].w,
+                                 raw[uu][3].x, raw[uu][3].y, raw[uu][3].z, raw[uu][3].w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                sumsq = fmaf(f[j], f[j], sumsq);
+                sumabs += fabsf(f[j]);
+                maxabs = fmaxf(maxabs, fabsf(f[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { b[2 * u][j] = (_Float16)f[j]; b[2 * u + 1][j] = (_Float16)f[8 + j]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
     sumabs += __shfl_xor(sumabs, 32, SN_WAVE);
@@ -406,18 +441,24 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     const float vmax = 0.5f * CN + 0.5f * X2 * X2 + X2 * C2;                 // >= any v (before the shift)
     const float E = 1.01f * (2.01f * kU16 * X2 * C2                           // fp16 rounding of x and c
                              + 5.96e-8f * (X1 + C1)                           // fp16 subnormal flush
-                             + (float)NSTEPS * kAccUlpPerMfma * X2 * C2       // MFMA fp32 accumulate
+                             + (float)NSTEPS * kAccUlpPerMfma * vmax          // MFMA fp32 accumulate (starts at |c|^2/2 + shift)
                              + vmax * (3.0f * 5.96e-8f + 3.1e-5f));           // hx/hc/adds rounding + key truncation (2^-15)
     const float shift = hx + 2.0f * E;                                        // keeps every key non-negative
     const float window = 2.0f * E;
     const bool bad = !(maxabs <= kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e30f);   // NaN-safe
 
-    unsigned m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu, m3 = 0xFFFFFFFFu;
-    Top3 top = {INFINITY, INFINITY, INFINITY, -1, -1, -1};
+    stamp(p, 1, lane, wave_id);
+    unsigned long long t_bar = 0, t_mfma = 0, t_acc = 0, t_keys = 0, t_vm = 0, t_st = 0;
+    unsigned m1[4], m2[4], m3[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) m1[g] = m2[g] = m3[g] = 0xFFFFFFFFu;
 
     for (int w = 0; w < n_tiles; ++w) {
-        __syncthreads();                 // tile w landed (vmcnt(0) + barrier); slot (w+2)%3 is free
-        if (w + 2 < n_tiles) issue_tile(w + 2, (w + 2) % kRing);
+        const unsigned long long tb0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        __syncthreads();                 // tile w is in LDS; the other slot is free
+        const unsigned long long tb1 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        t_bar += tb1 - tb0;
+        if (w + 1 < n_tiles) load_tile(w + 1);
         const unsigned char *slot = smem + (w % kRing) * kTileBytes;
         const unsigned char *frag = slot + lane * 16;
         // A fragments through a 4-deep register ring so ds_read latency hides behind the MFMAs
@@ -426,7 +467,15 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
         half8 a2 = *reinterpret_cast<const half8 *>(frag + 2 * 1024);
         half8 a3 = *reinterpret_cast<const half8 *>(frag + 3 * 1024);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 DS reads up front
-        f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        // accumulator starts at |c|^2/2 + shift, the MFMAs add -x.c  ->  v = dist^2/2 + 2E >= 0
+        const float *hc = reinterpret_cast<const float *>(slot + NSTEPS * 1024);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(hc + (g * 2 + h) * 4);
+            acc[4 * g + 0] = c4.x + shift; acc[4 * g + 1] = c4.y + shift;
+            acc[4 * g + 2] = c4.z + shift; acc[4 * g + 3] = c4.w + shift;
+        }
 #pragma unroll
         for (int s = 0; s < NSTEPS; s += 4) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[s + 0], acc, 0, 0, 0);
@@ -446,69 +495,97 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        // epilogue: v = acc + (|c|^2/2 + shift); keys; running top-3
-        const float *hc = reinterpret_cast<const float *>(slot + NSTEPS * 1024);
-        const unsigned tcode = (unsigned)(w & 15) << 4;
+        unsigned long long tb2 = 0;
+        if (p.stamps) {
+            tb2 = __builtin_amdgcn_s_memtime();
+            t_mfma += tb2 - tb1;
+            float probe;
+            asm volatile("v_mov_b32 %0, %1\n\ts_nop 4" : "=v"(probe) : "v"(acc[15]));   // waits for the last MFMA
+            asm volatile("" :: "v"(probe));
+            const unsigned long long tb3 = __builtin_amdgcn_s_memtime();
+            t_acc += tb3 - tb2;
+            tb2 = tb3;
+        }
+        // epilogue: keys = value bits with the low 8 mantissa bits replaced by (tile << 2 | e);
+        // one running top-3 per accumulator group g (words 8g + 4h + e of every tile)
+        const unsigned tcode = (unsigned)w << 2;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(hc + (g * 2 + h) * 4);
-            const float t[4] = {c4.x + shift, c4.y + shift, c4.z + shift, c4.w + shift};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int reg = 4 * g + e;
-                const float v = acc[reg] + t[e];
-                const unsigned k = (__float_as_uint(v) & 0xFFFFFF00u) | (tcode | (unsigned)reg);
-                top3_insert(k, m1, m2, m3);
+                const unsigned code = tcode | (unsigned)e;
+                const unsigned k = (__float_as_uint(acc[4 * g + e]) & 0xFFFFFF00u) | code;
+                top3_insert(k, m1[g], m2[g], m3[g]);
             }
         }
-        if ((w & 15) == 15 || w == n_tiles - 1) {        // unpack this 16-tile chunk
-            const int base = (w & ~15) * 32;
-            auto unpack = [&](unsigned k) {
-                const float v = __uint_as_float(k & 0xFFFFFF00u);
-                const int code = (int)(k & 0xFFu), reg = code & 15;
-                const int word = base + (code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (k < 0x7F800000u && word < p.M) cand_insert(top, v, word);   // finite, non-negative
-            };
-            unpack(m1); unpack(m2); unpack(m3);
-            m1 = m2 = m3 = 0xFFFFFFFFu;
+        if (p.stamps) {
+            asm volatile("" :: "v"(m1[0]), "v"(m1[1]), "v"(m1[2]), "v"(m1[3]), "v"(m3[0]), "v"(m3[1]), "v"(m3[2]), "v"(m3[3]));
+            const unsigned long long tb4 = __builtin_amdgcn_s_memtime();
+            t_keys += tb4 - tb2;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_vm += __builtin_amdgcn_s_memtime() - tb4;
         }
+        const unsigned long long tb5 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
+        if (w + 1 < n_tiles) store_tile((w + 1) % kRing);
+        if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_st += __builtin_amdgcn_s_memtime() - tb5; }
     }
 
-    // ---- merge the two half-lanes that share a token
-    Top3 oth;
-    oth.v0 = __shfl_xor(top.v0, 32, SN_WAVE); oth.w0 = __shfl_xor(top.w0, 32, SN_WAVE);
-    oth.v1 = __shfl_xor(top.v1, 32, SN_WAVE); oth.w1 = __shfl_xor(top.w1, 32, SN_WAVE);
-    oth.v2 = __shfl_xor(top.v2, 32, SN_WAVE); oth.w2 = __shfl_xor(top.w2, 32, SN_WAVE);
-    const float vbest = fminf(top.v0, oth.v0);
-    const int best_w = cand_less(top.v0, (int)((unsigned)top.w0 & 0x7fffffff), oth.v0, (int)((unsigned)oth.w0 & 0x7fffffff)) ? top.w0 : oth.w0;
-    const float cut = vbest + window;
-    // candidate set as a 6-bit mask over {top 0..2, oth 0..2}
-    unsigned cmask = 0;
-    if (top.w0 >= 0 && top.v0 <= cut) cmask |= 1u;
-    if (top.w1 >= 0 && top.v1 <= cut) cmask |= 2u;
-    if (top.w2 >= 0 && top.v2 <= cut) cmask |= 4u;
-    if (oth.w0 >= 0 && oth.v0 <= cut) cmask |= 8u;
-    if (oth.w1 >= 0 && oth.v1 <= cut) cmask |= 16u;
-    if (oth.w2 >= 0 && oth.v2 <= cut) cmask |= 32u;
-    const int nc = __popc(cmask);
-    // a lane whose third-best is still inside the window may hide a fourth
-    const bool overflow = bad || best_w < 0 || (cmask & 36u) != 0;
+    stamp(p, 2, lane, wave_id);
+    if (p.stamps && lane == 0) { p.stamps[(size_t)wave_id * 16 + 4] = t_bar; p.stamps[(size_t)wave_id * 16 + 5] = t_mfma; p.stamps[(size_t)wave_id * 16 + 6] = t_acc; p.stamps[(size_t)wave_id * 16 + 7] = t_keys; p.stamps[(size_t)wave_id * 16 + 8] = t_vm; p.stamps[(size_t)wave_id * 16 + 9] = t_st; }
+    // ---- candidates: every key within the window of the token's best, over both half-lanes
+    unsigned kmin = min(min(m1[0], m1[1]), min(m1[2], m1[3]));
+    const unsigned kmin_o = __shfl_xor(kmin, 32, SN_WAVE);
+    // word of a key: tile = code >> 2, e = code & 3, row = 8g + 4h + e
+    auto word_of = [&](unsigned k, int g, int hh) { return (int)(((k & 0xFFu) >> 2) * 32 + 8 * g + 4 * hh + (k & 3u)); };
+    int gmin = 0;
+#pragma unroll
+    for (int g = 1; g < 4; ++g) if (m1[g] == kmin) gmin = g;
+#pragma unroll
+    for (int g = 3; g >= 0; --g) if (m1[g] == kmin) gmin = g;      // lowest group on ties
+    const int my_best = word_of(kmin, gmin, h);
+    const int ot_best = __shfl_xor(my_best, 32, SN_WAVE);
+    const unsigned vmy = kmin & 0xFFFFFF00u, vot = kmin_o & 0xFFFFFF00u;
+    const bool mine = vmy < vot || (vmy == vot && my_best < ot_best);
+    const int best_w = mine ? my_best : ot_best;
+    const float vbest = __uint_as_float(mine ? vmy : vot);
+    const bool any_finite = (mine ? vmy : vot) < 0x7F800000u;
+    const unsigned cutkey = __float_as_uint(vbest + window) | 0xFFu;   // key <= cutkey  <=>  value <= cut
+    unsigned hmask = 0;                                                // 12 bits: group g -> bits 3g..3g+2
+    bool hover = false;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (m1[g] <= cutkey) hmask |= 1u << (3 * g);
+        if (m2[g] <= cutkey) hmask |= 2u << (3 * g);
+        if (m3[g] <= cutkey) { hmask |= 4u << (3 * g); hover = true; }   // a 4th may hide behind it
+    }
+    const unsigned omask = __shfl_xor(hmask, 32, SN_WAVE);
+    const bool oover = __shfl_xor((int)hover, 32, SN_WAVE) != 0;
+    const int nc = __popc(hmask) + __popc(omask);
+    const bool overflow = bad || !any_finite || hover || oover;
     const bool writer = valid && h == 0;
-    if (writer) p.out[out_index(p, n)] = best_w < 0 ? 0 : best_w;
+    if (writer) p.out[out_index(p, n)] = any_finite ? best_w : 0;
     const bool need_a = writer && !overflow && nc > 1;
     const bool need_b = writer && overflow;
     const unsigned long long mask_a = __ballot(need_a), mask_b = __ballot(need_b);
+    stamp(p, 3, lane, wave_id);
     if (mask_a) {
         int base = 0;
         const int leader = __ffsll((long long)mask_a) - 1;
         if (lane == leader) base = atomicAdd(&p.work[0], __popcll(mask_a));
         base = __shfl(base, leader, SN_WAVE);
-        if (need_a) {
-            int *ent = p.work + 8 + (int64_t)(base + __popcll(mask_a & ((1ull << lane) - 1ull))) * 8;
-            ent[0] = (int)n;
-            ent[1] = (int)cmask;
-            ent[2] = top.w0; ent[3] = top.w1; ent[4] = top.w2;
-            ent[5] = oth.w0; ent[6] = oth.w1; ent[7] = oth.w2;
+        int idx = need_a ? base + __popcll(mask_a & ((1ull << lane) - 1ull)) : -1;
+        const int idx_o = __shfl_xor(idx, 32, SN_WAVE);      // the h = 1 lane of the token writes its half too
+        if (h == 1) idx = idx_o;
+        if (idx >= 0) {
+            int *ent = p.work + 8 + (int64_t)idx * kEntryInts;
+            if (h == 0) { ent[0] = (int)n; ent[1] = (int)(hmask | (omask << 12)); }
+            int *wd = ent + 2 + 12 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                wd[3 * g + 0] = word_of(m1[g], g, h);
+                wd[3 * g + 1] = word_of(m2[g], g, h);
+                wd[3 * g + 2] = word_of(m3[g], g, h);
+            }
         }
     }
     if (mask_b) {
@@ -546,7 +623,7 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
-    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(2048), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(1024), dim3(256), 0, st, a);
     sn_prof_stop(1, st);
     return 0;
 }
@@ -585,10 +662,13 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
     return SN_OK;
 }
 
+/* diagnostics: device buffer of 16 x u64 per wave of the screen kernel (NULL = off) */
+extern "C" void sn_debug_set_stamps(void *device_buffer) { g_stamps = (unsigned long long *)device_buffer; }
+
 extern "C" size_t sn_assign_workspace_bytes(int64_t n_tokens)
 {
     if (n_tokens < 0) return 0;
-    return 32 + (size_t)n_tokens * 36;      // header + 8-int entries + overflow token ids
+    return 32 + (size_t)n_tokens * (kEntryInts * 4 + 4);      // header + entries + overflow token ids
 }
 
 extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
@@ -608,10 +688,11 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.x = x; a.n_tokens = n_tokens; a.n_inner = n_inner; a.xso = x_stride_outer; a.xsi = x_stride_inner;
     a.cb = codebook; a.packed = (const unsigned char *)packed; a.M = M; a.D = D;
     a.out = out; a.oso = out_stride_outer; a.osi = out_stride_inner; a.work = (int *)workspace;
-    a.overflow = workspace ? (int *)workspace + 8 + n_tokens * 8 : nullptr;
+    a.overflow = workspace ? (int *)workspace + 8 + n_tokens * kEntryInts : nullptr;
+    a.stamps = g_stamps;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
-    const bool screen_ok = mode == 0 && aligned && M % 32 == 0 && (D == 192 || D == 384 || D == 768);
+    const bool screen_ok = mode == 0 && aligned && M % 32 == 0 && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
     if (screen_ok) {
         SN_REQUIRE(workspace && workspace_bytes >= sn_assign_workspace_bytes(n_tokens), SN_ERR_WORKSPACE,
                    "sn_assign_words: workspace %zu < %zu bytes", workspace_bytes, sn_assign_workspace_bytes(n_tokens));

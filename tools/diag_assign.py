@@ -37,3 +37,46 @@ for name, tok in (("randn tokens", tokens), ("k-means-like", None)):
     print("   fp64 gap best->second: median %.3f, 1%% %.4f, min %.2e; |x|*|c|max median %.1f" % (
         gap.median(), gap.kthvalue(max(1, n_tok // 100)).values, gap.min(),
         (x64.norm(dim=1) * c64.norm(dim=1).max()).median()))
+
+# ---- in-kernel stamps of the screen kernel (shader cycles)
+import ctypes
+lib.sn_debug_set_stamps.argtypes = [ctypes.c_void_p]; lib.sn_debug_set_stamps.restype = None
+n_waves = ((n_tok + 127) // 128) * 4
+st = torch.zeros(n_waves * 16, dtype=torch.int64, device=dev)
+lib.sn_debug_set_stamps(st.data_ptr())
+x = tokens[:, 1:, :]
+for _ in range(3):
+    N.check(lib.sn_assign_words(N.ptr(x), x.shape[0], x.shape[1], x.stride(0), x.stride(1), N.ptr(cb), N.ptr(packed), bench.M, bench.D,
+                                N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws.numel(), 0, N.stream_ptr(dev)))
+torch.cuda.synchronize()
+lib.sn_debug_set_stamps(None)
+s8 = st.view(n_waves, 16).cpu().double()
+t0 = s8[:, 0].min()
+print("screen kernel stamps (cycles, 100MHz-ref memtime?):")
+print("  kernel span (first start -> last end): %.0f" % (s8[:, 3].max() - t0))
+print("  start skew  (last wave start - first): %.0f" % (s8[:, 0].max() - t0))
+print("  token load+convert: median %.0f  max %.0f" % ((s8[:, 1] - s8[:, 0]).median(), (s8[:, 1] - s8[:, 0]).max()))
+print("  main loop:          median %.0f  max %.0f" % ((s8[:, 2] - s8[:, 1]).median(), (s8[:, 2] - s8[:, 1]).max()))
+print("     of which barrier wait median %.0f, mfma section median %.0f" % (s8[:, 4].median(), s8[:, 5].median()))
+print("     wait for last MFMA median %.0f, key/insert VALU median %.0f" % (s8[:, 6].median(), s8[:, 7].median()))
+print("     vmcnt(0) wait for the staged tile median %.0f" % s8[:, 8].median())
+print("     ds_write of the staged tile median %.0f, chunk unpack median %.0f" % (s8[:, 9].median(), s8[:, 10].median()))
+print("  tail:               median %.0f" % ((s8[:, 3] - s8[:, 2]).median()))
+print("  per-wave total:     median %.0f  max %.0f" % ((s8[:, 3] - s8[:, 0]).median(), (s8[:, 3] - s8[:, 0]).max()))
+
+# ---- kernel times (HIP events) for both token sets, and overflow counts
+import ctypes as C
+for name, tok in (("randn", tokens), ("k-means-like", tok)):
+    x = tok[:, 1:, :]
+    lib.sn_profile_enable(20)
+    for _ in range(10):
+        N.check(lib.sn_assign_words(N.ptr(x), x.shape[0], x.shape[1], x.stride(0), x.stride(1), N.ptr(cb), N.ptr(packed), bench.M, bench.D,
+                                    N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws.numel(), 0, N.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    res = {}
+    for kid, kname in ((0, "screen"), (1, "rerank")):
+        n = lib.sn_profile_count(kid); buf = (C.c_float * n)(); lib.sn_profile_elapsed_ms(kid, buf, n)
+        res[kname] = sorted(buf)[n // 2] * 1e3
+    w = ws.view(torch.int32)
+    print(f"{name}: screen {res['screen']:.1f} us, rerank {res['rerank']:.1f} us, entries {int(w[0])}, overflow tokens {int(w[1])}")
+    lib.sn_profile_enable(0)
