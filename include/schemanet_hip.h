@@ -223,6 +223,12 @@ int sn_weighted_pool(const float *feat, const float *nodes, int G, int n, int E,
 int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, int E,
                     int similarity, float *pred, void *stream);
 
+/* per-class vote aggregation for evaluation: votes[argmax_k pred[b, k]] += 1 for every image
+ * (first index on ties, torch.argmax), votes[K] += 1 per image.  votes: [K + 1] f32, accumulated
+ * in place; merged across ranks with one all-reduce (replaces the meter.sync() of the reference,
+ * schema_inference/eval/evaluation.py:95-97). */
+int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "sn_mask_layernorm_act": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "sn_weighted_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_match_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sn_class_votes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

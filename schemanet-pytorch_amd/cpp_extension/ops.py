@@ -316,3 +316,15 @@ def match_scores(feat_inst, feat_kg, similarity="inner_product"):
         N.check(lib.sn_match_scores(N.ptr(a), N.ptr(b), B, K, E, SIMILARITY[similarity], N.ptr(pred), N.stream_ptr(dev)),
                 "sn_match_scores")
     return pred
+
+
+def class_votes_(pred, votes):
+    """votes [K + 1] f32 += per-class argmax counts of pred [B, K] (and the image count)."""
+    lib = N.require_gpu()
+    dev = _check_dev(pred, votes)
+    p = _f32c(pred)
+    B, K = p.shape
+    assert votes.dtype == torch.float32 and votes.is_contiguous() and votes.numel() == K + 1
+    with torch.cuda.device(dev):
+        N.check(lib.sn_class_votes(N.ptr(p), B, K, N.ptr(votes), N.stream_ptr(dev)), "sn_class_votes")
+    return votes

@@ -79,18 +79,27 @@ __global__ __launch_bounds__(256) void mask_layernorm_act_kernel(float *x, int64
 }
 
 // ------------------------------------------------------------------ weighted pooling
+// block = 64 columns x 4 row slices (one wave each); partial sums are combined in wave order,
+// so the result is deterministic
 __global__ __launch_bounds__(256) void weighted_pool_kernel(const float *feat, const float *nodes, int n, int E,
                                                             const int32_t *divisor_dev, float *out)
 {
-    const int g = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= E) return;
-    const float *f = feat + (int64_t)g * n * E + c;
+    __shared__ float part[4][SN_WAVE];
+    const int g = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * SN_WAVE + lane;
     const float *w = nodes + (int64_t)g * n;
     float acc = 0.0f;
-    for (int r = 0; r < n; ++r) acc = acc + f[(int64_t)r * E] * w[r];
-    const float div = divisor_dev ? (float)(*divisor_dev) : (float)n;
-    out[(int64_t)g * E + c] = acc / div;
+    if (c < E) {
+        const float *f = feat + (int64_t)g * n * E + c;
+        for (int r = wid; r < n; r += 4) acc = acc + f[(int64_t)r * E] * w[r];
+    }
+    part[wid][lane] = acc;
+    __syncthreads();
+    if (wid == 0 && c < E) {
+        const float total = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        const float div = divisor_dev ? (float)(*divisor_dev) : (float)n;
+        out[(int64_t)g * E + c] = total / div;
+    }
 }
 
 // ------------------------------------------------------------------ similarity scores
@@ -127,7 +136,46 @@ __global__ __launch_bounds__(256) void match_scores_kernel(const float *fi, cons
     }
 }
 
+// ------------------------------------------------------------------ per-class votes
+// one wave per image: argmax over the K scores (first index on ties, like torch.argmax) with
+// shuffle reductions, then one atomic add into the class's counter; votes[K] counts images.
+__global__ __launch_bounds__(256) void class_votes_kernel(const float *pred, int B, int K, float *votes)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += SN_WAVE) {
+        const float v = pred[(int64_t)b * K + k];
+        if (v > best || (v != v && best == best)) { best = v; bi = k; }     // NaN wins, like torch
+    }
+    if (bi == 0x7fffffff && lane < K) bi = lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, SN_WAVE);
+        const int oi = __shfl_xor(bi, off, SN_WAVE);
+        const bool take = (ov != ov && best == best) || (ov > best && best == best) || (ov == best && oi < bi) ||
+                          (ov != ov && best != best && oi < bi);
+        if (take) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        atomicAdd(&votes[bi < K ? bi : 0], 1.0f);
+        atomicAdd(&votes[K], 1.0f);
+    }
+}
+
 }  // namespace
+
+extern "C" int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream)
+{
+    SN_REQUIRE(B >= 0 && K > 0, SN_ERR_BAD_ARG, "sn_class_votes: bad B=%d K=%d", B, K);
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(pred && votes, SN_ERR_BAD_ARG, "sn_class_votes: NULL pointer");
+    hipLaunchKernelGGL(class_votes_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pred, B, K, votes);
+    SN_CHECK_LAUNCH("sn_class_votes");
+    return SN_OK;
+}
 
 extern "C" int sn_gcn_adjacency(const float *edges, int G, int n, float *adj, void *stream)
 {
@@ -164,7 +212,7 @@ extern "C" int sn_weighted_pool(const float *feat, const float *nodes, int G, in
     if (G == 0) return SN_OK;
     SN_REQUIRE(feat && nodes && out, SN_ERR_BAD_ARG, "sn_weighted_pool: NULL pointer");
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_weighted_pool: G=%d > 65535", G);
-    hipLaunchKernelGGL(weighted_pool_kernel, dim3((unsigned)((E + 255) / 256), (unsigned)G), dim3(256), 0,
+    hipLaunchKernelGGL(weighted_pool_kernel, dim3((unsigned)((E + SN_WAVE - 1) / SN_WAVE), (unsigned)G), dim3(256), 0,
                        (hipStream_t)stream, feat, nodes, n, E, divisor_dev, out);
     SN_CHECK_LAUNCH("sn_weighted_pool");
     return SN_OK;
