@@ -177,6 +177,14 @@ def main():
         alg_bytes = B * L * (D * 4 + 8)
         ach = alg_bytes / (avg["assign_screen"] * 1e-3) / 1e9 if avg["assign_screen"] else None
         graph_bytes = B * (L * L * 4 + L * 4 + L * 8) + B * (L * L * 4 + L * 12)   # attn in + padded edges/ids/weights out
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
+                for row in json.load(fh)["kernels"]:
+                    if row["kernel"].startswith("assign_screen_kernel<24>"):
+                        traffic = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "images/sec schema-inference (discretize+graph) DeiT-S CIFAR-100",
             "value": B * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -188,7 +196,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"image-parallel x{world}"},
             "roofline": {"bound": "hbm", "kernel": "assign_screen_kernel<24> (S1 fp16-MFMA screen)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                         "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["assign_screen"]},
             "kernels_ms": avg,
             "instance_graph_GBps": (graph_bytes / (avg["instance_graph"] * 1e-3) / 1e9) if avg["instance_graph"] else None,

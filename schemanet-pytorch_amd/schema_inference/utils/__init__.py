@@ -23,7 +23,9 @@ _LAZY = {
 def __getattr__(name):
     if name in _LAZY:
         mod = importlib.import_module(f"{__name__}.{_LAZY[name]}")   # found via the extended __path__
-        return getattr(mod, name)
+        obj = getattr(mod, name)
+        globals()[name] = obj       # like `from .x import x`: rebinds a name the submodule import shadowed
+        return obj
     raise AttributeError(name)
 
 

@@ -1,0 +1,80 @@
+"""CPU, build container only (skipped where /root/reference is absent, e.g. on the GPU box):
+the oracle against the LIVE reference on fresh seeded inputs, and the package-overlay claim of
+INTEGRATION.md.  Runs the reference in a subprocess because it shares module names with the
+drop-in packages."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_REF = os.path.isdir("/root/reference/schema_inference") and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "extension.so"))
+pytestmark = pytest.mark.skipif(not HAVE_REF, reason="reference checkout / oracle/_ref not present")
+
+_LIVE = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import datagen
+from oracle import ref_import, cabi, pyops
+ref = ref_import.load()
+T = torch.from_numpy
+torch.manual_seed(0)
+ok = True
+# S1: reference Discretization vs oracle on 4 seeds (D=384, M=512)
+for seed in range(4):
+    cb = datagen.bellish((512, 384), 100 + seed, 1.0)
+    x = datagen.bellish((196 * 4, 384), 200 + seed, 1.0)
+    x[::3] = cb[datagen.integers((len(x[::3]),), seed, 512)] + 0.4 * x[::3]
+    d = ref.discretization.Discretization(512, 384)
+    with torch.no_grad(): d.vocabulary.weight.copy_(T(cb))
+    _, ing = d(T(x).reshape(196, 4, 384))
+    mine = cabi.assign_words(x, cb)
+    ok &= np.array_equal(ing.reshape(-1).numpy(), mine)
+# graph: SchemaNet.forward vs oracle on random logits, M = 64 (many repeats per word)
+for seed in range(3):
+    ing = datagen.integers((3, 196), 300 + seed, 64)
+    attn = datagen.bellish((3, 196, 196), 400 + seed, 2.0); acls = datagen.bellish((3, 196), 500 + seed, 2.0)
+    sn = ref.graph.SchemaNet(num_vertices=64, num_classes=2, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0)
+    with torch.no_grad(): out = sn(T(ing), T(attn.copy()), T(acls.copy()))
+    w = np.full((2, 1), 0.5, np.float32)
+    mine = pyops.instance_graph(ing, attn, acls, w, w)
+    ok &= all(np.array_equal(a.numpy(), b) for a, b in zip(out["instance_ingredients"], mine["instance_ingredients"]))
+    ok &= all(np.allclose(a.numpy(), b, rtol=1e-5, atol=1e-8) for a, b in zip(out["instance_vertices"], mine["instance_vertices"]))
+    ok &= all(np.allclose(a.numpy(), b, rtol=1e-5, atol=1e-8) for a, b in zip(out["instance_edges"], mine["instance_edges"]))
+sys.exit(0 if ok else 3)
+'''
+
+_OVERLAY = r'''
+import sys, types, json
+pkg, ref = sys.argv[1] + "/schemanet-pytorch_amd", "/root/reference"
+sys.path[:0] = [pkg, ref]                                  # ours first, the reference behind (INTEGRATION.md level 2)
+import schema_inference.graph as g, discretization, cpp_extension
+assert g.__file__.startswith(pkg) and discretization.__file__.startswith(pkg) and cpp_extension.__file__.startswith(pkg)
+from schema_inference.loss.schema_inference_loss import SchemaInferenceLoss       # resolved in the reference checkout
+import schema_inference.loss as L
+assert L.__file__.startswith(ref), L.__file__
+from schema_inference.utils import IngredientModelWrapper
+assert sys.modules["schema_inference.utils"].__file__.startswith(pkg)
+# cv_lib-dependent helpers are resolved lazily from the reference (stub cv_lib like the oracle does)
+for name, attrs in (("cv_lib", {}), ("cv_lib.utils", {"to_json_str": lambda o: json.dumps(o, default=str)})):
+    m = types.ModuleType(name); m.__dict__.update(attrs); sys.modules[name] = m
+from schema_inference.utils import customs_param_group, LogArgs
+assert callable(customs_param_group) and customs_param_group.__module__ == "schema_inference.utils.customs_param_group"
+'''
+
+
+def _run(code, tmp_path):
+    f = tmp_path / "s.py"
+    f.write_text(code)
+    return subprocess.run([sys.executable, str(f), ROOT], capture_output=True, text=True, timeout=600)
+
+
+def test_oracle_matches_live_reference(tmp_path):
+    r = _run(_LIVE, tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_package_overlay_on_reference_checkout(tmp_path):
+    r = _run(_OVERLAY, tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
