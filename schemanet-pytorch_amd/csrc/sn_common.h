@@ -36,12 +36,23 @@ void sn_prof_start(int kernel_id, hipStream_t st);
 void sn_prof_stop(int kernel_id, hipStream_t st);
 
 // ---------------------------------------------------------------- device: wave reductions
-// xor-butterfly: every lane ends with the same value (fp add / max are commutative).
+// 64-lane all-reduce on the DPP network: four row-local steps (row_mirror, row_half_mirror,
+// quad mirror, quad xor-1) leave every lane with its 16-lane row total, v_readlane combines the
+// four rows.  ~11 instructions and no LDS crossbar (ds_bpermute) round trips.  Every lane ends
+// with the same value.  (The fp64 re-rank of S1 keeps the xor butterfly below: its summation
+// order is part of the oracle contract.)
+#define SN_DPP_F32(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xF, 0xF, false))
+#define SN_READLANE_F32(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))   // the builtin is int -> int
+
 __device__ __forceinline__ float sn_wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, SN_WAVE);
-    return v;
+    v += SN_DPP_F32(v, 0x140);      // row_mirror        i <-> 15 - i
+    v += SN_DPP_F32(v, 0x141);      // row_half_mirror   i <-> 7 - i inside each half row
+    v += SN_DPP_F32(v, 0x1B);       // quad_perm [3,2,1,0]
+    v += SN_DPP_F32(v, 0xB1);       // quad_perm [1,0,3,2]
+    const float r0 = SN_READLANE_F32(v, 0), r1 = SN_READLANE_F32(v, 16);
+    const float r2 = SN_READLANE_F32(v, 32), r3 = SN_READLANE_F32(v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ double sn_wave_sum_f64(double v)
@@ -53,9 +64,24 @@ __device__ __forceinline__ double sn_wave_sum_f64(double v)
 
 __device__ __forceinline__ float sn_wave_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, SN_WAVE));
-    return v;
+    v = fmaxf(v, SN_DPP_F32(v, 0x140));
+    v = fmaxf(v, SN_DPP_F32(v, 0x141));
+    v = fmaxf(v, SN_DPP_F32(v, 0x1B));
+    v = fmaxf(v, SN_DPP_F32(v, 0xB1));
+    const float r0 = SN_READLANE_F32(v, 0), r1 = SN_READLANE_F32(v, 16);
+    const float r2 = SN_READLANE_F32(v, 32), r3 = SN_READLANE_F32(v, 48);
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+__device__ __forceinline__ float sn_wave_min(float v)
+{
+    v = fminf(v, SN_DPP_F32(v, 0x140));
+    v = fminf(v, SN_DPP_F32(v, 0x141));
+    v = fminf(v, SN_DPP_F32(v, 0x1B));
+    v = fminf(v, SN_DPP_F32(v, 0xB1));
+    const float r0 = SN_READLANE_F32(v, 0), r1 = SN_READLANE_F32(v, 16);
+    const float r2 = SN_READLANE_F32(v, 32), r3 = SN_READLANE_F32(v, 48);
+    return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 
 __device__ __forceinline__ int sn_wave_sum_i(int v)

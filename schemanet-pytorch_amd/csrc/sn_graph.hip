@@ -19,6 +19,7 @@ namespace {
 
 constexpr int kCellsPerLane = 4;               // 4 x 64 lanes = 256 output columns per row
 constexpr int kMaxCols = kCellsPerLane * SN_WAVE;
+constexpr int kTFloats = 512;                   // feat_h << ceil(log2(feat_w)) <= 2 L <= 392
 
 __host__ __device__ inline size_t up16(size_t x) { return (x + 15) & ~size_t(15); }
 
@@ -29,7 +30,7 @@ struct Lds {
     float *A;                  // [L, L] soft-maxed attention of this image (edges only)
     int64_t *words;            // [L]
     float *acls;               // [L] soft-maxed attention to the cls token
-    float *T;                  // [L] grid similarity by (|drow|, |dcol|)
+    float *T;                  // [512] grid similarity by (|drow| << tshift) + |dcol|
     int *rev;                  // [256] output row/col -> group (or -1)
     unsigned short *gstart;    // [L+1] group g owns pos_sorted[gstart[g] .. gstart[g+1])
     unsigned short *prc;       // [L] (row << 8) | col of each position on the feature grid
@@ -37,14 +38,19 @@ struct Lds {
     unsigned char *flag;       // [L] first-occurrence flag / keep flag
     float *red;                // [64] reduction scratch
     int *misc;                 // [16]
+    unsigned short *pless;     // [L] per position: number of kept positions holding a smaller word
+    unsigned short *pcnt;      // [L] per position: occurrences of its word
+    float *psum;               // [L] per first occurrence: attention sum of its word (position order)
+    unsigned char *pgroup;     // [L] per first occurrence: index of its word among the sorted distinct words
 };
 
 __host__ __device__ inline size_t lds_bytes(int L, bool with_attn)
 {
     size_t n = 0;
     if (with_attn) n += up16((size_t)L * L * 4);
-    n += up16((size_t)L * 8) + up16((size_t)L * 4) * 2 + up16(kMaxCols * 4);
+    n += up16((size_t)L * 8) + up16((size_t)L * 4) + up16(kTFloats * 4) + up16(kMaxCols * 4);
     n += up16((size_t)(L + 1) * 2) + up16((size_t)L * 2) + up16(L) * 2 + up16(64 * 4) + up16(16 * 4);
+    n += up16((size_t)L * 2) * 2 + up16((size_t)L * 4) + up16(L);
     return n;
 }
 
@@ -54,14 +60,18 @@ __device__ inline Lds carve(unsigned char *p, int L, bool with_attn)
     s.A = (float *)p;                 if (with_attn) p += up16((size_t)L * L * 4);
     s.words = (int64_t *)p;           p += up16((size_t)L * 8);
     s.acls = (float *)p;              p += up16((size_t)L * 4);
-    s.T = (float *)p;                 p += up16((size_t)L * 4);
+    s.T = (float *)p;                 p += up16(kTFloats * 4);
     s.rev = (int *)p;                 p += up16(kMaxCols * 4);
     s.gstart = (unsigned short *)p;   p += up16((size_t)(L + 1) * 2);
     s.prc = (unsigned short *)p;      p += up16((size_t)L * 2);
     s.pos_sorted = p;                 p += up16(L);
     s.flag = p;                       p += up16(L);
     s.red = (float *)p;               p += up16(64 * 4);
-    s.misc = (int *)p;
+    s.misc = (int *)p;                p += up16(16 * 4);
+    s.pless = (unsigned short *)p;    p += up16((size_t)L * 2);
+    s.pcnt = (unsigned short *)p;     p += up16((size_t)L * 2);
+    s.psum = (float *)p;              p += up16((size_t)L * 4);
+    s.pgroup = p;
     return s;
 }
 
@@ -71,40 +81,38 @@ __device__ inline Lds carve(unsigned char *p, int L, bool with_attn)
 // all-clamped row becomes NaN exactly like torch: (-inf) - (-inf)).
 // src points at element (row 0, col 0) of head 0; rows are `stride_r` floats apart.
 // ------------------------------------------------------------------------------------------
-__device__ inline void load_row4(const float *row, int L, int lane, bool vec, float x[4])
+// Branch-free row load: out-of-range lanes read a clamped (valid) address and are masked later.
+template <bool kVec>
+__device__ __forceinline__ void load_row4(const float *row, int L, int lane, float x[4])
 {
-    if (vec) {                      // L % 4 == 0 and 16-byte aligned rows: one dwordx4 per lane
-        if (lane * 4 < L) {
-            const float4 v = *reinterpret_cast<const float4 *>(row + lane * 4);
-            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-        } else {
-            x[0] = x[1] = x[2] = x[3] = 0.0f;
-        }
+    if (kVec) {                     // L % 4 == 0 and 16-byte aligned rows: one dwordx4 per lane
+        const int c = min(lane * 4, L - 4);
+        const float4 v = *reinterpret_cast<const float4 *>(row + c);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = lane + SN_WAVE * k;
-            x[k] = c < L ? row[c] : 0.0f;
-        }
+        for (int k = 0; k < 4; ++k) x[k] = row[min(lane + SN_WAVE * k, L - 1)];
     }
 }
 
-__device__ inline int col_of(int lane, int k, bool vec) { return vec ? lane * 4 + k : lane + SN_WAVE * k; }
+template <bool kVec>
+__device__ __forceinline__ int col_of(int lane, int k) { return kVec ? lane * 4 + k : lane + SN_WAVE * k; }
 
-__device__ inline void softmax_row4(float x[4], int L, int lane, bool vec, bool use_clamp, float clamp)
+template <bool kVec>
+__device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool use_clamp, float clamp)
 {
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bool ok = col_of(lane, k, vec) < L;
-        if (ok && use_clamp && x[k] < clamp) x[k] = -INFINITY;
-        if (ok) m = fmaxf(m, x[k]);
+        const bool ok = col_of<kVec>(lane, k) < L;
+        x[k] = (ok && use_clamp && x[k] < clamp) ? -INFINITY : x[k];
+        m = ok ? fmaxf(m, x[k]) : m;
     }
     m = sn_wave_max(m);
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bool ok = col_of(lane, k, vec) < L;
+        const bool ok = col_of<kVec>(lane, k) < L;
         x[k] = ok ? expf(x[k] - m) : 0.0f;
         s += x[k];
     }
@@ -113,36 +121,58 @@ __device__ inline void softmax_row4(float x[4], int L, int lane, bool vec, bool 
     for (int k = 0; k < 4; ++k) x[k] = x[k] / s;
 }
 
+template <bool kVec>
+__device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src, int64_t stride_r, int heads,
+                                                      int64_t stride_h, int L, bool is_logits, bool use_clamp,
+                                                      float clamp, int wid, int nw, int lane)
+{
+    constexpr int kRowsInFlight = 4;        // HBM latency: 4 rows (x heads) of loads in flight per wave
+    for (int r0 = wid; r0 < L; r0 += nw * kRowsInFlight) {
+        float x[kRowsInFlight][4];
+#pragma unroll
+        for (int i = 0; i < kRowsInFlight; ++i)
+            load_row4<kVec>(src + (int64_t)min(r0 + nw * i, L - 1) * stride_r, L, lane, x[i]);
+        for (int h = 1; h < heads; ++h) {
+            float y[kRowsInFlight][4];
+#pragma unroll
+            for (int i = 0; i < kRowsInFlight; ++i)
+                load_row4<kVec>(src + h * stride_h + (int64_t)min(r0 + nw * i, L - 1) * stride_r, L, lane, y[i]);
+#pragma unroll
+            for (int i = 0; i < kRowsInFlight; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[i][k] += y[i][k];
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsInFlight; ++i) {
+            const int r = r0 + nw * i;
+            if (heads > 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[i][k] = x[i][k] / (float)heads;
+            }
+            if (is_logits) softmax_row4<kVec>(x[i], L, lane, use_clamp, clamp);
+            if (r < L) {                                   // wave-uniform
+                if (kVec) {
+                    if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = lane + SN_WAVE * k;
+                        if (c < L) A[r * L + c] = x[i][k];
+                    }
+                }
+            }
+        }
+    }
+}
+
 __device__ inline void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
                                         int64_t stride_h, int L, bool is_logits, bool use_clamp,
                                         float clamp, int wid, int nw, int lane)
 {
     const bool vec = (L % 4 == 0) && (stride_r % 4 == 0) && (stride_h % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-    for (int r = wid; r < L; r += nw) {
-        float x[4];
-        load_row4(src + (int64_t)r * stride_r, L, lane, vec, x);
-        if (heads > 1) {
-            for (int h = 1; h < heads; ++h) {
-                float y[4];
-                load_row4(src + h * stride_h + (int64_t)r * stride_r, L, lane, vec, y);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] += y[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = x[k] / (float)heads;
-        }
-        if (is_logits) softmax_row4(x, L, lane, vec, use_clamp, clamp);
-        if (vec) {
-            if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[0], x[1], x[2], x[3]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = col_of(lane, k, vec);
-                if (c < L) A[r * L + c] = x[k];
-            }
-        }
-    }
+    if (vec) attn_rows_to_lds_impl<true>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
+    else attn_rows_to_lds_impl<false>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -150,17 +180,29 @@ __device__ inline void attn_rows_to_lds(float *A, const float *src, int64_t stri
 // depends only on (|drow|, |dcol|).  pow == 2 uses sqrt: integer inputs, correctly rounded
 // sqrt / div => bit-identical to the reference's torch.cdist based table.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int grid_shift(int feat_w)
+{
+    int sh = 0;
+    while ((1 << sh) < feat_w) ++sh;
+    return sh;
+}
+
 __device__ inline void build_grid_table(const Lds &s, int L, int feat_w, float alpha, float pw, int tid)
 {
-    if (tid < L) {
-        const int dr = tid / feat_w, dc = tid % feat_w;
-        float d;
-        if (pw == 2.0f) d = sqrtf((float)(dr * dr + dc * dc));
-        else d = powf(powf((float)dr, pw) + powf((float)dc, pw), 1.0f / pw);
-        d = d / alpha;
-        s.T[tid] = 1.0f / (1.0f + d);
-        s.prc[tid] = (unsigned short)((dr << 8) | dc);
+    const int sh = grid_shift(feat_w), feat_h = L / feat_w;
+    for (int i = tid; i < kTFloats; i += blockDim.x) {
+        const int dr = i >> sh, dc = i & ((1 << sh) - 1);
+        float v = 0.0f;
+        if (dr < feat_h && dc < feat_w) {
+            float d;
+            if (pw == 2.0f) d = sqrtf((float)(dr * dr + dc * dc));
+            else d = powf(powf((float)dr, pw) + powf((float)dc, pw), 1.0f / pw);
+            d = d / alpha;
+            v = 1.0f / (1.0f + d);
+        }
+        s.T[i] = v;
     }
+    if (tid < L) s.prc[tid] = (unsigned short)(((tid / feat_w) << 8) | (tid % feat_w));
 }
 
 __device__ inline float geo_at(const Lds &s, const float *geo, int L, int feat_w, int p, int q)
@@ -168,7 +210,7 @@ __device__ inline float geo_at(const Lds &s, const float *geo, int L, int feat_w
     if (geo) return geo[p * L + q];
     const int a = s.prc[p], b = s.prc[q];
     const int dr = abs((a >> 8) - (b >> 8)), dc = abs((a & 255) - (b & 255));
-    return s.T[dr * feat_w + dc];
+    return s.T[(dr << grid_shift(feat_w)) + dc];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -179,47 +221,94 @@ __device__ inline float geo_at(const Lds &s, const float *geo, int L, int feat_w
 // ------------------------------------------------------------------------------------------
 struct PosInfo { int group, cnt, first; float attn_sum; };
 
+// Wave-parallel: every wave takes positions p = wid, wid+nw, ...; the 64 lanes hold the words of
+// q = lane + 64k (k < 4, L <= 256) and count with ballots + popcounts:
+//   cnt  = #{q : w_q == w_p}      rank = #{q < p : w_q == w_p}      less = #{q : w_q < w_p}
+// so position p lands at pos_sorted[less + rank]; a second ballot pass over the first-occurrence
+// flags gives the index of the word among the sorted distinct words.
 __device__ inline PosInfo group_positions(const Lds &s, int L, int tid, bool kept, bool want_sum)
 {
-    PosInfo r = {0, 0, 0, 0.0f};
-    if (tid == 0) s.misc[0] = 0;
+    const int lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    if (tid == 0) { s.misc[0] = 0; s.misc[1] = 0; }
     if (tid < L) s.flag[tid] = kept ? 1 : 0;
     __syncthreads();
-    int rank = 0, less = 0;
-    int64_t w = 0;
-    if (tid < L && kept) {
-        w = s.words[tid];
-        for (int q = 0; q < L; ++q) {
-            if (!s.flag[q]) continue;
-            const int64_t wq = s.words[q];
-            const int same = (wq == w);
-            r.cnt += same;
-            rank += same & (q < tid);
-            less += (wq < w);
-            if (want_sum && same) r.attn_sum = r.attn_sum + s.acls[q];   // utils.cpp:9 order
+    int64_t wq[4];
+    bool vq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = lane + SN_WAVE * k;
+        vq[k] = q < L && s.flag[q] != 0;
+        wq[k] = vq[k] ? s.words[q] : 0;
+    }
+    if (wid == 0) {
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) total += __popcll(__ballot(vq[k]));
+        if (lane == 0) s.misc[1] = total;
+    }
+    for (int p = wid; p < L; p += nw) {
+        if (!__builtin_amdgcn_readfirstlane((int)s.flag[p])) continue;
+        const int64_t wp = s.words[p];
+        int cnt = 0, less = 0, rank = 0;
+        unsigned long long eq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            eq[k] = __ballot(vq[k] && wq[k] == wp);
+            less += __popcll(__ballot(vq[k] && wq[k] < wp));
+            cnt += __popcll(eq[k]);
+            const int lo = p - SN_WAVE * k;                       // bits below position p in chunk k
+            const unsigned long long below = lo >= SN_WAVE ? ~0ull : (lo > 0 ? ((1ull << lo) - 1ull) : 0ull);
+            rank += __popcll(eq[k] & below);
         }
-        r.first = (rank == 0);
+        float sum = 0.0f;
+        if (want_sum && rank == 0) {                                 // position order (utils.cpp:9)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned long long m = eq[k];
+                while (m) {
+                    const int bit = __ffsll((long long)m) - 1;
+                    sum = sum + s.acls[SN_WAVE * k + bit];
+                    m &= m - 1;
+                }
+            }
+        }
+        if (lane == 0) {
+            s.pless[p] = (unsigned short)less;
+            s.pcnt[p] = (unsigned short)cnt;
+            s.psum[p] = sum;
+            s.pos_sorted[less + rank] = (unsigned char)p;
+            s.flag[p] = (unsigned char)(1 | (rank == 0 ? 2 : 0));
+        }
     }
     __syncthreads();
-    if (tid < L) s.flag[tid] = (unsigned char)((kept ? 1 : 0) | (r.first ? 2 : 0));
-    __syncthreads();
-    if (tid < L && kept) {
+    bool fq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = lane + SN_WAVE * k;
+        fq[k] = vq[k] && (s.flag[q] & 2) != 0;
+    }
+    for (int p = wid; p < L; p += nw) {
+        if (!(__builtin_amdgcn_readfirstlane((int)s.flag[p]) & 2)) continue;
+        const int64_t wp = s.words[p];
         int g = 0;
-        for (int q = 0; q < L; ++q) g += ((s.flag[q] & 2) != 0) & (s.words[q] < w);
-        r.group = g;
-        s.pos_sorted[less + rank] = (unsigned char)tid;
-        if (r.first) {
-            s.gstart[g] = (unsigned short)less;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g += __popcll(__ballot(fq[k] && wq[k] < wp));
+        if (lane == 0) {
+            s.pgroup[p] = (unsigned char)g;
+            s.gstart[g] = s.pless[p];
             atomicMax(&s.misc[0], g + 1);
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        int total = 0;
-        for (int q = 0; q < L; ++q) total += (s.flag[q] & 1);
-        s.gstart[s.misc[0]] = (unsigned short)total;
-    }
+    if (tid == 0) s.gstart[s.misc[0]] = (unsigned short)s.misc[1];
     __syncthreads();
+    PosInfo r = {0, 0, 0, 0.0f};
+    if (tid < L && kept) {
+        r.first = (s.flag[tid] & 2) != 0;
+        r.cnt = s.pcnt[tid];
+        r.group = r.first ? s.pgroup[tid] : 0;
+        r.attn_sum = r.first ? s.psum[tid] : 0.0f;
+    }
     return r;
 }
 
@@ -237,35 +326,127 @@ __device__ inline float block_max_nan(const Lds &s, float v, bool valid, int tid
     return nanf_ > 0.0f ? NAN : out;
 }
 
-// one cell: sequential fp32 sums over (p in group gi) x (q in group gj), p-major
-__device__ inline void cell_sums(const Lds &s, const float *geo, int L, int feat_w, int gi, int gj,
-                                 int mean, float &out_geo, float &out_attn)
+// Edge cells.  A lane owns up to 4 output columns for every row its wave processes, so the
+// positions of its columns' words are cached in registers once (<= 4 positions per word; longer
+// lists fall back to LDS).  One cell = sequential fp32 sums over (p in group gi) x (q in group
+// gj), p-major (large_scale_feat_to_e.cpp:99-125).
+constexpr int kQCache = 4;
+
+struct ColCache {
+    int cnt[kCellsPerLane];                 // positions of the column's word (0 = no column)
+    int ja[kCellsPerLane];                  // start in pos_sorted
+    int q4[kCellsPerLane][kQCache];         // byte offset of the position inside an attention row
+    int qr[kCellsPerLane][kQCache];         // grid row of the position
+    int qc4[kCellsPerLane][kQCache];        // 4 * grid column
+    int tmax[kCellsPerLane];                // wave-uniform: largest cnt of chunk k over the 64 lanes
+};
+
+__device__ inline void cache_columns(const Lds &s, const int (&gj)[kCellsPerLane], ColCache &cc)
 {
-    const int ia = s.gstart[gi], ib = s.gstart[gi + 1];
-    const int ja = s.gstart[gj], jb = s.gstart[gj + 1];
-    float sa = 0.0f, sg = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        cc.cnt[k] = 0; cc.ja[k] = 0;
+        if (gj[k] >= 0) { cc.ja[k] = s.gstart[gj[k]]; cc.cnt[k] = s.gstart[gj[k] + 1] - cc.ja[k]; }
+        int tm = 0;
+#pragma unroll
+        for (int t = 0; t < kQCache; ++t) {
+            const int q = t < cc.cnt[k] ? s.pos_sorted[cc.ja[k] + t] : 0;
+            const int rc = s.prc[q];
+            cc.q4[k][t] = q * 4;
+            cc.qr[k][t] = rc >> 8;
+            cc.qc4[k][t] = (rc & 255) * 4;
+        }
+        tm = (int)sn_wave_max((float)cc.cnt[k]);
+        cc.tmax[k] = tm;
+    }
+}
+
+template <bool kGrid>
+__device__ __forceinline__ void row_cells_impl(const Lds &s, const float *geo, int L, int feat_w, int gi, const ColCache &cc,
+                                               bool any_long, int mean, float (&c0)[kCellsPerLane], float (&c1)[kCellsPerLane])
+{
+    const int ia = __builtin_amdgcn_readfirstlane((int)s.gstart[gi]);
+    const int ib = __builtin_amdgcn_readfirstlane((int)s.gstart[gi + 1]);
+    const int tsh = grid_shift(feat_w) + 2;                 // byte shift of a table row
+    float sa[kCellsPerLane], sg[kCellsPerLane];
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) { sa[k] = 0.0f; sg[k] = 0.0f; }
     for (int x = ia; x < ib; ++x) {
-        const int p = s.pos_sorted[x];
-        for (int y = ja; y < jb; ++y) {
-            const int q = s.pos_sorted[y];
-            sa = sa + s.A[p * L + q];
-            sg = sg + geo_at(s, geo, L, feat_w, p, q);
+        const int p = __builtin_amdgcn_readfirstlane((int)s.pos_sorted[x]);
+        const int prc = __builtin_amdgcn_readfirstlane((int)s.prc[p]);
+        const unsigned pr = prc >> 8, pc4 = (prc & 255) * 4;
+        const char *arow = reinterpret_cast<const char *>(s.A + p * L);
+        const char *tbase = reinterpret_cast<const char *>(s.T);
+        const float *grow = kGrid ? nullptr : geo + (int64_t)p * L;
+        (void)any_long;
+#pragma unroll
+        for (int k = 0; k < kCellsPerLane; ++k) {
+#pragma unroll
+            for (int t = 0; t < kQCache; ++t) {             // positions cached in registers
+                if (t >= cc.tmax[k]) break;                 // wave-uniform: nobody has a t-th position
+                const bool on = t < cc.cnt[k];
+                float av = *reinterpret_cast<const float *>(arow + cc.q4[k][t]);
+                float gv;
+                if (kGrid) {
+                    const unsigned dr = __usad(pr, (unsigned)cc.qr[k][t], 0u);
+                    const unsigned off = (dr << tsh) + __usad(pc4, (unsigned)cc.qc4[k][t], 0u);
+                    gv = *reinterpret_cast<const float *>(tbase + off);
+                } else {
+                    gv = grow[cc.q4[k][t] >> 2];
+                }
+                av = on ? av : 0.0f;                        // x + 0 == x: unused slots do not disturb the sum order
+                gv = on ? gv : 0.0f;
+                sa[k] = sa[k] + av;
+                sg[k] = sg[k] + gv;
+            }
+            for (int t = kQCache; t < cc.tmax[k]; ++t) {    // words covering > 4 positions: list read from LDS
+                const bool on = t < cc.cnt[k];
+                const int q = on ? (int)s.pos_sorted[cc.ja[k] + t] : 0;
+                float av = *reinterpret_cast<const float *>(arow + q * 4);
+                float gv;
+                if (kGrid) {
+                    const int rc = s.prc[q];
+                    const unsigned dr = __usad(pr, (unsigned)(rc >> 8), 0u);
+                    const unsigned off = (dr << tsh) + __usad(pc4, (unsigned)((rc & 255) * 4), 0u);
+                    gv = *reinterpret_cast<const float *>(tbase + off);
+                } else {
+                    gv = grow[q];
+                }
+                av = on ? av : 0.0f;
+                gv = on ? gv : 0.0f;
+                sa[k] = sa[k] + av;
+                sg[k] = sg[k] + gv;
+            }
         }
     }
-    if (mean) {
-        const float n = (float)((ib - ia) * (jb - ja));
-        sa = sa / n;
-        sg = sg / n;
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        const bool has = cc.cnt[k] > 0;
+        const float n = (float)((ib - ia) * (has ? cc.cnt[k] : 1));
+        c0[k] = has ? (mean ? sg[k] / n : sg[k]) : 0.0f;
+        c1[k] = has ? (mean ? sa[k] / n : sa[k]) : 0.0f;
     }
-    out_geo = sg;
-    out_attn = sa;
+}
+
+__device__ inline void row_cells(const Lds &s, const float *geo, int L, int feat_w, int gi, const ColCache &cc,
+                                 bool any_long, int mean, float (&c0)[kCellsPerLane], float (&c1)[kCellsPerLane])
+{
+    if (geo) row_cells_impl<false>(s, geo, L, feat_w, gi, cc, any_long, mean, c0, c1);
+    else row_cells_impl<true>(s, geo, L, feat_w, gi, cc, any_long, mean, c0, c1);
 }
 
 // ------------------------------------------------------------------------------------------
 // S2 + S3 kernel
 // ------------------------------------------------------------------------------------------
+static unsigned long long *g_graph_stamps = nullptr;      // diagnostics only (sn_debug_set_graph_stamps)
+
+#define SN_GSTAMP(slot)                                                                          \
+    do {                                                                                          \
+        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 template <bool kEdges>
-__global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a)
+__global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a, unsigned long long *stamps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = a.L, b = blockIdx.x, tid = threadIdx.x;
@@ -273,6 +454,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     const Lds s = carve(smem, L, kEdges);
     const bool do_v = a.attn_cls != nullptr;
 
+    SN_GSTAMP(0);
     // ---- stream this image's attention map into LDS (the only large HBM read)
     if (kEdges) {
         attn_rows_to_lds(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
@@ -287,10 +469,10 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     if (do_v && wid == nw - 1) {
         const float *row = a.attn_cls + (int64_t)b * a.acls_stride_b;
         float x[4];
-        load_row4(row, L, lane, false, x);
+        load_row4<false>(row, L, lane, x);
         for (int h = 1; h < a.acls_heads; ++h) {
             float y[4];
-            load_row4(row + h * a.acls_stride_h, L, lane, false, y);
+            load_row4<false>(row + h * a.acls_stride_h, L, lane, y);
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] += y[k];
         }
@@ -307,7 +489,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                         (a.use_clamp_v && x[k] < a.clamp_v) ? -INFINITY : x[k];
                 }
             }
-            softmax_row4(x, L, lane, false, a.use_clamp_v != 0, a.clamp_v);
+            softmax_row4<false>(x, L, lane, a.use_clamp_v != 0, a.clamp_v);
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = sn_nan_to_num(x[k]);
         }
@@ -319,8 +501,10 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     }
     __syncthreads();
 
+    SN_GSTAMP(1);
     // ---- group positions by word
     const PosInfo me = group_positions(s, L, tid, tid < L, do_v);
+    SN_GSTAMP(2);
     const int n_groups = s.misc[0];
     const bool owner = tid < L && me.first;
 
@@ -352,6 +536,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
         for (int c = n_groups + tid; c < a.n_pad; c += blockDim.x) a.out_ids[(int64_t)b * a.n_pad + c] = a.pad_id;
     }
     if (!kEdges) return;
+    SN_GSTAMP(3);
 
     // ---- output row of every group: canonical rank, or the caller's dictionary
     // (large_scale_feat_to_e.cpp:117-118; missing key -> 0; on collisions the last (gi, gj) in
@@ -377,21 +562,31 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     }
     __syncthreads();
 
+    SN_GSTAMP(4);
     // ---- edges: one wave per output row, lanes over output columns
     // (large_scale_feat_to_e.cpp:90-140)
     const float w0 = a.w_e[0], w1 = a.w_e[1];
+    int gcol[kCellsPerLane];
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        const int c = lane + SN_WAVE * k;
+        gcol[k] = c < n_out ? s.rev[c] : -1;
+    }
+    ColCache cc;
+    cache_columns(s, gcol, cc);
+    const bool any_long = __any(cc.cnt[0] > kQCache || cc.cnt[1] > kQCache || cc.cnt[2] > kQCache || cc.cnt[3] > kQCache) != 0;
     for (int r = wid; r < a.n_pad; r += nw) {
         const int gi = (r < n_out && r < kMaxCols) ? s.rev[r] : -1;
         float c0[kCellsPerLane], c1[kCellsPerLane];
         float t0 = 0.0f, t1 = 0.0f;
+        if (gi >= 0) {
+            row_cells(s, a.geo, L, a.feat_w, gi, cc, any_long, a.mean, c0, c1);
+        } else {
 #pragma unroll
-        for (int k = 0; k < kCellsPerLane; ++k) {
-            const int c = lane + SN_WAVE * k;
-            const int gj = (gi >= 0 && c < n_out) ? s.rev[c] : -1;
-            c0[k] = 0.0f; c1[k] = 0.0f;
-            if (gj >= 0) cell_sums(s, a.geo, L, a.feat_w, gi, gj, a.mean, c0[k], c1[k]);
-            t0 += c0[k]; t1 += c1[k];
+            for (int k = 0; k < kCellsPerLane; ++k) { c0[k] = 0.0f; c1[k] = 0.0f; }
         }
+#pragma unroll
+        for (int k = 0; k < kCellsPerLane; ++k) { t0 += c0[k]; t1 += c1[k]; }
         t0 = sn_wave_sum(t0);     // instance_edges.sum(1, keepdim)  :135
         t1 = sn_wave_sum(t1);
         const int64_t rowbase = ((int64_t)b * a.n_pad + r) * a.n_pad;
@@ -416,6 +611,8 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if (a.out_e) a.out_e[rowbase + c] = 0.0f;
         }
     }
+    __syncthreads();
+    SN_GSTAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -433,8 +630,8 @@ __global__ __launch_bounds__(256) void full_vertices_kernel(
     const bool want_attn = !ingredients_only && attn_cls != nullptr;
     if (want_attn && wid == nw - 1) {
         float x[4];
-        load_row4(attn_cls + (int64_t)b * L, L, lane, false, x);
-        if (is_logits) softmax_row4(x, L, lane, false, use_clamp != 0, clamp);   // no nan_to_num (:202)
+        load_row4<false>(attn_cls + (int64_t)b * L, L, lane, x);
+        if (is_logits) softmax_row4<false>(x, L, lane, use_clamp != 0, clamp);   // no nan_to_num (:202)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = lane + SN_WAVE * k;
@@ -499,17 +696,19 @@ __global__ __launch_bounds__(1024) void limited_edges_kernel(
     if (tid < L && me.first && my_slot >= 0) s.rev[me.group] = my_slot;
     __syncthreads();
     const float w0 = w_e ? w_e[0] : 0.0f, w1 = w_e ? w_e[1] : 0.0f;
+    int gcol[kCellsPerLane];
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) gcol[k] = (lane + SN_WAVE * k) < n_groups ? lane + SN_WAVE * k : -1;
+    ColCache cc;
+    cache_columns(s, gcol, cc);
+    const bool any_long = __any(cc.cnt[0] > kQCache || cc.cnt[1] > kQCache || cc.cnt[2] > kQCache || cc.cnt[3] > kQCache) != 0;
     for (int gi = wid; gi < n_groups; gi += nw) {
         const int si = s.rev[gi];
         float c0[kCellsPerLane], c1[kCellsPerLane];
         float t0 = 0.0f, t1 = 0.0f;
+        row_cells(s, geo, L, feat_w, gi, cc, any_long, mean, c0, c1);
 #pragma unroll
-        for (int k = 0; k < kCellsPerLane; ++k) {
-            const int gj = lane + SN_WAVE * k;
-            c0[k] = 0.0f; c1[k] = 0.0f;
-            if (gj < n_groups) cell_sums(s, geo, L, feat_w, gi, gj, mean, c0[k], c1[k]);
-            t0 += c0[k]; t1 += c1[k];
-        }
+        for (int k = 0; k < kCellsPerLane; ++k) { t0 += c0[k]; t1 += c1[k]; }
         t0 = sn_wave_sum(t0);     // normalize_sum_(edges_attr, dim=2)  schema_net.py:249
         t1 = sn_wave_sum(t1);
 #pragma unroll
@@ -637,15 +836,18 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
         int rc = ensure_lds((const void *)instance_graph_kernel<true>, lds, "sn_instance_graph");
         if (rc) return rc;
         sn_prof_start(2, st);
-        hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a);
+        hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps);
         sn_prof_stop(2, st);
     } else {
         const size_t lds = lds_bytes(a.L, false);
-        hipLaunchKernelGGL(instance_graph_kernel<false>, dim3(a.B), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(instance_graph_kernel<false>, dim3(a.B), dim3(256), lds, st, a, (unsigned long long *)nullptr);
     }
     SN_CHECK_LAUNCH("sn_instance_graph");
     return SN_OK;
 }
+
+/* diagnostics: device buffer of 8 x u64 per image for instance_graph_kernel<true> (NULL = off) */
+extern "C" void sn_debug_set_graph_stamps(void *device_buffer) { g_graph_stamps = (unsigned long long *)device_buffer; }
 
 extern "C" int sn_full_vertices(const int64_t *ingredients, int64_t ing_stride_b, int64_t ing_stride_l,
                                 const float *attn_cls, int B, int L, int M, int is_logits, int use_clamp,
