@@ -118,9 +118,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device)               # "nccl" is RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import cpp_extension
@@ -132,7 +133,7 @@ def main():
         disc.vocabulary.weight.copy_(codebook)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -156,12 +157,12 @@ def main():
             pred = m.forward_padded(g, atlas)
             ev[4].record()
             ops.class_votes_(pred, votes)                # per-class vote aggregation (HIP, no host sync)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(votes)                       # per-class schema statistics over RCCL
         barrier()
         dt = time.perf_counter() - t0
     t_max = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max.item())
     assert int(votes[K].item()) == B * args.steps * world
@@ -215,7 +216,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     lib.sn_profile_enable(0)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -30,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTokPerWave = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTokPerBlock = kTokPerWave * kWavesPerBlock;
-constexpr int kRing = 2;               // LDS slots for codebook tiles (register-staged double buffer)
+constexpr int kRing = 3;               // LDS slots for codebook tiles (LDS-DMA ring, two tiles in flight)
 constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
 constexpr int kEntryInts = 32;          // work-list entry: [0] token, [1] 24-bit candidate mask, [2..25] words
 constexpr int kMaxTilesScreen = 64;     // 6-bit tile code in the keys -> M <= 2048 on the MFMA path
@@ -370,28 +370,28 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
     const int n_tiles = lay.n_tiles;
 
-    // codebook tiles: global -> registers (issued before the MFMAs of the previous tile) -> LDS
-    // (written after them): plain loads so that hipcc's counted vmcnt keeps them in flight across
-    // the compute phase (an LDS-DMA prefetch is drained by the vmcnt(0) hipcc puts before every
-    // ds_read that follows it).
-    constexpr int kCopies = (kTileBytes + 4095) / 4096;          // 16-B pieces per thread
-    f32x4 stage[kCopies];
-    auto load_tile = [&](int w) {
-        const unsigned char *src = tiles + (size_t)w * kTileBytes + tid * 16;
+    // codebook tiles: L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
+    // VGPRs).  Issued through inline asm and waited for by hand: when hipcc sees an LDS-DMA it
+    // drains it with vmcnt(0) before every later ds_read, which serialises the prefetch.  Wave w
+    // issues chunks w, w+4, ...; a counted vmcnt at the top of each tile keeps the tile after next
+    // in flight across the barrier.
+    constexpr int kDmaPerWave = (kChunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    auto issue_tile = [&](int w, int slot) {
 #pragma unroll
-        for (int j = 0; j < kCopies; ++j)
-            if (j * 4096 + tid * 16 < kTileBytes) stage[j] = *reinterpret_cast<const f32x4 *>(src + j * 4096);
-    };
-    auto store_tile = [&](int slot) {
-        unsigned char *dst = smem + slot * kTileBytes + tid * 16;
-#pragma unroll
-        for (int j = 0; j < kCopies; ++j)
-            if (j * 4096 + tid * 16 < kTileBytes) *reinterpret_cast<f32x4 *>(dst + j * 4096) = stage[j];
+        for (int j = 0; j < kDmaPerWave; ++j) {
+            const int c = min(wid + kWavesPerBlock * j, kChunks - 1);     // (waves 1..3 repeat the last chunk: same bytes)
+            const unsigned char *src = tiles + (size_t)w * kTileBytes + c * 1024 + lane * 16;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + c * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
     };
     const int wave_id = blockIdx.x * kWavesPerBlock + wid;
     stamp(p, 0, lane, wave_id);
-    load_tile(0);
-    store_tile(0);
+    issue_tile(0, 0);
+    if (n_tiles > 1) issue_tile(1, 1);
 
     // ---- this wave's 32 tokens: fp32 -> fp16 B fragments, kept in registers for the whole kernel
     const int64_t n = (int64_t)blockIdx.x * kTokPerBlock + wid * kTokPerWave + r;
@@ -455,10 +455,14 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
 
     for (int w = 0; w < n_tiles; ++w) {
         const unsigned long long tb0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
-        __syncthreads();                 // tile w is in LDS; the other slot is free
+        // tile w has landed for this wave once at most the DMAs of tile w+1 are outstanding; the
+        // barrier then makes every wave's part visible and frees slot (w+2) % 3 (read at tile w-1)
+        if (w + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         const unsigned long long tb1 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
         t_bar += tb1 - tb0;
-        if (w + 1 < n_tiles) load_tile(w + 1);
+        if (w + 2 < n_tiles) issue_tile(w + 2, (w + 2) % kRing);
         const unsigned char *slot = smem + (w % kRing) * kTileBytes;
         const unsigned char *frag = slot + lane * 16;
         // A fragments through a 4-deep register ring so ds_read latency hides behind the MFMAs
@@ -522,12 +526,7 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
             asm volatile("" :: "v"(m1[0]), "v"(m1[1]), "v"(m1[2]), "v"(m1[3]), "v"(m3[0]), "v"(m3[1]), "v"(m3[2]), "v"(m3[3]));
             const unsigned long long tb4 = __builtin_amdgcn_s_memtime();
             t_keys += tb4 - tb2;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            t_vm += __builtin_amdgcn_s_memtime() - tb4;
         }
-        const unsigned long long tb5 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
-        if (w + 1 < n_tiles) store_tile((w + 1) % kRing);
-        if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_st += __builtin_amdgcn_s_memtime() - tb5; }
     }
 
     stamp(p, 2, lane, wave_id);

@@ -59,8 +59,6 @@ print("  token load+convert: median %.0f  max %.0f" % ((s8[:, 1] - s8[:, 0]).med
 print("  main loop:          median %.0f  max %.0f" % ((s8[:, 2] - s8[:, 1]).median(), (s8[:, 2] - s8[:, 1]).max()))
 print("     of which barrier wait median %.0f, mfma section median %.0f" % (s8[:, 4].median(), s8[:, 5].median()))
 print("     wait for last MFMA median %.0f, key/insert VALU median %.0f" % (s8[:, 6].median(), s8[:, 7].median()))
-print("     vmcnt(0) wait for the staged tile median %.0f" % s8[:, 8].median())
-print("     ds_write of the staged tile median %.0f, chunk unpack median %.0f" % (s8[:, 9].median(), s8[:, 10].median()))
 print("  tail:               median %.0f" % ((s8[:, 3] - s8[:, 2]).median()))
 print("  per-wave total:     median %.0f  max %.0f" % ((s8[:, 3] - s8[:, 0]).median(), (s8[:, 3] - s8[:, 0]).max()))
 
