@@ -45,10 +45,10 @@ constexpr float kAccUlpPerMfma = 8.0f * 5.9604645e-8f;
 //   tiles   [n_tiles][n_steps + 1][1 KiB]   per 32-word tile: n_steps chunks of fp16 MFMA A-fragments
 //                                           holding -c (negated), then one chunk whose first 128 B
 //                                           are |c|^2 / 2 (fp32) in accumulator-row order
-//   cn64    [M_pad] f64  |c|^2 (oracle summation order)     cbT [D][M_pad] f32 (transposed copy)
+//   cn64    [M_pad] f64  |c|^2 (oracle summation order)
 //   scal    [0] max |c|_2  [1] max |c|_1  [2] max |c|^2  [3] max |c_mk|   (uint bits of floats)
 struct PackLayout {
-    size_t tiles_off, cn64_off, cbt_off, scal_off, total;
+    size_t tiles_off, cn64_off, scal_off, total;
     int n_tiles, n_steps, tile_bytes, m_pad;
 };
 
@@ -61,8 +61,7 @@ __host__ __device__ inline PackLayout pack_layout(int M, int D)
     p.tile_bytes = (p.n_steps + 1) * 1024;
     p.tiles_off = 0;
     p.cn64_off = (size_t)p.n_tiles * p.tile_bytes;
-    p.cbt_off = p.cn64_off + (((size_t)p.m_pad * 8 + 255) & ~size_t(255));
-    p.scal_off = p.cbt_off + (((size_t)p.m_pad * D * 4 + 255) & ~size_t(255));
+    p.scal_off = p.cn64_off + (((size_t)p.m_pad * 8 + 255) & ~size_t(255));
     p.total = p.scal_off + 256;
     return p;
 }
@@ -84,7 +83,7 @@ __device__ __forceinline__ double dot64(const double (&x)[NT], const float *c, i
 // codebook_prepare
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_frag_kernel(const float *cb, int M, int D, unsigned char *tiles,
-                                                        int n_steps, int tile_bytes, float *cbT, int m_pad)
+                                                        int n_steps, int tile_bytes)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [M_pad, D]
     const int m = (int)(idx / D), k = (int)(idx % D);
@@ -95,7 +94,6 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float *cb, int M, 
     const float v = m < M ? cb[(int64_t)m * D + k] : 0.0f;
     _Float16 *frag = (_Float16 *)(tiles + (size_t)w * tile_bytes + (size_t)s * 1024);
     frag[(i + 32 * h) * 8 + j] = (_Float16)(-v);
-    cbT[(int64_t)k * m_pad + m] = v;
 }
 
 __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, int D, int m_pad, unsigned char *tiles,
@@ -216,12 +214,14 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 //            re-ranked in fp64.  All fp64 scores use the oracle's summation order.
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxSurvivors = 64;
+constexpr int kOverflowBlocks = 64;     // blocks reserved for phase B
 
 template <int NT>
 __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
 {
     __shared__ float xs[NT * SN_WAVE];
-    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) _Float16 xh[NT * SN_WAVE];
+    __shared__ float red[12];
     __shared__ int surv[kMaxSurvivors];
     __shared__ int n_surv;
     __shared__ double best_s[4];
@@ -229,13 +229,12 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const PackLayout lay = pack_layout(p.M, p.D);
     const double *cn64 = (const double *)(p.packed + lay.cn64_off);
-    const float *cbT = (const float *)(p.packed + lay.cbt_off);
     const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
 
-    // ---- phase A
+    // ---- phase A (blocks kOverflowBlocks .. gridDim.x - 1)
     const int count = p.work[0];
-    const int n_waves = gridDim.x * kWavesPerBlock;
-    for (int e = blockIdx.x * kWavesPerBlock + wid; e < count; e += n_waves) {
+    const int n_waves = ((int)gridDim.x - kOverflowBlocks) * kWavesPerBlock;
+    for (int e = ((int)blockIdx.x - kOverflowBlocks) * kWavesPerBlock + wid; e < count && (int)blockIdx.x >= kOverflowBlocks; e += n_waves) {
         const int *ent = p.work + 8 + (int64_t)e * kEntryInts;
         const int64_t n = ent[0];
         const int cmask = ent[1];
@@ -253,65 +252,88 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
         // (all candidates NaN cannot happen: such tokens are routed to the overflow list)
     }
 
-    // ---- phase B
-    const int n_over = p.work[1];
-    for (int e = blockIdx.x; e < n_over; e += gridDim.x) {
+    // ---- phase B: every word of the overflow tokens, from the fp16 tile image (L2-hot: the screen
+    // kernel has just streamed it) with v_dot2_f32_f16; candidates = everything inside the fp16
+    // error window of the best, then fp64.
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    const unsigned char *tiles = p.packed + lay.tiles_off;
+    const int n_over = (int)blockIdx.x < kOverflowBlocks ? p.work[1] : 0;     // blocks 0 .. kOverflowBlocks - 1 only
+    for (int e = blockIdx.x; e < n_over; e += kOverflowBlocks) {
         const int64_t n = p.overflow[e];
         const float *row = token_row(p, n);
         __syncthreads();
-        float sq = 0.0f;
+        float sq = 0.0f, sabs = 0.0f, mabs = 0.0f;
         for (int k = tid; k < NT * SN_WAVE; k += 256) {
             const float v = k < p.D ? row[k] : 0.0f;
             xs[k] = v;
+            xh[k] = (_Float16)v;
             sq = fmaf(v, v, sq);
+            sabs += fabsf(v);
+            mabs = fmaxf(mabs, fabsf(v));
         }
         if (tid == 0) n_surv = 0;
-        sq = sn_wave_sum(sq);
-        if (lane == 0) red[wid] = sq;
+        sq = sn_wave_sum(sq); sabs = sn_wave_sum(sabs); mabs = sn_wave_max(mabs);
+        if (lane == 0) { red[wid] = sq; red[4 + wid] = sabs; red[8 + wid] = mabs; }
         __syncthreads();
         const float X2 = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * 1.001f;
-        const float C2 = __uint_as_float(scal[0]), CN = __uint_as_float(scal[2]);
-        // |fp32 chain - exact| <= gamma_D * sum|x_k c_k|  (+ the |c|^2/2 rounding)
-        const float e32 = 1.01f * ((float)(p.D + 2) * 5.9604645e-8f * X2 * C2 + 6.0e-8f * CN);
-        const bool finite = e32 < 1.0e30f;        // false for NaN / inf tokens
+        const float X1 = ((red[4] + red[5]) + (red[6] + red[7])) * 1.001f;
+        const float XM = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+        const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
+        const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
+        const float vmax = 0.5f * CN + X2 * C2;
+        // |score_fp16 - score_exact| <= e16: fp16 rounding of both operands, subnormal flush,
+        // fp32 accumulation of the dot2 chain, rounding of |c|^2/2
+        const float e16 = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1) +
+                                   2.0f * (float)(p.D + 2) * 5.9604645e-8f * vmax + 1.2e-7f * vmax);
+        const bool finite = (XM <= kHugeIn) && (CMAX <= kHugeIn) && (e16 < 1.0e30f);   // false for NaN / inf / huge
         float smin = INFINITY;
-        // pass 1: fp32 score of every word (thread = word, coalesced reads of the transposed
-        // codebook, 8 loads in flight), kept in registers for pass 2 (<= 8 words per thread)
         float sc[8];
 #pragma unroll
-        for (int j0 = 0; j0 < 8; j0 += 2) {                 // two words per thread at a time: 32 loads in flight
-            const int ma = tid + 256 * j0, mb = ma + 256;
-            sc[j0] = INFINITY; sc[j0 + 1] = INFINITY;
-            if (ma >= p.M) continue;
+        for (int j = 0; j < 8; j += 2) {                                 // two words per thread in flight
+            const int ma = tid + 256 * j, mb = ma + 256;
+            sc[j] = INFINITY; sc[j + 1] = INFINITY;
+            if (ma >= p.M || !finite) continue;
             const bool has_b = mb < p.M;
-            const float *ca = cbT + ma, *cbp = cbT + (has_b ? mb : ma);
+            const int i = ma & 31;                                       // (mb & 31) == i as well
+            const unsigned char *ta = tiles + (size_t)(ma >> 5) * lay.tile_bytes;
+            const unsigned char *tb = tiles + (size_t)((has_b ? mb : ma) >> 5) * lay.tile_bytes;
             float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
-            for (int k = 0; k < p.D; k += 16) {
-                float va[16], vb[16];
+            for (int s2 = 0; s2 < lay.n_steps; s2 += 2) {                // two k-steps = 32 consecutive k
+                float4 fa[4], fb[4];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) { va[q] = ca[(int64_t)(k + q) * lay.m_pad]; vb[q] = cbp[(int64_t)(k + q) * lay.m_pad]; }
+                for (int q = 0; q < 4; ++q) {                            // (step s2 + (q & 1), half q >> 1)
+                    const size_t off = (size_t)(s2 + (q & 1)) * 1024 + (i + 32 * (q >> 1)) * 16;
+                    fa[q] = *reinterpret_cast<const float4 *>(ta + off);
+                    fb[q] = *reinterpret_cast<const float4 *>(tb + off);
+                }
 #pragma unroll
-                for (int q = 0; q < 16; q += 2) {
-                    a0 = fmaf(xs[k + q], va[q], a0); a1 = fmaf(xs[k + q + 1], va[q + 1], a1);
-                    b0 = fmaf(xs[k + q], vb[q], b0); b1 = fmaf(xs[k + q + 1], vb[q + 1], b1);
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 16 * s2 + 16 * (q >> 1) + 8 * (q & 1);
+                    const half2_t *x2 = reinterpret_cast<const half2_t *>(xh + k0);
+                    const half2_t *ca = reinterpret_cast<const half2_t *>(&fa[q]);
+                    const half2_t *cb2 = reinterpret_cast<const half2_t *>(&fb[q]);
+                    a0 = __builtin_amdgcn_fdot2(x2[0], ca[0], a0, false);  b0 = __builtin_amdgcn_fdot2(x2[0], cb2[0], b0, false);
+                    a1 = __builtin_amdgcn_fdot2(x2[1], ca[1], a1, false);  b1 = __builtin_amdgcn_fdot2(x2[1], cb2[1], b1, false);
+                    a0 = __builtin_amdgcn_fdot2(x2[2], ca[2], a0, false);  b0 = __builtin_amdgcn_fdot2(x2[2], cb2[2], b0, false);
+                    a1 = __builtin_amdgcn_fdot2(x2[3], ca[3], a1, false);  b1 = __builtin_amdgcn_fdot2(x2[3], cb2[3], b1, false);
                 }
             }
-            sc[j0] = (float)(0.5 * cn64[ma]) - (a0 + a1);
-            smin = fminf(smin, sc[j0]);
-            if (has_b) { sc[j0 + 1] = (float)(0.5 * cn64[mb]) - (b0 + b1); smin = fminf(smin, sc[j0 + 1]); }
+            const int g = i >> 3, hh = (i >> 2) & 1, ee = i & 3;
+            const size_t hoff = (size_t)lay.n_steps * 1024 + ((g * 2 + hh) * 4 + ee) * 4;
+            sc[j] = *reinterpret_cast<const float *>(ta + hoff) + (a0 + a1);      // dist^2/2 - |x|^2/2 (tiles hold -c)
+            smin = fminf(smin, sc[j]);
+            if (has_b) { sc[j + 1] = *reinterpret_cast<const float *>(tb + hoff) + (b0 + b1); smin = fminf(smin, sc[j + 1]); }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) smin = fminf(smin, __shfl_xor(smin, off, SN_WAVE));
+        smin = sn_wave_min(smin);
         __syncthreads();
         if (lane == 0) red[wid] = smin;
         __syncthreads();
         smin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-        // pass 2: survivors inside the rigorous fp32 window
         bool too_many = p.M > 2048;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int m = tid + 256 * j;
-            if (m < p.M && finite && sc[j] <= smin + 2.0f * e32) {
+            if (m < p.M && finite && sc[j] <= smin + 2.0f * e16) {
                 const int slot = atomicAdd(&n_surv, 1);
                 if (slot < kMaxSurvivors) surv[slot] = m;
             }
@@ -622,7 +644,7 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
-    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(1024), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(kOverflowBlocks + 2048), dim3(256), 0, st, a);
     sn_prof_stop(1, st);
     return 0;
 }
@@ -653,7 +675,7 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
     }
     const int64_t elems = (int64_t)lay.m_pad * D;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)(elems / 256)), dim3(256), 0, st, codebook, M, D,
-                       base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (float *)(base + lay.cbt_off), lay.m_pad);
+                       base + lay.tiles_off, lay.n_steps, lay.tile_bytes);
     hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((lay.m_pad + 3) / 4)), dim3(256), 0, st, codebook, M, D, lay.m_pad,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (double *)(base + lay.cn64_off),
                        (unsigned *)(base + lay.scal_off));

@@ -55,10 +55,38 @@ __device__ __forceinline__ float sn_wave_sum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// fp64 xor butterfly (off = 32, 16, 8, 4, 2, 1): the summation order of the oracle's sno_dot64.
+// Same values as six __shfl_xor steps, but moved with v_permlane32/16_swap and DPP instead of
+// ds_bpermute (checked bit for bit on MI355X by tools/f64sum_probe).  xor 8 / xor 4 use
+// row_ror:8 / row_ror:4: after the previous step the values have period 16 / 8 inside a row, so
+// the rotated lane holds exactly the value of the xor lane.
+__device__ __forceinline__ double sn_f64_from(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+
+#define SN_DPP_U32(v, ctrl) ((unsigned)__builtin_amdgcn_mov_dpp((int)(v), (ctrl), 0xF, 0xF, false))
+
 __device__ __forceinline__ double sn_wave_sum_f64(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, SN_WAVE);
+    const int lane = threadIdx.x & 63;
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v += sn_f64_from(lane < 32 ? a[1] : a[0], lane < 32 ? b[1] : b[0]);
+    }
+    lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+    {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v += sn_f64_from((lane & 16) ? a[0] : a[1], (lane & 16) ? b[0] : b[1]);
+    }
+    lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+    v += sn_f64_from(SN_DPP_U32(lo, 0x128), SN_DPP_U32(hi, 0x128));      // row_ror:8  == xor 8
+    lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+    v += sn_f64_from(SN_DPP_U32(lo, 0x124), SN_DPP_U32(hi, 0x124));      // row_ror:4  == xor 4
+    lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+    v += sn_f64_from(SN_DPP_U32(lo, 0x4E), SN_DPP_U32(hi, 0x4E));        // quad_perm [2,3,0,1] == xor 2
+    lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+    v += sn_f64_from(SN_DPP_U32(lo, 0xB1), SN_DPP_U32(hi, 0xB1));        // quad_perm [1,0,3,2] == xor 1
     return v;
 }
 

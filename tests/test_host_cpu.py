@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.sn_abi_version() == N.ABI_VERSION
     assert lib.sn_last_error() is not None
     # size helpers are pure host code
-    assert lib.sn_codebook_pack_bytes(512, 384) == 16 * 25 * 1024 + 4096 + 512 * 384 * 4 + 256
+    assert lib.sn_codebook_pack_bytes(512, 384) == 16 * 25 * 1024 + 4096 + 256
     assert lib.sn_codebook_pack_bytes(512, 30) == 0
     assert lib.sn_assign_workspace_bytes(50176) == 32 + 50176 * 132
 
