@@ -20,6 +20,7 @@
 #include "sn_common.h"
 
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -55,7 +56,7 @@ struct PackLayout {
 __host__ __device__ inline PackLayout pack_layout(int M, int D)
 {
     PackLayout p;
-    p.n_tiles = (M + 31) / 32;
+    p.n_tiles = 2 * ((M + 63) / 64);      // even: the screen kernel walks tiles in pairs; padding words carry |c|^2 = inf
     p.n_steps = D / 16;
     p.m_pad = p.n_tiles * 32;
     p.tile_bytes = (p.n_steps + 1) * 1024;
@@ -395,19 +396,40 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     // codebook tiles: L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
     // VGPRs).  Issued through inline asm and waited for by hand: when hipcc sees an LDS-DMA it
     // drains it with vmcnt(0) before every later ds_read, which serialises the prefetch.  Wave w
-    // issues chunks w, w+4, ...; a counted vmcnt at the top of each tile keeps the tile after next
-    // in flight across the barrier.
-    constexpr int kDmaPerWave = (kChunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    // copies kDmaPerWave consecutive chunks starting at chunk w * (kDmaPerWave - 1) (neighbouring
+    // waves overlap by one chunk: same bytes); the instruction's immediate offset advances the
+    // global AND the LDS address (tools/glds_probe), so M0 is set once per 4 KiB.
+    static_assert(kChunks % kWavesPerBlock == 1, "chunk split assumes (NSTEPS + 1) = 4 q + 1");
+    constexpr int kDmaPerWave = kChunks / kWavesPerBlock + 1;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     auto issue_tile = [&](int w, int slot) {
+        const int c0 = wid * (kDmaPerWave - 1);
+        const unsigned char *src = tiles + (size_t)w * kTileBytes + c0 * 1024 + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + c0 * 1024);
 #pragma unroll
-        for (int j = 0; j < kDmaPerWave; ++j) {
-            const int c = min(wid + kWavesPerBlock * j, kChunks - 1);     // (waves 1..3 repeat the last chunk: same bytes)
-            const unsigned char *src = tiles + (size_t)w * kTileBytes + c * 1024 + lane * 16;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + c * 1024);
+        for (int j0 = 0; j0 < kDmaPerWave; j0 += 4) {
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            const unsigned char *sj = src + j0 * 1024;
+            const unsigned dj = dst + j0 * 1024;
+            if (j0 + 4 <= kDmaPerWave) {
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
+            } else if (j0 + 3 == kDmaPerWave) {
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
+            } else if (j0 + 2 == kDmaPerWave) {
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
+            } else {
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
+            }
         }
     };
     const int wave_id = blockIdx.x * kWavesPerBlock + wid;
@@ -470,89 +492,75 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     const bool bad = !(maxabs <= kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e30f);   // NaN-safe
 
     stamp(p, 1, lane, wave_id);
-    unsigned long long t_bar = 0, t_mfma = 0, t_acc = 0, t_keys = 0, t_vm = 0, t_st = 0;
     unsigned m1[4], m2[4], m3[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) m1[g] = m2[g] = m3[g] = 0xFFFFFFFFu;
 
-    for (int w = 0; w < n_tiles; ++w) {
-        const unsigned long long tb0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
-        // tile w has landed for this wave once at most the DMAs of tile w+1 are outstanding; the
-        // barrier then makes every wave's part visible and frees slot (w+2) % 3 (read at tile w-1)
-        if (w + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const unsigned long long tb1 = p.stamps ? __builtin_amdgcn_s_memtime() : 0;
-        t_bar += tb1 - tb0;
-        if (w + 2 < n_tiles) issue_tile(w + 2, (w + 2) % kRing);
-        const unsigned char *slot = smem + (w % kRing) * kTileBytes;
-        const unsigned char *frag = slot + lane * 16;
-        // A fragments through a 4-deep register ring so ds_read latency hides behind the MFMAs
-        half8 a0 = *reinterpret_cast<const half8 *>(frag + 0 * 1024);
-        half8 a1 = *reinterpret_cast<const half8 *>(frag + 1 * 1024);
-        half8 a2 = *reinterpret_cast<const half8 *>(frag + 2 * 1024);
-        half8 a3 = *reinterpret_cast<const half8 *>(frag + 3 * 1024);
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // 4 DS reads up front
-        // accumulator starts at |c|^2/2 + shift, the MFMAs add -x.c  ->  v = dist^2/2 + 2E >= 0
-        const float *hc = reinterpret_cast<const float *>(slot + NSTEPS * 1024);
-        f32x16 acc;
+    // ---- main loop, software pipelined inside each wave.  The A-fragment stream is continuous
+    // across tiles (register ring of kRingA ds_read_b128 in flight); two accumulator sets alternate,
+    // so while the MFMAs of tile w run, the wave (a) turns the accumulators of tile w-1 into keys
+    // (5 VALU per value, spread over the first 16 MFMA gaps), (b) at step 15 waits for the DMA of
+    // tile w+1, passes the block barrier and issues the DMA of tile w+2 into the slot tile w-1
+    // occupied, (c) from step 16 on reads tile w+1's first fragments and initialises its
+    // accumulators (|c|^2/2 + shift).  One barrier per tile, no exposed LDS or DMA latency.
+    constexpr int kRingA = (NSTEPS % 8 == 0) ? 8 : 4;
+    static_assert(NSTEPS % kRingA == 0 && NSTEPS >= 2 * kRingA, "ring phase must repeat every tile");
+    constexpr int kInitStep = NSTEPS - kRingA;            // first step that touches tile w+1
+    constexpr int kKeysPerStep = (16 + kInitStep - 1) / kInitStep;
+    half8 ar[kRingA];
+    f32x16 accA, accB;
+    auto frag_at = [&](int tile, int step) {
+        return *reinterpret_cast<const half8 *>(smem + (tile % kRing) * kTileBytes + step * 1024 + lane * 16);
+    };
+    auto init_group = [&](f32x16 &acc, int tile, int g) {
+        const float *hc = reinterpret_cast<const float *>(smem + (tile % kRing) * kTileBytes + NSTEPS * 1024);
+        const float4 c4 = *reinterpret_cast<const float4 *>(hc + (g * 2 + h) * 4);
+        acc[4 * g + 0] = c4.x + shift; acc[4 * g + 1] = c4.y + shift;
+        acc[4 * g + 2] = c4.z + shift; acc[4 * g + 3] = c4.w + shift;
+    };
+    auto key_value = [&](float v, int tile, int idx) {
+        const unsigned code = (((unsigned)tile & 63u) << 2) | (unsigned)(idx & 3);
+        const unsigned k = (__float_as_uint(v) & 0xFFFFFF00u) | code;
+        top3_insert(k, m1[idx >> 2], m2[idx >> 2], m3[idx >> 2]);
+    };
+    auto tile_step = [&](int w, f32x16 &cur, f32x16 &oth) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(hc + (g * 2 + h) * 4);
-            acc[4 * g + 0] = c4.x + shift; acc[4 * g + 1] = c4.y + shift;
-            acc[4 * g + 2] = c4.z + shift; acc[4 * g + 3] = c4.w + shift;
-        }
+        for (int s = 0; s < NSTEPS; ++s) {
+            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], cur, 0, 0, 0);
+            if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
+            else ar[s % kRingA] = frag_at(w + 1, s + kRingA - NSTEPS);      // (stale slot after the last tile: unused)
+            // the 16 accumulators of tile w-1 become keys during the first kInitStep gaps
+            // (w == 0: oth holds +inf, those keys never win)
 #pragma unroll
-        for (int s = 0; s < NSTEPS; s += 4) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[s + 0], acc, 0, 0, 0);
-            if (s + 4 < NSTEPS) a0 = *reinterpret_cast<const half8 *>(frag + (s + 4) * 1024);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA ...
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // ... then the DS read 4 steps ahead
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[s + 1], acc, 0, 0, 0);
-            if (s + 5 < NSTEPS) a1 = *reinterpret_cast<const half8 *>(frag + (s + 5) * 1024);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b[s + 2], acc, 0, 0, 0);
-            if (s + 6 < NSTEPS) a2 = *reinterpret_cast<const half8 *>(frag + (s + 6) * 1024);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3, b[s + 3], acc, 0, 0, 0);
-            if (s + 7 < NSTEPS) a3 = *reinterpret_cast<const half8 *>(frag + (s + 7) * 1024);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        unsigned long long tb2 = 0;
-        if (p.stamps) {
-            tb2 = __builtin_amdgcn_s_memtime();
-            t_mfma += tb2 - tb1;
-            float probe;
-            asm volatile("v_mov_b32 %0, %1\n\ts_nop 4" : "=v"(probe) : "v"(acc[15]));   // waits for the last MFMA
-            asm volatile("" :: "v"(probe));
-            const unsigned long long tb3 = __builtin_amdgcn_s_memtime();
-            t_acc += tb3 - tb2;
-            tb2 = tb3;
-        }
-        // epilogue: keys = value bits with the low 8 mantissa bits replaced by (tile << 2 | e);
-        // one running top-3 per accumulator group g (words 8g + 4h + e of every tile)
-        const unsigned tcode = (unsigned)w << 2;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned code = tcode | (unsigned)e;
-                const unsigned k = (__float_as_uint(acc[4 * g + e]) & 0xFFFFFF00u) | code;
-                top3_insert(k, m1[g], m2[g], m3[g]);
+            for (int q = s * kKeysPerStep; q < (s + 1) * kKeysPerStep && q < 16; ++q) key_value(oth[q], w - 1, q);
+            if (s >= kInitStep && s < kInitStep + 4) init_group(oth, w + 1, s - kInitStep);
+            __builtin_amdgcn_sched_barrier(0);                              // pin: MFMA, its DS read, this gap's VALU
+            if (s == kInitStep - 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's part of tile w+1 has landed
+                __builtin_amdgcn_s_barrier();                               // ... everybody's; tile w-1 is no longer read
+                if (w + 2 < n_tiles) issue_tile(w + 2, (w + 2) % kRing);
             }
         }
-        if (p.stamps) {
-            asm volatile("" :: "v"(m1[0]), "v"(m1[1]), "v"(m1[2]), "v"(m1[3]), "v"(m3[0]), "v"(m3[1]), "v"(m3[2]), "v"(m3[3]));
-            const unsigned long long tb4 = __builtin_amdgcn_s_memtime();
-            t_keys += tb4 - tb2;
-        }
+    };
+    // prologue: tile 0 in LDS, ring primed, accumulators of tile 0 initialised
+    if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < kRingA; ++q) ar[q] = frag_at(0, q);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) init_group(accA, 0, g);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accB[q] = INFINITY;
+    for (int w = 0; w < n_tiles; w += 2) {                    // n_tiles is even (pack_layout)
+        tile_step(w, accA, accB);
+        tile_step(w + 1, accB, accA);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may be in flight when the LDS is released
+#pragma unroll
+    for (int q = 0; q < 16; ++q) key_value(accB[q], n_tiles - 1, q);      // keys of the last tile
 
     stamp(p, 2, lane, wave_id);
-    if (p.stamps && lane == 0) { p.stamps[(size_t)wave_id * 16 + 4] = t_bar; p.stamps[(size_t)wave_id * 16 + 5] = t_mfma; p.stamps[(size_t)wave_id * 16 + 6] = t_acc; p.stamps[(size_t)wave_id * 16 + 7] = t_keys; p.stamps[(size_t)wave_id * 16 + 8] = t_vm; p.stamps[(size_t)wave_id * 16 + 9] = t_st; }
     // ---- candidates: every key within the window of the token's best, over both half-lanes
     unsigned kmin = min(min(m1[0], m1[1]), min(m1[2], m1[3]));
     const unsigned kmin_o = __shfl_xor(kmin, 32, SN_WAVE);
@@ -630,9 +638,10 @@ int launch_exact(const AssignArgs &a, hipStream_t st)
 template <int NSTEPS>
 int launch_screen(const AssignArgs &a, hipStream_t st)
 {
-    const size_t lds = (size_t)kRing * (NSTEPS + 1) * 1024;
+    size_t lds = (size_t)kRing * (NSTEPS + 1) * 1024;
+    if (const char *pad = getenv("SN_ASSIGN_LDS_PAD")) lds += (size_t)atoi(pad);     // diagnostics: force 1 workgroup per CU
     static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
+    if ((!attr_set || getenv("SN_ASSIGN_LDS_PAD")) && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)assign_screen_kernel<NSTEPS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sn_set_error("sn_assign_words: LDS attribute: %s", hipGetErrorString(e)); return SN_ERR_LAUNCH; }
@@ -683,6 +692,16 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
     return SN_OK;
 }
 
+/* diagnostics: resident workgroups per CU the runtime reports for the screen kernel (D = 384) with
+ * `lds` bytes of dynamic LDS */
+extern "C" int sn_debug_screen_occupancy(int lds)
+{
+    int n = -1;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)assign_screen_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)assign_screen_kernel<24>, 256, (size_t)lds) != hipSuccess) return -1;
+    return n;
+}
+
 /* diagnostics: device buffer of 16 x u64 per wave of the screen kernel (NULL = off) */
 extern "C" void sn_debug_set_stamps(void *device_buffer) { g_stamps = (unsigned long long *)device_buffer; }
 
@@ -713,7 +732,7 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.stamps = g_stamps;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
-    const bool screen_ok = mode == 0 && aligned && M % 32 == 0 && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
+    const bool screen_ok = mode == 0 && aligned && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
     if (screen_ok) {
         SN_REQUIRE(workspace && workspace_bytes >= sn_assign_workspace_bytes(n_tokens), SN_ERR_WORKSPACE,
                    "sn_assign_words: workspace %zu < %zu bytes", workspace_bytes, sn_assign_workspace_bytes(n_tokens));
