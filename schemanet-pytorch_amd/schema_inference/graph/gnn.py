@@ -103,9 +103,21 @@ class GNN(nn.Module):
             n_valid = (~feat_mask).sum(dim=1).to(torch.int32)   # masks are suffix masks (match.py:48-51)
         if feat_mask is None and n_valid is not None and not fused:
             feat_mask = torch.arange(nodes.shape[1], device=nodes.device)[None, :] >= n_valid[:, None]
-        feat = self.embedding(ingredients)
         adj = ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges)
-        for layer in self.layers:
+        layers = list(self.layers)
+        first = layers[0] if layers else None
+        if fused and first is not None and isinstance(first.g_conv.linear, nn.Linear) and (first._is_relu or first._is_none):
+            # layer 1 re-associated: (adj @ Emb[ids]) @ W^T + b == adj @ (Emb @ W^T)[ids] + b, so the
+            # [G*n, E] x [E, E] Linear becomes one [(M+1), E] x [E, E] GEMM shared by every graph
+            lin = first.g_conv.linear
+            table = torch.nn.functional.linear(self.embedding.weight, lin.weight)
+            feat = torch.baddbmm(lin.bias, adj, torch.nn.functional.embedding(ingredients, table))
+            feat = ops.mask_layernorm_act_(feat, first.norm.weight, first.norm.bias, first.norm.eps,
+                                           n_valid=n_valid, relu=first._is_relu)
+            layers = layers[1:]
+        else:
+            feat = self.embedding(ingredients)
+        for layer in layers:
             feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused)
         if fused:
             pooled = ops.weighted_pool(feat, nodes, divisor)

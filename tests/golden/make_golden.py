@@ -260,9 +260,54 @@ def wrapper():
          attn_cls=out["attn_cls"].numpy())
 
 
+# --------------------------------------------------------------------------- one training step
+def train_step():
+    """SchemaNetTrainer.train_iter without the optimizer (worker_schema_net.py:120-141):
+    normalize() -> forward with autograd -> SchemaInferenceLoss -> weighted sum -> backward.
+    Pins the autograd reach of the path (w_v, w_e through the `@ w`, the atlas through
+    get_atlas, the GNN)."""
+    B, L, M, K, n_max, E = 4, 196, 256, 5, 64, 48
+    ing, attn, attn_cls = datagen.graph_case(B, L, M, seed=11)
+    label = np.asarray([1, 4, 0, 2], np.int64)
+    sn = make_schema_net(M, K, n_max=n_max, seed=7)
+    torch.manual_seed(8)
+    cls_ing = torch.stack([torch.randperm(M)[:n_max] for _ in range(K)])
+    sn.register_class_vertices(cls_ing)
+    with torch.no_grad():
+        sn.vertex_attribute_weights.tensor.copy_(torch.tensor([[0.4], [0.7]]))
+        sn.edge_attribute_weights.tensor.copy_(torch.tensor([[0.8], [0.3]]))
+    torch.manual_seed(5)
+    m = ref.graph.Matcher(similarity="inner_product", num_codes=M,
+                          gnn_cfg=dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu"))
+    state_sn = {k: v.clone() for k, v in sn.state_dict().items()}
+    state_m = {k: v.clone() for k, v in m.state_dict().items()}
+    sn.train(); m.train()
+    sn.normalize()
+    inst = sn(T(ing), T(attn.copy()), T(attn_cls.copy()))
+    atlas = sn.get_atlas()
+    pred = m(inst, atlas)
+    out = dict(pred=pred, **atlas)
+    loss_fn = ref.SchemaInferenceLoss()
+    loss_dict = loss_fn(out, {"label": T(label)})
+    weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+    loss = sum(loss_dict[k] * w for k, w in weights.items())
+    loss.backward()
+    rec = dict(case=np.asarray([B, L, M, 11, K, n_max, E]), label=label, pred=pred.detach().numpy(),
+               loss=loss.detach().numpy(), **{"loss:" + k: v.detach().numpy() for k, v in loss_dict.items()})
+    for k, v in state_sn.items():
+        rec["sn:" + k] = v.numpy()
+    for k, v in state_m.items():
+        rec["m:" + k] = v.numpy()
+    for name, prm in list(sn.named_parameters()) + [("matcher." + n, q) for n, q in m.named_parameters()]:
+        if prm.grad is not None:
+            rec["grad:" + name] = prm.grad.numpy()
+    save("train_step.npz", **rec)
+
+
 if __name__ == "__main__":
     g1_assign()
     ext_small()
     graph()
     matcher()
     wrapper()
+    train_step()
