@@ -195,7 +195,7 @@ def main():
                                    "512-word codebook, head-averaged attention logits [256,197,197], K=100, "
                                    "n_max=512, GNN E=256 x 2 layers; atlas recomputed every step",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"image-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "assign_screen_kernel<24> (S1 fp16-MFMA screen)",
+            "roofline": {"bound": "hbm", "kernel": "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",

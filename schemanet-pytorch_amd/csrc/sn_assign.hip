@@ -22,6 +22,20 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+// timing experiments only (results are wrong when any of these is set)
+#ifndef SN_EXP_NOKEYS
+#define SN_EXP_NOKEYS 0
+#endif
+#ifndef SN_EXP_KEYSRC
+#define SN_EXP_KEYSRC 0
+#endif
+#ifndef SN_EXP_NOBARRIER
+#define SN_EXP_NOBARRIER 0
+#endif
+#ifndef SN_EXP_NODMA
+#define SN_EXP_NODMA 0
+#endif
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -30,10 +44,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTokPerWave = 32;
 constexpr int kWavesPerBlock = 4;
-constexpr int kTokPerBlock = kTokPerWave * kWavesPerBlock;
-constexpr int kRing = 3;               // LDS slots for codebook tiles (LDS-DMA ring, two tiles in flight)
 constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
-constexpr int kEntryInts = 32;          // work-list entry: [0] token, [1] 24-bit candidate mask, [2..25] words
+constexpr int kCodeBytes = 24;          // per-token candidate record: one key code per candidate slot
+constexpr int kWsPerToken = 4 + kCodeBytes + 4;   // flag word + codes + overflow-list slot
 constexpr int kMaxTilesScreen = 64;     // 6-bit tile code in the keys -> M <= 2048 on the MFMA path
 constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
@@ -144,7 +157,9 @@ struct AssignArgs {
     int M, D;
     int64_t *out;
     int64_t oso, osi;
-    int *work;          // [0] #entries, [1] #overflow tokens; entries (8 ints each) from int 8;
+    int *work;          // header: [1] #overflow tokens
+    unsigned *flags;    // per token: 0 = final, bit 31 = overflow (full scan), else 24-bit candidate mask
+    unsigned char *codes;   // per token 24 key codes (tile << 2 | e), written only for flagged tokens
     int *overflow;      // token ids that need a full scan
     unsigned long long *stamps;   // diagnostics only (sn_debug_set_stamps): 16 u64 slots per wave
 };
@@ -232,25 +247,53 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
     const double *cn64 = (const double *)(p.packed + lay.cn64_off);
     const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
 
-    // ---- phase A (blocks kOverflowBlocks .. gridDim.x - 1)
-    const int count = p.work[0];
-    const int n_waves = ((int)gridDim.x - kOverflowBlocks) * kWavesPerBlock;
-    for (int e = ((int)blockIdx.x - kOverflowBlocks) * kWavesPerBlock + wid; e < count && (int)blockIdx.x >= kOverflowBlocks; e += n_waves) {
-        const int *ent = p.work + 8 + (int64_t)e * kEntryInts;
-        const int64_t n = ent[0];
-        const int cmask = ent[1];
-        double x[NT];
-        load_token64<NT>(x, token_row(p, n), p.D, lane);
-        double best = (double)INFINITY;
-        int bi = 0x7fffffff;
-        for (int c = 0; c < kMaxCand; ++c) {
-            if (!((cmask >> c) & 1)) continue;
-            const int m = ent[2 + c];
-            const double s = cn64[m] - 2.0 * dot64<NT>(x, p.cb + (int64_t)m * p.D, p.D, lane);
-            if (s < best || (s == best && m < bi)) { best = s; bi = m; }
+    // ---- phase A (blocks kOverflowBlocks .. gridDim.x - 1): a block owns 32 consecutive tokens per
+    // round, reads their flag words, and its four waves share the flagged ones round-robin.
+    // Candidate slot c = 12 h + 3 g + j holds code (tile << 2 | e): word = 32 tile + 8 g + 4 h + e.
+    const int64_t n_chunks = (p.n_tokens + 31) / 32;
+    for (int64_t chunk = (int64_t)blockIdx.x - kOverflowBlocks; chunk < n_chunks && (int)blockIdx.x >= kOverflowBlocks;
+         chunk += (int64_t)gridDim.x - kOverflowBlocks) {
+        const int64_t t = chunk * 32 + (lane & 31);
+        const unsigned flag = (lane < 32 && t < p.n_tokens) ? p.flags[t] : 0u;
+        unsigned long long todo = __ballot(flag != 0u && !(flag >> 31));
+        for (int i = 0; todo; ++i) {
+            const int tl = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            if ((i & 3) != wid) continue;
+            const int64_t n = chunk * 32 + tl;
+            const unsigned cmask = (unsigned)__shfl((int)flag, tl, SN_WAVE);
+            int my_word = 0;
+            if (lane < kMaxCand) {
+                const unsigned code = p.codes[n * kCodeBytes + lane];
+                const int hh = lane / 12, g = (lane % 12) / 3;
+                my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
+            }
+            double x[NT];
+            load_token64<NT>(x, token_row(p, n), p.D, lane);
+            double best = (double)INFINITY;
+            int bi = 0x7fffffff;
+            for (unsigned cm = cmask; cm;) {                 // two candidates per round: their loads overlap
+                const int ca = __ffs((int)cm) - 1;
+                cm &= cm - 1;
+                const bool two = cm != 0u;
+                const int cb2 = two ? __ffs((int)cm) - 1 : ca;
+                if (two) cm &= cm - 1;
+                const int ma = __shfl(my_word, ca, SN_WAVE), mb = __shfl(my_word, cb2, SN_WAVE);
+                const float *ra = p.cb + (int64_t)ma * p.D, *rb = p.cb + (int64_t)mb * p.D;
+                double pa = 0.0, pb = 0.0;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const int k = lane + SN_WAVE * t2;
+                    if (k < p.D) { pa = fma(x[t2], (double)ra[k], pa); pb = fma(x[t2], (double)rb[k], pb); }
+                }
+                const double sa = cn64[ma] - 2.0 * sn_wave_sum_f64(pa);
+                const double sb = cn64[mb] - 2.0 * sn_wave_sum_f64(pb);
+                if (sa < best || (sa == best && ma < bi)) { best = sa; bi = ma; }
+                if (two && (sb < best || (sb == best && mb < bi))) { best = sb; bi = mb; }
+            }
+            if (bi != 0x7fffffff && lane == 0) p.out[out_index(p, n)] = bi;
+            // (all candidates NaN cannot happen: such tokens are routed to the overflow list)
         }
-        if (bi != 0x7fffffff && lane == 0) p.out[out_index(p, n)] = bi;
-        // (all candidates NaN cannot happen: such tokens are routed to the overflow list)
     }
 
     // ---- phase B: every word of the overflow tokens, from the fp16 tile image (L2-hot: the screen
@@ -372,21 +415,19 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
 //   v[word] = |c|^2/2 + (|x|^2/2 + 2E) - x.c      (= dist^2/2 + 2E  >= 0)
 // as packed keys (float bits with the low 8 mantissa bits replaced by a word code).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void top3_insert(unsigned k, unsigned &m1, unsigned &m2, unsigned &m3)
+__device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c)
 {
-    const unsigned hi = max(k, m2);
-    m2 = max(min(k, m1), min(max(k, m1), m2));   // v_med3_u32
-    m1 = min(k, m1);
-    m3 = min(m3, hi);
+    return max(min(a, b), min(max(a, b), c));    // v_med3_u32
 }
 
-template <int NSTEPS>
-__global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_kernel(const AssignArgs p)
+// NW waves per workgroup (32 tokens each) share one codebook-tile ring of R LDS slots.
+template <int NSTEPS, int NW, int R>
+__global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_kernel(const AssignArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kChunks = NSTEPS + 1;
     constexpr int kTileBytes = kChunks * 1024;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const PackLayout lay = pack_layout(p.M, p.D);
     const unsigned char *tiles = p.packed + lay.tiles_off;
@@ -396,49 +437,37 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     // codebook tiles: L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
     // VGPRs).  Issued through inline asm and waited for by hand: when hipcc sees an LDS-DMA it
     // drains it with vmcnt(0) before every later ds_read, which serialises the prefetch.  Wave w
-    // copies kDmaPerWave consecutive chunks starting at chunk w * (kDmaPerWave - 1) (neighbouring
-    // waves overlap by one chunk: same bytes); the instruction's immediate offset advances the
-    // global AND the LDS address (tools/glds_probe), so M0 is set once per 4 KiB.
-    static_assert(kChunks % kWavesPerBlock == 1, "chunk split assumes (NSTEPS + 1) = 4 q + 1");
-    constexpr int kDmaPerWave = kChunks / kWavesPerBlock + 1;
+    // copies chunks w, w + NW, w + 2 NW, ...: kDmaMin of them, one more on the first kDmaExtra waves.
+    constexpr int kDmaMin = kChunks / NW, kDmaExtra = kChunks % NW;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     auto issue_tile = [&](int w, int slot) {
-        const int c0 = wid * (kDmaPerWave - 1);
-        const unsigned char *src = tiles + (size_t)w * kTileBytes + c0 * 1024 + lane * 16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + c0 * 1024);
+        const unsigned char *src = tiles + (size_t)w * kTileBytes + wid * 1024 + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + wid * 1024);
 #pragma unroll
-        for (int j0 = 0; j0 < kDmaPerWave; j0 += 4) {
+        for (int j = 0; j <= kDmaMin; ++j) {
+            if (j == kDmaMin && (kDmaExtra == 0 || wid >= kDmaExtra)) break;      // wave-uniform
             unsigned keep;
-            const unsigned char *sj = src + j0 * 1024;
-            const unsigned dj = dst + j0 * 1024;
-            if (j0 + 4 <= kDmaPerWave) {
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                             "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
-            } else if (j0 + 3 == kDmaPerWave) {
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                             "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
-            } else if (j0 + 2 == kDmaPerWave) {
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
-            } else {
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                             "global_load_lds_dwordx4 %1, off\n\t"
-                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(sj), "s"(dj) : "memory");
-            }
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\t"
+                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src + (size_t)j * NW * 1024), "s"(dst + j * NW * 1024) : "memory");
         }
     };
-    const int wave_id = blockIdx.x * kWavesPerBlock + wid;
+    // wait until this wave's copies of all but the newest `ahead` tiles have landed (the first
+    // kDmaExtra waves over-wait by up to `ahead` chunks: the immediate must be a constant)
+    auto wait_tiles = [&](int ahead) {
+        if (R >= 5 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaMin) : "memory");
+        else if (R >= 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaMin) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    static_assert(R >= 3 && R <= 5, "ring depth");
+    const int wave_id = blockIdx.x * NW + wid;
     stamp(p, 0, lane, wave_id);
-    issue_tile(0, 0);
-    if (n_tiles > 1) issue_tile(1, 1);
+#pragma unroll
+    for (int t = 0; t < R - 1; ++t)
+        if (t < n_tiles) issue_tile(t, t);
 
     // ---- this wave's 32 tokens: fp32 -> fp16 B fragments, kept in registers for the whole kernel
-    const int64_t n = (int64_t)blockIdx.x * kTokPerBlock + wid * kTokPerWave + r;
+    const int64_t n = (int64_t)blockIdx.x * (kTokPerWave * NW) + wid * kTokPerWave + r;
     const bool valid = n < p.n_tokens;
     const float *row = token_row(p, valid ? n : 0);
     half8 b[NSTEPS];
@@ -499,52 +528,89 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     // ---- main loop, software pipelined inside each wave.  The A-fragment stream is continuous
     // across tiles (register ring of kRingA ds_read_b128 in flight); two accumulator sets alternate,
     // so while the MFMAs of tile w run, the wave (a) turns the accumulators of tile w-1 into keys
-    // (5 VALU per value, spread over the first 16 MFMA gaps), (b) at step 15 waits for the DMA of
-    // tile w+1, passes the block barrier and issues the DMA of tile w+2 into the slot tile w-1
-    // occupied, (c) from step 16 on reads tile w+1's first fragments and initialises its
-    // accumulators (|c|^2/2 + shift).  One barrier per tile, no exposed LDS or DMA latency.
+    // (4 VALU per value, one value per MFMA gap from step 2 on - hand-placed, see key_insert),
+    // (b) at step kInitStep-1 waits for the DMA of tile w+1, passes the block barrier and issues the
+    // DMA of tile w+R-1 into the slot tile w-1 occupied, (c) from step kInitStep on reads tile w+1's
+    // first fragments and initialises its accumulators (|c|^2/2 + shift).  One barrier per tile.
     constexpr int kRingA = (NSTEPS % 8 == 0) ? 8 : 4;
     static_assert(NSTEPS % kRingA == 0 && NSTEPS >= 2 * kRingA, "ring phase must repeat every tile");
     constexpr int kInitStep = NSTEPS - kRingA;            // first step that touches tile w+1
-    constexpr int kKeysPerStep = (16 + kInitStep - 1) / kInitStep;
+    constexpr int kKeyStep0 = 2;                          // first gap with a key (see key_insert)
+    constexpr int kKeysPerStep = (16 + (NSTEPS - kKeyStep0) - 1) / (NSTEPS - kKeyStep0);
+    static_assert(kKeyStep0 + (3 + kKeysPerStep) / kKeysPerStep <= kInitStep, "group 0 must be keyed before it is re-initialised");
     half8 ar[kRingA];
     f32x16 accA, accB;
+    unsigned keymask = 0xFFFFFF00u;
+    asm volatile("" : "+v"(keymask));                     // keep the mask in a VGPR (VOP3 has no literals on gfx9)
     auto frag_at = [&](int tile, int step) {
-        return *reinterpret_cast<const half8 *>(smem + (tile % kRing) * kTileBytes + step * 1024 + lane * 16);
+        return *reinterpret_cast<const half8 *>(smem + (tile % R) * kTileBytes + step * 1024 + lane * 16);
     };
     auto init_group = [&](f32x16 &acc, int tile, int g) {
-        const float *hc = reinterpret_cast<const float *>(smem + (tile % kRing) * kTileBytes + NSTEPS * 1024);
+        const float *hc = reinterpret_cast<const float *>(smem + (tile % R) * kTileBytes + NSTEPS * 1024);
         const float4 c4 = *reinterpret_cast<const float4 *>(hc + (g * 2 + h) * 4);
         acc[4 * g + 0] = c4.x + shift; acc[4 * g + 1] = c4.y + shift;
         acc[4 * g + 2] = c4.z + shift; acc[4 * g + 3] = c4.w + shift;
     };
-    auto key_value = [&](float v, int tile, int idx) {
+    // key = (value bits & ~0xFF) | code, inserted into the sorted triple (m1 <= m2 <= m3) of its
+    // accumulator group: m3 = med3(k, m2, m3); m2 = med3(k, m1, m2); m1 = min(k, m1).
+    // Written as volatile asm because hipcc otherwise gathers all key arithmetic of a tile pair in
+    // the loop latch (the matrix pipe idles meanwhile and the accumulators get copied).  The asm
+    // reads MFMA results the compiler's hazard recogniser cannot see: callers place it at least two
+    // MFMA issues (> 64 cycles) after the last MFMA that wrote `v`.
+    auto key_insert = [&](float v, unsigned code, int g) {
+        unsigned k;
+        asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
+                     "v_med3_u32 %3, %0, %2, %3\n\t"
+                     "v_med3_u32 %2, %0, %1, %2\n\t"
+                     "v_min_u32 %1, %0, %1"
+                     : "=&v"(k), "+v"(m1[g]), "+v"(m2[g]), "+v"(m3[g]) : "v"(v), "v"(keymask), "s"(code));
+    };
+    auto key_value = [&](float v, int tile, int idx) {     // same thing in C++ (compiler-scheduled, hazard-checked)
         const unsigned code = (((unsigned)tile & 63u) << 2) | (unsigned)(idx & 3);
         const unsigned k = (__float_as_uint(v) & 0xFFFFFF00u) | code;
-        top3_insert(k, m1[idx >> 2], m2[idx >> 2], m3[idx >> 2]);
+        const int g = idx >> 2;
+        m3[g] = med3u(k, m2[g], m3[g]);
+        m2[g] = med3u(k, m1[g], m2[g]);
+        m1[g] = min(k, m1[g]);
     };
+    unsigned long long t_sync = 0, t_dma = 0;             // diagnostics (only when stamps are on)
     auto tile_step = [&](int w, f32x16 &cur, f32x16 &oth) {
+        const unsigned code0 = (((unsigned)(w - 1)) & 63u) << 2;
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
             cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], cur, 0, 0, 0);
             if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
             else ar[s % kRingA] = frag_at(w + 1, s + kRingA - NSTEPS);      // (stale slot after the last tile: unused)
-            // the 16 accumulators of tile w-1 become keys during the first kInitStep gaps
-            // (w == 0: oth holds +inf, those keys never win)
+            // the 16 accumulators of tile w-1 become keys (w == 0: oth holds +inf, those keys never win)
+            if (s >= kKeyStep0 && !SN_EXP_NOKEYS) {
 #pragma unroll
-            for (int q = s * kKeysPerStep; q < (s + 1) * kKeysPerStep && q < 16; ++q) key_value(oth[q], w - 1, q);
+                for (int q = (s - kKeyStep0) * kKeysPerStep; q < (s - kKeyStep0 + 1) * kKeysPerStep && q < 16; ++q)
+                    key_insert(SN_EXP_KEYSRC ? shift : oth[q], code0 | (unsigned)(q & 3), q >> 2);
+            }
             if (s >= kInitStep && s < kInitStep + 4) init_group(oth, w + 1, s - kInitStep);
             __builtin_amdgcn_sched_barrier(0);                              // pin: MFMA, its DS read, this gap's VALU
             if (s == kInitStep - 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's part of tile w+1 has landed
-                __builtin_amdgcn_s_barrier();                               // ... everybody's; tile w-1 is no longer read
-                if (w + 2 < n_tiles) issue_tile(w + 2, (w + 2) % kRing);
+                int ahead = n_tiles - 2 - w;                                 // tiles in flight beyond w+1
+                ahead = ahead < 0 ? 0 : (ahead > R - 3 ? R - 3 : ahead);
+                unsigned long long ta = 0, tb = 0;
+                if (p.stamps) ta = __builtin_amdgcn_s_memtime();
+                wait_tiles(ahead);                                          // this wave's part of tile w+1 has landed
+                if (!SN_EXP_NOBARRIER) __builtin_amdgcn_s_barrier();        // ... everybody's; tile w-1 is no longer read
+                if (p.stamps) tb = __builtin_amdgcn_s_memtime();
+                if (w + R - 1 < n_tiles && !SN_EXP_NODMA) issue_tile(w + R - 1, (w + R - 1) % R);
+                if (p.stamps) { t_sync += tb - ta; t_dma += __builtin_amdgcn_s_memtime() - tb; }
             }
         }
     };
     // prologue: tile 0 in LDS, ring primed, accumulators of tile 0 initialised
-    if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        int ahead = n_tiles - 1;
+        ahead = ahead > R - 2 ? R - 2 : ahead;
+        if (R >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kDmaMin) : "memory");
+        else if (R >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaMin) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaMin) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int q = 0; q < kRingA; ++q) ar[q] = frag_at(0, q);
@@ -561,6 +627,7 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     for (int q = 0; q < 16; ++q) key_value(accB[q], n_tiles - 1, q);      // keys of the last tile
 
     stamp(p, 2, lane, wave_id);
+    if (p.stamps && lane == 0) { p.stamps[(size_t)wave_id * 16 + 4] = t_sync; p.stamps[(size_t)wave_id * 16 + 5] = t_dma; }
     // ---- candidates: every key within the window of the token's best, over both half-lanes
     unsigned kmin = min(min(m1[0], m1[1]), min(m1[2], m1[3]));
     const unsigned kmin_o = __shfl_xor(kmin, 32, SN_WAVE);
@@ -593,31 +660,24 @@ __global__ __launch_bounds__(256, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_ker
     const bool overflow = bad || !any_finite || hover || oover;
     const bool writer = valid && h == 0;
     if (writer) p.out[out_index(p, n)] = any_finite ? best_w : 0;
-    const bool need_a = writer && !overflow && nc > 1;
-    const bool need_b = writer && overflow;
-    const unsigned long long mask_a = __ballot(need_a), mask_b = __ballot(need_b);
-    stamp(p, 3, lane, wave_id);
-    if (mask_a) {
-        int base = 0;
-        const int leader = __ffsll((long long)mask_a) - 1;
-        if (lane == leader) base = atomicAdd(&p.work[0], __popcll(mask_a));
-        base = __shfl(base, leader, SN_WAVE);
-        int idx = need_a ? base + __popcll(mask_a & ((1ull << lane) - 1ull)) : -1;
-        const int idx_o = __shfl_xor(idx, 32, SN_WAVE);      // the h = 1 lane of the token writes its half too
-        if (h == 1) idx = idx_o;
-        if (idx >= 0) {
-            int *ent = p.work + 8 + (int64_t)idx * kEntryInts;
-            if (h == 0) { ent[0] = (int)n; ent[1] = (int)(hmask | (omask << 12)); }
-            int *wd = ent + 2 + 12 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                wd[3 * g + 0] = word_of(m1[g], g, h);
-                wd[3 * g + 1] = word_of(m2[g], g, h);
-                wd[3 * g + 2] = word_of(m3[g], g, h);
-            }
-        }
+    // No compaction here: a chip-wide atomic per wave on one counter costs more than the whole
+    // MFMA loop when every wave has a flagged token.  Each token gets a flag word (dense, coalesced)
+    // and, if flagged, its 24 candidate codes at a fixed slot; the re-rank kernel walks the flags.
+    const bool flagged = !overflow && nc > 1;
+    if (writer) p.flags[n] = overflow ? 0x80000000u : (flagged ? (hmask | (omask << 12)) : 0u);
+    if (valid && flagged) {                                // both half-lanes of the token write their 12 codes
+        unsigned *cd = reinterpret_cast<unsigned *>(p.codes + (int64_t)n * kCodeBytes + 12 * h);
+        const unsigned c0 = m1[0] & 0xFFu, c1 = m2[0] & 0xFFu, c2 = m3[0] & 0xFFu, c3 = m1[1] & 0xFFu;
+        const unsigned c4 = m2[1] & 0xFFu, c5 = m3[1] & 0xFFu, c6 = m1[2] & 0xFFu, c7 = m2[2] & 0xFFu;
+        const unsigned c8 = m3[2] & 0xFFu, c9 = m1[3] & 0xFFu, c10 = m2[3] & 0xFFu, c11 = m3[3] & 0xFFu;
+        cd[0] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        cd[1] = c4 | (c5 << 8) | (c6 << 16) | (c7 << 24);
+        cd[2] = c8 | (c9 << 8) | (c10 << 16) | (c11 << 24);
     }
-    if (mask_b) {
+    const bool need_b = writer && overflow;
+    const unsigned long long mask_b = __ballot(need_b);
+    stamp(p, 3, lane, wave_id);
+    if (mask_b) {                                          // rare: tokens the screen cannot bound
         int base = 0;
         const int leader = __ffsll((long long)mask_b) - 1;
         if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
@@ -635,27 +695,38 @@ int launch_exact(const AssignArgs &a, hipStream_t st)
     return 0;
 }
 
-template <int NSTEPS>
+template <int NSTEPS, int NW, int R>
 int launch_screen(const AssignArgs &a, hipStream_t st)
 {
-    size_t lds = (size_t)kRing * (NSTEPS + 1) * 1024;
+    size_t lds = (size_t)R * (NSTEPS + 1) * 1024;
     if (const char *pad = getenv("SN_ASSIGN_LDS_PAD")) lds += (size_t)atoi(pad);     // diagnostics: force 1 workgroup per CU
     static bool attr_set = false;
     if ((!attr_set || getenv("SN_ASSIGN_LDS_PAD")) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)assign_screen_kernel<NSTEPS>,
+        hipError_t e = hipFuncSetAttribute((const void *)assign_screen_kernel<NSTEPS, NW, R>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sn_set_error("sn_assign_words: LDS attribute: %s", hipGetErrorString(e)); return SN_ERR_LAUNCH; }
         attr_set = true;
     }
-    const unsigned grid = (unsigned)((a.n_tokens + kTokPerBlock - 1) / kTokPerBlock);
+    const int tok_per_block = kTokPerWave * NW;
+    const unsigned grid = (unsigned)((a.n_tokens + tok_per_block - 1) / tok_per_block);
     sn_prof_start(0, st);
-    hipLaunchKernelGGL(assign_screen_kernel<NSTEPS>, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R>), dim3(grid), dim3(64 * NW), lds, st, a);
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
-    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(kOverflowBlocks + 2048), dim3(256), 0, st, a);
+    const int64_t chunks = (a.n_tokens + 31) / 32;
+    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
     sn_prof_stop(1, st);
     return 0;
+}
+
+// workgroup shape of the screen kernel: 0 = 4 waves x 3-slot ring (two workgroups per CU),
+// 1 = 8 waves x 5-slot ring (one workgroup per CU, half the LDS-DMA traffic per token)
+int screen_variant()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SN_ASSIGN_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
 }
 
 }  // namespace
@@ -697,8 +768,8 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
 extern "C" int sn_debug_screen_occupancy(int lds)
 {
     int n = -1;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)assign_screen_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)assign_screen_kernel<24>, 256, (size_t)lds) != hipSuccess) return -1;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)assign_screen_kernel<24, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)assign_screen_kernel<24, 4, 3>, 256, (size_t)lds) != hipSuccess) return -1;
     return n;
 }
 
@@ -708,7 +779,7 @@ extern "C" void sn_debug_set_stamps(void *device_buffer) { g_stamps = (unsigned 
 extern "C" size_t sn_assign_workspace_bytes(int64_t n_tokens)
 {
     if (n_tokens < 0) return 0;
-    return 32 + (size_t)n_tokens * (kEntryInts * 4 + 4);      // header + entries + overflow token ids
+    return 32 + (size_t)n_tokens * kWsPerToken;      // header + flag words + candidate codes + overflow token ids
 }
 
 extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
@@ -728,7 +799,10 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.x = x; a.n_tokens = n_tokens; a.n_inner = n_inner; a.xso = x_stride_outer; a.xsi = x_stride_inner;
     a.cb = codebook; a.packed = (const unsigned char *)packed; a.M = M; a.D = D;
     a.out = out; a.oso = out_stride_outer; a.osi = out_stride_inner; a.work = (int *)workspace;
-    a.overflow = workspace ? (int *)workspace + 8 + n_tokens * kEntryInts : nullptr;
+    unsigned char *ws = (unsigned char *)workspace;
+    a.flags = ws ? (unsigned *)(ws + 32) : nullptr;
+    a.codes = ws ? ws + 32 + (size_t)n_tokens * 4 : nullptr;
+    a.overflow = ws ? (int *)(ws + 32 + (size_t)n_tokens * (4 + kCodeBytes)) : nullptr;
     a.stamps = g_stamps;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
@@ -741,9 +815,10 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
             return SN_ERR_LAUNCH;
         }
         int rc = 0;
-        if (D == 192) rc = launch_screen<12>(a, st);
-        else if (D == 384) rc = launch_screen<24>(a, st);
-        else rc = launch_screen<48>(a, st);
+        const bool wide = screen_variant() == 1;
+        if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st);
+        else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : launch_screen<24, 4, 3>(a, st);
+        else rc = launch_screen<48, 4, 3>(a, st);
         if (rc) return rc;
     } else {
         const int nt = (D + 63) / 64;

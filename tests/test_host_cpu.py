@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     # size helpers are pure host code
     assert lib.sn_codebook_pack_bytes(512, 384) == 16 * 25 * 1024 + 4096 + 256
     assert lib.sn_codebook_pack_bytes(512, 30) == 0
-    assert lib.sn_assign_workspace_bytes(50176) == 32 + 50176 * 132
+    assert lib.sn_assign_workspace_bytes(50176) == 32 + 50176 * 32
 
 
 def test_graph_args_struct_matches_header(lib):

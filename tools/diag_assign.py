@@ -23,11 +23,12 @@ for name, tok in (("randn tokens", tokens), ("k-means-like", None)):
                                 N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws.numel(), 0, N.stream_ptr(dev)))
     torch.cuda.synchronize()
     w = ws.view(torch.int32)
-    cnt = int(w[0])
-    ent = w[8:8 + cnt * 8].view(cnt, 8)
-    ovf = int((ent[:, 1] == 255).sum())
-    nc = torch.tensor([bin(int(v)).count("1") for v in ent[:, 1].tolist() if v != 255])
-    print(f"{name}: tokens {n_tok}, work-list {cnt} ({100*cnt/n_tok:.2f}%), overflow {ovf}, "
+    flags = w[8:8 + n_tok]
+    ovf = int((flags < 0).sum())
+    fl = flags[flags > 0]
+    cnt = int(fl.numel())
+    nc = torch.tensor([bin(int(v)).count("1") for v in fl.tolist()])
+    print(f"{name}: tokens {n_tok}, flagged {cnt} ({100*cnt/n_tok:.2f}%), overflow {ovf}, "
           f"candidates/hist {torch.bincount(nc, minlength=7).tolist() if len(nc) else []}")
     # gap statistics in fp64
     x64 = x.reshape(-1, bench.D).double(); c64 = cb.double()
@@ -57,8 +58,8 @@ print("  kernel span (first start -> last end): %.0f" % (s8[:, 3].max() - t0))
 print("  start skew  (last wave start - first): %.0f" % (s8[:, 0].max() - t0))
 print("  token load+convert: median %.0f  max %.0f" % ((s8[:, 1] - s8[:, 0]).median(), (s8[:, 1] - s8[:, 0]).max()))
 print("  main loop:          median %.0f  max %.0f" % ((s8[:, 2] - s8[:, 1]).median(), (s8[:, 2] - s8[:, 1]).max()))
-print("     of which barrier wait median %.0f, mfma section median %.0f" % (s8[:, 4].median(), s8[:, 5].median()))
-print("     wait for last MFMA median %.0f, key/insert VALU median %.0f" % (s8[:, 6].median(), s8[:, 7].median()))
+print("     of which dma-wait + barrier: median %.0f max %.0f; issuing the next tile's DMA: median %.0f max %.0f" % (
+    s8[:, 4].median(), s8[:, 4].max(), s8[:, 5].median(), s8[:, 5].max()))
 print("  tail:               median %.0f" % ((s8[:, 3] - s8[:, 2]).median()))
 print("  per-wave total:     median %.0f  max %.0f" % ((s8[:, 3] - s8[:, 0]).median(), (s8[:, 3] - s8[:, 0]).max()))
 
@@ -76,5 +77,5 @@ for name, tok in (("randn", tokens), ("k-means-like", tok)):
         n = lib.sn_profile_count(kid); buf = (C.c_float * n)(); lib.sn_profile_elapsed_ms(kid, buf, n)
         res[kname] = sorted(buf)[n // 2] * 1e3
     w = ws.view(torch.int32)
-    print(f"{name}: screen {res['screen']:.1f} us, rerank {res['rerank']:.1f} us, entries {int(w[0])}, overflow tokens {int(w[1])}")
+    print(f"{name}: screen {res['screen']:.1f} us, rerank {res['rerank']:.1f} us, flagged {int((w[8:8 + n_tok] > 0).sum())}, overflow tokens {int(w[1])}")
     lib.sn_profile_enable(0)
