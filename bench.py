@@ -182,7 +182,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
                 for row in json.load(fh)["kernels"]:
-                    if row["kernel"].startswith("assign_screen_kernel<24>"):
+                    if row["kernel"].startswith("assign_screen_kernel<24"):
                         traffic = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
         except (OSError, KeyError, ValueError):
             pass

@@ -44,10 +44,10 @@ int sn_device_ok(void);
 /* ------------------------------------------------------------------------------------------
  * per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figure; off by default, zero cost when off).
- * kernel ids: 0 = assignment screen (fp16 MFMA), 1 = assignment re-rank (fp64),
+ * kernel ids: 4 = GCN GEMM (split-fp16 MFMA); 0 = assignment screen (fp16 MFMA), 1 = assignment re-rank (fp64),
  *             2 = instance graph (S2+S3), 3 = atlas normalise
  * ------------------------------------------------------------------------------------------ */
-#define SN_PROF_KERNELS 4
+#define SN_PROF_KERNELS 5
 /* max_samples > 0: (re)start recording up to that many launches per kernel; 0: stop + free. */
 int sn_profile_enable(int max_samples);
 /* Number of launches recorded so far for kernel_id. */
@@ -228,6 +228,44 @@ int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, 
  * in place; merged across ranks with one all-reduce (replaces the meter.sync() of the reference,
  * schema_inference/eval/evaluation.py:95-97). */
 int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream);
+
+/* ---- S4 on the matrix cores: GCN layers with split-fp16 operands ----------------------------
+ * Replaces torch.bmm(adj, feat) + nn.Linear + masked_fill + LayerNorm + ReLU + pooling of the
+ * reference's GNN (schema_inference/graph/gnn.py:20-98).  Every operand is a pair of fp16 planes
+ * (x = hi + lo, 22 significant bits), a product is three fp16 MFMAs accumulated in fp32.
+ * All planes are row-major with K contiguous, rows 16-byte aligned and zero-padded to a multiple
+ * of 32 in K. */
+
+/* adj = (E + E^T)/2 + I  (gnn.py:27-30) as planes [G][n][ld], ld % 32 == 0, columns >= n zero. */
+int sn_gcn_adjacency_planes(const float *edges, int G, int n, int ld, void *adj_hi, void *adj_lo,
+                            void *stream);
+
+/* Zt[g][f][j] = table[ids[g][j]][f] as planes [G][E][ld] (columns >= n and ids outside
+ * [0, rows_table) give zero): the transposed, gathered B operand of layer 1
+ * (gnn.py:64-66 with the Linear folded into the embedding table). */
+int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n,
+                         int ld, int E, void *out_hi, void *out_lo, void *stream);
+
+/* hi/lo split of a contiguous fp32 array (weights). */
+int sn_split_planes(const float *x, int64_t count, void *out_hi, void *out_lo, void *stream);
+
+/* C[b] = A[b] . Bt[b]^T for b < batches, A [m][lda], Bt [n][ldb], k % 32 == 0 (batch strides in
+ * fp16 elements, 0 = shared operand).  Epilogue, in this order: + bias[n]; rows >= rows_valid[b]
+ * set to 0 (gnn.py:43-45); LayerNorm over the n == 256 columns with gamma/beta/eps (gnn.py:46);
+ * ReLU; then any of: fp32 C [m][ldc]; hi/lo planes [m][ldcp] (columns [n, cp_cols) zero-filled);
+ * pooled[b][n] += sum_m pool_w[b][m] * C[m][n] (atomic; zero `pooled` first; gnn.py:96). */
+typedef struct sn_gemm_args {
+    const void *a_hi, *a_lo; int64_t a_batch_stride; int lda;
+    const void *b_hi, *b_lo; int64_t b_batch_stride; int ldb;
+    int m, n, k, batches;
+    float *c; int64_t c_batch_stride; int ldc;
+    void *c_hi, *c_lo; int64_t cp_batch_stride; int ldcp, cp_cols;
+    const float *bias;
+    const float *gamma, *beta; float eps; int layernorm, relu;
+    const int32_t *rows_valid;
+    const float *pool_w; int64_t pool_w_stride; float *pooled;
+} sn_gemm_args;
+int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@ reference-compatible shims (CPU tensors in, lists out) live in cpp_extension/__i
 """
 from ctypes import byref, c_void_p
 
+
 import torch
 
 from . import _native as N
@@ -275,6 +276,116 @@ def gcn_adjacency(edges):
     with torch.cuda.device(dev):
         N.check(lib.sn_gcn_adjacency(N.ptr(e), G, n, N.ptr(adj), N.stream_ptr(dev)), "sn_gcn_adjacency")
     return adj
+
+
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def pad32(n):
+    return (int(n) + 31) // 32 * 32
+
+
+def gcn_adjacency_planes(edges):
+    """(E + E^T)/2 + I as fp16 hi/lo planes [G, n, pad32(n)] (pad columns zero)."""
+    lib = N.require_gpu()
+    dev = _check_dev(edges)
+    e = _f32c(edges)
+    G, n, _ = e.shape
+    ld = pad32(n)
+    hi = torch.empty((G, n, ld), dtype=torch.float16, device=dev)
+    lo = torch.empty_like(hi)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, ld, N.ptr(hi), N.ptr(lo), N.stream_ptr(dev)),
+                "sn_gcn_adjacency_planes")
+    return hi, lo
+
+
+def gcn_gather_planes(table, ids, ld=None):
+    """Zt[g, f, j] = table[ids[g, j], f] as fp16 hi/lo planes [G, E, ld]."""
+    lib = N.require_gpu()
+    dev = _check_dev(table, ids)
+    t = _f32c(table.detach())
+    ids = ids.contiguous()
+    assert ids.dtype == torch.int64
+    G, n = ids.shape
+    rows, E = t.shape
+    ld = pad32(n) if ld is None else ld
+    hi = torch.empty((G, E, ld), dtype=torch.float16, device=dev)
+    lo = torch.empty_like(hi)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_gcn_gather_planes(N.ptr(t), rows, N.ptr(ids), G, n, ld, E, N.ptr(hi), N.ptr(lo), N.stream_ptr(dev)),
+                "sn_gcn_gather_planes")
+    return hi, lo
+
+
+def split_planes(x):
+    """fp32 tensor -> (hi, lo) fp16 tensors of the same shape with hi + lo ~= x (22 bits)."""
+    lib = N.require_gpu()
+    dev = _check_dev(x)
+    xc = _f32c(x.detach())
+    hi = torch.empty(xc.shape, dtype=torch.float16, device=dev)
+    lo = torch.empty_like(hi)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_split_planes(N.ptr(xc), xc.numel(), N.ptr(hi), N.ptr(lo), N.stream_ptr(dev)), "sn_split_planes")
+    return hi, lo
+
+
+def gcn_gemm(a, b, m, n, k, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
+             want_c=False, want_planes=0, pool_w=None, pooled=None):
+    """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm).
+
+    a, b: (hi, lo) fp16 tensors [batches or 1, rows, ld] (K contiguous, zero padded to k).
+    layernorm: (gamma, beta, eps) or None.  want_planes: 0 or the number of output plane columns
+    (>= n; the extra columns are zero-filled).  pool_w [batches, m] + pooled [batches, n]
+    (accumulated in place).  Returns dict(c=..., planes=(hi, lo), pooled=...)."""
+    lib = N.require_gpu()
+    a_hi, a_lo = a
+    b_hi, b_lo = b
+    dev = _check_dev(a_hi, a_lo, b_hi, b_lo)
+    for t in (a_hi, a_lo, b_hi, b_lo):
+        assert t.dtype == torch.float16 and t.dim() == 3 and t.is_contiguous()
+    args = N.GemmArgs()
+    args.a_hi, args.a_lo = _dp(a_hi), _dp(a_lo)
+    args.lda = a_hi.shape[2]
+    args.a_batch_stride = a_hi.shape[1] * a_hi.shape[2] if a_hi.shape[0] > 1 else 0
+    args.b_hi, args.b_lo = _dp(b_hi), _dp(b_lo)
+    args.ldb = b_hi.shape[2]
+    args.b_batch_stride = b_hi.shape[1] * b_hi.shape[2] if b_hi.shape[0] > 1 else 0
+    assert a_hi.shape[0] in (1, batches) and b_hi.shape[0] in (1, batches)
+    assert a_hi.shape[1] >= m and b_hi.shape[1] >= n
+    args.m, args.n, args.k, args.batches = int(m), int(n), int(k), int(batches)
+    out = {}
+    keep = []
+    if want_c:
+        c = torch.empty((batches, m, n), dtype=torch.float32, device=dev)
+        args.c, args.c_batch_stride, args.ldc = _dp(c), m * n, n
+        out["c"] = c
+    if want_planes:
+        cols = int(want_planes)
+        ch = torch.empty((batches, m, cols), dtype=torch.float16, device=dev)
+        cl = torch.empty_like(ch)
+        args.c_hi, args.c_lo, args.cp_batch_stride, args.ldcp, args.cp_cols = _dp(ch), _dp(cl), m * cols, cols, cols
+        out["planes"] = (ch, cl)
+    if bias is not None:
+        bt = _f32c(bias.detach()); keep.append(bt)
+        args.bias = _dp(bt)
+    if layernorm is not None:
+        g_, b_, eps = layernorm
+        g_, b_ = _f32c(g_.detach()), _f32c(b_.detach()); keep += [g_, b_]
+        args.gamma, args.beta, args.eps, args.layernorm = _dp(g_), _dp(b_), float(eps), 1
+    args.relu = int(bool(relu))
+    if rows_valid is not None:
+        assert rows_valid.dtype == torch.int32
+        args.rows_valid = _dp(rows_valid)
+    if pool_w is not None:
+        pw = _f32c(pool_w); keep.append(pw)
+        assert pw.shape == (batches, m) and pooled is not None and pooled.shape == (batches, n) and pooled.is_contiguous()
+        args.pool_w, args.pool_w_stride, args.pooled = _dp(pw), m, _dp(pooled)
+        out["pooled"] = pooled
+    with torch.cuda.device(dev):
+        N.check(lib.sn_gcn_gemm(byref(args), N.stream_ptr(dev)), "sn_gcn_gemm")
+    return out
 
 
 def mask_layernorm_act_(x, gamma, beta, eps, n_valid=None, relu=True):

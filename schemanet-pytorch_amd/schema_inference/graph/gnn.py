@@ -8,6 +8,7 @@ HIP kernels (csrc/sn_match.hip); the dense bmm / Linear GEMMs are plain library 
 (rocBLAS via torch), fp32 so the scores stay within the 1e-5 budget.
 Training (any input or parameter requires grad): the same maths as differentiable torch ops.
 """
+import os
 from typing import Callable, Optional
 
 import torch
@@ -88,6 +89,39 @@ class GNN(nn.Module):
             return False
         return any(t.requires_grad for t in tensors if t is not None) or any(p.requires_grad for p in self.parameters())
 
+    def _mfma_ok(self) -> bool:
+        """The split-fp16 MFMA path (csrc/sn_gcn.hip) covers the shipped configuration: two layers
+        with a Linear projection, ReLU / no activation and embed_dim 256."""
+        if os.environ.get("SN_GCN_MFMA", "1") == "0" or self.embed_dim != 256 or len(self.layers) != 2:
+            return False
+        return all(isinstance(l.g_conv.linear, nn.Linear) and (l._is_relu or l._is_none) for l in self.layers)
+
+    def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor):
+        """Inference on the matrix cores: three GEMM launches per call, every elementwise step an
+        epilogue (bias, pad-row mask, LayerNorm, ReLU, hi/lo split, node-weighted pooling).
+            H1     = act(LN1(adj @ (Emb @ W1^T)[ids] + b1))
+            Zt2    = W2 @ H1^T                                   (so that adj @ Zt2^T = adj @ H1 @ W2^T)
+            pooled = sum_i nodes_i * act(LN2(adj @ Zt2^T + b2))_i
+        """
+        G, n = ingredients.shape
+        E = self.embed_dim
+        l1, l2 = self.layers
+        adj = ops.gcn_adjacency_planes(edges)
+        ld = adj[0].shape[2]
+        table = torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight)
+        zt1 = ops.gcn_gather_planes(table, ingredients, ld)
+        h1 = ops.gcn_gemm(adj, zt1, n, E, ld, G, bias=l1.g_conv.linear.bias,
+                          layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
+                          rows_valid=n_valid, want_planes=E)["planes"]
+        w2h, w2l = ops.split_planes(l2.g_conv.linear.weight)
+        zt2 = ops.gcn_gemm((w2h[None], w2l[None]), h1, E, n, E, G, want_planes=ld)["planes"]
+        pooled = torch.zeros((G, E), dtype=torch.float32, device=nodes.device)
+        ops.gcn_gemm(adj, zt2, n, E, ld, G, bias=l2.g_conv.linear.bias,
+                     layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
+                     rows_valid=n_valid, pool_w=nodes, pooled=pooled)
+        pooled = pooled / (divisor.to(pooled.dtype) if divisor is not None else n)
+        return self.fc(pooled)
+
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
                 feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
                 divisor: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -101,6 +135,8 @@ class GNN(nn.Module):
         fused = nodes.is_cuda and not self._differentiable(nodes, edges)
         if n_valid is None and feat_mask is not None:
             n_valid = (~feat_mask).sum(dim=1).to(torch.int32)   # masks are suffix masks (match.py:48-51)
+        if fused and self._mfma_ok():
+            return self._forward_mfma(nodes, edges, ingredients, n_valid, divisor)
         if feat_mask is None and n_valid is not None and not fused:
             feat_mask = torch.arange(nodes.shape[1], device=nodes.device)[None, :] >= n_valid[:, None]
         adj = ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges)
