@@ -229,37 +229,49 @@ int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, 
  * schema_inference/eval/evaluation.py:95-97). */
 int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream);
 
+/* out[g][o] = bias[o] + sum_e (pooled_sum[g][e] / divisor) * weight[o][e]: the mean over the padded
+ * length followed by the GNN's final Linear (gnn.py:96-98).  divisor = *divisor_dev (int32 on the
+ * device, e.g. the batch-maximum vertex count) when non-NULL, else divisor_host. */
+int sn_pool_fc(const float *pooled_sum, int G, int E, const int32_t *divisor_dev, float divisor_host,
+               const float *weight, const float *bias, int E_out, float *out, void *stream);
+
 /* ---- S4 on the matrix cores: GCN layers with split-fp16 operands ----------------------------
  * Replaces torch.bmm(adj, feat) + nn.Linear + masked_fill + LayerNorm + ReLU + pooling of the
  * reference's GNN (schema_inference/graph/gnn.py:20-98).  Every operand is a pair of fp16 planes
  * (x = hi + lo, 22 significant bits), a product is three fp16 MFMAs accumulated in fp32.
- * All planes are row-major with K contiguous, rows 16-byte aligned and zero-padded to a multiple
- * of 32 in K. */
+ * Planes are BLOCKED in MFMA fragment order: a [rows, k] operand is ceil(rows/32) x ceil(k/16)
+ * blocks of 1 KiB; element (row, kk) lives in block (row >> 5, kk >> 4) at fp16 index
+ * ((kk >> 3 & 1) * 32 + (row & 31)) * 8 + (kk & 7); rows / k beyond the operand are zero. */
 
-/* adj = (E + E^T)/2 + I  (gnn.py:27-30) as planes [G][n][ld], ld % 32 == 0, columns >= n zero. */
-int sn_gcn_adjacency_planes(const float *edges, int G, int n, int ld, void *adj_hi, void *adj_lo,
-                            void *stream);
+/* fp16 elements of one plane of a [rows, k] operand (per batch entry). */
+int64_t sn_gcn_plane_elems(int rows, int k);
 
-/* Zt[g][f][j] = table[ids[g][j]][f] as planes [G][E][ld] (columns >= n and ids outside
- * [0, rows_table) give zero): the transposed, gathered B operand of layer 1
- * (gnn.py:64-66 with the Linear folded into the embedding table). */
-int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n,
-                         int ld, int E, void *out_hi, void *out_lo, void *stream);
+/* adj = (E + E^T)/2 + I  (gnn.py:27-30) as blocked planes of a [n, n] operand per graph. */
+int sn_gcn_adjacency_planes(const float *edges, int G, int n, void *adj_hi, void *adj_lo, void *stream);
 
-/* hi/lo split of a contiguous fp32 array (weights). */
-int sn_split_planes(const float *x, int64_t count, void *out_hi, void *out_lo, void *stream);
+/* Zt[g][f][j] = table[ids[g][j]][f] as blocked planes of an [E, n] operand per graph (ids outside
+ * [0, rows_table) give zero): the transposed, gathered B operand of layer 1 (gnn.py:64-66 with the
+ * Linear folded into the embedding table). */
+int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int E,
+                         void *out_hi, void *out_lo, void *stream);
 
-/* C[b] = A[b] . Bt[b]^T for b < batches, A [m][lda], Bt [n][ldb], k % 32 == 0 (batch strides in
- * fp16 elements, 0 = shared operand).  Epilogue, in this order: + bias[n]; rows >= rows_valid[b]
- * set to 0 (gnn.py:43-45); LayerNorm over the n == 256 columns with gamma/beta/eps (gnn.py:46);
- * ReLU; then any of: fp32 C [m][ldc]; hi/lo planes [m][ldcp] (columns [n, cp_cols) zero-filled);
+/* hi/lo split of fp32 x [batches][rows][ld] (cols valid per row, batch stride in floats) into
+ * blocked planes of a [rows, cols] operand per batch entry. */
+int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
+                    void *out_hi, void *out_lo, void *stream);
+
+/* C[b] = A[b] . Bt[b]^T for b < batches; A = planes of an [m, k] operand, Bt = planes of an [n, k]
+ * operand, k % 16 == 0 (the padded k of the planes); batch strides in fp16 elements, 0 = shared
+ * operand.  Epilogue, in this order: + bias[n]; rows >= rows_valid[b] set to 0 (gnn.py:43-45);
+ * LayerNorm over the n == 256 columns with gamma/beta/eps (gnn.py:46); ReLU; then any of: fp32 C
+ * [m][ldc]; blocked hi/lo planes of C as an [m, cp_cols] operand (columns [n, cp_cols) zero);
  * pooled[b][n] += sum_m pool_w[b][m] * C[m][n] (atomic; zero `pooled` first; gnn.py:96). */
 typedef struct sn_gemm_args {
-    const void *a_hi, *a_lo; int64_t a_batch_stride; int lda;
-    const void *b_hi, *b_lo; int64_t b_batch_stride; int ldb;
+    const void *a_hi, *a_lo; int64_t a_batch_stride;
+    const void *b_hi, *b_lo; int64_t b_batch_stride;
     int m, n, k, batches;
     float *c; int64_t c_batch_stride; int ldc;
-    void *c_hi, *c_lo; int64_t cp_batch_stride; int ldcp, cp_cols;
+    void *c_hi, *c_lo; int64_t cp_batch_stride; int cp_cols;
     const float *bias;
     const float *gamma, *beta; float eps; int layernorm, relu;
     const int32_t *rows_valid;

@@ -48,11 +48,11 @@ class GraphArgs(Structure):
 class GemmArgs(Structure):
     """struct sn_gemm_args (include/schemanet_hip.h)."""
     _fields_ = [
-        ("a_hi", c_void_p), ("a_lo", c_void_p), ("a_batch_stride", c_int64), ("lda", c_int),
-        ("b_hi", c_void_p), ("b_lo", c_void_p), ("b_batch_stride", c_int64), ("ldb", c_int),
+        ("a_hi", c_void_p), ("a_lo", c_void_p), ("a_batch_stride", c_int64),
+        ("b_hi", c_void_p), ("b_lo", c_void_p), ("b_batch_stride", c_int64),
         ("m", c_int), ("n", c_int), ("k", c_int), ("batches", c_int),
         ("c", c_void_p), ("c_batch_stride", c_int64), ("ldc", c_int),
-        ("c_hi", c_void_p), ("c_lo", c_void_p), ("cp_batch_stride", c_int64), ("ldcp", c_int), ("cp_cols", c_int),
+        ("c_hi", c_void_p), ("c_lo", c_void_p), ("cp_batch_stride", c_int64), ("cp_cols", c_int),
         ("bias", c_void_p),
         ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("layernorm", c_int), ("relu", c_int),
         ("rows_valid", c_void_p),
@@ -86,9 +86,11 @@ _SIGNATURES = {
     "sn_weighted_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_match_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sn_class_votes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "sn_split_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sn_pool_fc": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "sn_gcn_plane_elems": (c_int64, [c_int, c_int]),
+    "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -282,27 +282,53 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
-def pad32(n):
-    return (int(n) + 31) // 32 * 32
+class Planes:
+    """A [batches, rows, k] fp32 operand as two blocked fp16 planes (include/schemanet_hip.h, S4):
+    hi/lo are flat [batches, plane_elems] tensors; `rows`/`k` are the logical extent, `kpad` the
+    k of the blocks (multiple of 16)."""
+
+    __slots__ = ("hi", "lo", "batches", "rows", "k", "kpad")
+
+    def __init__(self, hi, lo, batches, rows, k):
+        self.hi, self.lo, self.batches, self.rows, self.k = hi, lo, batches, rows, k
+        self.kpad = (k + 15) // 16 * 16
+
+    @property
+    def stride(self):
+        return self.hi.shape[1] if self.batches > 1 else 0
+
+    def to_dense(self):
+        """[batches, rows, k] fp32 reconstruction hi + lo (tests / debugging)."""
+        rb, kb = (self.rows + 31) // 32, self.kpad // 16
+        def un(p):
+            x = p.float().view(self.batches, rb, kb, 2, 32, 8)           # [g, rb, kb, h, r, e]
+            x = x.permute(0, 1, 4, 2, 3, 5).reshape(self.batches, rb * 32, kb * 16)
+            return x
+        full = un(self.hi) + un(self.lo)
+        return full[:, :self.rows, :self.k], full
+
+
+def _alloc_planes(lib, dev, batches, rows, k):
+    elems = lib.sn_gcn_plane_elems(int(rows), int(k))
+    hi = torch.empty((batches, elems), dtype=torch.float16, device=dev)
+    return Planes(hi, torch.empty_like(hi), batches, rows, k)
 
 
 def gcn_adjacency_planes(edges):
-    """(E + E^T)/2 + I as fp16 hi/lo planes [G, n, pad32(n)] (pad columns zero)."""
+    """(E + E^T)/2 + I of [G, n, n] edges as blocked fp16 hi/lo planes."""
     lib = N.require_gpu()
     dev = _check_dev(edges)
     e = _f32c(edges)
     G, n, _ = e.shape
-    ld = pad32(n)
-    hi = torch.empty((G, n, ld), dtype=torch.float16, device=dev)
-    lo = torch.empty_like(hi)
+    out = _alloc_planes(lib, dev, G, n, n)
     with torch.cuda.device(dev):
-        N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, ld, N.ptr(hi), N.ptr(lo), N.stream_ptr(dev)),
+        N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                 "sn_gcn_adjacency_planes")
-    return hi, lo
+    return out
 
 
-def gcn_gather_planes(table, ids, ld=None):
-    """Zt[g, f, j] = table[ids[g, j], f] as fp16 hi/lo planes [G, E, ld]."""
+def gcn_gather_planes(table, ids):
+    """Zt[g, f, j] = table[ids[g, j], f] as blocked planes of a [G, E, n] operand."""
     lib = N.require_gpu()
     dev = _check_dev(table, ids)
     t = _f32c(table.detach())
@@ -310,51 +336,43 @@ def gcn_gather_planes(table, ids, ld=None):
     assert ids.dtype == torch.int64
     G, n = ids.shape
     rows, E = t.shape
-    ld = pad32(n) if ld is None else ld
-    hi = torch.empty((G, E, ld), dtype=torch.float16, device=dev)
-    lo = torch.empty_like(hi)
+    out = _alloc_planes(lib, dev, G, E, n)
     with torch.cuda.device(dev):
-        N.check(lib.sn_gcn_gather_planes(N.ptr(t), rows, N.ptr(ids), G, n, ld, E, N.ptr(hi), N.ptr(lo), N.stream_ptr(dev)),
+        N.check(lib.sn_gcn_gather_planes(N.ptr(t), rows, N.ptr(ids), G, n, E, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                 "sn_gcn_gather_planes")
-    return hi, lo
+    return out
 
 
 def split_planes(x):
-    """fp32 tensor -> (hi, lo) fp16 tensors of the same shape with hi + lo ~= x (22 bits)."""
+    """fp32 [rows, k] or [batches, rows, k] -> blocked hi/lo planes with hi + lo ~= x (22 bits)."""
     lib = N.require_gpu()
     dev = _check_dev(x)
     xc = _f32c(x.detach())
-    hi = torch.empty(xc.shape, dtype=torch.float16, device=dev)
-    lo = torch.empty_like(hi)
+    if xc.dim() == 2:
+        xc = xc[None]
+    B_, rows, k = xc.shape
+    out = _alloc_planes(lib, dev, B_, rows, k)
     with torch.cuda.device(dev):
-        N.check(lib.sn_split_planes(N.ptr(xc), xc.numel(), N.ptr(hi), N.ptr(lo), N.stream_ptr(dev)), "sn_split_planes")
-    return hi, lo
+        N.check(lib.sn_split_planes(N.ptr(xc), B_, rows, k, k, rows * k, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+                "sn_split_planes")
+    return out
 
 
-def gcn_gemm(a, b, m, n, k, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
+def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
              want_c=False, want_planes=0, pool_w=None, pooled=None):
-    """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm).
+    """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
-    a, b: (hi, lo) fp16 tensors [batches or 1, rows, ld] (K contiguous, zero padded to k).
-    layernorm: (gamma, beta, eps) or None.  want_planes: 0 or the number of output plane columns
-    (>= n; the extra columns are zero-filled).  pool_w [batches, m] + pooled [batches, n]
-    (accumulated in place).  Returns dict(c=..., planes=(hi, lo), pooled=...)."""
+    layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
+    (>= n; the extra columns are zero).  pool_w [batches, m] + pooled [batches, n] (accumulated in
+    place).  Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
-    a_hi, a_lo = a
-    b_hi, b_lo = b
-    dev = _check_dev(a_hi, a_lo, b_hi, b_lo)
-    for t in (a_hi, a_lo, b_hi, b_lo):
-        assert t.dtype == torch.float16 and t.dim() == 3 and t.is_contiguous()
+    dev = _check_dev(a.hi, a.lo, b.hi, b.lo)
+    assert a.kpad == b.kpad and a.batches in (1, batches) and b.batches in (1, batches)
+    m, n = a.rows, b.rows
     args = N.GemmArgs()
-    args.a_hi, args.a_lo = _dp(a_hi), _dp(a_lo)
-    args.lda = a_hi.shape[2]
-    args.a_batch_stride = a_hi.shape[1] * a_hi.shape[2] if a_hi.shape[0] > 1 else 0
-    args.b_hi, args.b_lo = _dp(b_hi), _dp(b_lo)
-    args.ldb = b_hi.shape[2]
-    args.b_batch_stride = b_hi.shape[1] * b_hi.shape[2] if b_hi.shape[0] > 1 else 0
-    assert a_hi.shape[0] in (1, batches) and b_hi.shape[0] in (1, batches)
-    assert a_hi.shape[1] >= m and b_hi.shape[1] >= n
-    args.m, args.n, args.k, args.batches = int(m), int(n), int(k), int(batches)
+    args.a_hi, args.a_lo, args.a_batch_stride = _dp(a.hi), _dp(a.lo), a.stride
+    args.b_hi, args.b_lo, args.b_batch_stride = _dp(b.hi), _dp(b.lo), b.stride
+    args.m, args.n, args.k, args.batches = int(m), int(n), int(a.kpad), int(batches)
     out = {}
     keep = []
     if want_c:
@@ -362,11 +380,9 @@ def gcn_gemm(a, b, m, n, k, batches, bias=None, layernorm=None, relu=False, rows
         args.c, args.c_batch_stride, args.ldc = _dp(c), m * n, n
         out["c"] = c
     if want_planes:
-        cols = int(want_planes)
-        ch = torch.empty((batches, m, cols), dtype=torch.float16, device=dev)
-        cl = torch.empty_like(ch)
-        args.c_hi, args.c_lo, args.cp_batch_stride, args.ldcp, args.cp_cols = _dp(ch), _dp(cl), m * cols, cols, cols
-        out["planes"] = (ch, cl)
+        cp = _alloc_planes(lib, dev, batches, m, int(want_planes))
+        args.c_hi, args.c_lo, args.cp_batch_stride, args.cp_cols = _dp(cp.hi), _dp(cp.lo), cp.hi.shape[1], cp.kpad
+        out["planes"] = cp
     if bias is not None:
         bt = _f32c(bias.detach()); keep.append(bt)
         args.bias = _dp(bt)
@@ -385,6 +401,26 @@ def gcn_gemm(a, b, m, n, k, batches, bias=None, layernorm=None, relu=False, rows
         out["pooled"] = pooled
     with torch.cuda.device(dev):
         N.check(lib.sn_gcn_gemm(byref(args), N.stream_ptr(dev)), "sn_gcn_gemm")
+    return out
+
+
+def pool_fc(pooled_sum, divisor, weight, bias):
+    """fc(pooled_sum / divisor): divisor is an int32 [1] device tensor or a python number."""
+    lib = N.require_gpu()
+    dev = _check_dev(pooled_sum, weight, bias)
+    p = _f32c(pooled_sum)
+    w = _f32c(weight.detach())
+    b = None if bias is None else _f32c(bias.detach())
+    G, E = p.shape
+    out = torch.empty((G, w.shape[0]), dtype=torch.float32, device=dev)
+    if torch.is_tensor(divisor):
+        assert divisor.dtype == torch.int32 and divisor.device == dev
+        ddev, dhost = N.ptr(divisor), 0.0
+    else:
+        ddev, dhost = None, float(divisor)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_pool_fc(N.ptr(p), G, E, ddev, dhost, N.ptr(w), N.ptr(b), w.shape[0], N.ptr(out), N.stream_ptr(dev)),
+                "sn_pool_fc")
     return out
 
 

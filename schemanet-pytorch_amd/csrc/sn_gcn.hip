@@ -18,11 +18,14 @@
 // Bias, padding mask, LayerNorm, ReLU, the hi/lo split of the result and the node-weighted pooling are
 // epilogues on the accumulator tile.
 //
-// Tiling: 512 threads = 8 waves (2 per SIMD) own a 256 x 256 output tile, wave (wm, wn) a 64 x 128
-// sub-tile = 2 x 4 MFMA 32x32 accumulators (128 VGPRs).  A k-stage is 32 wide: 64 KiB of LDS holding
-// both planes of both operands in MFMA fragment order, filled by LDS-DMA (global_load_lds_dwordx4,
-// 8 per wave per stage) into a 2-stage ring; one barrier per stage; 48 MFMAs and 24 ds_read_b128
-// per wave per stage.
+// Tiling: 256 threads = 4 waves own a 128 x 256 output tile, wave (wm, wn) a 64 x 128 sub-tile = 2 x 4
+// MFMA 32x32 accumulators (128 VGPRs); two workgroups per CU (two waves per SIMD that are NOT in
+// lockstep: while one workgroup waits at its stage barrier or issues DMA the other multiplies).  A
+// k-stage is one MFMA k-step (16): 24 KiB of LDS holding both planes of both operands in MFMA fragment
+// order, filled by LDS-DMA (global_load_lds_dwordx4, 6 contiguous 1 KiB blocks per wave per stage) into
+// a 3-stage ring (96 KiB per CU in flight: the products stream their operands from HBM at an arithmetic
+// intensity near the ridge, so latency hiding decides the speed); one barrier, 24 MFMAs and
+// 12 ds_read_b128 per wave per stage.
 #include "sn_common.h"
 
 #include <hip/hip_fp16.h>
@@ -33,10 +36,24 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTile = 256;              // output tile edge
-constexpr int kStageK = 32;             // k per stage
-constexpr int kStageBytes = 64 * 1024;  // [A: 8 m-tiles][2 planes][2 k16] + [B: 8 n-tiles][2 planes][2 k16] x 1 KiB
-constexpr int kGemmThreads = 512;
+constexpr int kTileM = 128, kTileN = 256;   // output tile of a workgroup
+constexpr int kStageK = 16;             // k per stage (one MFMA k-step)
+constexpr int kChunksA = (kTileM / 32) * 2, kChunksB = (kTileN / 32) * 2;   // 1 KiB blocks per stage: [row block][plane]
+constexpr int kStageBytes = (kChunksA + kChunksB) * 1024;                    // 24 KiB
+constexpr int kRing = 3;                // LDS stages: two in flight behind the one being multiplied (72 KiB -> 2 workgroups / CU)
+constexpr int kGemmThreads = 256;
+constexpr int kDmaPerWave = (kChunksA + kChunksB) / (kGemmThreads / 64);     // 6
+constexpr int kBlockElems = 512;        // fp16 elements of one 32-row x 16-k block (1 KiB)
+
+// Operand planes are stored BLOCKED, in the order the MFMA consumes them: plane[g][row >> 5][k >> 4] is a
+// 1 KiB block holding element (row, k) at ((k >> 3 & 1) * 32 + (row & 31)) * 8 + (k & 7) - i.e. lane
+// (r, h) of a wave finds its 8 consecutive k of row r at byte lane * 16.  One LDS-DMA instruction moves
+// one block (contiguous 1 KiB of global memory -> contiguous 1 KiB of LDS), every ds_read_b128 of a
+// fragment is lane-linear, and consecutive k-stages of a row block are consecutive blocks.
+__host__ __device__ inline int64_t blocked_index(int row, int k, int kb_count)
+{
+    return ((int64_t)(row >> 5) * kb_count + (k >> 4)) * kBlockElems + (((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
+}
 
 __device__ __forceinline__ void split2(float x, _Float16 &hi, _Float16 &lo)
 {
@@ -44,112 +61,138 @@ __device__ __forceinline__ void split2(float x, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)(x - (float)hi);
 }
 
-// ------------------------------------------------------------------ producers of operand planes
-// adj = (E + E^T) / 2 + I as hi/lo planes [G][n][ld], zero for columns >= n (reference gnn.py:27-30)
-__global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int ld, _Float16 *out_h, _Float16 *out_l)
+// 8 consecutive k of one row -> one 16-byte piece per plane
+__device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h, _Float16 *out_l, int64_t o)
 {
-    __shared__ float tr[64][65];
+    half8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 a, b;
+        split2(v[e], a, b);
+        h[e] = a;
+        l[e] = b;
+    }
+    *reinterpret_cast<half8 *>(out_h + o) = h;
+    *reinterpret_cast<half8 *>(out_l + o) = l;
+}
+
+// ------------------------------------------------------------------ producers of operand planes
+// adj = (E + E^T) / 2 + I (reference gnn.py:27-30) as blocked hi/lo planes, rows and columns >= n zero.
+// One workgroup per 64 x 64 tile: E tile and E^T tile through LDS, then one 16-byte piece per thread pair.
+__global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
+                                                               _Float16 *out_h, _Float16 *out_l)
+{
+    __shared__ float te[64][65], tt[64][65];
     const int g = blockIdx.z, bi = blockIdx.y * 64, bj = blockIdx.x * 64;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float *e = edges + (int64_t)g * n * n;
-    // E^T tile: rows bj.., columns bi..
+    // branch-free loads (clamped index + select): a conditional load per element would serialise them
+    float ve[16], vt[16];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = bj + ty * 8 + rr;
+    for (int it = 0; it < 16; ++it) {
+        const int rr = ty + 4 * it;
+        const int i = bi + rr, j = bj + tx;
+        const bool ok = i < n && j < n;
+        ve[it] = e[ok ? (int64_t)i * n + j : 0];                              // E[i][j]
+        const int i2 = bj + rr, j2 = bi + tx;
+        const bool ok2 = i2 < n && j2 < n;
+        vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                           // E[j][i] stored at [j - bj][i - bi]
+        ve[it] = ok ? ve[it] : 0.0f;
+        vt[it] = ok2 ? vt[it] : 0.0f;
+    }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = bi + tx + 32 * c;
-            tr[ty * 8 + rr][tx + 32 * c] = (row < n && col < n) ? e[(int64_t)row * n + col] : 0.0f;
-        }
+    for (int it = 0; it < 16; ++it) {
+        te[ty + 4 * it][tx] = ve[it];
+        tt[ty + 4 * it][tx] = vt[it];
     }
     __syncthreads();
+    // pieces: 64 rows x 8 (k / 8); thread -> row il = tid & 63, pieces pc = tid >> 6, + 4
+    for (int pc = ty; pc < 8; pc += 4) {
+        const int il = tx, i = bi + il, j0 = bj + pc * 8;
+        if ((i >> 5) * 32 >= ((n + 31) & ~31) || j0 >= kb_count * 16) continue;
+        float v[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int il = ty * 8 + rr, i = bi + il;
-        const int j = bj + 2 * tx;
-        if (i >= n || j >= ld) continue;
-        float v[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int jj = j + c;
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q;
             float x = 0.0f;
-            if (jj < n) {
-                x = (e[(int64_t)i * n + jj] + tr[2 * tx + c][il]) / 2.0f;
-                if (i == jj) x = x + 1.0f;
+            if (i < n && j < n) {
+                x = (te[il][pc * 8 + q] + tt[pc * 8 + q][il]) * 0.5f;       // == / 2 exactly
+                if (i == j) x = x + 1.0f;
             }
-            v[c] = x;
+            v[q] = x;
         }
-        _Float16 h0, l0, h1, l1;
-        split2(v[0], h0, l0);
-        split2(v[1], h1, l1);
-        const half2v h = {h0, h1}, l = {l0, l1};
-        const int64_t o = ((int64_t)g * n + i) * ld + j;
-        *reinterpret_cast<half2v *>(out_h + o) = h;
-        *reinterpret_cast<half2v *>(out_l + o) = l;
+        store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(i, j0, kb_count));
     }
 }
 
-// Zt[g][f][j] = table[ids[g][j]][f] as hi/lo planes [G][E][ld], zero for j >= n.
-// (layer 1 re-associated: adj @ Emb[ids] @ W^T == adj @ (Emb @ W^T)[ids], gnn.py:64-66 + 30)
-__global__ __launch_bounds__(256) void gather_planes_kernel(const float *table, int rows_table, const int64_t *ids, int n, int ld, int E,
-                                                            _Float16 *out_h, _Float16 *out_l)
+// Zt[g][f][j] = table[ids[g][j]][f] as blocked planes (rows f < E, k = j; j >= n and ids outside the
+// table give zero).  (layer 1 re-associated: adj @ Emb[ids] @ W^T == adj @ (Emb @ W^T)[ids], gnn.py:64-66 + 30)
+__global__ __launch_bounds__(256) void gather_planes_kernel(const float *table, int rows_table, const int64_t *ids, int n, int kb_count,
+                                                            int E, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l)
 {
     __shared__ float tile[64][65];
     __shared__ int rid[64];
     const int g = blockIdx.y, j0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     if (threadIdx.x < 64) {
         const int j = j0 + threadIdx.x;
-        int64_t id = j < n ? ids[(int64_t)g * n + j] : -1;
+        const int64_t id = j < n ? ids[(int64_t)g * n + j] : -1;
         rid[threadIdx.x] = (id >= 0 && id < rows_table) ? (int)id : -1;
     }
     __syncthreads();
     for (int f0 = 0; f0 < E; f0 += 64) {
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {               // wave wid loads rows wid*16 .. +15, 64 features each
+        for (int rr = 0; rr < 16; ++rr) {               // wave wid loads table rows of nodes wid*16 .. +15, 64 features each
             const int jl = wid * 16 + rr, row = rid[jl], f = f0 + lane;
-            tile[jl][lane] = (row >= 0 && f < E) ? table[(int64_t)row * E + f] : 0.0f;
+            const bool ok = row >= 0 && f < E;
+            const float v = table[ok ? (int64_t)row * E + f : 0];          // branch-free: clamped index + select
+            tile[jl][lane] = ok ? v : 0.0f;
         }
         __syncthreads();
+        for (int pc = wid; pc < 8; pc += 4) {           // piece = (feature f0 + lane, nodes j0 + 8 pc .. + 7)
+            const int f = f0 + lane, jj = j0 + pc * 8;
+            if (f < ((E + 31) & ~31) && jj < kb_count * 16) {
+                float v[8];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int fl = ty * 8 + rr, f = f0 + fl, j = j0 + 2 * tx;
-            if (f < E && j < ld) {
-                _Float16 h0, l0, h1, l1;
-                split2(tile[2 * tx][fl], h0, l0);
-                split2(tile[2 * tx + 1][fl], h1, l1);
-                const half2v h = {h0, h1}, l = {l0, l1};
-                const int64_t o = ((int64_t)g * E + f) * ld + j;
-                *reinterpret_cast<half2v *>(out_h + o) = h;
-                *reinterpret_cast<half2v *>(out_l + o) = l;
+                for (int q = 0; q < 8; ++q) v[q] = f < E ? tile[pc * 8 + q][lane] : 0.0f;
+                store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(f, jj, kb_count));
             }
         }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void split_planes_kernel(const float *x, int64_t count, _Float16 *out_h, _Float16 *out_l)
+// fp32 [batches][rows][ld] (cols valid) -> blocked planes, zero padded to 32 rows / 16 k
+__global__ __launch_bounds__(256) void split_planes_kernel(const float *x, int rows, int cols, int64_t ld, int64_t x_batch_stride,
+                                                           int kb_count, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < count) split2(x[i], out_h[i], out_l[i]);
+    const int g = blockIdx.y;
+    const int rows_pad = (rows + 31) & ~31;
+    const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;         // over [rows_pad][kb_count * 2]
+    const int row = (int)(piece % rows_pad), pk = (int)(piece / rows_pad); // consecutive threads -> consecutive rows (16 B apart)
+    if (pk >= kb_count * 2) return;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = pk * 8 + q;
+        v[q] = (row < rows && k < cols) ? x[(int64_t)g * x_batch_stride + (int64_t)row * ld + k] : 0.0f;
+    }
+    store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(row, pk * 8, kb_count));
 }
 
 // ------------------------------------------------------------------ the GEMM
 struct GemmArgs {
     const _Float16 *a_hi, *a_lo;
     int64_t a_batch_stride;
-    int lda;
     const _Float16 *b_hi, *b_lo;
     int64_t b_batch_stride;
-    int ldb;
     int m, n, k;
     float *c;
     int64_t c_batch_stride;
     int ldc;
     _Float16 *c_hi, *c_lo;
     int64_t cp_batch_stride;
-    int ldcp, cp_cols;
+    int cp_cols;
     const float *bias, *gamma, *beta;
     float eps;
     int relu;
@@ -157,7 +200,9 @@ struct GemmArgs {
     const float *pool_w;
     int64_t pool_w_stride;
     float *pooled;
+    unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
 };
+static unsigned long long *g_gemm_stamps = nullptr;
 
 template <bool LN>
 __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArgs p)
@@ -166,32 +211,33 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
-    const int batch = blockIdx.z, tile_m = blockIdx.y * kTile, tile_n = blockIdx.x * kTile;
+    const int batch = blockIdx.z, tile_m = blockIdx.y * kTileM, tile_n = blockIdx.x * kTileN;
+    const int kb_count = p.k / kStageK;
 
-    // ---- LDS-DMA sources: wave w copies chunks 8w .. 8w+7 of a stage.  chunk c < 32: A m-tile c>>2,
-    // plane (c>>1)&1, k16 step c&1; c >= 32: the same for B.  Lane (r, h) supplies row r, k = 8h..8h+7.
-    const _Float16 *src[8];
+    // ---- LDS-DMA sources: wave w copies chunks 6w .. 6w+5 of a stage.  chunk c < 8: A row block c>>1,
+    // plane c&1; c >= 8: the same for B.  A chunk is one contiguous 1 KiB block of the blocked plane.
+    const _Float16 *src[kDmaPerWave];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = wid * 8 + j;
-        const bool is_b = c >= 32;
-        const int t = (c & 31) >> 2, plane = (c >> 1) & 1, ks = c & 1;
-        int row = (is_b ? tile_n : tile_m) + t * 32 + r;
-        const int lim = is_b ? p.n : p.m;
-        row = row < lim ? row : lim - 1;                                   // clamp: padded rows are discarded in the epilogue
-        const _Float16 *base = is_b ? (plane ? p.b_lo : p.b_hi) + (int64_t)batch * p.b_batch_stride + (int64_t)row * p.ldb
-                                    : (plane ? p.a_lo : p.a_hi) + (int64_t)batch * p.a_batch_stride + (int64_t)row * p.lda;
-        src[j] = base + ks * 16 + h * 8;
+    for (int j = 0; j < kDmaPerWave; ++j) {
+        const int c = wid * kDmaPerWave + j;
+        const bool is_b = c >= kChunksA;
+        const int t = (is_b ? c - kChunksA : c) >> 1, plane = c & 1;
+        const int rb_max = ((is_b ? p.n : p.m) - 1) >> 5;
+        int rb = ((is_b ? tile_n : tile_m) >> 5) + t;
+        rb = rb < rb_max ? rb : rb_max;                                    // clamp: rows past the end are discarded in the epilogue
+        const _Float16 *base = is_b ? (plane ? p.b_lo : p.b_hi) + (int64_t)batch * p.b_batch_stride
+                                    : (plane ? p.a_lo : p.a_hi) + (int64_t)batch * p.a_batch_stride;
+        src[j] = base + (int64_t)rb * kb_count * kBlockElems + lane * 8;
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    auto issue_stage = [&](int t, int buf) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * kStageBytes + wid * 8 * 1024);
+    auto issue_stage = [&](int t) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (t % kRing) * kStageBytes + wid * kDmaPerWave * 1024);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < kDmaPerWave; ++j) {
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                          "global_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src[j] + (int64_t)t * kStageK), "s"(dst + j * 1024) : "memory");
+                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src[j] + (int64_t)t * kBlockElems), "s"(dst + j * 1024) : "memory");
         }
     };
 
@@ -203,47 +249,55 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
-    const int n_stages = p.k / kStageK;
-    issue_stage(0, 0);
+    const int n_stages = kb_count;
+    unsigned long long t_begin = 0, t_wait = 0, t_issue = 0, t_loop_end = 0;
+    if (p.stamps) t_begin = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int t = 0; t < kRing - 1; ++t)
+        if (t < n_stages) issue_stage(t);
     for (int t = 0; t < n_stages; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of stage t has landed
-        __builtin_amdgcn_s_barrier();                          // ... everybody's; stage t-1's buffer is free
-        if (t + 1 < n_stages) issue_stage(t + 1, (t + 1) & 1);
-        const unsigned char *sa = smem + (t & 1) * kStageBytes, *sb = sa + 32 * 1024;
+        unsigned long long ta = 0, tb = 0;
+        if (p.stamps) ta = __builtin_amdgcn_s_memtime();
+        // this wave's part of stage t has landed: at most the younger stage is outstanding
+        if (t + 1 < n_stages) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // ... everybody's; the slot of stage t-1 is free
+        if (p.stamps) tb = __builtin_amdgcn_s_memtime();
+        if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+        if (p.stamps) { t_wait += tb - ta; t_issue += __builtin_amdgcn_s_memtime() - tb; }
+        const unsigned char *sa = smem + (t % kRing) * kStageBytes, *sb = sa + kChunksA * 1024;
+        half8 ah[2], al[2], bh[4], bl[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 ah[2], al[2], bh[4], bl[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int mt = 2 * wm + i;
-                ah[i] = *reinterpret_cast<const half8 *>(sa + ((mt * 2 + 0) * 2 + ks) * 1024 + lane * 16);
-                al[i] = *reinterpret_cast<const half8 *>(sa + ((mt * 2 + 1) * 2 + ks) * 1024 + lane * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nt = 4 * wn + j;
-                bh[j] = *reinterpret_cast<const half8 *>(sb + ((nt * 2 + 0) * 2 + ks) * 1024 + lane * 16);
-                bl[j] = *reinterpret_cast<const half8 *>(sb + ((nt * 2 + 1) * 2 + ks) * 1024 + lane * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            const int mt = 2 * wm + i;
+            ah[i] = *reinterpret_cast<const half8 *>(sa + (mt * 2 + 0) * 1024 + lane * 16);
+            al[i] = *reinterpret_cast<const half8 *>(sa + (mt * 2 + 1) * 1024 + lane * 16);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nt = 4 * wn + j;
+            bh[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 0) * 1024 + lane * 16);
+            bl[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 1) * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_s_barrier();                              // LDS is reused by the epilogue
+    if (p.stamps) t_loop_end = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue.  Accumulator layout: lane (r, h) of tile (i, j) holds column n = tile_n + (4wn+j)*32 + r,
     // rows m = tile_m + (2wm+i)*32 + (q & 3) + 8 (q >> 2) + 4 h for q = 0..15.
-    float *red = reinterpret_cast<float *>(smem);              // [2 (wn)][256 rows]
+    float *red = reinterpret_cast<float *>(smem);              // [2 (wn)][128 rows]
     const int nv = p.rows_valid ? p.rows_valid[batch] : p.m;
     float bias[4], gam[4], bet[4];
 #pragma unroll
@@ -265,22 +319,22 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     if (LN) {
         // LayerNorm over the 256 columns of a row: 4 lane-local values x 32 lanes x the two wn waves.
         // Two passes (mean, then centred sum of squares); the row statistics live in LDS, not registers.
-        float *red2 = red + 512;
+        float *red2 = red + 2 * kTileM;
         auto row_of = [&](int i, int q) { return (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h; };
-        auto half_sum = [&](float s) {
-            s += __shfl_xor(s, 16, SN_WAVE);
-            s += __shfl_xor(s, 8, SN_WAVE);
-            s += __shfl_xor(s, 4, SN_WAVE);
-            s += __shfl_xor(s, 2, SN_WAVE);
-            s += __shfl_xor(s, 1, SN_WAVE);
-            return s;
+        auto half_sum = [&](float s) {                     // total over the 32 lanes of this lane's half, on the DPP network
+            s += SN_DPP_F32(s, 0x140);                       // row_mirror
+            s += SN_DPP_F32(s, 0x141);                       // row_half_mirror
+            s += SN_DPP_F32(s, 0x1B);                        // quad_perm [3,2,1,0]
+            s += SN_DPP_F32(s, 0xB1);                        // quad_perm [1,0,3,2]: every lane holds its 16-lane row total
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            return s + __uint_as_float((lane & 16) ? sw[0] : sw[1]);      // + the other row of the half (xor 16)
         };
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const float s = half_sum((acc[i][0][q] + acc[i][1][q]) + (acc[i][2][q] + acc[i][3][q]));
-                if (r == 0) red[wn * 256 + row_of(i, q)] = s;
+                if (r == 0) red[wn * kTileM + row_of(i, q)] = s;
             }
         __syncthreads();
 #pragma unroll
@@ -288,7 +342,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = row_of(i, q);
-                const float mean = (red[row] + red[256 + row]) / 256.0f;
+                const float mean = (red[row] + red[kTileM + row]) / 256.0f;
                 float s = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -296,7 +350,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                     s = fmaf(acc[i][j][q], acc[i][j][q], s);
                 }
                 s = half_sum(s);
-                if (r == 0) red2[wn * 256 + row] = s;
+                if (r == 0) red2[wn * kTileM + row] = s;
             }
         __syncthreads();
 #pragma unroll
@@ -304,7 +358,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = row_of(i, q);
-                const float rstd = 1.0f / sqrtf((red2[row] + red2[256 + row]) / 256.0f + p.eps);
+                const float rstd = 1.0f / sqrtf((red2[row] + red2[kTileM + row]) / 256.0f + p.eps);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j][q] = acc[i][j][q] * rstd * gam[j] + bet[j];
             }
@@ -319,26 +373,67 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = fmaxf(acc[i][j][q], 0.0f);
     }
     // ---- stores
+    if (p.c) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int m = tile_m + (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (m >= p.m) continue;
+            for (int q = 0; q < 16; ++q) {
+                const int m = tile_m + (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (m >= p.m) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = tile_n + (4 * wn + j) * 32 + r;
+                    if (n < p.n) p.c[(int64_t)batch * p.c_batch_stride + (int64_t)m * p.ldc + n] = acc[i][j][q];
+                }
+            }
+    }
+    // Blocked hi/lo planes of the result (row m, k = n).  The accumulator holds a column per lane; the
+    // planes want 8 consecutive k per 16-byte piece, so each wave transposes its 32 x 128 sub-tile through
+    // its own LDS region as packed (hi | lo << 16) dwords, [k/8][row][k%8] with a padded k/8 stride
+    // (conflict-free writes), and writes whole 1 KiB blocks: lanes 0-31 = rows of the k-half 0, 32-63 of half 1.
+    if (p.c_hi) {
+        constexpr int kC8Stride = 32 * 8 + 8;                                  // dwords
+        unsigned *stg = reinterpret_cast<unsigned *>(smem + 4096) + wid * (16 * kC8Stride);
+        const int kb_out = p.cp_cols / kStageK;
+        const int rb_count = (p.m + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = (tile_m >> 5) + 2 * wm + i;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = tile_n + (4 * wn + j) * 32 + r;
-                const float v = acc[i][j][q];
-                if (p.c && n < p.n) p.c[(int64_t)batch * p.c_batch_stride + (int64_t)m * p.ldc + n] = v;
-                if (p.c_hi && n < p.cp_cols) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+                    const bool keep = rb * 32 + row < p.m && n < p.n;
                     _Float16 hi, lo;
-                    split2(n < p.n ? v : 0.0f, hi, lo);
-                    const int64_t o = (int64_t)batch * p.cp_batch_stride + (int64_t)m * p.ldcp + n;
-                    p.c_hi[o] = hi;
-                    p.c_lo[o] = lo;
+                    split2(keep ? acc[i][j][q] : 0.0f, hi, lo);
+                    const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    stg[(j * 4 + (r >> 3)) * kC8Stride + row * 8 + (r & 7)] = packed;
+                }
+            }
+            // (same wave wrote what it reads: LDS operations of a wave complete in order)
+            if (rb < rb_count) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int c8 = 2 * it + h;                                 // k / 8 inside the wave's 128 columns
+                    const int kb = (tile_n >> 4) + wn * 8 + it;
+                    const uint4 lo4 = *reinterpret_cast<const uint4 *>(stg + c8 * kC8Stride + r * 8);
+                    const uint4 hi4 = *reinterpret_cast<const uint4 *>(stg + c8 * kC8Stride + r * 8 + 4);
+                    if (kb < kb_out) {
+                        uint4 ph, pl;
+                        ph.x = __builtin_amdgcn_perm(lo4.y, lo4.x, 0x05040100u); pl.x = __builtin_amdgcn_perm(lo4.y, lo4.x, 0x07060302u);
+                        ph.y = __builtin_amdgcn_perm(lo4.w, lo4.z, 0x05040100u); pl.y = __builtin_amdgcn_perm(lo4.w, lo4.z, 0x07060302u);
+                        ph.z = __builtin_amdgcn_perm(hi4.y, hi4.x, 0x05040100u); pl.z = __builtin_amdgcn_perm(hi4.y, hi4.x, 0x07060302u);
+                        ph.w = __builtin_amdgcn_perm(hi4.w, hi4.z, 0x05040100u); pl.w = __builtin_amdgcn_perm(hi4.w, hi4.z, 0x07060302u);
+                        const int64_t o = (int64_t)batch * p.cp_batch_stride + ((int64_t)rb * kb_out + kb) * kBlockElems + lane * 8;
+                        *reinterpret_cast<uint4 *>(p.c_hi + o) = ph;
+                        *reinterpret_cast<uint4 *>(p.c_lo + o) = pl;
+                    }
                 }
             }
         }
+    }
     // ---- node-weighted pooling of the tile's rows (gnn.py:96: sum_i w_i H[i, :], the caller divides)
     if (p.pooled) {
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -351,17 +446,21 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[j] = fmaf(w, acc[i][j][q], part[j]);
             }
-        float *pr = reinterpret_cast<float *>(smem) + 1024;    // [4 (wm)][256 cols]
+        float *pr = reinterpret_cast<float *>(smem) + 512;     // [2 (wm)][256 cols], bytes 2048..4095
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             part[j] += __shfl_xor(part[j], 32, SN_WAVE);
             if (h == 0) pr[wm * 256 + (4 * wn + j) * 32 + r] = part[j];
         }
         __syncthreads();
-        if (tid < 256) {
+        {
             const int n = tile_n + tid;
-            if (n < p.n) atomicAdd(&p.pooled[(int64_t)batch * p.n + n], (pr[tid] + pr[256 + tid]) + (pr[512 + tid] + pr[768 + tid]));
+            if (n < p.n) atomicAdd(&p.pooled[(int64_t)batch * p.n + n], pr[tid] + pr[256 + tid]);
         }
+    }
+    if (p.stamps && lane == 0) {
+        unsigned long long *st = p.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+        st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_wait; st[4] = t_issue;
     }
 }
 
@@ -370,45 +469,57 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 // ============================================================================================
 // C ABI
 // ============================================================================================
-extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, int ld, void *adj_hi, void *adj_lo, void *stream)
+extern "C" int64_t sn_gcn_plane_elems(int rows, int k)
+{
+    if (rows <= 0 || k <= 0) return 0;
+    return (int64_t)((rows + 31) / 32) * ((k + 15) / 16) * kBlockElems;
+}
+
+extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, void *adj_hi, void *adj_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: bad G=%d n=%d", G, n);
     if (G == 0) return SN_OK;
     SN_REQUIRE(edges && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: NULL pointer");
-    SN_REQUIRE(ld >= n && ld % kStageK == 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: ld=%d must be a multiple of 32 >= n=%d", ld, n);
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes: G=%d > 65535", G);
-    hipLaunchKernelGGL(adjacency_planes_kernel, dim3((unsigned)((ld + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)G), dim3(256), 0,
-                       (hipStream_t)stream, edges, n, ld, (_Float16 *)adj_hi, (_Float16 *)adj_lo);
+    const int kb = (n + 15) / 16;
+    const unsigned tiles = (unsigned)((((n + 31) & ~31) + 63) / 64);
+    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
 
-extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int ld, int E,
+extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int E,
                                     void *out_hi, void *out_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0 && E > 0 && rows_table > 0, SN_ERR_BAD_ARG, "sn_gcn_gather_planes: bad G=%d n=%d E=%d", G, n, E);
     if (G == 0) return SN_OK;
     SN_REQUIRE(table && ids && out_hi && out_lo, SN_ERR_BAD_ARG, "sn_gcn_gather_planes: NULL pointer");
-    SN_REQUIRE(ld >= n && ld % kStageK == 0, SN_ERR_BAD_ARG, "sn_gcn_gather_planes: ld=%d must be a multiple of 32 >= n=%d", ld, n);
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_gather_planes: G=%d > 65535", G);
-    hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((ld + 63) / 64), (unsigned)G), dim3(256), 0, (hipStream_t)stream, table,
-                       rows_table, ids, n, ld, E, (_Float16 *)out_hi, (_Float16 *)out_lo);
+    const int kb = (n + 15) / 16;
+    hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((kb * 16 + 63) / 64), (unsigned)G), dim3(256), 0, (hipStream_t)stream, table,
+                       rows_table, ids, n, kb, E, sn_gcn_plane_elems(E, n), (_Float16 *)out_hi, (_Float16 *)out_lo);
     SN_CHECK_LAUNCH("sn_gcn_gather_planes");
     return SN_OK;
 }
 
-extern "C" int sn_split_planes(const float *x, int64_t count, void *out_hi, void *out_lo, void *stream)
+extern "C" int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride, void *out_hi,
+                               void *out_lo, void *stream)
 {
-    SN_REQUIRE(count >= 0, SN_ERR_BAD_ARG, "sn_split_planes: negative count");
-    if (count == 0) return SN_OK;
+    SN_REQUIRE(batches >= 0 && rows > 0 && cols > 0 && ld >= cols, SN_ERR_BAD_ARG, "sn_split_planes: bad shape");
+    if (batches == 0) return SN_OK;
     SN_REQUIRE(x && out_hi && out_lo, SN_ERR_BAD_ARG, "sn_split_planes: NULL pointer");
-    const int64_t blocks = (count + 255) / 256;
-    SN_REQUIRE(blocks <= 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_split_planes: too many elements");
-    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, count, (_Float16 *)out_hi,
-                       (_Float16 *)out_lo);
+    SN_REQUIRE(batches <= 65535, SN_ERR_UNSUPPORTED, "sn_split_planes: batches=%d > 65535", batches);
+    const int kb = (cols + 15) / 16;
+    const int64_t pieces = (int64_t)((rows + 31) & ~31) * kb * 2;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((pieces + 255) / 256), (unsigned)batches), dim3(256), 0, (hipStream_t)stream, x,
+                       rows, cols, ld, batch_stride, kb, sn_gcn_plane_elems(rows, cols), (_Float16 *)out_hi, (_Float16 *)out_lo);
     SN_CHECK_LAUNCH("sn_split_planes");
     return SN_OK;
 }
+
+/* diagnostics: device buffer of 8 x u64 per wave of the GEMM kernel (NULL = off) */
+extern "C" void sn_debug_set_gemm_stamps(void *device_buffer) { g_gemm_stamps = (unsigned long long *)device_buffer; }
 
 extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
 {
@@ -417,29 +528,28 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
                u->m, u->n, u->k, u->batches);
     if (u->batches == 0) return SN_OK;
     SN_REQUIRE(u->a_hi && u->a_lo && u->b_hi && u->b_lo, SN_ERR_BAD_ARG, "sn_gcn_gemm: NULL operand plane");
-    SN_REQUIRE(u->k % kStageK == 0 && u->lda >= u->k && u->ldb >= u->k, SN_ERR_BAD_ARG,
-               "sn_gcn_gemm: k=%d must be a multiple of 32 (zero-padded planes) with lda=%d, ldb=%d >= k", u->k, u->lda, u->ldb);
-    SN_REQUIRE(u->lda % 8 == 0 && u->ldb % 8 == 0 && u->a_batch_stride % 8 == 0 && u->b_batch_stride % 8 == 0, SN_ERR_BAD_ARG,
-               "sn_gcn_gemm: plane rows must be 16-byte aligned");
-    SN_REQUIRE(((uintptr_t)u->a_hi | (uintptr_t)u->a_lo | (uintptr_t)u->b_hi | (uintptr_t)u->b_lo) % 16 == 0, SN_ERR_BAD_ARG,
-               "sn_gcn_gemm: planes must be 16-byte aligned");
+    SN_REQUIRE(u->k % kStageK == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: k=%d must be a multiple of 16 (the planes' padded k)", u->k);
+    SN_REQUIRE(((uintptr_t)u->a_hi | (uintptr_t)u->a_lo | (uintptr_t)u->b_hi | (uintptr_t)u->b_lo) % 16 == 0 &&
+                   u->a_batch_stride % 8 == 0 && u->b_batch_stride % 8 == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: planes must be 16-byte aligned");
     SN_REQUIRE(u->c || u->c_hi || u->pooled, SN_ERR_BAD_ARG, "sn_gcn_gemm: no output requested");
-    SN_REQUIRE(!u->c_hi || (u->c_lo && u->cp_cols >= u->n && u->ldcp >= u->cp_cols), SN_ERR_BAD_ARG, "sn_gcn_gemm: bad output planes");
+    SN_REQUIRE(!u->c_hi || (u->c_lo && u->cp_cols >= u->n && u->cp_cols % kStageK == 0), SN_ERR_BAD_ARG, "sn_gcn_gemm: bad output planes");
     SN_REQUIRE(!u->c || u->ldc >= u->n, SN_ERR_BAD_ARG, "sn_gcn_gemm: ldc=%d < n=%d", u->ldc, u->n);
-    SN_REQUIRE(!u->layernorm || (u->n == kTile && u->gamma && u->beta), SN_ERR_UNSUPPORTED,
+    SN_REQUIRE(!u->layernorm || (u->n == kTileN && u->gamma && u->beta), SN_ERR_UNSUPPORTED,
                "sn_gcn_gemm: the LayerNorm epilogue needs n == 256 (got %d) and gamma/beta", u->n);
     SN_REQUIRE(!u->pooled || u->pool_w, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooling without weights");
     SN_REQUIRE(u->batches <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: batches=%d > 65535", u->batches);
     GemmArgs a;
-    a.a_hi = (const _Float16 *)u->a_hi; a.a_lo = (const _Float16 *)u->a_lo; a.a_batch_stride = u->a_batch_stride; a.lda = u->lda;
-    a.b_hi = (const _Float16 *)u->b_hi; a.b_lo = (const _Float16 *)u->b_lo; a.b_batch_stride = u->b_batch_stride; a.ldb = u->ldb;
+    a.a_hi = (const _Float16 *)u->a_hi; a.a_lo = (const _Float16 *)u->a_lo; a.a_batch_stride = u->a_batch_stride;
+    a.b_hi = (const _Float16 *)u->b_hi; a.b_lo = (const _Float16 *)u->b_lo; a.b_batch_stride = u->b_batch_stride;
     a.m = u->m; a.n = u->n; a.k = u->k;
     a.c = u->c; a.c_batch_stride = u->c_batch_stride; a.ldc = u->ldc;
-    a.c_hi = (_Float16 *)u->c_hi; a.c_lo = (_Float16 *)u->c_lo; a.cp_batch_stride = u->cp_batch_stride; a.ldcp = u->ldcp; a.cp_cols = u->cp_cols;
+    a.c_hi = (_Float16 *)u->c_hi; a.c_lo = (_Float16 *)u->c_lo; a.cp_batch_stride = u->cp_batch_stride; a.cp_cols = u->cp_cols;
     a.bias = u->bias; a.gamma = u->gamma; a.beta = u->beta; a.eps = u->eps; a.relu = u->relu;
     a.rows_valid = u->rows_valid; a.pool_w = u->pool_w; a.pool_w_stride = u->pool_w_stride; a.pooled = u->pooled;
-    const dim3 grid((unsigned)((u->n + kTile - 1) / kTile), (unsigned)((u->m + kTile - 1) / kTile), (unsigned)u->batches);
-    const size_t lds = 2 * (size_t)kStageBytes;
+    a.stamps = g_gemm_stamps;
+    const int cols = (u->c_hi && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
+    const dim3 grid((unsigned)((cols + kTileN - 1) / kTileN), (unsigned)((u->m + kTileM - 1) / kTileM), (unsigned)u->batches);
+    const size_t lds = (size_t)kRing * kStageBytes;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute((const void *)gcn_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -103,36 +103,68 @@ __global__ __launch_bounds__(256) void weighted_pool_kernel(const float *feat, c
 }
 
 // ------------------------------------------------------------------ similarity scores
-// block = 4 waves, one image per block; each wave walks classes k = wid, wid+4, ...
+// block = 4 waves = 16 classes of one image; a wave owns 4 classes whose three reductions run
+// interleaved (one class at a time is a chain of dependent shuffles: latency-bound).
+constexpr int kScoreCols = 16;
 __global__ __launch_bounds__(256) void match_scores_kernel(const float *fi, const float *fk, int K, int E,
                                                            int similarity, float *pred)
 {
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int k0 = blockIdx.y * kScoreCols + wid * 4;
+    if (k0 >= K) return;
     const float *a = fi + (int64_t)b * E;
+    float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float na = 0.0f;
-    if (similarity == 1) {
-        for (int c = lane; c < E; c += SN_WAVE) na += a[c] * a[c];
-        na = sqrtf(sn_wave_sum(na));
-    }
-    for (int k = wid; k < K; k += 4) {
-        const float *c_ = fk + (int64_t)k * E;
-        float dot = 0.0f, nb = 0.0f, d2 = 0.0f;
-        for (int c = lane; c < E; c += SN_WAVE) {
-            const float x = a[c], y = c_[c];
-            dot += x * y;
-            nb += y * y;
-            d2 += (x - y) * (x - y);
+    for (int c = lane; c < E; c += SN_WAVE) {
+        const float x = a[c];
+        na += x * x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j < K ? k0 + j : K - 1;
+            const float y = fk[(int64_t)k * E + c];
+            dot[j] += x * y;
+            nb[j] += y * y;
+            d2[j] += (x - y) * (x - y);
         }
+    }
+    if (similarity == 1) na = sqrtf(sn_wave_sum(na));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
         float r;
         if (similarity == 0) {
-            r = sn_wave_sum(dot);
+            r = sn_wave_sum(dot[j]);
         } else if (similarity == 1) {          // (cosine_similarity + 1) / 2, eps = 1e-8
-            const float den = fmaxf(na, 1.0e-8f) * fmaxf(sqrtf(sn_wave_sum(nb)), 1.0e-8f);
-            r = (sn_wave_sum(dot) / den + 1.0f) / 2.0f;
+            const float den = fmaxf(na, 1.0e-8f) * fmaxf(sqrtf(sn_wave_sum(nb[j])), 1.0e-8f);
+            r = (sn_wave_sum(dot[j]) / den + 1.0f) / 2.0f;
         } else {                               // 1 / (1 + |a - b|_2)
-            r = 1.0f / (1.0f + sqrtf(sn_wave_sum(d2)));
+            r = 1.0f / (1.0f + sqrtf(sn_wave_sum(d2[j])));
         }
-        if (lane == 0) pred[(int64_t)b * K + k] = r;
+        if (lane == 0 && k0 + j < K) pred[(int64_t)b * K + k0 + j] = r;
+    }
+}
+
+// ------------------------------------------------------------------ pooled / divisor -> fc
+// out[g][o] = bias[o] + sum_e (pooled[g][e] / div) * W[o][e]     (reference gnn.py:96-98)
+__global__ __launch_bounds__(256) void pool_fc_kernel(const float *pooled, const int32_t *div_dev, float div_host, const float *W,
+                                                      const float *bias, int E, int E_out, float *out)
+{
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int o0 = blockIdx.y * kScoreCols + wid * 4;
+    if (o0 >= E_out) return;
+    const float div = div_dev ? (float)div_dev[0] : div_host;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = lane; c < E; c += SN_WAVE) {
+        const float x = pooled[(int64_t)g * E + c] / div;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + j < E_out ? o0 + j : E_out - 1;
+            acc[j] = fmaf(x, W[(int64_t)o * E + c], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float r = sn_wave_sum(acc[j]);
+        if (lane == 0 && o0 + j < E_out) out[(int64_t)g * E_out + o0 + j] = r + (bias ? bias[o0 + j] : 0.0f);
     }
 }
 
@@ -225,8 +257,23 @@ extern "C" int sn_match_scores(const float *feat_inst, const float *feat_kg, int
     if (B == 0) return SN_OK;
     SN_REQUIRE(feat_inst && feat_kg && pred, SN_ERR_BAD_ARG, "sn_match_scores: NULL pointer");
     SN_REQUIRE(similarity >= 0 && similarity <= 2, SN_ERR_BAD_ARG, "sn_match_scores: similarity=%d", similarity);
-    hipLaunchKernelGGL(match_scores_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, feat_inst, feat_kg,
-                       K, E, similarity, pred);
+    SN_REQUIRE(B <= 0x7fffffff / 1 && (K + kScoreCols - 1) / kScoreCols <= 65535, SN_ERR_UNSUPPORTED, "sn_match_scores: K=%d too large", K);
+    hipLaunchKernelGGL(match_scores_kernel, dim3((unsigned)B, (unsigned)((K + kScoreCols - 1) / kScoreCols)), dim3(256), 0,
+                       (hipStream_t)stream, feat_inst, feat_kg, K, E, similarity, pred);
     SN_CHECK_LAUNCH("sn_match_scores");
+    return SN_OK;
+}
+
+extern "C" int sn_pool_fc(const float *pooled_sum, int G, int E, const int32_t *divisor_dev, float divisor_host, const float *weight,
+                          const float *bias, int E_out, float *out, void *stream)
+{
+    SN_REQUIRE(G >= 0 && E > 0 && E_out > 0, SN_ERR_BAD_ARG, "sn_pool_fc: bad G=%d E=%d E_out=%d", G, E, E_out);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(pooled_sum && weight && out, SN_ERR_BAD_ARG, "sn_pool_fc: NULL pointer");
+    SN_REQUIRE(divisor_dev || divisor_host != 0.0f, SN_ERR_BAD_ARG, "sn_pool_fc: no divisor");
+    SN_REQUIRE((E_out + kScoreCols - 1) / kScoreCols <= 65535, SN_ERR_UNSUPPORTED, "sn_pool_fc: E_out=%d too large", E_out);
+    hipLaunchKernelGGL(pool_fc_kernel, dim3((unsigned)G, (unsigned)((E_out + kScoreCols - 1) / kScoreCols)), dim3(256), 0,
+                       (hipStream_t)stream, pooled_sum, divisor_dev, divisor_host, weight, bias, E, E_out, out);
+    SN_CHECK_LAUNCH("sn_pool_fc");
     return SN_OK;
 }

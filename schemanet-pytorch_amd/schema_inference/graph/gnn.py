@@ -106,21 +106,19 @@ class GNN(nn.Module):
         G, n = ingredients.shape
         E = self.embed_dim
         l1, l2 = self.layers
-        adj = ops.gcn_adjacency_planes(edges)
-        ld = adj[0].shape[2]
+        adj = ops.gcn_adjacency_planes(edges)                                       # A  [G, n, n]
         table = torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight)
-        zt1 = ops.gcn_gather_planes(table, ingredients, ld)
-        h1 = ops.gcn_gemm(adj, zt1, n, E, ld, G, bias=l1.g_conv.linear.bias,
+        zt1 = ops.gcn_gather_planes(table, ingredients)                             # Bt [G, E, n]
+        h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                           layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
-                          rows_valid=n_valid, want_planes=E)["planes"]
-        w2h, w2l = ops.split_planes(l2.g_conv.linear.weight)
-        zt2 = ops.gcn_gemm((w2h[None], w2l[None]), h1, E, n, E, G, want_planes=ld)["planes"]
+                          rows_valid=n_valid, want_planes=E)["planes"]              # [G, n, E]
+        w2 = ops.split_planes(l2.g_conv.linear.weight)                              # A  [1, E, E]
+        zt2 = ops.gcn_gemm(w2, h1, G, want_planes=n)["planes"]                      # [G, E, n]
         pooled = torch.zeros((G, E), dtype=torch.float32, device=nodes.device)
-        ops.gcn_gemm(adj, zt2, n, E, ld, G, bias=l2.g_conv.linear.bias,
+        ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                      layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
                      rows_valid=n_valid, pool_w=nodes, pooled=pooled)
-        pooled = pooled / (divisor.to(pooled.dtype) if divisor is not None else n)
-        return self.fc(pooled)
+        return ops.pool_fc(pooled, divisor if divisor is not None else n, self.fc.weight, self.fc.bias)
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
                 feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
