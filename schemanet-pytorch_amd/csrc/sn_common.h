@@ -57,7 +57,7 @@ __device__ __forceinline__ float sn_wave_sum(float v)
 
 // fp64 xor butterfly (off = 32, 16, 8, 4, 2, 1): the summation order of the oracle's sno_dot64.
 // Same values as six __shfl_xor steps, but moved with v_permlane32/16_swap and DPP instead of
-// ds_bpermute (checked bit for bit on MI355X by tools/f64sum_probe).  xor 8 / xor 4 use
+// ds_bpermute (checked bit for bit on MI355X: the S1 parity tests compare every index with the oracle).  xor 8 / xor 4 use
 // row_ror:8 / row_ror:4: after the previous step the values have period 16 / 8 inside a row, so
 // the rotated lane holds exactly the value of the xor lane.
 __device__ __forceinline__ double sn_f64_from(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = row_of(i, q);
-                const float mean = (red[row] + red[kTileM + row]) / 256.0f;
+                const float mean = (red[row] + red[kTileM + row]) * (1.0f / 256.0f);      // n == 256: exact
                 float s = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -353,12 +353,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 if (r == 0) red2[wn * kTileM + row] = s;
             }
         __syncthreads();
+        float *rstd_row = red2 + 2 * kTileM;                    // one correctly rounded 1/sqrt per row, not per lane
+        if (tid < kTileM) rstd_row[tid] = 1.0f / sqrtf((red2[tid] + red2[kTileM + tid]) * (1.0f / 256.0f) + p.eps);
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int row = row_of(i, q);
-                const float rstd = 1.0f / sqrtf((red2[row] + red2[kTileM + row]) / 256.0f + p.eps);
+                const float rstd = rstd_row[row_of(i, q)];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j][q] = acc[i][j][q] * rstd * gam[j] + bet[j];
             }
