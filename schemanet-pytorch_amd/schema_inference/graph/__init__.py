@@ -42,9 +42,12 @@ class SchemaNetPredictor(nn.Module):
                 output = self.ingredient_wrapper.taps(x)
             else:
                 output = self.ingredient_wrapper(x)
+        # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
+        # instance branch on the current one; joined inside forward_padded
+        atlas = self.matcher.atlas_features_async(self.schema_net.get_atlas)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"])
-        class_dict = self.schema_net.get_atlas()
-        ret["pred"] = self.matcher.forward_padded(graph, class_dict)
+        ret["pred"] = self.matcher.forward_padded(graph, atlas.class_dict, feat_kg=atlas)
+        class_dict = atlas.class_dict
         ret.update(class_dict)
         if requires_graph:
             n = int(graph["n_max"].item())

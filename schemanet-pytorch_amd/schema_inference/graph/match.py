@@ -10,6 +10,22 @@ from cpp_extension import ops
 from .gnn import GNN
 
 
+class _AtlasHandle:
+    """Class-graph features being computed on the side stream (Matcher.atlas_features_async)."""
+
+    def __init__(self, class_dict, feat, done):
+        self.class_dict, self.feat, self.done = class_dict, feat, done
+
+    def join(self) -> torch.Tensor:
+        if self.done is not None:
+            main = torch.cuda.current_stream(self.feat.device)
+            main.wait_event(self.done)
+            for t in [self.feat] + [v for v in self.class_dict.values() if torch.is_tensor(v)]:
+                t.record_stream(main)                        # allocated on the side stream, consumed here
+            self.done = None
+        return self.feat
+
+
 class Matcher(nn.Module):
     """Same constructor and state-dict (`gnn.*`) as the reference.  `forward` keeps the
     reference's list-based contract; `forward_padded` consumes the padded batch produced by
@@ -39,14 +55,42 @@ class Matcher(nn.Module):
         return self.gnn(nodes=class_dict["class_vertices"], edges=class_dict["class_edges"],
                         ingredients=class_dict["class_ingredients"])
 
+    # ---- atlas branch on its own HIP stream -------------------------------------------------
+    # The class-graph branch (atlas normalisation -> GNN over K graphs) depends only on parameters,
+    # the instance branch (S1 -> instance graphs -> GNN over the batch) only on the images; they
+    # meet at the similarity.  Without autograd the class branch runs on a side stream so that the
+    # two chains fill each other's gaps (most kernels of either chain leave HBM or the matrix pipe
+    # half idle); the result is joined with an event, no host synchronisation.
+    def atlas_features_async(self, get_class_dict):
+        """Start `get_class_dict()` (e.g. `schema_net.get_atlas`) + the class-graph GNN on the side
+        stream.  Returns a handle for `forward_padded(..., feat_kg=handle)`; `handle.class_dict` is
+        usable on the current stream after the join."""
+        dev = next(self.gnn.parameters()).device
+        if dev.type != "cuda" or torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters()):
+            class_dict = get_class_dict()
+            return _AtlasHandle(class_dict, self.atlas_features(class_dict), None)
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        self._side_stream.wait_stream(main)                 # parameters / earlier work are visible
+        with torch.cuda.stream(self._side_stream):
+            class_dict = get_class_dict()
+            feat = self.atlas_features(class_dict)
+            done = torch.cuda.Event()
+            done.record(self._side_stream)
+        return _AtlasHandle(class_dict, feat, done)
+
     def forward_padded(self, graph: Dict[str, torch.Tensor], class_dict: Dict[str, torch.Tensor],
-                       feat_kg: torch.Tensor = None) -> torch.Tensor:
+                       feat_kg=None) -> torch.Tensor:
         """graph: ids [bs, n_pad], vertices [bs, n_pad], edges [bs, n_pad, n_pad], n [bs] i32,
         n_max [1] i32 (device).  The pooling divides by n_max, i.e. by the length the reference
-        pads to (max_i n_i, match.py:46; gnn.py:96), so the result does not depend on n_pad."""
+        pads to (max_i n_i, match.py:46; gnn.py:96), so the result does not depend on n_pad.
+        feat_kg: precomputed class features [K, E] or a handle of `atlas_features_async`."""
         feat_instance = self.gnn(nodes=graph["vertices"], edges=graph["edges"], ingredients=graph["ids"],
                                  n_valid=graph["n"], divisor=graph["n_max"])
-        if feat_kg is None:
+        if isinstance(feat_kg, _AtlasHandle):
+            feat_kg = feat_kg.join()
+        elif feat_kg is None:
             feat_kg = self.atlas_features(class_dict)
         return self.similarity(feat_instance, feat_kg)
 
