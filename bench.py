@@ -59,9 +59,14 @@ def make_model(device):
     return disc.to(device), sn.to(device), m.to(device)
 
 
+def FUSED_ATLAS(sn):
+    """atlas normalisation feeding the GCN operand directly (no [K,n,n] class_edges round trip)"""
+    return lambda: sn.get_atlas(fused_adjacency=os.environ.get("SN_FUSED_ATLAS", "1") != "0")
+
+
 def step(disc, sn, m, tokens, attn):
     ing = disc.assign(tokens[:, 1:, :])                                          # S1 (alone on the GPU: HBM-bound)
-    atlas = m.atlas_features_async(sn.get_atlas)                                 # side stream, after S1: atlas normalise + class-graph GNN
+    atlas = m.atlas_features_async(FUSED_ATLAS(sn))                              # side stream, after S1: atlas normalise + class-graph GNN
     g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False)   # S2 + S3
     return m.forward_padded(g, atlas.class_dict, feat_kg=atlas)                  # S4 (instance GNN, join, scores)
 
@@ -150,7 +155,7 @@ def main():
             ev[0].record()
             ing = disc.assign(tokens[:, 1:, :])              # S1 runs alone (the side stream starts behind it)
             ev[1].record()
-            atlas = m.atlas_features_async(sn.get_atlas)     # class branch on the side stream (overlaps everything below)
+            atlas = m.atlas_features_async(FUSED_ATLAS(sn))  # class branch on the side stream (overlaps everything below)
             ev[2].record()
             g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False)
             ev[3].record()

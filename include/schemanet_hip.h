@@ -243,6 +243,17 @@ int sn_pool_fc(const float *pooled_sum, int G, int E, const int32_t *divisor_dev
  * blocks of 1 KiB; element (row, kk) lives in block (row >> 5, kk >> 4) at fp16 index
  * ((kk >> 3 & 1) * 32 + (row & 31)) * 8 + (kk & 7); rows / k beyond the operand are zero. */
 
+/* Fused atlas -> GCN operand route (no materialised class_edges):
+ *  sn_atlas_prune_rowsum: class_vertices, the in-place pruning of edge_weights (schema_net.py:164)
+ *    and row_sum[k][i] = sum_j max(pruned edge_weights[k][i][j], 0);
+ *  sn_gcn_atlas_adjacency_planes: adj = (E + E^T)/2 + I with E[i][j] = nan_to_num(max(w_ij, 0) /
+ *    row_sum[i]) (diagonal zero when remove_self_loop) - the same values sn_atlas_normalize followed
+ *    by sn_gcn_adjacency_planes produce, without writing and re-reading the [K, n, n] atlas. */
+int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,
+                          float prune_threshold, float *class_vertices, float *row_sum, void *stream);
+int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n,
+                                  int remove_self_loop, void *adj_hi, void *adj_lo, void *stream);
+
 /* fp16 elements of one plane of a [rows, k] operand (per batch entry). */
 int64_t sn_gcn_plane_elems(int rows, int k);
 

@@ -266,6 +266,25 @@ def atlas_normalize(vertex_weights, edge_weights, prune_threshold=None, remove_s
     return cv, ce
 
 
+def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, remove_self_loop=False):
+    """Fused atlas route: -> (class_vertices [K,n], Planes of (E + E^T)/2 + I with E the normalised
+    class edges); edge_weights is pruned IN PLACE; the [K,n,n] class_edges tensor is never written."""
+    lib = N.require_gpu()
+    dev = _check_dev(vertex_weights, edge_weights)
+    K, n = vertex_weights.shape
+    assert vertex_weights.is_contiguous() and edge_weights.is_contiguous()
+    cv = torch.empty((K, n), dtype=torch.float32, device=dev)
+    rs = torch.empty((K, n), dtype=torch.float32, device=dev)
+    out = _alloc_planes(lib, dev, K, n, n)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_atlas_prune_rowsum(N.ptr(vertex_weights), N.ptr(edge_weights), K, n, int(prune_threshold is not None),
+                                          float(prune_threshold or 0.0), N.ptr(cv), N.ptr(rs), N.stream_ptr(dev)),
+                "sn_atlas_prune_rowsum")
+        N.check(lib.sn_gcn_atlas_adjacency_planes(N.ptr(edge_weights), N.ptr(rs), K, n, int(remove_self_loop), N.ptr(out.hi),
+                                                  N.ptr(out.lo), N.stream_ptr(dev)), "sn_gcn_atlas_adjacency_planes")
+    return cv, out
+
+
 # ------------------------------------------------------------------------------- S4
 def gcn_adjacency(edges):
     lib = N.require_gpu()

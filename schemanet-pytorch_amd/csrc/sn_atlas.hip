@@ -17,7 +17,7 @@ constexpr int kRowsPerBlock = 16;
 
 __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, float *ew, int n,
                                                               int use_prune, float thr,
-                                                              int remove_self_loop, float *cv, float *ce)
+                                                              int remove_self_loop, float *cv, float *ce, float *rowsum)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *keep = smem;                       // [n] vertex survives pruning
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
             s += fmaxf(x, 0.0f);
         }
         s = sn_wave_sum(s);
+        if (rowsum && lane == 0) rowsum[(int64_t)k * n + i] = s;
         if (!ce) continue;
         float *out = ce + ((int64_t)k * n + i) * n;
         for (int j = lane; j < n; j += SN_WAVE) {
@@ -81,8 +82,29 @@ extern "C" int sn_atlas_normalize(const float *vertex_weights, float *edge_weigh
     const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
     sn_prof_start(3, (hipStream_t)stream);
     hipLaunchKernelGGL(atlas_normalize_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights,
-                       edge_weights, n, use_prune, prune_threshold, remove_self_loop, class_vertices, class_edges);
+                       edge_weights, n, use_prune, prune_threshold, remove_self_loop, class_vertices, class_edges, (float *)nullptr);
     sn_prof_stop(3, (hipStream_t)stream);
     SN_CHECK_LAUNCH("sn_atlas_normalize");
+    return SN_OK;
+}
+
+/* First half of the fused atlas -> adjacency route: vertices, in-place pruning and the row sums of the
+ * clamped edge weights; the normalised edges themselves are never materialised
+ * (sn_gcn_atlas_adjacency_planes applies the division while it builds the GCN operand). */
+extern "C" int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,
+                                     float prune_threshold, float *class_vertices, float *row_sum, void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_atlas_prune_rowsum: bad K=%d n=%d", K, n);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(vertex_weights && edge_weights && row_sum, SN_ERR_BAD_ARG, "sn_atlas_prune_rowsum: NULL pointer");
+    SN_REQUIRE(n <= 32768, SN_ERR_UNSUPPORTED, "sn_atlas_prune_rowsum: n=%d > 32768", n);
+    const dim3 grid((unsigned)K, (unsigned)((n + kRowsPerBlock - 1) / kRowsPerBlock));
+    SN_REQUIRE(grid.y <= 65535, SN_ERR_UNSUPPORTED, "sn_atlas_prune_rowsum: n too large");
+    const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
+    sn_prof_start(3, (hipStream_t)stream);
+    hipLaunchKernelGGL(atlas_normalize_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights, edge_weights, n, use_prune,
+                       prune_threshold, 0, class_vertices, (float *)nullptr, row_sum);
+    sn_prof_stop(3, (hipStream_t)stream);
+    SN_CHECK_LAUNCH("sn_atlas_prune_rowsum");
     return SN_OK;
 }

@@ -79,8 +79,11 @@ __device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h
 // ------------------------------------------------------------------ producers of operand planes
 // adj = (E + E^T) / 2 + I (reference gnn.py:27-30) as blocked hi/lo planes, rows and columns >= n zero.
 // One workgroup per 64 x 64 tile: E tile and E^T tile through LDS, then one 16-byte piece per thread pair.
+// With `rowsum` the input is the pruned, un-normalised atlas: the edge value is then
+// nan_to_num(max(x, 0) / rowsum[row]) (zero on the diagonal when remove_self_loop), exactly what
+// atlas_normalize_kernel would have written (schema_net.py:152-175) - the normalised atlas is never stored.
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
-                                                               _Float16 *out_h, _Float16 *out_l)
+                                                               _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop)
 {
     __shared__ float te[64][65], tt[64][65];
     const int g = blockIdx.z, bi = blockIdx.y * 64, bj = blockIdx.x * 64;
@@ -99,6 +102,13 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
         vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                           // E[j][i] stored at [j - bj][i - bi]
         ve[it] = ok ? ve[it] : 0.0f;
         vt[it] = ok2 ? vt[it] : 0.0f;
+        if (rowsum) {
+            const float si = rowsum[(int64_t)g * n + (ok ? i : 0)], sj = rowsum[(int64_t)g * n + (ok2 ? i2 : 0)];
+            ve[it] = ok ? sn_nan_to_num(fmaxf(ve[it], 0.0f) / si) : 0.0f;
+            vt[it] = ok2 ? sn_nan_to_num(fmaxf(vt[it], 0.0f) / sj) : 0.0f;
+            if (remove_self_loop && i == j) ve[it] = 0.0f;
+            if (remove_self_loop && i2 == j2) vt[it] = 0.0f;
+        }
     }
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
@@ -486,8 +496,23 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, void *a
     const int kb = (n + 15) / 16;
     const unsigned tiles = (unsigned)((((n + 31) & ~31) + 63) / 64);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo);
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
+    return SN_OK;
+}
+
+extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n, int remove_self_loop,
+                                             void *adj_hi, void *adj_lo, void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: bad K=%d n=%d", K, n);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(pruned_edge_weights && row_sum && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: NULL pointer");
+    SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes: K=%d > 65535", K);
+    const int kb = (n + 15) / 16;
+    const unsigned tiles = (unsigned)((((n + 31) & ~31) + 63) / 64);
+    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+                       kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop);
+    SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }
 

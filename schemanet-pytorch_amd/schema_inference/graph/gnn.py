@@ -96,7 +96,7 @@ class GNN(nn.Module):
             return False
         return all(isinstance(l.g_conv.linear, nn.Linear) and (l._is_relu or l._is_none) for l in self.layers)
 
-    def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor):
+    def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor, adj=None):
         """Inference on the matrix cores: three GEMM launches per call, every elementwise step an
         epilogue (bias, pad-row mask, LayerNorm, ReLU, hi/lo split, node-weighted pooling).
             H1     = act(LN1(adj @ (Emb @ W1^T)[ids] + b1))
@@ -106,7 +106,8 @@ class GNN(nn.Module):
         G, n = ingredients.shape
         E = self.embed_dim
         l1, l2 = self.layers
-        adj = ops.gcn_adjacency_planes(edges)                                       # A  [G, n, n]
+        if adj is None:
+            adj = ops.gcn_adjacency_planes(edges)                                   # A  [G, n, n]
         table = torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight)
         zt1 = ops.gcn_gather_planes(table, ingredients)                             # Bt [G, E, n]
         h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
@@ -122,7 +123,7 @@ class GNN(nn.Module):
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
                 feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
-                divisor: Optional[torch.Tensor] = None) -> torch.Tensor:
+                divisor: Optional[torch.Tensor] = None, adjacency=None) -> torch.Tensor:
         """nodes [G, n], edges [G, n, n], ingredients [G, n] -> graph feature [G, embed_dim].
 
         feat_mask (bool [G, n], True = padding) is the reference argument (gnn.py:78-98).
@@ -130,6 +131,10 @@ class GNN(nn.Module):
         replaces the padded length in the mean pooling (gnn.py:96) so that graphs padded to a
         fixed n_pad give the same result as graphs padded to the batch maximum.
         """
+        if adjacency is not None:        # prebuilt (E + E^T)/2 + I planes (SchemaNet.get_atlas(fused_adjacency=True))
+            if not (nodes.is_cuda and self._mfma_ok()) or self._differentiable(nodes):
+                raise RuntimeError("adjacency planes need the inference MFMA path (embed_dim 256, 2 Linear layers, no autograd)")
+            return self._forward_mfma(nodes, None, ingredients, n_valid, divisor, adj=adjacency)
         fused = nodes.is_cuda and not self._differentiable(nodes, edges)
         if n_valid is None and feat_mask is not None:
             n_valid = (~feat_mask).sum(dim=1).to(torch.int32)   # masks are suffix masks (match.py:48-51)

@@ -1,4 +1,5 @@
 """Instance-graph vs class-graph matching (reference schema_inference/graph/match.py)."""
+import os
 from typing import Any, Dict, List
 
 import torch
@@ -20,8 +21,10 @@ class _AtlasHandle:
         if self.done is not None:
             main = torch.cuda.current_stream(self.feat.device)
             main.wait_event(self.done)
-            for t in [self.feat] + [v for v in self.class_dict.values() if torch.is_tensor(v)]:
-                t.record_stream(main)                        # allocated on the side stream, consumed here
+            for v in [self.feat] + list(self.class_dict.values()):
+                for t in ((v.hi, v.lo) if hasattr(v, "hi") else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)                        # allocated on the side stream, consumed here
             self.done = None
         return self.feat
 
@@ -52,6 +55,9 @@ class Matcher(nn.Module):
 
     def atlas_features(self, class_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
         """GNN over the K class graphs -> [K, E]  (reference match.py:66-70)."""
+        if "class_adjacency" in class_dict:          # fused atlas route (no class_edges tensor)
+            return self.gnn(nodes=class_dict["class_vertices"], edges=None, ingredients=class_dict["class_ingredients"],
+                            adjacency=class_dict["class_adjacency"])
         return self.gnn(nodes=class_dict["class_vertices"], edges=class_dict["class_edges"],
                         ingredients=class_dict["class_ingredients"])
 
@@ -66,7 +72,8 @@ class Matcher(nn.Module):
         stream.  Returns a handle for `forward_padded(..., feat_kg=handle)`; `handle.class_dict` is
         usable on the current stream after the join."""
         dev = next(self.gnn.parameters()).device
-        if dev.type != "cuda" or torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters()):
+        serial = os.environ.get("SN_SIDE_STREAM", "1") == "0"           # diagnostics: everything on one stream
+        if serial or dev.type != "cuda" or torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters()):
             class_dict = get_class_dict()
             return _AtlasHandle(class_dict, self.atlas_features(class_dict), None)
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:

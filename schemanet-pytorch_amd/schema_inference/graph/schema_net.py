@@ -160,10 +160,18 @@ class SchemaNet(nn.Module):
             ew = ew.masked_fill(eye, 0)
         return ew
 
-    def get_atlas(self, detach: bool = False) -> Dict[str, torch.Tensor]:
+    def get_atlas(self, detach: bool = False, fused_adjacency: bool = False) -> Dict[str, torch.Tensor]:
         """reference :177-184.  Without autograd the whole normalisation is one fused HIP pass
-        over edge_weights (csrc/sn_atlas.hip), including the in-place pruning."""
+        over edge_weights (csrc/sn_atlas.hip), including the in-place pruning.
+
+        fused_adjacency=True (inference only) skips the [K, n, n] `class_edges` tensor: the dict
+        then carries `class_adjacency` = the GCN operand (E + E^T)/2 + I as split-fp16 planes, built
+        straight from the pruned parameters (same values, one pass less over the atlas); `Matcher`
+        consumes it directly."""
         vw, ew = self.vertex_weights.tensor, self.edge_weights.tensor
+        if fused_adjacency and vw.is_cuda and (detach or not self._needs_grad(vw, ew)):
+            cv, adj = ops.atlas_adjacency_planes(vw.detach(), ew.detach(), self.prune_node_threshold, self.remove_self_loop)
+            return {"class_vertices": cv, "class_adjacency": adj, "class_ingredients": self.class_ingredients.tensor}
         if vw.is_cuda and (detach or not self._needs_grad(vw, ew)):
             cv, ce = ops.atlas_normalize(vw.detach(), ew.detach(), self.prune_node_threshold, self.remove_self_loop)
         else:
