@@ -210,6 +210,7 @@ struct GemmArgs {
     const float *pool_w;
     int64_t pool_w_stride;
     float *pooled;
+    int batches, tiles_x, tiles_y;   // logical grid (the launch is 1-D, see the XCD remap in the kernel)
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
 };
 static unsigned long long *g_gemm_stamps = nullptr;
@@ -221,7 +222,15 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
-    const int batch = blockIdx.z, tile_m = blockIdx.y * kTileM, tile_n = blockIdx.x * kTileN;
+    // XCD-aware block -> tile map.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with
+    // its own L2; the row tiles of one graph all stream the same Bt operand, so they must be neighbours
+    // on ONE XCD (then Bt comes from HBM once, not once per row tile): id % 8 labels the XCD, id / 8 walks
+    // that XCD's graphs (xcd, xcd + 8, ...) tile by tile.
+    const int per_graph = p.tiles_x * p.tiles_y;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int batch = (slot / per_graph) * 8 + xcd, tile = slot % per_graph;
+    if (batch >= p.batches) return;                            // (whole workgroup, before any barrier)
+    const int tile_m = (tile / p.tiles_x) * kTileM, tile_n = (tile % p.tiles_x) * kTileN;
     const int kb_count = p.k / kStageK;
 
     // ---- LDS-DMA sources: wave w copies chunks 6w .. 6w+5 of a stage.  chunk c < 8: A row block c>>1,
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         }
     }
     if (p.stamps && lane == 0) {
-        unsigned long long *st = p.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wid) * 8;
+        unsigned long long *st = p.stamps + ((size_t)blockIdx.x * 4 + wid) * 8;
         st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_wait; st[4] = t_issue;
     }
 }
@@ -575,7 +584,10 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.rows_valid = u->rows_valid; a.pool_w = u->pool_w; a.pool_w_stride = u->pool_w_stride; a.pooled = u->pooled;
     a.stamps = g_gemm_stamps;
     const int cols = (u->c_hi && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
-    const dim3 grid((unsigned)((cols + kTileN - 1) / kTileN), (unsigned)((u->m + kTileM - 1) / kTileM), (unsigned)u->batches);
+    a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + kTileM - 1) / kTileM;
+    const int64_t n_blocks = (int64_t)8 * ((u->batches + 7) / 8) * a.tiles_x * a.tiles_y;
+    SN_REQUIRE(n_blocks <= 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: grid too large");
+    const dim3 grid((unsigned)n_blocks);
     const size_t lds = (size_t)kRing * kStageBytes;
     static bool attr_set = false;
     if (!attr_set) {
