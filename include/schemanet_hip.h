@@ -229,10 +229,11 @@ int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, 
  * schema_inference/eval/evaluation.py:95-97). */
 int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream);
 
-/* out[g][o] = bias[o] + sum_e (pooled_sum[g][e] / divisor) * weight[o][e]: the mean over the padded
- * length followed by the GNN's final Linear (gnn.py:96-98).  divisor = *divisor_dev (int32 on the
- * device, e.g. the batch-maximum vertex count) when non-NULL, else divisor_host. */
-int sn_pool_fc(const float *pooled_sum, int G, int E, const int32_t *divisor_dev, float divisor_host,
+/* out[g][o] = bias[o] + sum_e (pooled[g][e] / divisor) * weight[o][e] with pooled[g][e] = sum_t
+ * pooled_parts[g][t][e], t < parts: the mean over the padded length followed by the GNN's final
+ * Linear (gnn.py:96-98).  divisor = *divisor_dev (int32 on the device, e.g. the batch-maximum
+ * vertex count) when non-NULL, else divisor_host. */
+int sn_pool_fc(const float *pooled_parts, int G, int parts, int E, const int32_t *divisor_dev, float divisor_host,
                const float *weight, const float *bias, int E_out, float *out, void *stream);
 
 /* ---- S4 on the matrix cores: GCN layers with split-fp16 operands ----------------------------
@@ -276,7 +277,9 @@ int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld,
  * operand.  Epilogue, in this order: + bias[n]; rows >= rows_valid[b] set to 0 (gnn.py:43-45);
  * LayerNorm over the n == 256 columns with gamma/beta/eps (gnn.py:46); ReLU; then any of: fp32 C
  * [m][ldc]; blocked hi/lo planes of C as an [m, cp_cols] operand (columns [n, cp_cols) zero);
- * pooled[b][n] += sum_m pool_w[b][m] * C[m][n] (atomic; zero `pooled` first; gnn.py:96). */
+ * pooled[b][t][n] = sum over the rows m of row tile t (128 rows) of pool_w[b][m] * C[m][n], t <
+ * ceil(m / 128): partial sums of the node-weighted pooling (gnn.py:96), added up in a fixed order
+ * by sn_pool_fc (no atomics: results are bit-reproducible). */
 typedef struct sn_gemm_args {
     const void *a_hi, *a_lo; int64_t a_batch_stride;
     const void *b_hi, *b_lo; int64_t b_batch_stride;

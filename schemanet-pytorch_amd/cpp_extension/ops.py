@@ -378,12 +378,13 @@ def split_planes(x):
 
 
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
-             want_c=False, want_planes=0, pool_w=None, pooled=None):
+             want_c=False, want_planes=0, pool_w=None):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
-    (>= n; the extra columns are zero).  pool_w [batches, m] + pooled [batches, n] (accumulated in
-    place).  Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
+    (>= n; the extra columns are zero).  pool_w [batches, m] -> "pooled" [batches, ceil(m/128), n]:
+    per-row-tile partial sums of sum_m pool_w[m] C[m, :] (add them up, or hand them to pool_fc).
+    Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
     dev = _check_dev(a.hi, a.lo, b.hi, b.lo)
     assert a.kpad == b.kpad and a.batches in (1, batches) and b.batches in (1, batches)
@@ -415,7 +416,8 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
         args.rows_valid = _dp(rows_valid)
     if pool_w is not None:
         pw = _f32c(pool_w); keep.append(pw)
-        assert pw.shape == (batches, m) and pooled is not None and pooled.shape == (batches, n) and pooled.is_contiguous()
+        assert pw.shape == (batches, m)
+        pooled = torch.empty((batches, (m + 127) // 128, n), dtype=torch.float32, device=dev)
         args.pool_w, args.pool_w_stride, args.pooled = _dp(pw), m, _dp(pooled)
         out["pooled"] = pooled
     with torch.cuda.device(dev):
@@ -424,13 +426,16 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
 
 
 def pool_fc(pooled_sum, divisor, weight, bias):
-    """fc(pooled_sum / divisor): divisor is an int32 [1] device tensor or a python number."""
+    """fc(pooled / divisor) with pooled = pooled_sum [G, E] or the sum over dim 1 of [G, parts, E]
+    (the per-row-tile partial sums of gcn_gemm); divisor: int32 [1] device tensor or a number."""
     lib = N.require_gpu()
     dev = _check_dev(pooled_sum, weight, bias)
     p = _f32c(pooled_sum)
     w = _f32c(weight.detach())
     b = None if bias is None else _f32c(bias.detach())
-    G, E = p.shape
+    if p.dim() == 2:
+        p = p[:, None, :]
+    G, parts, E = p.shape
     out = torch.empty((G, w.shape[0]), dtype=torch.float32, device=dev)
     if torch.is_tensor(divisor):
         assert divisor.dtype == torch.int32 and divisor.device == dev
@@ -438,7 +443,7 @@ def pool_fc(pooled_sum, divisor, weight, bias):
     else:
         ddev, dhost = None, float(divisor)
     with torch.cuda.device(dev):
-        N.check(lib.sn_pool_fc(N.ptr(p), G, E, ddev, dhost, N.ptr(w), N.ptr(b), w.shape[0], N.ptr(out), N.stream_ptr(dev)),
+        N.check(lib.sn_pool_fc(N.ptr(p), G, parts, E, ddev, dhost, N.ptr(w), N.ptr(b), w.shape[0], N.ptr(out), N.stream_ptr(dev)),
                 "sn_pool_fc")
     return out
 

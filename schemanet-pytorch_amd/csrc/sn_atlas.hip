@@ -39,6 +39,48 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
     }
     __syncthreads();
 
+    // fused route (no class_edges output, n % 4 == 0): a wave takes its 4 rows together, 16 bytes per
+    // lane per load, all loads of a 256-column chunk in flight before the first use
+    if (!ce && (n & 3) == 0) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int i0 = blockIdx.y * kRowsPerBlock + wid * 4;
+        float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j0 = 0; j0 < n; j0 += 256) {
+            const int j = j0 + lane * 4;
+            const bool in = j < n;
+            f32x4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q < n ? i0 + q : n - 1;
+                x[q] = *reinterpret_cast<const f32x4 *>(ew + ((int64_t)k * n + i) * n + (in ? j : 0));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q;
+                if (i >= n || !in) continue;
+                const bool keep_i = keep[i] != 0;
+                bool dirty = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = x[q][e];
+                    if (use_prune && !(keep_i && keep[j + e])) {
+                        dirty = dirty || v != 0.0f || v != v;
+                        v = 0.0f;
+                        x[q][e] = 0.0f;
+                    }
+                    s[q] += fmaxf(v, 0.0f);
+                }
+                if (dirty) *reinterpret_cast<f32x4 *>(ew + ((int64_t)k * n + i) * n + j) = x[q];   // masked_fill_(~mask, 0)  :164
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = sn_wave_sum(s[q]);
+            if (rowsum && lane == 0 && i0 + q < n) rowsum[(int64_t)k * n + i0 + q] = t;
+        }
+        return;
+    }
+
     // class edges: 4 waves x 4 rows each
     for (int rr = wid; rr < kRowsPerBlock; rr += 4) {
         const int i = blockIdx.y * kRowsPerBlock + rr;

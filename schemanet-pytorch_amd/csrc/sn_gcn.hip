@@ -474,9 +474,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
             if (h == 0) pr[wm * 256 + (4 * wn + j) * 32 + r] = part[j];
         }
         __syncthreads();
-        {
+        {   // one partial row per row tile: pooled[batch][tile_y][n] (summed in a fixed order by sn_pool_fc: deterministic)
             const int n = tile_n + tid;
-            if (n < p.n) atomicAdd(&p.pooled[(int64_t)batch * p.n + n], pr[tid] + pr[256 + tid]);
+            if (n < p.n) p.pooled[((int64_t)batch * p.tiles_y + tile / p.tiles_x) * p.n + n] = pr[tid] + pr[256 + tid];
         }
     }
     if (p.stamps && lane == 0) {

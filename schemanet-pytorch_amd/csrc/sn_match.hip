@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void match_scores_kernel(const float *fi, cons
 
 // ------------------------------------------------------------------ pooled / divisor -> fc
 // out[g][o] = bias[o] + sum_e (pooled[g][e] / div) * W[o][e]     (reference gnn.py:96-98)
-__global__ __launch_bounds__(256) void pool_fc_kernel(const float *pooled, const int32_t *div_dev, float div_host, const float *W,
+__global__ __launch_bounds__(256) void pool_fc_kernel(const float *pooled, int parts, const int32_t *div_dev, float div_host, const float *W,
                                                       const float *bias, int E, int E_out, float *out)
 {
     const int g = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void pool_fc_kernel(const float *pooled, const
     const float div = div_dev ? (float)div_dev[0] : div_host;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int c = lane; c < E; c += SN_WAVE) {
-        const float x = pooled[(int64_t)g * E + c] / div;
+        float ps = pooled[((int64_t)g * parts) * E + c];
+        for (int t = 1; t < parts; ++t) ps += pooled[((int64_t)g * parts + t) * E + c];     // fixed order
+        const float x = ps / div;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int o = o0 + j < E_out ? o0 + j : E_out - 1;
@@ -264,16 +266,16 @@ extern "C" int sn_match_scores(const float *feat_inst, const float *feat_kg, int
     return SN_OK;
 }
 
-extern "C" int sn_pool_fc(const float *pooled_sum, int G, int E, const int32_t *divisor_dev, float divisor_host, const float *weight,
-                          const float *bias, int E_out, float *out, void *stream)
+extern "C" int sn_pool_fc(const float *pooled_sum, int G, int parts, int E, const int32_t *divisor_dev, float divisor_host,
+                          const float *weight, const float *bias, int E_out, float *out, void *stream)
 {
-    SN_REQUIRE(G >= 0 && E > 0 && E_out > 0, SN_ERR_BAD_ARG, "sn_pool_fc: bad G=%d E=%d E_out=%d", G, E, E_out);
+    SN_REQUIRE(G >= 0 && parts > 0 && E > 0 && E_out > 0, SN_ERR_BAD_ARG, "sn_pool_fc: bad G=%d parts=%d E=%d E_out=%d", G, parts, E, E_out);
     if (G == 0) return SN_OK;
     SN_REQUIRE(pooled_sum && weight && out, SN_ERR_BAD_ARG, "sn_pool_fc: NULL pointer");
     SN_REQUIRE(divisor_dev || divisor_host != 0.0f, SN_ERR_BAD_ARG, "sn_pool_fc: no divisor");
     SN_REQUIRE((E_out + kScoreCols - 1) / kScoreCols <= 65535, SN_ERR_UNSUPPORTED, "sn_pool_fc: E_out=%d too large", E_out);
     hipLaunchKernelGGL(pool_fc_kernel, dim3((unsigned)G, (unsigned)((E_out + kScoreCols - 1) / kScoreCols)), dim3(256), 0,
-                       (hipStream_t)stream, pooled_sum, divisor_dev, divisor_host, weight, bias, E, E_out, out);
+                       (hipStream_t)stream, pooled_sum, parts, divisor_dev, divisor_host, weight, bias, E, E_out, out);
     SN_CHECK_LAUNCH("sn_pool_fc");
     return SN_OK;
 }

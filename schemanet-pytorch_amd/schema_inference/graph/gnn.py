@@ -115,10 +115,9 @@ class GNN(nn.Module):
                           rows_valid=n_valid, want_planes=E)["planes"]              # [G, n, E]
         w2 = ops.split_planes(l2.g_conv.linear.weight)                              # A  [1, E, E]
         zt2 = ops.gcn_gemm(w2, h1, G, want_planes=n)["planes"]                      # [G, E, n]
-        pooled = torch.zeros((G, E), dtype=torch.float32, device=nodes.device)
-        ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
-                     layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
-                     rows_valid=n_valid, pool_w=nodes, pooled=pooled)
+        pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
+                              layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
+                              rows_valid=n_valid, pool_w=nodes)["pooled"]               # [G, row tiles, E]
         return ops.pool_fc(pooled, divisor if divisor is not None else n, self.fc.weight, self.fc.bias)
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
