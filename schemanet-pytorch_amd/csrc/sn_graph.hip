@@ -98,7 +98,11 @@ __device__ __forceinline__ void load_row4(const float *row, int L, int lane, flo
 template <bool kVec>
 __device__ __forceinline__ int col_of(int lane, int k) { return kVec ? lane * 4 + k : lane + SN_WAVE * k; }
 
-template <bool kVec>
+// kFast (prediction path only): v_exp_f32 on (x - m) * log2(e) and one reciprocal per row instead of
+// libm-grade expf and a correctly rounded division per element: ~1e-6 relative on the probabilities,
+// inside the 1e-5 budget of the instance graph; the init statistics (bit-exact against the reference)
+// keep the exact form.
+template <bool kVec, bool kFast = false>
 __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool use_clamp, float clamp)
 {
     float m = -INFINITY;
@@ -113,15 +117,21 @@ __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool u
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool ok = col_of<kVec>(lane, k) < L;
-        x[k] = ok ? expf(x[k] - m) : 0.0f;
+        x[k] = ok ? (kFast ? __builtin_amdgcn_exp2f((x[k] - m) * 1.44269504088896340736f) : expf(x[k] - m)) : 0.0f;
         s += x[k];
     }
     s = sn_wave_sum(s);
+    if (kFast) {
+        const float r = 1.0f / s;                    // all-clamped row: m = -inf -> x = NaN, s = NaN, like torch
 #pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = x[k] / s;
+        for (int k = 0; k < 4; ++k) x[k] = x[k] * r;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = x[k] / s;
+    }
 }
 
-template <bool kVec>
+template <bool kVec, bool kFast>
 __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src, int64_t stride_r, int heads,
                                                       int64_t stride_h, int L, bool is_logits, bool use_clamp,
                                                       float clamp, int wid, int nw, int lane)
@@ -149,7 +159,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
 #pragma unroll
                 for (int k = 0; k < 4; ++k) x[i][k] = x[i][k] / (float)heads;
             }
-            if (is_logits) softmax_row4<kVec>(x[i], L, lane, use_clamp, clamp);
+            if (is_logits) softmax_row4<kVec, kFast>(x[i], L, lane, use_clamp, clamp);
             if (r < L) {                                   // wave-uniform
                 if (kVec) {
                     if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
@@ -165,14 +175,15 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
     }
 }
 
+template <bool kFast = false>
 __device__ inline void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
                                         int64_t stride_h, int L, bool is_logits, bool use_clamp,
                                         float clamp, int wid, int nw, int lane)
 {
     const bool vec = (L % 4 == 0) && (stride_r % 4 == 0) && (stride_h % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-    if (vec) attn_rows_to_lds_impl<true>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
-    else attn_rows_to_lds_impl<false>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
+    if (vec) attn_rows_to_lds_impl<true, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
+    else attn_rows_to_lds_impl<false, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     SN_GSTAMP(0);
     // ---- stream this image's attention map into LDS (the only large HBM read)
     if (kEdges) {
-        attn_rows_to_lds(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
+        attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
                          a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e,
                          wid, nw, lane);
         if (!a.geo) build_grid_table(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);
@@ -560,6 +571,9 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     } else if (owner && me.group < kMaxCols) {
         s.rev[me.group] = me.group;
     }
+    // s.flag is free after the grouping: it now holds the inverse of pos_sorted (position -> sorted index)
+    const int n_kept = s.misc[1];
+    if (tid < n_kept) s.flag[s.pos_sorted[tid]] = (unsigned char)tid;
     __syncthreads();
 
     SN_GSTAMP(4);
@@ -574,30 +588,133 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     }
     ColCache cc;
     cache_columns(s, gcol, cc);
-    const bool any_long = __any(cc.cnt[0] > kQCache || cc.cnt[1] > kQCache || cc.cnt[2] > kQCache || cc.cnt[3] > kQCache) != 0;
+    // Cells of output row r (group gi), two regular passes instead of a (p in gi) x (q in gj) loop per cell
+    // whose trip count is set by the longest word of the wave:
+    //   a) column sums over the group's rows: cs[q] = sum_{p in gi} A[p][q] (and of the grid similarity) for
+    //      ALL L positions q, lanes over q in position order - contiguous LDS reads, no divergence,
+    //      cnt(gi) iterations; over an image that is L row visits, whatever the word histogram;
+    //   b) cs is staged in LDS - in row p0 of A, the group's own first row, which nobody reads any more:
+    //      row p of A is only ever read by the wave that handles group(p) - and lane c gathers the
+    //      positions of ITS column's word: cell = sum_{q in gj} cs[q].
+    // Sum order: q-major instead of the reference's p-major (large_scale_feat_to_e.cpp:99-125): equal to
+    // fp32 rounding (1e-7); the init statistics keep the reference order (limited_edges_kernel).
+    int qv4[kCellsPerLane], qrow[kCellsPerLane], qcol4[kCellsPerLane], qsidx4[kCellsPerLane];
+    bool qok[kCellsPerLane];
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        const int q = lane + SN_WAVE * k;
+        qok[k] = q < L;
+        const int qq = qok[k] ? q : L - 1;
+        qv4[k] = qq * 4;
+        const int rc = a.geo ? 0 : (int)s.prc[qq];
+        qrow[k] = rc >> 8;
+        qcol4[k] = (rc & 255) * 4;
+        qsidx4[k] = (int)s.flag[qq] * 4;                    // where this position's column sum is staged (sorted order)
+    }
+    const int tsh = grid_shift(a.feat_w) + 2;               // byte shift of a table row
+    unsigned long long dt_a = 0, dt_b = 0;                  // diagnostics (stamps on): wave 0's time in passes a / b
     for (int r = wid; r < a.n_pad; r += nw) {
         const int gi = (r < n_out && r < kMaxCols) ? s.rev[r] : -1;
         float c0[kCellsPerLane], c1[kCellsPerLane];
         float t0 = 0.0f, t1 = 0.0f;
         if (gi >= 0) {
-            row_cells(s, a.geo, L, a.feat_w, gi, cc, any_long, a.mean, c0, c1);
-        } else {
+            const int ia = __builtin_amdgcn_readfirstlane((int)s.gstart[gi]);
+            const int ib = __builtin_amdgcn_readfirstlane((int)s.gstart[gi + 1]);
+            float csa[kCellsPerLane], csg[kCellsPerLane];
 #pragma unroll
-            for (int k = 0; k < kCellsPerLane; ++k) { c0[k] = 0.0f; c1[k] = 0.0f; }
+            for (int k = 0; k < kCellsPerLane; ++k) { csa[k] = 0.0f; csg[k] = 0.0f; }
+            unsigned long long ts0 = 0, ts1 = 0;
+            if (stamps) ts0 = __builtin_amdgcn_s_memtime();
+            for (int x = ia; x < ib; ++x) {                 // a) column sums over the rows of group gi
+                const int p = __builtin_amdgcn_readfirstlane((int)s.pos_sorted[x]);
+                const char *arow = reinterpret_cast<const char *>(s.A + p * L);
+                if (a.geo) {
+                    const float *grow = a.geo + (int64_t)p * L;
+#pragma unroll
+                    for (int k = 0; k < kCellsPerLane; ++k) {
+                        const float av = *reinterpret_cast<const float *>(arow + qv4[k]);
+                        const float gv = grow[qv4[k] >> 2];
+                        csa[k] += qok[k] ? av : 0.0f;
+                        csg[k] += qok[k] ? gv : 0.0f;
+                    }
+                } else {
+                    const int prc = __builtin_amdgcn_readfirstlane((int)s.prc[p]);
+                    const unsigned pr = prc >> 8, pc4 = (prc & 255) * 4;
+                    const char *tbase = reinterpret_cast<const char *>(s.T);
+#pragma unroll
+                    for (int k = 0; k < kCellsPerLane; ++k) {
+                        const float av = *reinterpret_cast<const float *>(arow + qv4[k]);
+                        const unsigned off = (__usad(pr, (unsigned)qrow[k], 0u) << tsh) + __usad(pc4, (unsigned)qcol4[k], 0u);
+                        const float gv = *reinterpret_cast<const float *>(tbase + off);
+                        csa[k] += qok[k] ? av : 0.0f;
+                        csg[k] += qok[k] ? gv : 0.0f;
+                    }
+                }
+            }
+            if (stamps) ts1 = __builtin_amdgcn_s_memtime();
+            // b) stage the column sums, in SORTED position order, in the group's first row; the positions of
+            // an output column's word are then a contiguous run: independent, pipelined LDS reads
+            char *stage = reinterpret_cast<char *>(s.A + __builtin_amdgcn_readfirstlane((int)s.pos_sorted[ia]) * L);
+            float sa[kCellsPerLane], sg[kCellsPerLane];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < kCellsPerLane; ++k)
+                    if (qok[k]) *reinterpret_cast<float *>(stage + qsidx4[k]) = pass ? csg[k] : csa[k];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < kCellsPerLane; ++k) {
+                    float acc = 0.0f;
+                    const char *run = stage + cc.ja[k] * 4;
+                    const int last = cc.cnt[k] > 0 ? cc.cnt[k] - 1 : 0;
+                    for (int t = 0; t < cc.tmax[k]; ++t) {  // wave-uniform trip count; lanes past their run re-read its end
+                        const float v = *reinterpret_cast<const float *>(run + (t < last ? t : last) * 4);
+                        acc += t < cc.cnt[k] ? v : 0.0f;
+                    }
+                    if (pass) sg[k] = acc; else sa[k] = acc;
+                }
+            }
+            if (stamps) { dt_a += ts1 - ts0; dt_b += __builtin_amdgcn_s_memtime() - ts1; }
+#pragma unroll
+            for (int k = 0; k < kCellsPerLane; ++k) {
+                const bool has = cc.cnt[k] > 0;
+                c0[k] = has ? sg[k] : 0.0f;
+                c1[k] = has ? sa[k] : 0.0f;
+            }
+            if (a.mean) {                                    // wave-uniform
+#pragma unroll
+                for (int k = 0; k < kCellsPerLane; ++k) {
+                    const float nn = (float)((ib - ia) * (cc.cnt[k] > 0 ? cc.cnt[k] : 1));
+                    c0[k] = c0[k] / nn;
+                    c1[k] = c1[k] / nn;
+                }
+            }
+        } else {                                             // padding row: zeros, nothing to normalise
+            const int64_t rowbase0 = ((int64_t)b * a.n_pad + r) * a.n_pad;
+            for (int c = lane; c < a.n_pad; c += SN_WAVE) {
+                if (a.out_e2) { a.out_e2[2 * (rowbase0 + c)] = 0.0f; a.out_e2[2 * (rowbase0 + c) + 1] = 0.0f; }
+                if (a.out_e) a.out_e[rowbase0 + c] = 0.0f;
+            }
+            continue;
         }
 #pragma unroll
         for (int k = 0; k < kCellsPerLane; ++k) { t0 += c0[k]; t1 += c1[k]; }
         t0 = sn_wave_sum(t0);     // instance_edges.sum(1, keepdim)  :135
         t1 = sn_wave_sum(t1);
+        const float i0 = 1.0f / t0, i1 = 1.0f / t1;          // one reciprocal per row (x * (1/t) vs x / t: 1 ulp)
+        // nan_to_num only matters when a row sum is 0 / inf / NaN (then some quotient is not finite)
+        const bool plain = t0 > 0.0f && t0 < INFINITY && t1 > 0.0f && t1 < INFINITY;      // wave-uniform
         const int64_t rowbase = ((int64_t)b * a.n_pad + r) * a.n_pad;
 #pragma unroll
         for (int k = 0; k < kCellsPerLane; ++k) {
             const int c = lane + SN_WAVE * k;
             if (c >= a.n_pad) continue;
             float e0 = 0.0f, e1 = 0.0f;
-            if (gi >= 0 && c < n_out) {
-                e0 = sn_nan_to_num(c0[k] / t0);
-                e1 = sn_nan_to_num(c1[k] / t1);
+            if (c < n_out) {
+                e0 = c0[k] * i0;
+                e1 = c1[k] * i1;
+                if (!plain) { e0 = sn_nan_to_num(e0); e1 = sn_nan_to_num(e1); }
                 if (a.remove_self_loop && c == r) { e0 = 0.0f; e1 = 0.0f; }
             }
             if (a.out_e2) { a.out_e2[2 * (rowbase + c)] = e0; a.out_e2[2 * (rowbase + c) + 1] = e1; }
@@ -613,6 +730,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     }
     __syncthreads();
     SN_GSTAMP(5);
+    if (stamps && threadIdx.x == 0) { stamps[(size_t)blockIdx.x * 8 + 6] = dt_a; stamps[(size_t)blockIdx.x * 8 + 7] = dt_b; }
 }
 
 // ------------------------------------------------------------------------------------------

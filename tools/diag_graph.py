@@ -22,5 +22,6 @@ names = ["attn rows -> LDS, cls softmax, sync", "group positions", "vertices out
 for i, nm in enumerate(names):
     d = s[:, i + 1] - s[:, i]
     print("%-40s median %8.0f  max %8.0f cycles" % (nm, d.median(), d.max()))
+print("wave 0 of each block: pass a (column sums) median %.0f max %.0f; pass b (stage + gather) median %.0f max %.0f" % (s[:, 6].median(), s[:, 6].max(), s[:, 7].median(), s[:, 7].max()))
 print("total per block median %.0f max %.0f; n_i median %d" % ((s[:, 5] - s[:, 0]).median(), (s[:, 5] - s[:, 0]).max(), g["n"].float().median()))
 
