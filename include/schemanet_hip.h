@@ -246,8 +246,8 @@ int sn_pool_fc(const float *pooled_parts, int G, int parts, int E, const int32_t
 
 /* Fused atlas -> GCN operand route (no materialised class_edges):
  *  sn_atlas_prune_rowsum: class_vertices, the in-place pruning of edge_weights (schema_net.py:164)
- *    and row_sum[k][i] = sum_j max(pruned edge_weights[k][i][j], 0);
- *  sn_gcn_atlas_adjacency_planes: adj = (E + E^T)/2 + I with E[i][j] = nan_to_num(max(w_ij, 0) /
+ *    and row_sum[k][i] = 1 / sum_j max(pruned edge_weights[k][i][j], 0) (0 when that sum is 0, inf or NaN);
+ *  sn_gcn_atlas_adjacency_planes: adj = (E + E^T)/2 + I with E[i][j] = nan_to_num(max(w_ij, 0) *
  *    row_sum[i]) (diagonal zero when remove_self_loop) - the same values sn_atlas_normalize followed
  *    by sn_gcn_adjacency_planes produce, without writing and re-reading the [K, n, n] atlas. */
 int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,

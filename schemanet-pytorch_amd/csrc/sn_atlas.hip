@@ -15,6 +15,11 @@ namespace {
 
 constexpr int kRowsPerBlock = 16;
 
+// what sn_gcn_atlas_adjacency_planes multiplies a clamped edge weight with: 1 / row sum, or 0 when the
+// quotient x / s would be NaN or 0 anyway (s == 0: all x are 0; s = inf or NaN) - nan_to_num(x / s) == x * scale
+// up to one rounding (one correctly rounded reciprocal per row instead of a division per element)
+__device__ __forceinline__ float row_scale(float s) { return (s > 0.0f && s < INFINITY) ? 1.0f / s : 0.0f; }
+
 __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, float *ew, int n,
                                                               int use_prune, float thr,
                                                               int remove_self_loop, float *cv, float *ce, float *rowsum)
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float t = sn_wave_sum(s[q]);
-            if (rowsum && lane == 0 && i0 + q < n) rowsum[(int64_t)k * n + i0 + q] = t;
+            if (rowsum && lane == 0 && i0 + q < n) rowsum[(int64_t)k * n + i0 + q] = row_scale(t);
         }
         return;
     }
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
             s += fmaxf(x, 0.0f);
         }
         s = sn_wave_sum(s);
-        if (rowsum && lane == 0) rowsum[(int64_t)k * n + i] = s;
+        if (rowsum && lane == 0) rowsum[(int64_t)k * n + i] = row_scale(s);
         if (!ce) continue;
         float *out = ce + ((int64_t)k * n + i) * n;
         for (int j = lane; j < n; j += SN_WAVE) {

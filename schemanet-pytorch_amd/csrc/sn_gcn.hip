@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
         vt[it] = ok2 ? vt[it] : 0.0f;
         if (rowsum) {
             const float si = rowsum[(int64_t)g * n + (ok ? i : 0)], sj = rowsum[(int64_t)g * n + (ok2 ? i2 : 0)];
-            ve[it] = ok ? sn_nan_to_num(fmaxf(ve[it], 0.0f) / si) : 0.0f;
-            vt[it] = ok2 ? sn_nan_to_num(fmaxf(vt[it], 0.0f) / sj) : 0.0f;
+            ve[it] = ok ? sn_nan_to_num(fmaxf(ve[it], 0.0f) * si) : 0.0f;      // si = 1 / row sum (sn_atlas_prune_rowsum)
+            vt[it] = ok2 ? sn_nan_to_num(fmaxf(vt[it], 0.0f) * sj) : 0.0f;
             if (remove_self_loop && i == j) ve[it] = 0.0f;
             if (remove_self_loop && i2 == j2) vt[it] = 0.0f;
         }
@@ -340,37 +340,63 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         // Two passes (mean, then centred sum of squares); the row statistics live in LDS, not registers.
         float *red2 = red + 2 * kTileM;
         auto row_of = [&](int i, int q) { return (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h; };
-        auto half_sum = [&](float s) {                     // total over the 32 lanes of this lane's half, on the DPP network
-            s += SN_DPP_F32(s, 0x140);                       // row_mirror
-            s += SN_DPP_F32(s, 0x141);                       // row_half_mirror
-            s += SN_DPP_F32(s, 0x1B);                        // quad_perm [3,2,1,0]
-            s += SN_DPP_F32(s, 0xB1);                        // quad_perm [1,0,3,2]: every lane holds its 16-lane row total
-            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-            return s + __uint_as_float((lane & 16) ? sw[0] : sw[1]);      // + the other row of the half (xor 16)
+        // Row totals over the 32 lanes of a half by recursive halving: at every level a lane keeps half of
+        // its values and hands the other half to its partner (xor 16 via v_permlane16_swap, then the DPP
+        // mirrors inside the 16-lane row), so 32 values cost 31 exchanges instead of 32 full reductions,
+        // and lane l ends with the total of value index l & 31 = (i, q) = (l >> 4 & 1, l & 15).
+        auto reduce32 = [&](float (&v)[32]) -> float {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {                    // partner lane ^ 16
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 16]), false, false);
+                v[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                     // partner 15 - i (row_mirror): opposite bit 3
+                const float give = b3 ? v[k] : v[k + 8], keep = b3 ? v[k + 8] : v[k];
+                v[k] = keep + SN_DPP_F32(give, 0x140);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                     // partner 7 - i inside the half row: opposite bit 2
+                const float give = b2 ? v[k] : v[k + 4], keep = b2 ? v[k + 4] : v[k];
+                v[k] = keep + SN_DPP_F32(give, 0x141);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                     // partner 3 - i inside the quad: opposite bit 1
+                const float give = b1 ? v[k] : v[k + 2], keep = b1 ? v[k + 2] : v[k];
+                v[k] = keep + SN_DPP_F32(give, 0x1B);
+            }
+            const float give = b0 ? v[0] : v[1], keep = b0 ? v[1] : v[0];
+            return keep + SN_DPP_F32(give, 0xB1);             // partner i ^ 1
         };
+        const int my_row = row_of((lane >> 4) & 1, lane & 15);          // the row whose total this lane ends with
+        {
+            float v[32];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float s = half_sum((acc[i][0][q] + acc[i][1][q]) + (acc[i][2][q] + acc[i][3][q]));
-                if (r == 0) red[wn * kTileM + row_of(i, q)] = s;
-            }
+                for (int q = 0; q < 16; ++q) v[i * 16 + q] = (acc[i][0][q] + acc[i][1][q]) + (acc[i][2][q] + acc[i][3][q]);
+            red[wn * kTileM + my_row] = reduce32(v);
+        }
         __syncthreads();
+        {
+            float v[32];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = row_of(i, q);
-                const float mean = (red[row] + red[kTileM + row]) * (1.0f / 256.0f);      // n == 256: exact
-                float s = 0.0f;
+                for (int q = 0; q < 16; ++q) {
+                    const int row = row_of(i, q);
+                    const float mean = (red[row] + red[kTileM + row]) * (1.0f / 256.0f);      // n == 256: exact
+                    float s2 = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j][q] -= mean;
-                    s = fmaf(acc[i][j][q], acc[i][j][q], s);
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j][q] -= mean;
+                        s2 = fmaf(acc[i][j][q], acc[i][j][q], s2);
+                    }
+                    v[i * 16 + q] = s2;
                 }
-                s = half_sum(s);
-                if (r == 0) red2[wn * kTileM + row] = s;
-            }
+            red2[wn * kTileM + my_row] = reduce32(v);
+        }
         __syncthreads();
         float *rstd_row = red2 + 2 * kTileM;                    // one correctly rounded 1/sqrt per row, not per lane
         if (tid < kTileM) rstd_row[tid] = 1.0f / sqrtf((red2[tid] + red2[kTileM + tid]) * (1.0f / 256.0f) + p.eps);
