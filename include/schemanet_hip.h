@@ -258,14 +258,18 @@ int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float 
 /* fp16 elements of one plane of a [rows, k] operand (per batch entry). */
 int64_t sn_gcn_plane_elems(int rows, int k);
 
-/* adj = (E + E^T)/2 + I  (gnn.py:27-30) as blocked planes of a [n, n] operand per graph. */
-int sn_gcn_adjacency_planes(const float *edges, int G, int n, void *adj_hi, void *adj_lo, void *stream);
+/* adj = (E + E^T)/2 + I  (gnn.py:27-30) as blocked planes of a [n, n] operand per graph.
+ * extent_dev (optional, here and below): int32 on the device, e.g. the largest vertex count of the
+ * batch; blocks whose rows / k lie entirely beyond it (rounded up to 32 / 16) are not produced and
+ * must not be consumed - sn_gcn_gemm's m_extent / k_extent skip exactly those. */
+int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, void *adj_hi,
+                            void *adj_lo, void *stream);
 
 /* Zt[g][f][j] = table[ids[g][j]][f] as blocked planes of an [E, n] operand per graph (ids outside
  * [0, rows_table) give zero): the transposed, gathered B operand of layer 1 (gnn.py:64-66 with the
  * Linear folded into the embedding table). */
 int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int E,
-                         void *out_hi, void *out_lo, void *stream);
+                         const int32_t *extent_dev, void *out_hi, void *out_lo, void *stream);
 
 /* hi/lo split of fp32 x [batches][rows][ld] (cols valid per row, batch stride in floats) into
  * blocked planes of a [rows, cols] operand per batch entry. */
@@ -290,6 +294,8 @@ typedef struct sn_gemm_args {
     const float *gamma, *beta; float eps; int layernorm, relu;
     const int32_t *rows_valid;
     const float *pool_w; int64_t pool_w_stride; float *pooled;
+    const int32_t *m_extent, *k_extent;   /* device scalars or NULL: row tiles >= *m_extent are skipped (their
+                                             pooled partial is zero), the k loop stops at *k_extent */
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 

@@ -57,6 +57,7 @@ class GemmArgs(Structure):
         ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("layernorm", c_int), ("relu", c_int),
         ("rows_valid", c_void_p),
         ("pool_w", c_void_p), ("pool_w_stride", c_int64), ("pooled", c_void_p),
+        ("m_extent", c_void_p), ("k_extent", c_void_p),
     ]
 
 
@@ -90,8 +91,8 @@ _SIGNATURES = {
     "sn_atlas_prune_rowsum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_atlas_adjacency_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_plane_elems": (c_int64, [c_int, c_int]),
-    "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
 }

@@ -333,20 +333,21 @@ def _alloc_planes(lib, dev, batches, rows, k):
     return Planes(hi, torch.empty_like(hi), batches, rows, k)
 
 
-def gcn_adjacency_planes(edges):
-    """(E + E^T)/2 + I of [G, n, n] edges as blocked fp16 hi/lo planes."""
+def gcn_adjacency_planes(edges, extent=None):
+    """(E + E^T)/2 + I of [G, n, n] edges as blocked fp16 hi/lo planes.  extent: optional int32 [1]
+    device tensor (largest vertex count of the batch): blocks beyond it are not produced."""
     lib = N.require_gpu()
     dev = _check_dev(edges)
     e = _f32c(edges)
     G, n, _ = e.shape
     out = _alloc_planes(lib, dev, G, n, n)
     with torch.cuda.device(dev):
-        N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+        N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                 "sn_gcn_adjacency_planes")
     return out
 
 
-def gcn_gather_planes(table, ids):
+def gcn_gather_planes(table, ids, extent=None):
     """Zt[g, f, j] = table[ids[g, j], f] as blocked planes of a [G, E, n] operand."""
     lib = N.require_gpu()
     dev = _check_dev(table, ids)
@@ -357,7 +358,7 @@ def gcn_gather_planes(table, ids):
     rows, E = t.shape
     out = _alloc_planes(lib, dev, G, E, n)
     with torch.cuda.device(dev):
-        N.check(lib.sn_gcn_gather_planes(N.ptr(t), rows, N.ptr(ids), G, n, E, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+        N.check(lib.sn_gcn_gather_planes(N.ptr(t), rows, N.ptr(ids), G, n, E, N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                 "sn_gcn_gather_planes")
     return out
 
@@ -378,7 +379,7 @@ def split_planes(x):
 
 
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
-             want_c=False, want_planes=0, pool_w=None):
+             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
@@ -420,6 +421,10 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
         pooled = torch.empty((batches, (m + 127) // 128, n), dtype=torch.float32, device=dev)
         args.pool_w, args.pool_w_stride, args.pooled = _dp(pw), m, _dp(pooled)
         out["pooled"] = pooled
+    for name, t in (("m_extent", m_extent), ("k_extent", k_extent)):
+        if t is not None:
+            assert t.dtype == torch.int32 and t.device == dev
+            setattr(args, name, _dp(t))
     with torch.cuda.device(dev):
         N.check(lib.sn_gcn_gemm(byref(args), N.stream_ptr(dev)), "sn_gcn_gemm")
     return out

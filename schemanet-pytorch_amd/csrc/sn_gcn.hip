@@ -80,69 +80,122 @@ __device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h
 // adj = (E + E^T) / 2 + I (reference gnn.py:27-30) as blocked hi/lo planes, rows and columns >= n zero.
 // One workgroup per 64 x 64 tile: E tile and E^T tile through LDS, then one 16-byte piece per thread pair.
 // With `rowsum` the input is the pruned, un-normalised atlas: the edge value is then
-// nan_to_num(max(x, 0) / rowsum[row]) (zero on the diagonal when remove_self_loop), exactly what
-// atlas_normalize_kernel would have written (schema_net.py:152-175) - the normalised atlas is never stored.
+// nan_to_num(max(x, 0) * rowsum[row]) (rowsum = 1 / row sum; zero on the diagonal when remove_self_loop),
+// what atlas_normalize_kernel would have written (schema_net.py:152-175) - the normalised atlas is never stored.
+// adj is symmetric: a workgroup loads the tile pair E[I][J], E[J][I] once and writes BOTH adj[I][J] and
+// adj[J][I] (each atlas byte is read once, not twice).  Workgroup x of a graph owns row tiles x and T-1-x
+// and walks J >= I for each (T + 1 tile pairs per workgroup, whatever x): few fat workgroups - one per
+// 64 x 64 tile would be bound by the dispatch rate (~10 ns per workgroup chip-wide), not by HBM.
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
-                                                               _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop)
+                                                               _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
+                                                               const int32_t *extent)
 {
     __shared__ float te[64][65], tt[64][65];
-    const int g = blockIdx.z, bi = blockIdx.y * 64, bj = blockIdx.x * 64;
+    __shared__ float rs_i[64], rs_j[64];
+    const int g = blockIdx.y;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float *e = edges + (int64_t)g * n * n;
-    // branch-free loads (clamped index + select): a conditional load per element would serialise them
-    float ve[16], vt[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int rr = ty + 4 * it;
-        const int i = bi + rr, j = bj + tx;
-        const bool ok = i < n && j < n;
-        ve[it] = e[ok ? (int64_t)i * n + j : 0];                              // E[i][j]
-        const int i2 = bj + rr, j2 = bi + tx;
-        const bool ok2 = i2 < n && j2 < n;
-        vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                           // E[j][i] stored at [j - bj][i - bi]
-        ve[it] = ok ? ve[it] : 0.0f;
-        vt[it] = ok2 ? vt[it] : 0.0f;
-        if (rowsum) {
-            const float si = rowsum[(int64_t)g * n + (ok ? i : 0)], sj = rowsum[(int64_t)g * n + (ok2 ? i2 : 0)];
-            ve[it] = ok ? sn_nan_to_num(fmaxf(ve[it], 0.0f) * si) : 0.0f;      // si = 1 / row sum (sn_atlas_prune_rowsum)
-            vt[it] = ok2 ? sn_nan_to_num(fmaxf(vt[it], 0.0f) * sj) : 0.0f;
-            if (remove_self_loop && i == j) ve[it] = 0.0f;
-            if (remove_self_loop && i2 == j2) vt[it] = 0.0f;
-        }
+    int rows_lim = (n + 31) & ~31, k_lim = kb_count * 16;
+    if (extent) {                                              // nothing beyond the largest graph of the batch is ever read
+        const int ext = *extent;
+        rows_lim = min(rows_lim, (ext + 31) & ~31);
+        k_lim = min(k_lim, (ext + 15) & ~15);
     }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        te[ty + 4 * it][tx] = ve[it];
-        tt[ty + 4 * it][tx] = vt[it];
-    }
-    __syncthreads();
-    // pieces: 64 rows x 8 (k / 8); thread -> row il = tid & 63, pieces pc = tid >> 6, + 4
-    for (int pc = ty; pc < 8; pc += 4) {
-        const int il = tx, i = bi + il, j0 = bj + pc * 8;
-        if ((i >> 5) * 32 >= ((n + 31) & ~31) || j0 >= kb_count * 16) continue;
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = j0 + q;
-            float x = 0.0f;
-            if (i < n && j < n) {
-                x = (te[il][pc * 8 + q] + tt[pc * 8 + q][il]) * 0.5f;       // == / 2 exactly
-                if (i == j) x = x + 1.0f;
+    const int T = (rows_lim + 63) / 64;                        // rows_lim >= k_lim: tiles that matter, both ways
+    for (int half = 0; half < 2; ++half) {
+        const int I = half == 0 ? (int)blockIdx.x : T - 1 - (int)blockIdx.x;
+        if (I < 0 || I >= T || (half == 1 && I <= (int)blockIdx.x)) continue;      // (odd T: the middle tile once)
+        const int bi = I * 64;
+        for (int J = I; J < T; ++J) {
+            const int bj = J * 64;
+            __syncthreads();                                   // previous tile pair fully consumed
+            if (rowsum && threadIdx.x < 64) {
+                rs_i[threadIdx.x] = bi + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bi + threadIdx.x] : 0.0f;
+                rs_j[threadIdx.x] = bj + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bj + threadIdx.x] : 0.0f;
             }
-            v[q] = x;
+            // branch-free loads (clamped index + select): a conditional load per element would serialise them
+            float ve[16], vt[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int rr = ty + 4 * it;
+                const int i = bi + rr, j = bj + tx;
+                const bool ok = i < n && j < n;
+                ve[it] = e[ok ? (int64_t)i * n + j : 0];                      // E[I][J] tile, [i - bi][j - bj]
+                const int i2 = bj + rr, j2 = bi + tx;
+                const bool ok2 = i2 < n && j2 < n;
+                vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                   // E[J][I] tile, [j - bj][i - bi]
+                ve[it] = ok ? ve[it] : 0.0f;
+                vt[it] = ok2 ? vt[it] : 0.0f;
+            }
+            __syncthreads();                                   // row scales visible
+            if (rowsum) {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int rr = ty + 4 * it;
+                    // == nan_to_num(max(x, 0) / row sum): the scale is finite (0 for empty / non-finite rows), NaN
+                    // weights clamp to 0 in fmaxf, +inf to FLT_MAX
+                    ve[it] = fminf(fmaxf(ve[it], 0.0f), 3.402823466e+38f) * rs_i[rr];   // row bi + rr
+                    vt[it] = fminf(fmaxf(vt[it], 0.0f), 3.402823466e+38f) * rs_j[rr];   // row bj + rr
+                    if (remove_self_loop && bi + rr == bj + tx) ve[it] = 0.0f;
+                    if (remove_self_loop && bj + rr == bi + tx) vt[it] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                te[ty + 4 * it][tx] = ve[it];
+                tt[ty + 4 * it][tx] = vt[it];
+            }
+            __syncthreads();
+            // pieces: 64 rows x 8 (k / 8) per output tile; thread -> row tx, pieces ty, ty + 4
+            for (int pc = ty; pc < 8; pc += 4) {
+                {   // adj[I][J]: row i = bi + tx, k = bj + 8 pc ..
+                    const int i = bi + tx, j0 = bj + pc * 8;
+                    if (i < rows_lim && j0 < k_lim) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int j = j0 + q;
+                            float x = 0.0f;
+                            if (i < n && j < n) {
+                                x = (te[tx][pc * 8 + q] + tt[pc * 8 + q][tx]) * 0.5f;       // == / 2 exactly
+                                if (i == j) x = x + 1.0f;
+                            }
+                            v[q] = x;
+                        }
+                        store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(i, j0, kb_count));
+                    }
+                }
+                if (J != I) {   // adj[J][I] = adj[I][J]^T: row j = bj + tx, k = bi + 8 pc ..
+                    const int j = bj + tx, i0 = bi + pc * 8;
+                    if (j < rows_lim && i0 < k_lim) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int i = i0 + q;
+                            float x = 0.0f;
+                            if (i < n && j < n) {
+                                x = (tt[tx][pc * 8 + q] + te[pc * 8 + q][tx]) * 0.5f;
+                                if (i == j) x = x + 1.0f;
+                            }
+                            v[q] = x;
+                        }
+                        store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(j, i0, kb_count));
+                    }
+                }
+            }
         }
-        store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(i, j0, kb_count));
     }
 }
 
 // Zt[g][f][j] = table[ids[g][j]][f] as blocked planes (rows f < E, k = j; j >= n and ids outside the
 // table give zero).  (layer 1 re-associated: adj @ Emb[ids] @ W^T == adj @ (Emb @ W^T)[ids], gnn.py:64-66 + 30)
 __global__ __launch_bounds__(256) void gather_planes_kernel(const float *table, int rows_table, const int64_t *ids, int n, int kb_count,
-                                                            int E, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l)
+                                                            int E, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l, const int32_t *extent)
 {
     __shared__ float tile[64][65];
     __shared__ int rid[64];
     const int g = blockIdx.y, j0 = blockIdx.x * 64;
+    if (extent && j0 >= ((*extent + 15) & ~15)) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x < 64) {
         const int j = j0 + threadIdx.x;
@@ -150,25 +203,38 @@ __global__ __launch_bounds__(256) void gather_planes_kernel(const float *table, 
         rid[threadIdx.x] = (id >= 0 && id < rows_table) ? (int)id : -1;
     }
     __syncthreads();
-    for (int f0 = 0; f0 < E; f0 += 64) {
+    for (int fbase = 0; fbase < E; fbase += 256) {
+        // all table reads of this 64-node x 256-feature slab in flight before the first use (16 rows x 4 per lane)
+        float v[16][4];
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {               // wave wid loads table rows of nodes wid*16 .. +15, 64 features each
-            const int jl = wid * 16 + rr, row = rid[jl], f = f0 + lane;
-            const bool ok = row >= 0 && f < E;
-            const float v = table[ok ? (int64_t)row * E + f : 0];          // branch-free: clamped index + select
-            tile[jl][lane] = ok ? v : 0.0f;
-        }
-        __syncthreads();
-        for (int pc = wid; pc < 8; pc += 4) {           // piece = (feature f0 + lane, nodes j0 + 8 pc .. + 7)
-            const int f = f0 + lane, jj = j0 + pc * 8;
-            if (f < ((E + 31) & ~31) && jj < kb_count * 16) {
-                float v[8];
+        for (int rr = 0; rr < 16; ++rr) {               // wave wid owns the table rows of nodes wid*16 .. +15
+            const int row = rid[wid * 16 + rr];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = f < E ? tile[pc * 8 + q][lane] : 0.0f;
-                store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(f, jj, kb_count));
+            for (int c = 0; c < 4; ++c) {
+                const int f = fbase + c * 64 + lane;
+                const bool ok = row >= 0 && f < E;
+                const float x = table[ok ? (int64_t)row * E + f : 0];          // branch-free: clamped index + select
+                v[rr][c] = ok ? x : 0.0f;
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f0 = fbase + c * 64;
+            if (f0 >= ((E + 31) & ~31)) break;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) tile[wid * 16 + rr][lane] = v[rr][c];
+            __syncthreads();
+            for (int pc = wid; pc < 8; pc += 4) {           // piece = (feature f0 + lane, nodes j0 + 8 pc .. + 7)
+                const int f = f0 + lane, jj = j0 + pc * 8;
+                if (f < ((E + 31) & ~31) && jj < kb_count * 16) {
+                    float w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) w[q] = f < E ? tile[pc * 8 + q][lane] : 0.0f;
+                    store_piece(w, out_h, out_l, (int64_t)g * batch_stride + blocked_index(f, jj, kb_count));
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -211,6 +277,7 @@ struct GemmArgs {
     int64_t pool_w_stride;
     float *pooled;
     int batches, tiles_x, tiles_y;   // logical grid (the launch is 1-D, see the XCD remap in the kernel)
+    const int32_t *m_extent, *k_extent;   // device scalars (or NULL): rows / k beyond them are never consumed downstream
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
 };
 static unsigned long long *g_gemm_stamps = nullptr;
@@ -231,6 +298,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     const int batch = (slot / per_graph) * 8 + xcd, tile = slot % per_graph;
     if (batch >= p.batches) return;                            // (whole workgroup, before any barrier)
     const int tile_m = (tile / p.tiles_x) * kTileM, tile_n = (tile % p.tiles_x) * kTileN;
+    if (p.m_extent && tile_m >= *p.m_extent) {                 // a row tile past the largest graph of the batch
+        if (p.pooled && tid + tile_n < p.n) p.pooled[((int64_t)batch * p.tiles_y + tile / p.tiles_x) * p.n + tile_n + tid] = 0.0f;
+        return;
+    }
     const int kb_count = p.k / kStageK;
 
     // ---- LDS-DMA sources: wave w copies chunks 6w .. 6w+5 of a stage.  chunk c < 8: A row block c>>1,
@@ -268,7 +339,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
-    const int n_stages = kb_count;
+    int n_stages = kb_count;
+    if (p.k_extent) { const int lim = (*p.k_extent + kStageK - 1) / kStageK; n_stages = lim < n_stages ? lim : n_stages; }
     unsigned long long t_begin = 0, t_wait = 0, t_issue = 0, t_loop_end = 0;
     if (p.stamps) t_begin = __builtin_amdgcn_s_memtime();
 #pragma unroll
@@ -522,16 +594,16 @@ extern "C" int64_t sn_gcn_plane_elems(int rows, int k)
     return (int64_t)((rows + 31) / 32) * ((k + 15) / 16) * kBlockElems;
 }
 
-extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, void *adj_hi, void *adj_lo, void *stream)
+extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, void *adj_hi, void *adj_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: bad G=%d n=%d", G, n);
     if (G == 0) return SN_OK;
     SN_REQUIRE(edges && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: NULL pointer");
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
-    const unsigned tiles = (unsigned)((((n + 31) & ~31) + 63) / 64);
-    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0);
+    const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);      // a workgroup owns row tiles x and T-1-x
+    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
@@ -544,15 +616,15 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     SN_REQUIRE(pruned_edge_weights && row_sum && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: NULL pointer");
     SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes: K=%d > 65535", K);
     const int kb = (n + 15) / 16;
-    const unsigned tiles = (unsigned)((((n + 31) & ~31) + 63) / 64);
-    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
-                       kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop);
+    const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);
+    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+                       kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }
 
 extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int E,
-                                    void *out_hi, void *out_lo, void *stream)
+                                    const int32_t *extent_dev, void *out_hi, void *out_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0 && E > 0 && rows_table > 0, SN_ERR_BAD_ARG, "sn_gcn_gather_planes: bad G=%d n=%d E=%d", G, n, E);
     if (G == 0) return SN_OK;
@@ -560,7 +632,7 @@ extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const in
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_gather_planes: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
     hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((kb * 16 + 63) / 64), (unsigned)G), dim3(256), 0, (hipStream_t)stream, table,
-                       rows_table, ids, n, kb, E, sn_gcn_plane_elems(E, n), (_Float16 *)out_hi, (_Float16 *)out_lo);
+                       rows_table, ids, n, kb, E, sn_gcn_plane_elems(E, n), (_Float16 *)out_hi, (_Float16 *)out_lo, extent_dev);
     SN_CHECK_LAUNCH("sn_gcn_gather_planes");
     return SN_OK;
 }
@@ -609,6 +681,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.bias = u->bias; a.gamma = u->gamma; a.beta = u->beta; a.eps = u->eps; a.relu = u->relu;
     a.rows_valid = u->rows_valid; a.pool_w = u->pool_w; a.pool_w_stride = u->pool_w_stride; a.pooled = u->pooled;
     a.stamps = g_gemm_stamps;
+    a.m_extent = u->m_extent; a.k_extent = u->k_extent;
     const int cols = (u->c_hi && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
     a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + kTileM - 1) / kTileM;
     const int64_t n_blocks = (int64_t)8 * ((u->batches + 7) / 8) * a.tiles_x * a.tiles_y;

@@ -106,18 +106,21 @@ class GNN(nn.Module):
         G, n = ingredients.shape
         E = self.embed_dim
         l1, l2 = self.layers
+        # `divisor` (when given) is the largest vertex count of the batch, on the device: nothing beyond it
+        # (rounded up to the block sizes) is produced or multiplied - no host synchronisation needed
+        ext = divisor if (divisor is not None and torch.is_tensor(divisor)) else None
         if adj is None:
-            adj = ops.gcn_adjacency_planes(edges)                                   # A  [G, n, n]
+            adj = ops.gcn_adjacency_planes(edges, extent=ext)                       # A  [G, n, n]
         table = torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight)
-        zt1 = ops.gcn_gather_planes(table, ingredients)                             # Bt [G, E, n]
+        zt1 = ops.gcn_gather_planes(table, ingredients, extent=ext)                 # Bt [G, E, n]
         h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                           layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
-                          rows_valid=n_valid, want_planes=E)["planes"]              # [G, n, E]
+                          rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext)["planes"]   # [G, n, E]
         w2 = ops.split_planes(l2.g_conv.linear.weight)                              # A  [1, E, E]
         zt2 = ops.gcn_gemm(w2, h1, G, want_planes=n)["planes"]                      # [G, E, n]
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
-                              rows_valid=n_valid, pool_w=nodes)["pooled"]               # [G, row tiles, E]
+                              rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext)["pooled"]   # [G, row tiles, E]
         return ops.pool_fc(pooled, divisor if divisor is not None else n, self.fc.weight, self.fc.bias)
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
