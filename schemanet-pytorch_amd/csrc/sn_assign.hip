@@ -21,6 +21,7 @@
 
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <utility>
 
 // timing experiments only (results are wrong when any of these is set)
 #ifndef SN_EXP_NOKEYS
@@ -47,6 +48,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
 constexpr int kCodeBytes = 24;          // per-token candidate record: one key code per candidate slot
 constexpr int kWsPerToken = 4 + kCodeBytes + 4;   // flag word + codes + overflow-list slot
+constexpr int kWsPerToken2 = 8 + 64 + 4;          // screen2 records: 64-bit flag word + 16 code dwords + overflow-list slot
 constexpr int kMaxTilesScreen = 64;     // 6-bit tile code in the keys -> M <= 2048 on the MFMA path
 constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
@@ -61,10 +63,18 @@ constexpr float kAccUlpPerMfma = 8.0f * 5.9604645e-8f;
 //                                           are |c|^2 / 2 (fp32) in accumulator-row order
 //   cn64    [M_pad] f64  |c|^2 (oracle summation order)
 //   scal    [0] max |c|_2  [1] max |c|_1  [2] max |c|^2  [3] max |c_mk|   (uint bits of floats)
+//   frag2   [4 waves][nt2 tiles][ks2 k-steps][1 KiB]   (register-stationary screen, see assign_screen2_kernel)
+//                                           v_mfma_f32_16x16x32_f16 A-fragments of -c: wave q owns words
+//                                           [16 nt2 q, 16 nt2 (q+1)), tile a = 16 of them, lane (r, g) holds word
+//                                           row r at k = 32 j + {4g..4g+3, 16+4g..16+4g+3}
+//   hn2     [4][nt2][16] f32                |c|^2 / 2 in accumulator-row order (padding words: 1e30)
 struct PackLayout {
-    size_t tiles_off, cn64_off, scal_off, total;
+    size_t tiles_off, cn64_off, scal_off, frag2_off, hn2_off, total;
     int n_tiles, n_steps, tile_bytes, m_pad;
+    int nt2, ks2;                       // nt2 == 0: no register-stationary image for this shape
 };
+
+constexpr float kPadHalfNorm = 1.0e30f;     // |c|^2/2 of the padding words of the frag2 image (finite: keys stay ordered floats)
 
 __host__ __device__ inline PackLayout pack_layout(int M, int D)
 {
@@ -76,7 +86,14 @@ __host__ __device__ inline PackLayout pack_layout(int M, int D)
     p.tiles_off = 0;
     p.cn64_off = (size_t)p.n_tiles * p.tile_bytes;
     p.scal_off = p.cn64_off + (((size_t)p.m_pad * 8 + 255) & ~size_t(255));
-    p.total = p.scal_off + 256;
+    p.frag2_off = p.scal_off + 256;
+    // the whole fp16 codebook must fit the register file of one CU: 4 waves x nt2 x ks2 fragments of
+    // 4 registers, at most 96 fragments per wave
+    p.ks2 = D / 32;
+    p.nt2 = M <= 128 ? 2 : (M <= 256 ? 4 : (M <= 512 ? 8 : 0));
+    if (D % 32 != 0 || (p.ks2 != 6 && p.ks2 != 12) || p.nt2 * p.ks2 > 96) p.nt2 = 0;
+    p.hn2_off = p.frag2_off + (size_t)4 * p.nt2 * p.ks2 * 1024;
+    p.total = p.hn2_off + (((size_t)4 * p.nt2 * 64 + 255) & ~size_t(255));
     return p;
 }
 
@@ -110,8 +127,22 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float *cb, int M, 
     frag[(i + 32 * h) * 8 + j] = (_Float16)(-v);
 }
 
+// frag2 image: one thread per (word of the padded codebook, k)
+__global__ __launch_bounds__(256) void pack_frag2_kernel(const float *cb, int M, int D, unsigned char *frag2, float *hn2, int nt2, int ks2)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [64 nt2, D]
+    const int m = (int)(idx / D), k = (int)(idx % D);
+    const int q = m / (16 * nt2), a = (m / 16) % nt2, r = m & 15;
+    const int j = k >> 5, rem = k & 31;
+    const int g = (rem & 15) >> 2, e = (rem & 3) + 4 * (rem >> 4);
+    const float v = m < M ? cb[(int64_t)m * D + k] : 0.0f;
+    _Float16 *frag = (_Float16 *)(frag2 + ((size_t)(q * nt2 + a) * ks2 + j) * 1024);
+    frag[(r + 16 * g) * 8 + e] = (_Float16)(-v);
+    if (k == 0 && m >= M) hn2[(q * nt2 + a) * 16 + r] = kPadHalfNorm;      // real words: pack_norm_kernel
+}
+
 __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, int D, int m_pad, unsigned char *tiles,
-                                                        int n_steps, int tile_bytes, double *cn64, unsigned *scal)
+                                                        int n_steps, int tile_bytes, double *cn64, unsigned *scal, float *hn2, int nt2)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -138,6 +169,7 @@ __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, 
     if (lane == 0) {
         cn64[m] = p;
         *hc = (float)(0.5 * p);
+        if (nt2) hn2[(m / (16 * nt2) * nt2 + (m / 16) % nt2) * 16 + (m & 15)] = (float)(0.5 * p);
         const float up = 1.0f + 1.0e-6f;
         atomicMax(&scal[0], __float_as_uint(sqrtf((float)p) * up));
         atomicMax(&scal[1], __float_as_uint(l1 * (1.0f + 1.0e-4f)));
@@ -162,6 +194,12 @@ struct AssignArgs {
     unsigned char *codes;   // per token 24 key codes (tile << 2 | e), written only for flagged tokens
     int *overflow;      // token ids that need a full scan
     unsigned long long *stamps;   // diagnostics only (sn_debug_set_stamps): 16 u64 slots per wave
+    // register-stationary screen (assign_screen2_kernel): per token a 64-bit flag word (0 = final,
+    // bit 63 = overflow, else 48-bit candidate mask, bit 3c+j = key j of lane slot c = 4 q + g) and 16
+    // dwords of key codes (slot c: code_j << 8j, code = tile << 2 | row)
+    unsigned long long *flags64;
+    unsigned *codes32;
+    int64_t n_sets;     // ceil(n_tokens / 16)
 };
 
 __device__ __forceinline__ void stamp(const AssignArgs &p, int slot, int lane, int wave_id)
@@ -232,7 +270,9 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 constexpr int kMaxSurvivors = 64;
 constexpr int kOverflowBlocks = 64;     // blocks reserved for phase B
 
-template <int NT>
+// FMT 0: records of assign_screen_kernel (32-bit flag, 24 code bytes); FMT 1: records of
+// assign_screen2_kernel (64-bit flag, 16 code dwords, slot c = 4 q + g, key j: bit 3c + j).
+template <int NT, int FMT>
 __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
 {
     __shared__ float xs[NT * SN_WAVE];
@@ -254,29 +294,42 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
     for (int64_t chunk = (int64_t)blockIdx.x - kOverflowBlocks; chunk < n_chunks && (int)blockIdx.x >= kOverflowBlocks;
          chunk += (int64_t)gridDim.x - kOverflowBlocks) {
         const int64_t t = chunk * 32 + (lane & 31);
-        const unsigned flag = (lane < 32 && t < p.n_tokens) ? p.flags[t] : 0u;
-        unsigned long long todo = __ballot(flag != 0u && !(flag >> 31));
+        unsigned long long flag = 0ull;
+        if (lane < 32 && t < p.n_tokens) {
+            if constexpr (FMT == 0) { const unsigned f = p.flags[t]; flag = (f >> 31) ? (1ull << 63) : (unsigned long long)f; }
+            else flag = p.flags64[t];
+        }
+        unsigned long long todo = __ballot(flag != 0ull && !(flag >> 63));
         for (int i = 0; todo; ++i) {
             const int tl = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             if ((i & 3) != wid) continue;
             const int64_t n = chunk * 32 + tl;
-            const unsigned cmask = (unsigned)__shfl((int)flag, tl, SN_WAVE);
+            const unsigned long long cmask = ((unsigned long long)(unsigned)__shfl((int)(flag >> 32), tl, SN_WAVE) << 32) |
+                                             (unsigned long long)(unsigned)__shfl((int)flag, tl, SN_WAVE);
             int my_word = 0;
-            if (lane < kMaxCand) {
-                const unsigned code = p.codes[n * kCodeBytes + lane];
-                const int hh = lane / 12, g = (lane % 12) / 3;
-                my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
+            if constexpr (FMT == 0) {
+                if (lane < kMaxCand) {
+                    const unsigned code = p.codes[n * kCodeBytes + lane];
+                    const int hh = lane / 12, g = (lane % 12) / 3;
+                    my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
+                }
+            } else {
+                if (lane < 48 && ((cmask >> lane) & 1ull)) {          // only slots with a candidate were written
+                    const int c = lane / 3, jj = lane % 3;
+                    const unsigned code = (p.codes32[n * 16 + c] >> (8 * jj)) & 0xFFu;
+                    my_word = (c >> 2) * (16 * lay.nt2) + (int)(code >> 2) * 16 + 4 * (c & 3) + (int)(code & 3u);
+                }
             }
             double x[NT];
             load_token64<NT>(x, token_row(p, n), p.D, lane);
             double best = (double)INFINITY;
             int bi = 0x7fffffff;
-            for (unsigned cm = cmask; cm;) {                 // two candidates per round: their loads overlap
-                const int ca = __ffs((int)cm) - 1;
+            for (unsigned long long cm = cmask; cm;) {           // two candidates per round: their loads overlap
+                const int ca = __ffsll((long long)cm) - 1;
                 cm &= cm - 1;
-                const bool two = cm != 0u;
-                const int cb2 = two ? __ffs((int)cm) - 1 : ca;
+                const bool two = cm != 0ull;
+                const int cb2 = two ? __ffsll((long long)cm) - 1 : ca;
                 if (two) cm &= cm - 1;
                 const int ma = __shfl(my_word, ca, SN_WAVE), mb = __shfl(my_word, cb2, SN_WAVE);
                 const float *ra = p.cb + (int64_t)ma * p.D, *rb = p.cb + (int64_t)mb * p.D;
@@ -686,6 +739,359 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// mode 0, pass 1, register-stationary form (M <= 512 at D = 384 / 192: the whole fp16 codebook fits the
+// register file of one CU).
+//
+// One persistent workgroup (4 waves, one per SIMD, 512 registers each) per CU.  Wave q keeps the A
+// fragments of its quarter of the codebook (16 NT words x D, NT KS x 4 registers: 256 AGPRs + the
+// rest in VGPRs) for the whole kernel; token sets of 16 stream through:
+//   HBM --LDS-DMA (coalesced 128-B lines, piece-swizzled)--> raw fp32 slot
+//       --each wave converts a quarter of the k-steps--> fp16 B fragments in LDS (+ |x|^2 by a Gram MFMA)
+//       --every wave: v_mfma_f32_16x16x32_f16 against its own words--> keys (sorted triple per lane)
+//       --LDS min over the 16 lanes that hold a token--> window test, flag word, candidate codes.
+// Per token the codebook is never re-read from L2 and the tokens are read from HBM exactly once, in
+// flight while earlier sets are on the matrix pipe.  Values: u[word] = |c|^2/2 - x~.c~ (tokens and
+// words rounded to fp16, fp32 accumulate), keys = float bits with the low 8 mantissa bits replaced
+// by (tile << 2 | row), compared as floats.
+//
+// Software pipeline, one barrier per iteration `it` (set indices local to the workgroup):
+//   DMA(it+3)  CVT(it+1)  MMA(it) [+ keys of the previous accumulator group]  WIN(it)  CMP(it-2)  FLG(it-3)
+// ------------------------------------------------------------------------------------------
+constexpr int kS2RawSlots = 4;          // raw fp32 token sets in LDS (two or three of them in flight)
+constexpr int kS2SmallSlots = 8;        // ring of per-set scalars
+constexpr int kS2StashSlots = 4;
+constexpr float kBigKey = 3.0e38f;      // "no key yet"
+constexpr float kKeyLimit = 1.0e29f;    // above this a best value is a padding word / nothing finite
+// fp32 accumulate of v_mfma_f32_16x16x32_f16 (32 products per instruction): budget per instruction,
+// 2^-24 x max|partial| units (tools/mfma_probe16.hip measures the chain)
+constexpr float kAccUlpPerMfma2 = 16.0f * 5.9604645e-8f;
+
+struct S2Small {
+    float nrm[16];                      // |x~|^2 (sum over the four waves' k-steps)
+    float win[16];                      // 2E per token (NaN: token cannot be screened)
+    float best[16];                     // smallest key of the token
+    float pad_[16];
+    unsigned long long mask[16];        // candidate mask being assembled (bit 63: overflow)
+};
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) as straight-line code
+// (the MFMA stream below is far beyond the size a `#pragma unroll` is allowed to expand)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <bool AG>
+__device__ __forceinline__ void s2_mfma_first(f32x4 &d, const half8 &a, const half8 &b, const f32x4 &c)
+{
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "v"(b), "v"(c));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+
+template <bool AG>
+__device__ __forceinline__ void s2_mfma(f32x4 &d, const half8 &a, const half8 &b)
+{
+    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+
+template <int NT, int KS>
+__global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int GQ = NT / 2;                                  // tiles per accumulator group (two groups per set)
+    constexpr int NA = NT * KS < 64 ? NT * KS : 64;             // fragments pinned in AGPRs
+    constexpr int kSetRaw = KS * 2048, kSetFrag = KS * 1024;
+    constexpr int kDmaPerWave = KS / 2;                         // 1 KiB LDS-DMA instructions per wave and set
+    constexpr int kCvtMax = (KS + 3) / 4;                       // k-steps a wave converts per set
+    constexpr int kSteps = 2 * KS;                              // MFMA steps per set: (group, k-step)
+    constexpr int kVals = 4 * GQ;                               // accumulator values per lane and group
+    constexpr int kKeyStart = GQ >= 4 ? 1 : (GQ == 2 ? 2 : 4);  // first k-step with key work: >= 8 MFMA issues behind the group's last MFMA
+    static_assert(NT == 2 || NT == 4 || NT == 8, "tiles per wave");
+    static_assert(KS == 6 || KS == 12, "k-steps");
+    unsigned char *raw = smem;
+    unsigned char *frag = smem + kS2RawSlots * kSetRaw;
+    S2Small *small = reinterpret_cast<S2Small *>(frag + 2 * kSetFrag);
+    f32x4 *stash = reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(small) + kS2SmallSlots * sizeof(S2Small));
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tau = lane & 15, g = lane >> 4;
+    const PackLayout lay = pack_layout(p.M, p.D);
+    const unsigned char *frag2 = p.packed + lay.frag2_off;
+    const float *hn2 = reinterpret_cast<const float *>(p.packed + lay.hn2_off);
+    const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
+    const int wave_id = blockIdx.x * 4 + wid;
+    stamp(p, 0, lane, wave_id);
+
+    // this workgroup's sets: [sb, sb + ns)
+    const int64_t sb = (int64_t)blockIdx.x * p.n_sets / gridDim.x;
+    const int ns = (int)((int64_t)(blockIdx.x + 1) * p.n_sets / gridDim.x - sb);
+    const int n_tok32 = (int)p.n_tokens;
+    const int n_inner32 = (int)p.n_inner;
+
+    // ---- per-set scalars
+    if (tid < kS2SmallSlots * 16) {
+        S2Small &s0 = small[tid >> 4];
+        s0.nrm[tid & 15] = 0.0f; s0.win[tid & 15] = 0.0f; s0.best[tid & 15] = kBigKey; s0.mask[tid & 15] = 0ull;
+    }
+
+    // ---- token sets: HBM -> LDS by LDS-DMA.  Instruction x = 2 j + h (k-step j, token half h) copies the
+    // 128-B lines of 8 tokens; wave w issues x = w, w + 4, ...: always the same token half, so a lane
+    // needs one row pointer per set.  Lane l: token 8 h + l / 8, LDS piece slot l % 8 holds piece
+    // slot ^ ((token >> 1) & 7) of the line (conflict-free ds_read_b128 of the fragments below).
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    int d_o, d_i;                                               // (outer, inner) of the first token of the next set to copy
+    {
+        const int64_t n0 = sb * 16;
+        d_o = (int)(n0 / p.n_inner); d_i = (int)(n0 % p.n_inner);
+    }
+    int c_o = d_o, c_i = d_i;                                   // ... of the next set to compare (CMP)
+    const int last_o = (int)((p.n_tokens - 1) / p.n_inner), last_i = (int)((p.n_tokens - 1) % p.n_inner);
+    auto advance = [&](int &o, int &i) {
+        i += 16;
+        while (i >= n_inner32) { i -= n_inner32; ++o; }
+    };
+    auto issue_set = [&](int s) {
+        const int d = 8 * (wid & 1) + (lane >> 3);
+        int o = d_o, i = d_i + d;
+        while (i >= n_inner32) { i -= n_inner32; ++o; }
+        const int64_t n = (sb + s) * 16 + d;
+        if (n >= p.n_tokens) { o = last_o; i = last_i; }         // (tail of the last set: any valid row)
+        const int piece = (lane & 7) ^ ((d >> 1) & 7);
+        const float *src = p.x + (int64_t)o * p.xso + (int64_t)i * p.xsi + (wid >> 1) * 32 + piece * 4;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (s % kS2RawSlots) * kSetRaw + (wid >> 1) * 2048 + (wid & 1) * 1024);
+#pragma unroll
+        for (int x = 0; x < kDmaPerWave; ++x) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:%3\n\t"
+                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst + x * 4096 - x * 256), "i"(x * 256) : "memory");   // (the instruction offset moves the LDS address too)
+        }
+        advance(d_o, d_i);
+    };
+    for (int s = 0; s < 3 && s < ns; ++s) issue_set(s);
+
+    // ---- this wave's quarter of the codebook -> registers (stays there)
+    half8 A[NT][KS];
+    f32x4 hn[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+            A[a][j] = *reinterpret_cast<const half8 *>(frag2 + ((size_t)(wid * NT + a) * KS + j) * 1024 + lane * 16);
+        hn[a] = *reinterpret_cast<const f32x4 *>(hn2 + (wid * NT + a) * 16 + 4 * g);
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            if (a * KS + j < NA) asm volatile("" : "+a"(A[a][j]));
+            else asm volatile("" : "+v"(A[a][j]));
+        }
+        asm volatile("" : "+v"(hn[a]));
+    }
+    const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
+    const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
+
+    // ---- CVT(s): raw slot -> fp16 B fragments of k-steps wid, wid + 4, ... (+ Gram diagonal = |x~|^2)
+    f32x4 c_lo, c_hi;
+    f32x4 nacc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int swz = (tau >> 1) & 7;
+    const int rd_lo = tau * 128 + ((g ^ swz) << 4), rd_hi = tau * 128 + (((g + 4) ^ swz) << 4);
+    auto cvt_read = [&](int s, int c) {
+        const int j = wid + 4 * c;
+        if (j < KS) {
+            const unsigned char *base = raw + (s % kS2RawSlots) * kSetRaw + j * 2048;
+            c_lo = *reinterpret_cast<const f32x4 *>(base + rd_lo);
+            c_hi = *reinterpret_cast<const f32x4 *>(base + rd_hi);
+        }
+    };
+    auto cvt_write = [&](int s, int c) {
+        const int j = wid + 4 * c;
+        if (j < KS) {
+            half8 hb;
+            hb[0] = (_Float16)c_lo.x; hb[1] = (_Float16)c_lo.y; hb[2] = (_Float16)c_lo.z; hb[3] = (_Float16)c_lo.w;
+            hb[4] = (_Float16)c_hi.x; hb[5] = (_Float16)c_hi.y; hb[6] = (_Float16)c_hi.z; hb[7] = (_Float16)c_hi.w;
+            *reinterpret_cast<half8 *>(frag + (s & 1) * kSetFrag + j * 1024 + lane * 16) = hb;
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(nacc) : "v"(hb));       // Gram matrix of the 16 tokens
+        }
+    };
+    auto cvt_norm = [&](int s) {                             // diagonal (tau, tau): lane group tau >> 2, register tau & 3
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(nacc));                // MFMA -> VALU read distance (the asm MFMA is invisible to the hazard recogniser)
+        const float dg = (tau & 2) ? ((tau & 1) ? nacc[3] : nacc[2]) : ((tau & 1) ? nacc[1] : nacc[0]);
+        if (g == (tau >> 2)) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)&small[s % kS2SmallSlots].nrm[tau], dg, 0, 0, false);
+        nacc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+
+    // ---- WIN(s): error window of each token of the set (DESIGN.md "S1 error window")
+    auto win_stage = [&](int s) {
+        if (lane < 16) {
+            S2Small &sm = small[s % kS2SmallSlots];
+            const float nr = sm.nrm[lane];
+            const float X2 = sqrtf(nr) * 1.002f + 1.0e-6f;            // |x|_2 from the fp16-rounded token
+            const float X1 = X2 * sqrtf((float)p.D);
+            const float vmax = 0.5f * CN + X2 * C2;                    // >= |any partial sum|
+            const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
+                                     + (float)KS * kAccUlpPerMfma2 * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
+            const bool ok = (nr < 1.0e30f) && (CMAX <= kHugeIn) && (vmax < 1.0e28f);       // false for NaN / inf
+            sm.win[lane] = ok ? 2.0f * E : __builtin_nanf("");
+        }
+    };
+
+    // ---- CMP(s): which of this lane's three keys are inside the window of the token's best
+    auto cmp_stage = [&](int s) {
+        S2Small &sm = small[s % kS2SmallSlots];
+        const f32x4 t3 = stash[(s % kS2StashSlots) * 256 + tid];
+        const float cut = sm.best[tau] + sm.win[tau];                 // NaN window -> no hit -> overflow
+        const int64_t n = (sb + s) * 16 + tau;
+        const bool live = n < p.n_tokens && cut < kKeyLimit;
+        const bool h1 = live && t3.x <= cut, h2 = live && t3.y <= cut, h3 = live && t3.z <= cut;
+        const unsigned k1 = __float_as_uint(t3.x), k2 = __float_as_uint(t3.y), k3 = __float_as_uint(t3.z);
+        if (h1) {
+            int o = c_o, i = c_i + tau;
+            while (i >= n_inner32) { i -= n_inner32; ++o; }
+            p.out[(int64_t)o * p.oso + (int64_t)i * p.osi] = wid * (16 * NT) + (int)((k1 & 0xFFu) >> 2) * 16 + 4 * g + (int)(k1 & 3u);
+            const int c = wid * 4 + g;
+            unsigned long long bits = (unsigned long long)(1u | (h2 ? 2u : 0u) | (h3 ? 4u : 0u)) << (3 * c);
+            if (h3) bits |= 1ull << 63;                                // a fourth key may hide behind the third
+            __hip_atomic_fetch_or(&sm.mask[tau], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            p.codes32[n * 16 + c] = (k1 & 0xFFu) | ((k2 & 0xFFu) << 8) | ((k3 & 0xFFu) << 16);
+        }
+        advance(c_o, c_i);
+    };
+
+    // ---- FLG(s): flag word of each token, overflow list, recycle the scalar slot
+    auto flag_stage = [&](int s) {
+        if (lane < 16) {
+            S2Small &sm = small[s % kS2SmallSlots];
+            const int64_t n = (sb + s) * 16 + lane;
+            const unsigned long long mk = sm.mask[lane];
+            const unsigned long long cand = mk & 0xFFFFFFFFFFFFull;
+            const bool over = (mk >> 63) != 0ull || cand == 0ull;
+            const bool valid = n < p.n_tokens;
+            if (valid) p.flags64[n] = over ? (1ull << 63) : (__popcll(cand) > 1 ? cand : 0ull);
+            const bool need_b = valid && over;
+            const unsigned long long mask_b = __ballot(need_b);
+            if (mask_b) {
+                int base = 0;
+                const int leader = __ffsll((long long)mask_b) - 1;
+                if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
+                base = __shfl(base, leader, SN_WAVE);
+                if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;   // phase B writes out[]
+            }
+            sm.mask[lane] = 0ull; sm.best[lane] = kBigKey; sm.nrm[lane] = 0.0f;
+        }
+    };
+
+    // ---- prologue: sets 0..2 in flight, codebook in registers, set 0 converted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ns > 0) {
+#pragma unroll
+        for (int c = 0; c < kCvtMax; ++c) { cvt_read(0, c); cvt_write(0, c); }
+        cvt_norm(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp(p, 1, lane, wave_id);
+
+    f32x4 acc0[GQ], acc1[GQ];
+#pragma unroll
+    for (int t = 0; t < GQ; ++t) { acc0[t] = f32x4{kBigKey, kBigKey, kBigKey, kBigKey}; acc1[t] = acc0[t]; }
+    float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey;
+    unsigned keymask = 0xFFFFFF00u;
+    asm volatile("" : "+v"(keymask));
+    // key = (value bits & ~0xFF) | code into the sorted triple m1 <= m2 <= m3 (compared as floats).
+    // Volatile asm: callers keep it >= 8 MFMA issues behind the MFMA that wrote `v` (the hazard
+    // recogniser cannot see either side).
+    auto key_insert = [&](float v, unsigned code) {
+        float k;
+        asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
+                     "v_med3_f32 %3, %0, %2, %3\n\t"
+                     "v_med3_f32 %2, %0, %1, %2\n\t"
+                     "v_min_f32 %1, %0, %1"
+                     : "=&v"(k), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(v), "v"(keymask), "s"(code));
+    };
+    auto publish = [&](int s) {                                 // triple of set s is complete
+        __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&small[s % kS2SmallSlots].best[tau], m1, 0, 0, false);
+        stash[(s % kS2StashSlots) * 256 + tid] = f32x4{m1, m2, m3, 0.0f};
+        m1 = m2 = m3 = kBigKey;
+    };
+    half8 bq[3];
+
+    for (int it = 0; it < ns + 3; ++it) {
+        const bool do_mma = it < ns;
+        const bool do_cvt = it + 1 < ns;
+        const bool do_dma = it + 3 < ns;
+        const unsigned char *fb = frag + (it & 1) * kSetFrag + lane * 16;
+        if (do_mma) {
+            bq[0] = *reinterpret_cast<const half8 *>(fb);
+            bq[1] = *reinterpret_cast<const half8 *>(fb + 1024);
+        }
+        if (do_mma && wid == (it & 3)) win_stage(it);
+        if (it >= 2 && it - 2 < ns) cmp_stage(it - 2);
+        if (it >= 3 && wid == ((it - 3) & 3)) flag_stage(it - 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_mma) {
+            static_for<kSteps>([&](auto st_c) {
+                constexpr int st = decltype(st_c)::value;
+                constexpr int q = st / KS, j = st % KS;
+                if (st + 2 < kSteps) bq[(st + 2) % 3] = *reinterpret_cast<const half8 *>(fb + ((st + 2) % KS) * 1024);
+                if (st == KS && it > 0) publish(it - 1);                 // (keys of set it-1 ended with the previous step)
+#pragma unroll
+                for (int t = 0; t < GQ; ++t) {
+                    const int a = q * GQ + t;
+                    f32x4 &acc = q == 0 ? acc0[t] : acc1[t];
+                    if (j == 0) {
+                        if (a * KS + j < NA) s2_mfma_first<true>(acc, A[a][j], bq[st % 3], hn[a]);
+                        else s2_mfma_first<false>(acc, A[a][j], bq[st % 3], hn[a]);
+                    } else {
+                        if (a * KS + j < NA) s2_mfma<true>(acc, A[a][j], bq[st % 3]);
+                        else s2_mfma<false>(acc, A[a][j], bq[st % 3]);
+                    }
+                }
+                // keys of the previous accumulator group (q == 0: group 1 of set it-1; q == 1: group 0 of this set)
+                if (j >= kKeyStart && (q == 1 || it > 0)) {
+#pragma unroll
+                    for (int v = 0; v < kVals; ++v) {
+                        if (kKeyStart + (v * (KS - kKeyStart)) / kVals == j) {
+                            const int t = v >> 2, r = v & 3;
+                            const int a = (1 - q) * GQ + t;
+                            key_insert(q == 0 ? acc1[t][r] : acc0[t][r], (unsigned)(a << 2 | r));
+                        }
+                    }
+                }
+                // conversion of the next set, a quarter of its k-steps per wave
+                if (do_cvt) {
+#pragma unroll
+                    for (int c = 0; c < kCvtMax; ++c) {
+                        if (st == 1 + c * (kSteps / kCvtMax)) cvt_read(it + 1, c);
+                        if (st == 3 + c * (kSteps / kCvtMax)) cvt_write(it + 1, c);
+                    }
+                    if (st == kSteps - 2) cvt_norm(it + 1);
+                }
+                if (do_dma && st == KS + 1) issue_set(it + 3);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else if (it == ns && ns > 0) {                                 // drain: keys of the very last group
+#pragma unroll
+            for (int v = 0; v < kVals; ++v) key_insert(acc1[v >> 2][v & 3], (unsigned)((GQ + (v >> 2)) << 2 | (v & 3)));
+            publish(ns - 1);
+        }
+        if (do_dma) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    stamp(p, 2, lane, wave_id);
+    stamp(p, 3, lane, wave_id);
+}
+
 template <int NT>
 int launch_exact(const AssignArgs &a, hipStream_t st)
 {
@@ -715,12 +1121,48 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
     const int64_t chunks = (a.n_tokens + 31) / 32;
-    hipLaunchKernelGGL(assign_rerank_kernel<NT>, dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((assign_rerank_kernel<NT, 0>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
     sn_prof_stop(1, st);
     return 0;
 }
 
-// workgroup shape of the screen kernel: 0 = 4 waves x 3-slot ring (two workgroups per CU),
+int device_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int NT, int KS>
+int launch_screen2(const AssignArgs &a, hipStream_t st)
+{
+    const size_t lds = (size_t)kS2RawSlots * KS * 2048 + (size_t)2 * KS * 1024 + kS2SmallSlots * sizeof(S2Small) + (size_t)kS2StashSlots * 256 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)assign_screen2_kernel<NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sn_set_error("sn_assign_words: LDS attribute: %s", hipGetErrorString(e)); return SN_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    const int cus = device_cus();
+    const unsigned grid = (unsigned)(a.n_sets < cus ? a.n_sets : cus);     // one persistent workgroup per CU
+    sn_prof_start(0, st);
+    hipLaunchKernelGGL((assign_screen2_kernel<NT, KS>), dim3(grid), dim3(256), lds, st, a);
+    sn_prof_stop(0, st);
+    constexpr int NTR = KS / 2;                                             // fp64 re-rank: 64 k per lane-step
+    sn_prof_start(1, st);
+    const int64_t chunks = (a.n_tokens + 31) / 32;
+    hipLaunchKernelGGL((assign_rerank_kernel<NTR, 1>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
+    sn_prof_stop(1, st);
+    return 0;
+}
+
+// workgroup shape of the screen kernel: 2 (default where the shape allows it) = register-stationary
+// codebook (assign_screen2_kernel); token-stationary forms: 0 = 4 waves x 3-slot ring (two workgroups per CU),
 // 1 = 8 waves x 5-slot ring (one workgroup per CU, half the LDS-DMA traffic per token)
 int screen_variant()
 {
@@ -756,9 +1198,12 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
     const int64_t elems = (int64_t)lay.m_pad * D;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)(elems / 256)), dim3(256), 0, st, codebook, M, D,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes);
+    if (lay.nt2)
+        hipLaunchKernelGGL(pack_frag2_kernel, dim3((unsigned)((int64_t)64 * lay.nt2 * D / 256)), dim3(256), 0, st, codebook, M, D,
+                           base + lay.frag2_off, (float *)(base + lay.hn2_off), lay.nt2, lay.ks2);
     hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((lay.m_pad + 3) / 4)), dim3(256), 0, st, codebook, M, D, lay.m_pad,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (double *)(base + lay.cn64_off),
-                       (unsigned *)(base + lay.scal_off));
+                       (unsigned *)(base + lay.scal_off), (float *)(base + lay.hn2_off), lay.nt2);
     SN_CHECK_LAUNCH("sn_codebook_prepare");
     return SN_OK;
 }
@@ -779,7 +1224,7 @@ extern "C" void sn_debug_set_stamps(void *device_buffer) { g_stamps = (unsigned 
 extern "C" size_t sn_assign_workspace_bytes(int64_t n_tokens)
 {
     if (n_tokens < 0) return 0;
-    return 32 + (size_t)n_tokens * kWsPerToken;      // header + flag words + candidate codes + overflow token ids
+    return 32 + (size_t)n_tokens * kWsPerToken2;     // header + flag words + candidate codes + overflow token ids (the larger record format)
 }
 
 extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
@@ -804,6 +1249,9 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.codes = ws ? ws + 32 + (size_t)n_tokens * 4 : nullptr;
     a.overflow = ws ? (int *)(ws + 32 + (size_t)n_tokens * (4 + kCodeBytes)) : nullptr;
     a.stamps = g_stamps;
+    a.flags64 = ws ? (unsigned long long *)(ws + 32) : nullptr;
+    a.codes32 = ws ? (unsigned *)(ws + 32 + (size_t)n_tokens * 8) : nullptr;
+    a.n_sets = (n_tokens + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
     const bool screen_ok = mode == 0 && aligned && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
@@ -816,7 +1264,12 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
         }
         int rc = 0;
         const bool wide = screen_variant() == 1;
-        if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st);
+        const PackLayout lay = pack_layout(M, D);
+        if (screen_variant() == 2 && lay.nt2 != 0) {
+            a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (8 + 64));
+            if (lay.ks2 == 12) rc = lay.nt2 == 8 ? launch_screen2<8, 12>(a, st) : (lay.nt2 == 4 ? launch_screen2<4, 12>(a, st) : launch_screen2<2, 12>(a, st));
+            else rc = lay.nt2 == 8 ? launch_screen2<8, 6>(a, st) : (lay.nt2 == 4 ? launch_screen2<4, 6>(a, st) : launch_screen2<2, 6>(a, st));
+        } else if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st);
         else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : launch_screen<24, 4, 3>(a, st);
         else rc = launch_screen<48, 4, 3>(a, st);
         if (rc) return rc;
