@@ -767,13 +767,14 @@ constexpr float kKeyLimit = 1.0e29f;    // above this a best value is a padding 
 // 2^-24 x max|partial| units (tools/mfma_probe16.hip measures the chain)
 constexpr float kAccUlpPerMfma2 = 16.0f * 5.9604645e-8f;
 
-struct S2Small {
-    float nrm[16];                      // |x~|^2 (sum over the four waves' k-steps)
-    float win[16];                      // 2E per token (NaN: token cannot be screened)
-    float best[16];                     // smallest key of the token
-    float pad_[16];
-    unsigned long long mask[16];        // candidate mask being assembled (bit 63: overflow)
+struct S2Tok {                          // per token of a set in flight (LDS)
+    float best;                         // smallest key of the token (ds_min over the 16 lanes that hold it)
+    float win;                          // 2E (NaN: the token cannot be screened)
+    unsigned long long mask;            // candidate mask being assembled (bit 63: overflow)
+    float nrm;                          // |x~|^2, summed over the four waves' k-steps
+    float pad_[3];
 };
+struct S2Small { S2Tok tok[16]; };
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) as straight-line code
 // (the MFMA stream below is far beyond the size a `#pragma unroll` is allowed to expand)
@@ -807,13 +808,20 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     constexpr int kCvtMax = (KS + 3) / 4;                       // k-steps a wave converts per set
     constexpr int kSteps = 2 * KS;                              // MFMA steps per set: (group, k-step)
     constexpr int kVals = 4 * GQ;                               // accumulator values per lane and group
-    constexpr int kKeyStart = GQ >= 4 ? 1 : (GQ == 2 ? 2 : 4);  // first k-step with key work: >= 8 MFMA issues behind the group's last MFMA
+    constexpr int kKeyStart = GQ >= 2 ? 1 : 2;                  // first k-step with key work: >= 2 MFMA issues behind the group's last MFMA
+    constexpr int kKeyEnd = KS - 3;                             // last k-step with key work; then the accumulators are re-initialised from LDS
+    // key value v of a group is inserted at k-step key_step(v); the two halves of each insert go into
+    // the gaps behind consecutive MFMAs of that step (two VALU fit behind one 16x16x32 MFMA)
+    auto key_step = [](int v) constexpr { return kKeyStart + (v * (kKeyEnd + 1 - kKeyStart)) / kVals; };
+    auto keys_in_step = [key_step](int j) constexpr { int n = 0; for (int v = 0; v < kVals; ++v) n += key_step(v) == j; return n; };
+    auto key_rank = [key_step](int v) constexpr { int n = 0; for (int u = 0; u < v; ++u) n += key_step(u) == key_step(v); return n; };
     static_assert(NT == 2 || NT == 4 || NT == 8, "tiles per wave");
     static_assert(KS == 6 || KS == 12, "k-steps");
     unsigned char *raw = smem;
     unsigned char *frag = smem + kS2RawSlots * kSetRaw;
     S2Small *small = reinterpret_cast<S2Small *>(frag + 2 * kSetFrag);
     f32x4 *stash = reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(small) + kS2SmallSlots * sizeof(S2Small));
+    f32x4 *hnl = stash + kS2StashSlots * 256;                     // [4 waves][NT tiles][4 row groups] x 4 half norms
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tau = lane & 15, g = lane >> 4;
@@ -832,8 +840,8 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 
     // ---- per-set scalars
     if (tid < kS2SmallSlots * 16) {
-        S2Small &s0 = small[tid >> 4];
-        s0.nrm[tid & 15] = 0.0f; s0.win[tid & 15] = 0.0f; s0.best[tid & 15] = kBigKey; s0.mask[tid & 15] = 0ull;
+        S2Tok &t0 = small[tid >> 4].tok[tid & 15];
+        t0.best = kBigKey; t0.win = 0.0f; t0.mask = 0ull; t0.nrm = 0.0f;
     }
 
     // ---- token sets: HBM -> LDS by LDS-DMA.  Instruction x = 2 j + h (k-step j, token half h) copies the
@@ -848,14 +856,14 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     }
     int c_o = d_o, c_i = d_i;                                   // ... of the next set to compare (CMP)
     const int last_o = (int)((p.n_tokens - 1) / p.n_inner), last_i = (int)((p.n_tokens - 1) % p.n_inner);
-    auto advance = [&](int &o, int &i) {
+    auto advance = [&](int &o, int &i) {                       // (n_inner >= 16: at most one wrap per set)
         i += 16;
-        while (i >= n_inner32) { i -= n_inner32; ++o; }
+        if (i >= n_inner32) { i -= n_inner32; ++o; }
     };
     auto issue_set = [&](int s) {
         const int d = 8 * (wid & 1) + (lane >> 3);
         int o = d_o, i = d_i + d;
-        while (i >= n_inner32) { i -= n_inner32; ++o; }
+        if (i >= n_inner32) { i -= n_inner32; ++o; }
         const int64_t n = (sb + s) * 16 + d;
         if (n >= p.n_tokens) { o = last_o; i = last_i; }         // (tail of the last set: any valid row)
         const int piece = (lane & 7) ^ ((d >> 1) & 7);
@@ -874,14 +882,13 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 
     // ---- this wave's quarter of the codebook -> registers (stays there)
     half8 A[NT][KS];
-    f32x4 hn[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
         for (int j = 0; j < KS; ++j)
             A[a][j] = *reinterpret_cast<const half8 *>(frag2 + ((size_t)(wid * NT + a) * KS + j) * 1024 + lane * 16);
-        hn[a] = *reinterpret_cast<const f32x4 *>(hn2 + (wid * NT + a) * 16 + 4 * g);
     }
+    if (tid < 4 * NT * 4) hnl[tid] = *reinterpret_cast<const f32x4 *>(hn2 + tid * 4);     // |c|^2/2: LDS, re-read per accumulator chain
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
@@ -889,8 +896,8 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
             if (a * KS + j < NA) asm volatile("" : "+a"(A[a][j]));
             else asm volatile("" : "+v"(A[a][j]));
         }
-        asm volatile("" : "+v"(hn[a]));
     }
+    const f32x4 *hn_w = hnl + wid * NT * 4 + g;                  // tile a: hn_w[4 a] = rows 4g..4g+3 of the wave's tile a
     const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
     const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
 
@@ -901,7 +908,7 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     const int rd_lo = tau * 128 + ((g ^ swz) << 4), rd_hi = tau * 128 + (((g + 4) ^ swz) << 4);
     auto cvt_read = [&](int s, int c) {
         const int j = wid + 4 * c;
-        if (j < KS) {
+        if (KS % 4 == 0 || j < KS) {
             const unsigned char *base = raw + (s % kS2RawSlots) * kSetRaw + j * 2048;
             c_lo = *reinterpret_cast<const f32x4 *>(base + rd_lo);
             c_hi = *reinterpret_cast<const f32x4 *>(base + rd_hi);
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     };
     auto cvt_write = [&](int s, int c) {
         const int j = wid + 4 * c;
-        if (j < KS) {
+        if (KS % 4 == 0 || j < KS) {
             half8 hb;
             hb[0] = (_Float16)c_lo.x; hb[1] = (_Float16)c_lo.y; hb[2] = (_Float16)c_lo.z; hb[3] = (_Float16)c_lo.w;
             hb[4] = (_Float16)c_hi.x; hb[5] = (_Float16)c_hi.y; hb[6] = (_Float16)c_hi.z; hb[7] = (_Float16)c_hi.w;
@@ -920,56 +927,60 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     auto cvt_norm = [&](int s) {                             // diagonal (tau, tau): lane group tau >> 2, register tau & 3
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(nacc));                // MFMA -> VALU read distance (the asm MFMA is invisible to the hazard recogniser)
         const float dg = (tau & 2) ? ((tau & 1) ? nacc[3] : nacc[2]) : ((tau & 1) ? nacc[1] : nacc[0]);
-        if (g == (tau >> 2)) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)&small[s % kS2SmallSlots].nrm[tau], dg, 0, 0, false);
+        if (g == (tau >> 2)) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)&small[s & (kS2SmallSlots - 1)].tok[tau].nrm, dg, 0, 0, false);
         nacc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
 
-    // ---- WIN(s): error window of each token of the set (DESIGN.md "S1 error window")
-    auto win_stage = [&](int s) {
-        if (lane < 16) {
-            S2Small &sm = small[s % kS2SmallSlots];
-            const float nr = sm.nrm[lane];
-            const float X2 = sqrtf(nr) * 1.002f + 1.0e-6f;            // |x|_2 from the fp16-rounded token
-            const float X1 = X2 * sqrtf((float)p.D);
-            const float vmax = 0.5f * CN + X2 * C2;                    // >= |any partial sum|
-            const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
-                                     + (float)KS * kAccUlpPerMfma2 * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
-            const bool ok = (nr < 1.0e30f) && (CMAX <= kHugeIn) && (vmax < 1.0e28f);       // false for NaN / inf
-            sm.win[lane] = ok ? 2.0f * E : __builtin_nanf("");
-        }
+    // ---- WIN(s): error window of each token of the set (DESIGN.md "S1 error window"); lanes 0..15 of one wave
+    float w_nr = 0.0f;
+    auto win_read = [&](int s) { w_nr = small[s & (kS2SmallSlots - 1)].tok[tau].nrm; };
+    auto win_do = [&](int s) {
+        const float X2 = sqrtf(w_nr) * 1.002f + 1.0e-6f;              // |x|_2 from the fp16-rounded token
+        const float X1 = X2 * sqrtf((float)p.D);
+        const float vmax = 0.5f * CN + X2 * C2;                        // >= |any partial sum|
+        const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
+                                 + (float)KS * kAccUlpPerMfma2 * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
+        const bool ok = (w_nr < 1.0e30f) && (CMAX <= kHugeIn) && (vmax < 1.0e28f);       // false for NaN / inf
+        if (lane < 16) small[s & (kS2SmallSlots - 1)].tok[tau].win = ok ? 2.0f * E : __builtin_nanf("");
     };
 
     // ---- CMP(s): which of this lane's three keys are inside the window of the token's best
-    auto cmp_stage = [&](int s) {
-        S2Small &sm = small[s % kS2SmallSlots];
-        const f32x4 t3 = stash[(s % kS2StashSlots) * 256 + tid];
-        const float cut = sm.best[tau] + sm.win[tau];                 // NaN window -> no hit -> overflow
+    f32x4 c_t3;
+    float c_best = 0.0f, c_win = 0.0f;
+    auto cmp_read = [&](int s) {
+        c_t3 = stash[(s & (kS2StashSlots - 1)) * 256 + tid];
+        const S2Tok &tk = small[s & (kS2SmallSlots - 1)].tok[tau];
+        c_best = tk.best; c_win = tk.win;
+    };
+    auto cmp_do = [&](int s, bool en) {
+        const float cut = c_best + c_win;                              // NaN window -> no hit -> overflow
         const int64_t n = (sb + s) * 16 + tau;
-        const bool live = n < p.n_tokens && cut < kKeyLimit;
-        const bool h1 = live && t3.x <= cut, h2 = live && t3.y <= cut, h3 = live && t3.z <= cut;
-        const unsigned k1 = __float_as_uint(t3.x), k2 = __float_as_uint(t3.y), k3 = __float_as_uint(t3.z);
+        const bool live = en && n < p.n_tokens && cut < kKeyLimit;
+        const bool h1 = live && c_t3.x <= cut, h2 = live && c_t3.y <= cut, h3 = live && c_t3.z <= cut;
+        const unsigned k1 = __float_as_uint(c_t3.x), k2 = __float_as_uint(c_t3.y), k3 = __float_as_uint(c_t3.z);
+        int o = c_o, i = c_i + tau;
+        if (i >= n_inner32) { i -= n_inner32; ++o; }                   // (n_inner >= 16: at most one wrap)
         if (h1) {
-            int o = c_o, i = c_i + tau;
-            while (i >= n_inner32) { i -= n_inner32; ++o; }
             p.out[(int64_t)o * p.oso + (int64_t)i * p.osi] = wid * (16 * NT) + (int)((k1 & 0xFFu) >> 2) * 16 + 4 * g + (int)(k1 & 3u);
             const int c = wid * 4 + g;
             unsigned long long bits = (unsigned long long)(1u | (h2 ? 2u : 0u) | (h3 ? 4u : 0u)) << (3 * c);
             if (h3) bits |= 1ull << 63;                                // a fourth key may hide behind the third
-            __hip_atomic_fetch_or(&sm.mask[tau], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&small[s & (kS2SmallSlots - 1)].tok[tau].mask, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             p.codes32[n * 16 + c] = (k1 & 0xFFu) | ((k2 & 0xFFu) << 8) | ((k3 & 0xFFu) << 16);
         }
-        advance(c_o, c_i);
+        if (en) advance(c_o, c_i);
     };
 
-    // ---- FLG(s): flag word of each token, overflow list, recycle the scalar slot
-    auto flag_stage = [&](int s) {
+    // ---- FLG(s): flag word of each token, overflow list, recycle the scalar slot; lanes 0..15 of one wave
+    unsigned long long f_mk = 0ull;
+    auto flag_read = [&](int s) { f_mk = small[s & (kS2SmallSlots - 1)].tok[tau].mask; };
+    auto flag_do = [&](int s, bool en) {
         if (lane < 16) {
-            S2Small &sm = small[s % kS2SmallSlots];
+            S2Tok &tk = small[s & (kS2SmallSlots - 1)].tok[lane];
             const int64_t n = (sb + s) * 16 + lane;
-            const unsigned long long mk = sm.mask[lane];
-            const unsigned long long cand = mk & 0xFFFFFFFFFFFFull;
-            const bool over = (mk >> 63) != 0ull || cand == 0ull;
-            const bool valid = n < p.n_tokens;
+            const unsigned long long cand = f_mk & 0xFFFFFFFFFFFFull;
+            const bool over = (f_mk >> 63) != 0ull || cand == 0ull;
+            const bool valid = en && n < p.n_tokens;
             if (valid) p.flags64[n] = over ? (1ull << 63) : (__popcll(cand) > 1 ? cand : 0ull);
             const bool need_b = valid && over;
             const unsigned long long mask_b = __ballot(need_b);
@@ -980,7 +991,7 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
                 base = __shfl(base, leader, SN_WAVE);
                 if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;   // phase B writes out[]
             }
-            sm.mask[lane] = 0ull; sm.best[lane] = kBigKey; sm.nrm[lane] = 0.0f;
+            tk.best = kBigKey; tk.mask = 0ull; tk.nrm = 0.0f;
         }
     };
 
@@ -1001,7 +1012,7 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 
     f32x4 acc0[GQ], acc1[GQ];
 #pragma unroll
-    for (int t = 0; t < GQ; ++t) { acc0[t] = f32x4{kBigKey, kBigKey, kBigKey, kBigKey}; acc1[t] = acc0[t]; }
+    for (int t = 0; t < GQ; ++t) { acc0[t] = hn_w[4 * t]; acc1[t] = f32x4{kBigKey, kBigKey, kBigKey, kBigKey}; }
     float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey;
     unsigned keymask = 0xFFFFFF00u;
     asm volatile("" : "+v"(keymask));
@@ -1016,80 +1027,106 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
                      "v_min_f32 %1, %0, %1"
                      : "=&v"(k), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(v), "v"(keymask), "s"(code));
     };
-    auto publish = [&](int s) {                                 // triple of set s is complete
-        __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&small[s % kS2SmallSlots].best[tau], m1, 0, 0, false);
-        stash[(s % kS2StashSlots) * 256 + tid] = f32x4{m1, m2, m3, 0.0f};
+    float kk = 0.0f;                                            // the same insert in two halves (one MFMA gap each)
+    auto key_half_a = [&](float v, unsigned code) {
+        asm volatile("v_and_or_b32 %0, %3, %4, %5\n\tv_med3_f32 %2, %0, %1, %2" : "=&v"(kk), "+v"(m2), "+v"(m3) : "v"(v), "v"(keymask), "s"(code));
+    };
+    auto key_half_b = [&]() {
+        asm volatile("v_med3_f32 %2, %0, %1, %2\n\tv_min_f32 %1, %0, %1" : "+v"(kk), "+v"(m1), "+v"(m2));
+    };
+    auto publish = [&](int s) {                                 // triple of set s is complete (s == -1: all keys are kBigKey, a no-op)
+        __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&small[s & (kS2SmallSlots - 1)].tok[tau].best, m1, 0, 0, false);
+        stash[(s & (kS2StashSlots - 1)) * 256 + tid] = f32x4{m1, m2, m3, 0.0f};
         m1 = m2 = m3 = kBigKey;
     };
     half8 bq[3];
-
-    for (int it = 0; it < ns + 3; ++it) {
-        const bool do_mma = it < ns;
-        const bool do_cvt = it + 1 < ns;
-        const bool do_dma = it + 3 < ns;
-        const unsigned char *fb = frag + (it & 1) * kSetFrag + lane * 16;
-        if (do_mma) {
-            bq[0] = *reinterpret_cast<const half8 *>(fb);
-            bq[1] = *reinterpret_cast<const half8 *>(fb + 1024);
-        }
-        if (do_mma && wid == (it & 3)) win_stage(it);
-        if (it >= 2 && it - 2 < ns) cmp_stage(it - 2);
-        if (it >= 3 && wid == ((it - 3) & 3)) flag_stage(it - 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_mma) {
-            static_for<kSteps>([&](auto st_c) {
-                constexpr int st = decltype(st_c)::value;
-                constexpr int q = st / KS, j = st % KS;
-                if (st + 2 < kSteps) bq[(st + 2) % 3] = *reinterpret_cast<const half8 *>(fb + ((st + 2) % KS) * 1024);
-                if (st == KS && it > 0) publish(it - 1);                 // (keys of set it-1 ended with the previous step)
-#pragma unroll
-                for (int t = 0; t < GQ; ++t) {
-                    const int a = q * GQ + t;
-                    f32x4 &acc = q == 0 ? acc0[t] : acc1[t];
-                    if (j == 0) {
-                        if (a * KS + j < NA) s2_mfma_first<true>(acc, A[a][j], bq[st % 3], hn[a]);
-                        else s2_mfma_first<false>(acc, A[a][j], bq[st % 3], hn[a]);
-                    } else {
-                        if (a * KS + j < NA) s2_mfma<true>(acc, A[a][j], bq[st % 3]);
-                        else s2_mfma<false>(acc, A[a][j], bq[st % 3]);
-                    }
-                }
-                // keys of the previous accumulator group (q == 0: group 1 of set it-1; q == 1: group 0 of this set)
-                if (j >= kKeyStart && (q == 1 || it > 0)) {
-#pragma unroll
-                    for (int v = 0; v < kVals; ++v) {
-                        if (kKeyStart + (v * (KS - kKeyStart)) / kVals == j) {
-                            const int t = v >> 2, r = v & 3;
-                            const int a = (1 - q) * GQ + t;
-                            key_insert(q == 0 ? acc1[t][r] : acc0[t][r], (unsigned)(a << 2 | r));
-                        }
-                    }
-                }
-                // conversion of the next set, a quarter of its k-steps per wave
-                if (do_cvt) {
-#pragma unroll
-                    for (int c = 0; c < kCvtMax; ++c) {
-                        if (st == 1 + c * (kSteps / kCvtMax)) cvt_read(it + 1, c);
-                        if (st == 3 + c * (kSteps / kCvtMax)) cvt_write(it + 1, c);
-                    }
-                    if (st == kSteps - 2) cvt_norm(it + 1);
-                }
-                if (do_dma && st == KS + 1) issue_set(it + 3);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        } else if (it == ns && ns > 0) {                                 // drain: keys of the very last group
-#pragma unroll
-            for (int v = 0; v < kVals; ++v) key_insert(acc1[v >> 2][v & 3], (unsigned)((GQ + (v >> 2)) << 2 | (v & 3)));
-            publish(ns - 1);
-        }
-        if (do_dma) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
+    unsigned long long t_pre = 0, t_mma = 0, t_bar = 0;        // diagnostics (only when stamps are on)
+    auto end_of_iteration = [&](bool dma_issued) {
+        if (dma_issued) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");     // set it+2 has landed, it+3 stays in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+
+    // ---- main loop.  Everything except the DMA issue runs unconditionally (no per-step branches):
+    // in the first iterations the "previous" keys are kBigKey, CMP / FLG are predicated off by `en`,
+    // in the last one CVT converts a stale slot nobody reads.
+    for (int it = 0; it < ns; ++it) {
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+        if (p.stamps) ts0 = __builtin_amdgcn_s_memtime();
+        const bool do_dma = it + 3 < ns;
+        const unsigned char *fb = frag + (it & 1) * kSetFrag + lane * 16;
+        bq[0] = *reinterpret_cast<const half8 *>(fb);
+        bq[1] = *reinterpret_cast<const half8 *>(fb + 1024);
+        cmp_read(it - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p.stamps) ts1 = __builtin_amdgcn_s_memtime();
+        static_for<kSteps>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int q = st / KS, j = st % KS;
+            if (st == KS) publish(it - 1);                           // (keys of set it-1 ended with the previous step)
+            constexpr int nh = 2 * keys_in_step(j);                  // key halves of this step, dealt to the GQ gaps in order
+#pragma unroll
+            for (int t = 0; t < GQ; ++t) {
+                const int a = q * GQ + t;
+                f32x4 &acc = q == 0 ? acc0[t] : acc1[t];
+                if (a * KS + j < NA) s2_mfma<true>(acc, A[a][j], bq[st % 3]);
+                else s2_mfma<false>(acc, A[a][j], bq[st % 3]);
+                if (t == 0 && st + 2 < kSteps) bq[(st + 2) % 3] = *reinterpret_cast<const half8 *>(fb + ((st + 2) % KS) * 1024);
+                // keys of the previous accumulator group (q == 0: group 1 of set it-1; q == 1: group 0 of this set)
+#pragma unroll
+                for (int v = 0; v < kVals; ++v) {
+                    if (key_step(v) == j) {
+                        const int vt = v >> 2, r = v & 3, ka = (1 - q) * GQ + vt;
+                        if (((2 * key_rank(v)) * GQ) / (nh > 0 ? nh : 1) == t) key_half_a(q == 0 ? acc1[vt][r] : acc0[vt][r], (unsigned)(ka << 2 | r));
+                        if (((2 * key_rank(v) + 1) * GQ) / (nh > 0 ? nh : 1) == t) key_half_b();
+                    }
+                }
+                if (t + 1 < GQ) __builtin_amdgcn_sched_barrier(0);
+            }
+            // the chain that starts KS steps from now begins at |c|^2/2: its accumulators were keyed by step kKeyEnd
+            if (j == kKeyEnd + 1) {
+#pragma unroll
+                for (int t = 0; t < GQ; ++t) {
+                    if (q == 0) acc1[t] = hn_w[4 * (GQ + t)]; else acc0[t] = hn_w[4 * t];
+                }
+            }
+            // the other stages, spread over the steps
+            if (st == 2) cmp_do(it - 2, it >= 2);
+            if (st == 3 && wid == (it & 3)) win_read(it);
+            if (st == 5 && wid == (it & 3)) win_do(it);
+            if (st == 6 && wid == ((it + 2) & 3)) flag_read(it - 3);
+            if (st == 8 && wid == ((it + 2) & 3)) flag_do(it - 3, it >= 3);
+#pragma unroll
+            for (int c = 0; c < kCvtMax; ++c) {
+                if (st == 1 + c * (kSteps / kCvtMax)) cvt_read(it + 1, c);
+                if (st == 3 + c * (kSteps / kCvtMax)) cvt_write(it + 1, c);
+            }
+            if (st == kSteps - 2) cvt_norm(it + 1);
+            if (st == KS + 1 && do_dma) issue_set(it + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (p.stamps) ts2 = __builtin_amdgcn_s_memtime();
+        end_of_iteration(do_dma);
+        if (p.stamps) { t_pre += ts1 - ts0; t_mma += ts2 - ts1; t_bar += __builtin_amdgcn_s_memtime() - ts2; }
+    }
+    // ---- drain: keys of the very last group, then the compare / flag stages of the last sets
+    for (int it = ns; it < ns + 3 && ns > 0; ++it) {
+        if (it == ns) {
+#pragma unroll
+            for (int v = 0; v < kVals; ++v) key_insert(acc1[v >> 2][v & 3], (unsigned)((GQ + (v >> 2)) << 2 | (v & 3)));
+            publish(ns - 1);
+        }
+        if (it - 2 >= 0 && it - 2 < ns) { cmp_read(it - 2); cmp_do(it - 2, true); }
+        if (it - 3 >= 0 && it - 3 < ns && wid == ((it + 2) & 3)) { flag_read(it - 3); flag_do(it - 3, true); }
+        end_of_iteration(false);
     }
     stamp(p, 2, lane, wave_id);
-    stamp(p, 3, lane, wave_id);
+    if (p.stamps && lane == 0) {
+        p.stamps[(size_t)wave_id * 16 + 4] = t_pre; p.stamps[(size_t)wave_id * 16 + 5] = t_mma; p.stamps[(size_t)wave_id * 16 + 6] = t_bar;
+        p.stamps[(size_t)wave_id * 16 + 7] = (unsigned long long)ns;
+    }
 }
 
 template <int NT>
@@ -1141,7 +1178,7 @@ int device_cus()
 template <int NT, int KS>
 int launch_screen2(const AssignArgs &a, hipStream_t st)
 {
-    const size_t lds = (size_t)kS2RawSlots * KS * 2048 + (size_t)2 * KS * 1024 + kS2SmallSlots * sizeof(S2Small) + (size_t)kS2StashSlots * 256 * 16;
+    const size_t lds = (size_t)kS2RawSlots * KS * 2048 + (size_t)2 * KS * 1024 + kS2SmallSlots * sizeof(S2Small) + (size_t)kS2StashSlots * 256 * 16 + (size_t)4 * NT * 64;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)assign_screen2_kernel<NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1167,7 +1204,7 @@ int launch_screen2(const AssignArgs &a, hipStream_t st)
 int screen_variant()
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("SN_ASSIGN_VARIANT"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char *e = getenv("SN_ASSIGN_VARIANT"); v = e ? atoi(e) : 2; }
     return v;
 }
 
@@ -1265,7 +1302,7 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
         int rc = 0;
         const bool wide = screen_variant() == 1;
         const PackLayout lay = pack_layout(M, D);
-        if (screen_variant() == 2 && lay.nt2 != 0) {
+        if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 16) {
             a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (8 + 64));
             if (lay.ks2 == 12) rc = lay.nt2 == 8 ? launch_screen2<8, 12>(a, st) : (lay.nt2 == 4 ? launch_screen2<4, 12>(a, st) : launch_screen2<2, 12>(a, st));
             else rc = lay.nt2 == 8 ? launch_screen2<8, 6>(a, st) : (lay.nt2 == 4 ? launch_screen2<4, 6>(a, st) : launch_screen2<2, 6>(a, st));

@@ -56,3 +56,22 @@ for name, tok in (("randn", tokens), ("k-means-like", tok_km)):
     print(f"variant {variant} {name}: screen {res['screen'][0]:.1f} us (min {res['screen'][1]:.1f}) = {alg / res['screen'][0] / 1e3:.0f} GB/s "
           f"= {alg / res['screen'][0] / 1e3 / 80:.1f}% of 8 TB/s; rerank {res['rerank'][0]:.1f} us; flagged {flagged} ({100 * flagged / n_tok:.2f}%), "
           f"overflow {over}; mismatches vs exact kernel {bad}", flush=True)
+
+if variant == 2:      # in-kernel stamps of the register-stationary screen (shader clock ticks)
+    lib.sn_debug_set_stamps.argtypes = [C.c_void_p]; lib.sn_debug_set_stamps.restype = None
+    n_waves = 4 * 256
+    st = torch.zeros(n_waves * 16, dtype=torch.int64, device=dev)
+    lib.sn_debug_set_stamps(st.data_ptr())
+    x = tokens[:, 1:, :]
+    for _ in range(3):
+        N.check(lib.sn_assign_words(N.ptr(x), x.shape[0], x.shape[1], x.stride(0), x.stride(1), N.ptr(cb), N.ptr(packed), bench.M, bench.D,
+                                    N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws.numel(), 0, N.stream_ptr(dev)), "assign")
+    torch.cuda.synchronize()
+    lib.sn_debug_set_stamps(None)
+    s8 = st.view(n_waves, 16).cpu().double()
+    t0 = s8[:, 0].min()
+    q = lambda v: "median %.0f max %.0f" % (v.median(), v.max())
+    print("stamps (s_memtime ticks): kernel span %.0f; start skew %.0f" % (s8[:, 2].max() - t0, s8[:, 0].max() - t0))
+    print("  prologue (codebook -> registers, set 0 converted): " + q(s8[:, 1] - s8[:, 0]))
+    print("  loop: " + q(s8[:, 2] - s8[:, 1]) + "  sets per workgroup: " + q(s8[:, 7]))
+    print("    pre-stream stages (WIN/CMP/FLG): " + q(s8[:, 4]) + "; MFMA stream: " + q(s8[:, 5]) + "; wait+barrier: " + q(s8[:, 6]))
