@@ -48,7 +48,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
 constexpr int kCodeBytes = 24;          // per-token candidate record: one key code per candidate slot
 constexpr int kWsPerToken = 4 + kCodeBytes + 4;   // flag word + codes + overflow-list slot
-constexpr int kWsPerToken2 = 8 + 64 + 4;          // screen2 records: 64-bit flag word + 16 code dwords + overflow-list slot
+constexpr int kWsPerToken2 = 4 + 32 + 4;          // screen2 records: flag word + 8 code dwords + overflow-list slot
 constexpr int kMaxTilesScreen = 64;     // 6-bit tile code in the keys -> M <= 2048 on the MFMA path
 constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
@@ -64,10 +64,11 @@ constexpr float kAccUlpPerMfma = 8.0f * 5.9604645e-8f;
 //   cn64    [M_pad] f64  |c|^2 (oracle summation order)
 //   scal    [0] max |c|_2  [1] max |c|_1  [2] max |c|^2  [3] max |c_mk|   (uint bits of floats)
 //   frag2   [4 waves][nt2 tiles][ks2 k-steps][1 KiB]   (register-stationary screen, see assign_screen2_kernel)
-//                                           v_mfma_f32_16x16x32_f16 A-fragments of -c: wave q owns words
-//                                           [16 nt2 q, 16 nt2 (q+1)), tile a = 16 of them, lane (r, g) holds word
-//                                           row r at k = 32 j + {4g..4g+3, 16+4g..16+4g+3}
-//   hn2     [4][nt2][16] f32                |c|^2 / 2 in accumulator-row order (padding words: 1e30)
+//                                           v_mfma_f32_32x32x16_f16 A-fragments of -c: wave q owns words
+//                                           [32 nt2 q, 32 nt2 (q+1)), tile a = 32 of them, lane (r, h) of k-step js
+//                                           holds word row r at k = 32 (js / 2) + {4g..4g+3, 16+4g..16+4g+3},
+//                                           g = 2 (js & 1) + h (the order the token converter produces)
+//   hn2     [4][nt2][2 halves][16] f32      |c|^2 / 2 in accumulator-register order (padding words: 1e30)
 struct PackLayout {
     size_t tiles_off, cn64_off, scal_off, frag2_off, hn2_off, total;
     int n_tiles, n_steps, tile_bytes, m_pad;
@@ -89,11 +90,11 @@ __host__ __device__ inline PackLayout pack_layout(int M, int D)
     p.frag2_off = p.scal_off + 256;
     // the whole fp16 codebook must fit the register file of one CU: 4 waves x nt2 x ks2 fragments of
     // 4 registers, at most 96 fragments per wave
-    p.ks2 = D / 32;
-    p.nt2 = M <= 128 ? 2 : (M <= 256 ? 4 : (M <= 512 ? 8 : 0));
-    if (D % 32 != 0 || (p.ks2 != 6 && p.ks2 != 12) || p.nt2 * p.ks2 > 96) p.nt2 = 0;
+    p.ks2 = D / 16;
+    p.nt2 = M <= 256 ? 2 : (M <= 512 ? 4 : 0);
+    if (D % 32 != 0 || (p.ks2 != 12 && p.ks2 != 24) || p.nt2 * p.ks2 > 96) p.nt2 = 0;
     p.hn2_off = p.frag2_off + (size_t)4 * p.nt2 * p.ks2 * 1024;
-    p.total = p.hn2_off + (((size_t)4 * p.nt2 * 64 + 255) & ~size_t(255));
+    p.total = p.hn2_off + (((size_t)4 * p.nt2 * 128 + 255) & ~size_t(255));
     return p;
 }
 
@@ -128,17 +129,24 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float *cb, int M, 
 }
 
 // frag2 image: one thread per (word of the padded codebook, k)
+__device__ __forceinline__ int hn2_index(int m, int nt2)     // word m -> slot of its |c|^2/2 in hn2
+{
+    const int q = m / (32 * nt2), a = (m / 32) % nt2, r = m & 31;
+    return ((q * nt2 + a) * 2 + ((r >> 2) & 1)) * 16 + (r & 3) + 4 * (r >> 3);       // accumulator row = (reg & 3) + 8 (reg >> 2) + 4 half
+}
+
 __global__ __launch_bounds__(256) void pack_frag2_kernel(const float *cb, int M, int D, unsigned char *frag2, float *hn2, int nt2, int ks2)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [64 nt2, D]
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [128 nt2, D]
     const int m = (int)(idx / D), k = (int)(idx % D);
-    const int q = m / (16 * nt2), a = (m / 16) % nt2, r = m & 15;
-    const int j = k >> 5, rem = k & 31;
+    const int q = m / (32 * nt2), a = (m / 32) % nt2, r = m & 31;
+    const int c = k >> 5, rem = k & 31;
     const int g = (rem & 15) >> 2, e = (rem & 3) + 4 * (rem >> 4);
+    const int js = 2 * c + (g >> 1), h = g & 1;
     const float v = m < M ? cb[(int64_t)m * D + k] : 0.0f;
-    _Float16 *frag = (_Float16 *)(frag2 + ((size_t)(q * nt2 + a) * ks2 + j) * 1024);
-    frag[(r + 16 * g) * 8 + e] = (_Float16)(-v);
-    if (k == 0 && m >= M) hn2[(q * nt2 + a) * 16 + r] = kPadHalfNorm;      // real words: pack_norm_kernel
+    _Float16 *frag = (_Float16 *)(frag2 + ((size_t)(q * nt2 + a) * ks2 + js) * 1024);
+    frag[(r + 32 * h) * 8 + e] = (_Float16)(-v);
+    if (k == 0 && m >= M) hn2[hn2_index(m, nt2)] = kPadHalfNorm;           // real words: pack_norm_kernel
 }
 
 __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, int D, int m_pad, unsigned char *tiles,
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, 
     if (lane == 0) {
         cn64[m] = p;
         *hc = (float)(0.5 * p);
-        if (nt2) hn2[(m / (16 * nt2) * nt2 + (m / 16) % nt2) * 16 + (m & 15)] = (float)(0.5 * p);
+        if (nt2) hn2[hn2_index(m, nt2)] = (float)(0.5 * p);
         const float up = 1.0f + 1.0e-6f;
         atomicMax(&scal[0], __float_as_uint(sqrtf((float)p) * up));
         atomicMax(&scal[1], __float_as_uint(l1 * (1.0f + 1.0e-4f)));
@@ -194,12 +202,11 @@ struct AssignArgs {
     unsigned char *codes;   // per token 24 key codes (tile << 2 | e), written only for flagged tokens
     int *overflow;      // token ids that need a full scan
     unsigned long long *stamps;   // diagnostics only (sn_debug_set_stamps): 16 u64 slots per wave
-    // register-stationary screen (assign_screen2_kernel): per token a 64-bit flag word (0 = final,
-    // bit 63 = overflow, else 48-bit candidate mask, bit 3c+j = key j of lane slot c = 4 q + g) and 16
-    // dwords of key codes (slot c: code_j << 8j, code = tile << 2 | row)
-    unsigned long long *flags64;
+    // register-stationary screen (assign_screen2_kernel): the flag word has the same meaning (24-bit
+    // candidate mask, bit 3c+j = key j of lane slot c = 2 wave + accumulator half), the codes are 8
+    // dwords per token (slot c: code_j << 8j, code = tile << 4 | accumulator register)
     unsigned *codes32;
-    int64_t n_sets;     // ceil(n_tokens / 16)
+    int64_t n_sets;     // ceil(n_tokens / 32)
 };
 
 __device__ __forceinline__ void stamp(const AssignArgs &p, int slot, int lane, int wave_id)
@@ -270,8 +277,8 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 constexpr int kMaxSurvivors = 64;
 constexpr int kOverflowBlocks = 64;     // blocks reserved for phase B
 
-// FMT 0: records of assign_screen_kernel (32-bit flag, 24 code bytes); FMT 1: records of
-// assign_screen2_kernel (64-bit flag, 16 code dwords, slot c = 4 q + g, key j: bit 3c + j).
+// FMT 0: records of assign_screen_kernel (24 code bytes per token); FMT 1: records of
+// assign_screen2_kernel (8 code dwords, slot c = 2 wave + accumulator half, key j: bit 3c + j).
 template <int NT, int FMT>
 __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
 {
@@ -296,8 +303,8 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
         const int64_t t = chunk * 32 + (lane & 31);
         unsigned long long flag = 0ull;
         if (lane < 32 && t < p.n_tokens) {
-            if constexpr (FMT == 0) { const unsigned f = p.flags[t]; flag = (f >> 31) ? (1ull << 63) : (unsigned long long)f; }
-            else flag = p.flags64[t];
+            const unsigned f = p.flags[t];
+            flag = (f >> 31) ? (1ull << 63) : (unsigned long long)f;
         }
         unsigned long long todo = __ballot(flag != 0ull && !(flag >> 63));
         for (int i = 0; todo; ++i) {
@@ -315,10 +322,11 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
                     my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
                 }
             } else {
-                if (lane < 48 && ((cmask >> lane) & 1ull)) {          // only slots with a candidate were written
+                if (lane < 24 && ((cmask >> lane) & 1ull)) {          // only slots with a candidate were written
                     const int c = lane / 3, jj = lane % 3;
-                    const unsigned code = (p.codes32[n * 16 + c] >> (8 * jj)) & 0xFFu;
-                    my_word = (c >> 2) * (16 * lay.nt2) + (int)(code >> 2) * 16 + 4 * (c & 3) + (int)(code & 3u);
+                    const unsigned code = (p.codes32[n * 8 + c] >> (8 * jj)) & 0xFFu;
+                    const int reg = (int)(code & 15u);
+                    my_word = (c >> 1) * (32 * lay.nt2) + (int)(code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (c & 1);
                 }
             }
             double x[NT];
@@ -744,37 +752,35 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
 // register file of one CU).
 //
 // One persistent workgroup (4 waves, one per SIMD, 512 registers each) per CU.  Wave q keeps the A
-// fragments of its quarter of the codebook (16 NT words x D, NT KS x 4 registers: 256 AGPRs + the
-// rest in VGPRs) for the whole kernel; token sets of 16 stream through:
-//   HBM --LDS-DMA (coalesced 128-B lines, piece-swizzled)--> raw fp32 slot
-//       --each wave converts a quarter of the k-steps--> fp16 B fragments in LDS (+ |x|^2 by a Gram MFMA)
-//       --every wave: v_mfma_f32_16x16x32_f16 against its own words--> keys (sorted triple per lane)
-//       --LDS min over the 16 lanes that hold a token--> window test, flag word, candidate codes.
-// Per token the codebook is never re-read from L2 and the tokens are read from HBM exactly once, in
-// flight while earlier sets are on the matrix pipe.  Values: u[word] = |c|^2/2 - x~.c~ (tokens and
-// words rounded to fp16, fp32 accumulate), keys = float bits with the low 8 mantissa bits replaced
-// by (tile << 2 | row), compared as floats.
+// fragments of its quarter of the codebook (NT tiles of 32 words x D: NT KS x 4 registers, 256 AGPRs +
+// the rest in VGPRs) for the whole kernel; token sets of 32 stream through:
+//   HBM --LDS-DMA (coalesced 128-B lines, piece-swizzled, two half sets of 16)--> raw fp32 slots
+//       --each wave converts a quarter of the 32-float chunks--> fp16 B fragments in LDS (+ |x|^2 by a Gram MFMA)
+//       --every wave: v_mfma_f32_32x32x16_f16 against its own words, one tile at a time--> keys (sorted triple per lane)
+//       --LDS min over the 8 lanes that hold a token--> window test, flag word, candidate codes.
+// The codebook is read from L2 once per CU and the tokens from HBM exactly once, in flight while
+// earlier sets are on the matrix pipe.  Values: u[word] = |c|^2/2 - x~.c~ (tokens and words rounded to
+// fp16, fp32 accumulate), keys = float bits with the low 8 mantissa bits replaced by (tile << 4 | reg),
+// compared as floats.  A lone wave per SIMD issues one instruction per ~4 cycles, so everything that
+// is not an MFMA is counted: the key arithmetic rides in the same asm statement as the MFMA it hides
+// behind, the other stages are dealt over the remaining gaps.
 //
 // Software pipeline, one barrier per iteration `it` (set indices local to the workgroup):
-//   DMA(it+3)  CVT(it+1)  MMA(it) [+ keys of the previous accumulator group]  WIN(it)  CMP(it-2)  FLG(it-3)
+//   DMA(it+2)  CVT(it+1)  MMA(it) [+ keys of the previous tile]  WIN(it)  CMP(it-2)  FLG(it-3)
 // ------------------------------------------------------------------------------------------
-constexpr int kS2RawSlots = 4;          // raw fp32 token sets in LDS (two or three of them in flight)
+constexpr int kS2RawSlots = 4;          // raw fp32 half sets (16 tokens) in LDS: set it+1 being converted, set it+2 in flight
 constexpr int kS2SmallSlots = 8;        // ring of per-set scalars
-constexpr int kS2StashSlots = 4;
+constexpr int kS2StashSlots = 2;
 constexpr float kBigKey = 3.0e38f;      // "no key yet"
 constexpr float kKeyLimit = 1.0e29f;    // above this a best value is a padding word / nothing finite
-// fp32 accumulate of v_mfma_f32_16x16x32_f16 (32 products per instruction): budget per instruction,
-// 2^-24 x max|partial| units (tools/mfma_probe16.hip measures the chain)
-constexpr float kAccUlpPerMfma2 = 16.0f * 5.9604645e-8f;
 
 struct S2Tok {                          // per token of a set in flight (LDS)
-    float best;                         // smallest key of the token (ds_min over the 16 lanes that hold it)
+    float best;                         // smallest key of the token (ds_min over the 8 lanes that hold it)
     float win;                          // 2E (NaN: the token cannot be screened)
-    unsigned long long mask;            // candidate mask being assembled (bit 63: overflow)
-    float nrm;                          // |x~|^2, summed over the four waves' k-steps
-    float pad_[3];
+    unsigned mask;                      // candidate mask being assembled: bit 3c + j = key j of slot c = 2 wave + half (bit 31: overflow)
+    float nrm;                          // |x~|^2, summed over the four waves' chunks
 };
-struct S2Small { S2Tok tok[16]; };
+struct S2Small { S2Tok tok[32]; };
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) as straight-line code
 // (the MFMA stream below is far beyond the size a `#pragma unroll` is allowed to expand)
@@ -783,48 +789,71 @@ __device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int,
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <bool AG>
-__device__ __forceinline__ void s2_mfma_first(f32x4 &d, const half8 &a, const half8 &b, const f32x4 &c)
+// One MFMA step and up to two key halves in ONE asm statement (nothing can be scheduled, and no s_nop
+// inserted, between them).  Key insert of value v with code c into the sorted triple m1 <= m2 <= m3:
+//   half A: k = (v & ~0xFF) | c;  m3 = med3(k, m2, m3)      half B: m2 = med3(k, m1, m2);  m1 = min(k, m1)
+// PAT 0: MFMA   1: MFMA, A   2: MFMA, B   3: MFMA, A, B   4: MFMA, B, A (B finishes the previous value)
+#define S2_MF "v_mfma_f32_32x32x16_f16 %[acc], %[a], %[b], %[acc]\n\t"
+#define S2_KA "v_and_or_b32 %[kk], %[v], %[km], %[code]\n\tv_med3_f32 %[m3], %[kk], %[m2], %[m3]\n\t"
+#define S2_KB "v_med3_f32 %[m2], %[kk], %[m1], %[m2]\n\tv_min_f32 %[m1], %[kk], %[m1]\n\t"
+#define S2_OUT [acc] "+v"(acc), [kk] "+v"(kk), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3)
+#define S2_IN(ACLS) [a] ACLS(a), [b] "v"(b), [v] "v"(v), [km] "v"(keymask), [code] "i"(CODE)
+template <bool AG, int PAT, int CODE>
+__device__ __forceinline__ void s2_step(f32x16 &acc, const half8 &a, const half8 &b, float &kk, float &m1, float &m2, float &m3,
+                                        float v, unsigned keymask)
 {
-    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "v"(b), "v"(c));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    if constexpr (AG) {
+        if constexpr (PAT == 0) asm volatile(S2_MF : [acc] "+v"(acc) : [a] "a"(a), [b] "v"(b));
+        if constexpr (PAT == 1) asm volatile(S2_MF S2_KA : S2_OUT : S2_IN("a"));
+        if constexpr (PAT == 2) asm volatile(S2_MF S2_KB : S2_OUT : S2_IN("a"));
+        if constexpr (PAT == 3) asm volatile(S2_MF S2_KA S2_KB : S2_OUT : S2_IN("a"));
+        if constexpr (PAT == 4) asm volatile(S2_MF S2_KB S2_KA : S2_OUT : S2_IN("a"));
+    } else {
+        if constexpr (PAT == 0) asm volatile(S2_MF : [acc] "+v"(acc) : [a] "v"(a), [b] "v"(b));
+        if constexpr (PAT == 1) asm volatile(S2_MF S2_KA : S2_OUT : S2_IN("v"));
+        if constexpr (PAT == 2) asm volatile(S2_MF S2_KB : S2_OUT : S2_IN("v"));
+        if constexpr (PAT == 3) asm volatile(S2_MF S2_KA S2_KB : S2_OUT : S2_IN("v"));
+        if constexpr (PAT == 4) asm volatile(S2_MF S2_KB S2_KA : S2_OUT : S2_IN("v"));
+    }
 }
-
-template <bool AG>
-__device__ __forceinline__ void s2_mfma(f32x4 &d, const half8 &a, const half8 &b)
+template <int CODE>
+__device__ __forceinline__ void s2_key_a(float &kk, float &m2, float &m3, float v, unsigned keymask)
 {
-    if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "a"(a), "v"(b));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+    asm volatile(S2_KA : [kk] "+v"(kk), [m2] "+v"(m2), [m3] "+v"(m3) : [v] "v"(v), [km] "v"(keymask), [code] "i"(CODE));
 }
+__device__ __forceinline__ void s2_key_b(float &kk, float &m1, float &m2)
+{
+    asm volatile(S2_KB : [kk] "+v"(kk), [m1] "+v"(m1), [m2] "+v"(m2));
+}
+#undef S2_MF
+#undef S2_KA
+#undef S2_KB
+#undef S2_OUT
+#undef S2_IN
 
 template <int NT, int KS>
 __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int GQ = NT / 2;                                  // tiles per accumulator group (two groups per set)
+    constexpr int KC = KS / 2;                                  // 32-float chunks per token
     constexpr int NA = NT * KS < 64 ? NT * KS : 64;             // fragments pinned in AGPRs
-    constexpr int kSetRaw = KS * 2048, kSetFrag = KS * 1024;
-    constexpr int kDmaPerWave = KS / 2;                         // 1 KiB LDS-DMA instructions per wave and set
-    constexpr int kCvtMax = (KS + 3) / 4;                       // k-steps a wave converts per set
-    constexpr int kSteps = 2 * KS;                              // MFMA steps per set: (group, k-step)
-    constexpr int kVals = 4 * GQ;                               // accumulator values per lane and group
-    constexpr int kKeyStart = GQ >= 2 ? 1 : 2;                  // first k-step with key work: >= 2 MFMA issues behind the group's last MFMA
-    constexpr int kKeyEnd = KS - 3;                             // last k-step with key work; then the accumulators are re-initialised from LDS
-    // key value v of a group is inserted at k-step key_step(v); the two halves of each insert go into
-    // the gaps behind consecutive MFMAs of that step (two VALU fit behind one 16x16x32 MFMA)
-    auto key_step = [](int v) constexpr { return kKeyStart + (v * (kKeyEnd + 1 - kKeyStart)) / kVals; };
-    auto keys_in_step = [key_step](int j) constexpr { int n = 0; for (int v = 0; v < kVals; ++v) n += key_step(v) == j; return n; };
-    auto key_rank = [key_step](int v) constexpr { int n = 0; for (int u = 0; u < v; ++u) n += key_step(u) == key_step(v); return n; };
-    static_assert(NT == 2 || NT == 4 || NT == 8, "tiles per wave");
-    static_assert(KS == 6 || KS == 12, "k-steps");
+    constexpr int kHalfRaw = KC * 2048, kSetFrag = KS * 1024;   // bytes: raw half set (16 tokens), fp16 fragments of a set
+    constexpr int kDmaPerWave = KC / 2;                         // 1 KiB LDS-DMA instructions per wave and half set
+    constexpr int kCvtPerHalf = (KC + 3) / 4;                   // chunks a wave converts per half set
+    constexpr int kSteps = NT * KS;                             // MFMA steps per set: (tile, k-step)
+    constexpr int kKeyStart = 2, kKeyEnd = KS - 5;              // k-steps of a tile phase that carry key halves of the previous tile
+    constexpr int kKeySteps = kKeyEnd - kKeyStart + 1;
+    static_assert(NT == 2 || NT == 4, "tiles per wave");
+    static_assert(KS == 12 || KS == 24, "k-steps");
     unsigned char *raw = smem;
-    unsigned char *frag = smem + kS2RawSlots * kSetRaw;
+    unsigned char *frag = smem + kS2RawSlots * kHalfRaw;
     S2Small *small = reinterpret_cast<S2Small *>(frag + 2 * kSetFrag);
     f32x4 *stash = reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(small) + kS2SmallSlots * sizeof(S2Small));
-    f32x4 *hnl = stash + kS2StashSlots * 256;                     // [4 waves][NT tiles][4 row groups] x 4 half norms
+    f32x4 *hnl = stash + kS2StashSlots * 256;                     // [4 waves][NT tiles][2 halves][4] x 4 half norms
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tau = lane & 15, g = lane >> 4;
+    const int tok = lane & 31, hh = lane >> 5;                   // MFMA side: token column, accumulator row half
+    const int tau = lane & 15, g = lane >> 4;                    // conversion side: token of the half set, piece pair
     const PackLayout lay = pack_layout(p.M, p.D);
     const unsigned char *frag2 = p.packed + lay.frag2_off;
     const float *hn2 = reinterpret_cast<const float *>(p.packed + lay.hn2_off);
@@ -835,50 +864,49 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     // this workgroup's sets: [sb, sb + ns)
     const int64_t sb = (int64_t)blockIdx.x * p.n_sets / gridDim.x;
     const int ns = (int)((int64_t)(blockIdx.x + 1) * p.n_sets / gridDim.x - sb);
-    const int n_tok32 = (int)p.n_tokens;
     const int n_inner32 = (int)p.n_inner;
 
     // ---- per-set scalars
-    if (tid < kS2SmallSlots * 16) {
-        S2Tok &t0 = small[tid >> 4].tok[tid & 15];
-        t0.best = kBigKey; t0.win = 0.0f; t0.mask = 0ull; t0.nrm = 0.0f;
+    for (int i = tid; i < kS2SmallSlots * 32; i += 256) {
+        S2Tok &t0 = small[i >> 5].tok[i & 31];
+        t0.best = kBigKey; t0.win = 0.0f; t0.mask = 0u; t0.nrm = 0.0f;
     }
 
-    // ---- token sets: HBM -> LDS by LDS-DMA.  Instruction x = 2 j + h (k-step j, token half h) copies the
-    // 128-B lines of 8 tokens; wave w issues x = w, w + 4, ...: always the same token half, so a lane
-    // needs one row pointer per set.  Lane l: token 8 h + l / 8, LDS piece slot l % 8 holds piece
-    // slot ^ ((token >> 1) & 7) of the line (conflict-free ds_read_b128 of the fragments below).
+    // ---- token half sets: HBM -> LDS by LDS-DMA.  Instruction x = 2 c + h (32-float chunk c, token half h)
+    // copies the 128-B lines of 8 tokens; wave w issues x = w, w + 4, ...: always the same token half, so a
+    // lane needs one row pointer per half set.  Lane l: token 8 h + l / 8, LDS piece slot l % 8 holds
+    // piece slot ^ ((token >> 1) & 7) of the line (conflict-free ds_read_b128 of the fragments below).
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    int d_o, d_i;                                               // (outer, inner) of the first token of the next set to copy
+    int d_o, d_i;                                               // (outer, inner) of the first token of the next half set to copy
     {
-        const int64_t n0 = sb * 16;
+        const int64_t n0 = sb * 32;
         d_o = (int)(n0 / p.n_inner); d_i = (int)(n0 % p.n_inner);
     }
     int c_o = d_o, c_i = d_i;                                   // ... of the next set to compare (CMP)
     const int last_o = (int)((p.n_tokens - 1) / p.n_inner), last_i = (int)((p.n_tokens - 1) % p.n_inner);
-    auto advance = [&](int &o, int &i) {                       // (n_inner >= 16: at most one wrap per set)
-        i += 16;
+    auto advance = [&](int &o, int &i, int by) {                 // (n_inner >= 32: at most one wrap)
+        i += by;
         if (i >= n_inner32) { i -= n_inner32; ++o; }
     };
-    auto issue_set = [&](int s) {
+    auto issue_half = [&](int hs) {                              // hs = 2 set + half, local to the workgroup
         const int d = 8 * (wid & 1) + (lane >> 3);
         int o = d_o, i = d_i + d;
         if (i >= n_inner32) { i -= n_inner32; ++o; }
-        const int64_t n = (sb + s) * 16 + d;
+        const int64_t n = sb * 32 + (int64_t)hs * 16 + d;
         if (n >= p.n_tokens) { o = last_o; i = last_i; }         // (tail of the last set: any valid row)
         const int piece = (lane & 7) ^ ((d >> 1) & 7);
         const float *src = p.x + (int64_t)o * p.xso + (int64_t)i * p.xsi + (wid >> 1) * 32 + piece * 4;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (s % kS2RawSlots) * kSetRaw + (wid >> 1) * 2048 + (wid & 1) * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (hs & (kS2RawSlots - 1)) * kHalfRaw + (wid >> 1) * 2048 + (wid & 1) * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
 #pragma unroll
-        for (int x = 0; x < kDmaPerWave; ++x) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:%3\n\t"
-                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst + x * 4096 - x * 256), "i"(x * 256) : "memory");   // (the instruction offset moves the LDS address too)
-        }
-        advance(d_o, d_i);
+        for (int x = 0; x < kDmaPerWave; ++x)                    // (the instruction offset moves the LDS address too)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
+                         :: "v"(src), "s"(dst + x * 4096 - x * 256), "i"(x * 256) : "memory");
+        asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
+        advance(d_o, d_i, 16);
     };
-    for (int s = 0; s < 3 && s < ns; ++s) issue_set(s);
+    for (int hs = 0; hs < 4 && hs < 2 * ns; ++hs) issue_half(hs);
 
     // ---- this wave's quarter of the codebook -> registers (stays there)
     half8 A[NT][KS];
@@ -888,7 +916,7 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
         for (int j = 0; j < KS; ++j)
             A[a][j] = *reinterpret_cast<const half8 *>(frag2 + ((size_t)(wid * NT + a) * KS + j) * 1024 + lane * 16);
     }
-    if (tid < 4 * NT * 4) hnl[tid] = *reinterpret_cast<const f32x4 *>(hn2 + tid * 4);     // |c|^2/2: LDS, re-read per accumulator chain
+    if (tid < 4 * NT * 2 * 4) hnl[tid] = *reinterpret_cast<const f32x4 *>(hn2 + tid * 4);    // |c|^2/2: LDS, re-read per accumulator chain
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
@@ -897,51 +925,54 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
             else asm volatile("" : "+v"(A[a][j]));
         }
     }
-    const f32x4 *hn_w = hnl + wid * NT * 4 + g;                  // tile a: hn_w[4 a] = rows 4g..4g+3 of the wave's tile a
+    const f32x4 *hn_w = hnl + (wid * NT * 2 + hh) * 4;           // tile a: hn_w[8 a + i], i = 0..3: accumulator registers 4 i .. 4 i + 3
     const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
     const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
 
-    // ---- CVT(s): raw slot -> fp16 B fragments of k-steps wid, wid + 4, ... (+ Gram diagonal = |x~|^2)
+    // ---- CVT: raw half set -> fp16 B fragments of chunks wid, wid + 4, ... (+ Gram diagonal = |x~|^2).
+    // Lane (tau, g) converts the floats {4g..4g+3, 16+4g..16+4g+3} of the chunk: k-step 2 c + (g >> 1), row half g & 1.
     f32x4 c_lo, c_hi;
     f32x4 nacc = {0.0f, 0.0f, 0.0f, 0.0f};
     const int swz = (tau >> 1) & 7;
     const int rd_lo = tau * 128 + ((g ^ swz) << 4), rd_hi = tau * 128 + (((g + 4) ^ swz) << 4);
-    auto cvt_read = [&](int s, int c) {
-        const int j = wid + 4 * c;
-        if (KS % 4 == 0 || j < KS) {
-            const unsigned char *base = raw + (s % kS2RawSlots) * kSetRaw + j * 2048;
+    const int wr_off = (g >> 1) * 1024 + (tau + 32 * (g & 1)) * 16;
+    auto cvt_read = [&](int hs, int c) {
+        const int ch = wid + 4 * c;
+        if (KC % 4 == 0 || ch < KC) {
+            const unsigned char *base = raw + (hs & (kS2RawSlots - 1)) * kHalfRaw + ch * 2048;
             c_lo = *reinterpret_cast<const f32x4 *>(base + rd_lo);
             c_hi = *reinterpret_cast<const f32x4 *>(base + rd_hi);
         }
     };
-    auto cvt_write = [&](int s, int c) {
-        const int j = wid + 4 * c;
-        if (KS % 4 == 0 || j < KS) {
+    auto cvt_write = [&](int hs, int c) {
+        const int ch = wid + 4 * c;
+        if (KC % 4 == 0 || ch < KC) {
             half8 hb;
             hb[0] = (_Float16)c_lo.x; hb[1] = (_Float16)c_lo.y; hb[2] = (_Float16)c_lo.z; hb[3] = (_Float16)c_lo.w;
             hb[4] = (_Float16)c_hi.x; hb[5] = (_Float16)c_hi.y; hb[6] = (_Float16)c_hi.z; hb[7] = (_Float16)c_hi.w;
-            *reinterpret_cast<half8 *>(frag + (s & 1) * kSetFrag + j * 1024 + lane * 16) = hb;
+            *reinterpret_cast<half8 *>(frag + ((hs >> 1) & 1) * kSetFrag + ch * 2048 + (hs & 1) * 256 + wr_off) = hb;
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(nacc) : "v"(hb));       // Gram matrix of the 16 tokens
         }
     };
-    auto cvt_norm = [&](int s) {                             // diagonal (tau, tau): lane group tau >> 2, register tau & 3
+    auto cvt_norm = [&](int hs) {                            // diagonal (tau, tau): lane group tau >> 2, register tau & 3
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(nacc));                // MFMA -> VALU read distance (the asm MFMA is invisible to the hazard recogniser)
         const float dg = (tau & 2) ? ((tau & 1) ? nacc[3] : nacc[2]) : ((tau & 1) ? nacc[1] : nacc[0]);
-        if (g == (tau >> 2)) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)&small[s & (kS2SmallSlots - 1)].tok[tau].nrm, dg, 0, 0, false);
+        if (g == (tau >> 2))
+            __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)&small[(hs >> 1) & (kS2SmallSlots - 1)].tok[16 * (hs & 1) + tau].nrm, dg, 0, 0, false);
         nacc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
 
-    // ---- WIN(s): error window of each token of the set (DESIGN.md "S1 error window"); lanes 0..15 of one wave
+    // ---- WIN(s): error window of each token of the set (DESIGN.md "S1 error window"); lanes 0..31 of one wave
     float w_nr = 0.0f;
-    auto win_read = [&](int s) { w_nr = small[s & (kS2SmallSlots - 1)].tok[tau].nrm; };
+    auto win_read = [&](int s) { w_nr = small[s & (kS2SmallSlots - 1)].tok[tok].nrm; };
     auto win_do = [&](int s) {
         const float X2 = sqrtf(w_nr) * 1.002f + 1.0e-6f;              // |x|_2 from the fp16-rounded token
         const float X1 = X2 * sqrtf((float)p.D);
         const float vmax = 0.5f * CN + X2 * C2;                        // >= |any partial sum|
         const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
-                                 + (float)KS * kAccUlpPerMfma2 * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
+                                 + (float)KS * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
         const bool ok = (w_nr < 1.0e30f) && (CMAX <= kHugeIn) && (vmax < 1.0e28f);       // false for NaN / inf
-        if (lane < 16) small[s & (kS2SmallSlots - 1)].tok[tau].win = ok ? 2.0f * E : __builtin_nanf("");
+        if (lane < 32) small[s & (kS2SmallSlots - 1)].tok[tok].win = ok ? 2.0f * E : __builtin_nanf("");
     };
 
     // ---- CMP(s): which of this lane's three keys are inside the window of the token's best
@@ -949,39 +980,39 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     float c_best = 0.0f, c_win = 0.0f;
     auto cmp_read = [&](int s) {
         c_t3 = stash[(s & (kS2StashSlots - 1)) * 256 + tid];
-        const S2Tok &tk = small[s & (kS2SmallSlots - 1)].tok[tau];
+        const S2Tok &tk = small[s & (kS2SmallSlots - 1)].tok[tok];
         c_best = tk.best; c_win = tk.win;
     };
     auto cmp_do = [&](int s, bool en) {
         const float cut = c_best + c_win;                              // NaN window -> no hit -> overflow
-        const int64_t n = (sb + s) * 16 + tau;
+        const int64_t n = (sb + s) * 32 + tok;
         const bool live = en && n < p.n_tokens && cut < kKeyLimit;
         const bool h1 = live && c_t3.x <= cut, h2 = live && c_t3.y <= cut, h3 = live && c_t3.z <= cut;
         const unsigned k1 = __float_as_uint(c_t3.x), k2 = __float_as_uint(c_t3.y), k3 = __float_as_uint(c_t3.z);
-        int o = c_o, i = c_i + tau;
-        if (i >= n_inner32) { i -= n_inner32; ++o; }                   // (n_inner >= 16: at most one wrap)
+        int o = c_o, i = c_i + tok;
+        if (i >= n_inner32) { i -= n_inner32; ++o; }                   // (n_inner >= 32: at most one wrap)
         if (h1) {
-            p.out[(int64_t)o * p.oso + (int64_t)i * p.osi] = wid * (16 * NT) + (int)((k1 & 0xFFu) >> 2) * 16 + 4 * g + (int)(k1 & 3u);
-            const int c = wid * 4 + g;
-            unsigned long long bits = (unsigned long long)(1u | (h2 ? 2u : 0u) | (h3 ? 4u : 0u)) << (3 * c);
-            if (h3) bits |= 1ull << 63;                                // a fourth key may hide behind the third
-            __hip_atomic_fetch_or(&small[s & (kS2SmallSlots - 1)].tok[tau].mask, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            p.codes32[n * 16 + c] = (k1 & 0xFFu) | ((k2 & 0xFFu) << 8) | ((k3 & 0xFFu) << 16);
+            const int reg = (int)(k1 & 15u);                           // word row inside its 32 x 32 tile: (reg & 3) + 8 (reg >> 2) + 4 hh
+            p.out[(int64_t)o * p.oso + (int64_t)i * p.osi] = wid * (32 * NT) + (int)((k1 & 0xFFu) >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            const int c = wid * 2 + hh;
+            const unsigned bits = ((1u | (h2 ? 2u : 0u) | (h3 ? 4u : 0u)) << (3 * c)) | (h3 ? 0x80000000u : 0u);   // h3: a fourth key may hide behind the third
+            __hip_atomic_fetch_or(&small[s & (kS2SmallSlots - 1)].tok[tok].mask, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            p.codes32[n * 8 + c] = (k1 & 0xFFu) | ((k2 & 0xFFu) << 8) | ((k3 & 0xFFu) << 16);
         }
-        if (en) advance(c_o, c_i);
+        if (en) advance(c_o, c_i, 32);
     };
 
-    // ---- FLG(s): flag word of each token, overflow list, recycle the scalar slot; lanes 0..15 of one wave
-    unsigned long long f_mk = 0ull;
-    auto flag_read = [&](int s) { f_mk = small[s & (kS2SmallSlots - 1)].tok[tau].mask; };
+    // ---- FLG(s): flag word of each token, overflow list, recycle the scalar slot; lanes 0..31 of one wave
+    unsigned f_mk = 0u;
+    auto flag_read = [&](int s) { f_mk = small[s & (kS2SmallSlots - 1)].tok[tok].mask; };
     auto flag_do = [&](int s, bool en) {
-        if (lane < 16) {
+        if (lane < 32) {
             S2Tok &tk = small[s & (kS2SmallSlots - 1)].tok[lane];
-            const int64_t n = (sb + s) * 16 + lane;
-            const unsigned long long cand = f_mk & 0xFFFFFFFFFFFFull;
-            const bool over = (f_mk >> 63) != 0ull || cand == 0ull;
+            const int64_t n = (sb + s) * 32 + lane;
+            const unsigned cand = f_mk & 0xFFFFFFu;
+            const bool over = (f_mk >> 31) != 0u || cand == 0u;
             const bool valid = en && n < p.n_tokens;
-            if (valid) p.flags64[n] = over ? (1ull << 63) : (__popcll(cand) > 1 ? cand : 0ull);
+            if (valid) p.flags[n] = over ? 0x80000000u : (__popc(cand) > 1 ? cand : 0u);
             const bool need_b = valid && over;
             const unsigned long long mask_b = __ballot(need_b);
             if (mask_b) {
@@ -991,140 +1022,144 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
                 base = __shfl(base, leader, SN_WAVE);
                 if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;   // phase B writes out[]
             }
-            tk.best = kBigKey; tk.mask = 0ull; tk.nrm = 0.0f;
+            tk.best = kBigKey; tk.mask = 0u; tk.nrm = 0.0f;
         }
     };
 
-    // ---- prologue: sets 0..2 in flight, codebook in registers, set 0 converted
+    // ---- prologue: sets 0, 1 in flight, codebook in registers, set 0 converted
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ns > 0) {
 #pragma unroll
-        for (int c = 0; c < kCvtMax; ++c) { cvt_read(0, c); cvt_write(0, c); }
-        cvt_norm(0);
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int c = 0; c < kCvtPerHalf; ++c) { cvt_read(h2, c); cvt_write(h2, c); }
+            cvt_norm(h2);
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     stamp(p, 1, lane, wave_id);
 
-    f32x4 acc0[GQ], acc1[GQ];
+    // accumulators: tile a uses buffer a & 1; a buffer is keyed while the next tile runs, then re-initialised
+    // to |c|^2/2 of the tile after that (4 ds_read_b128 straight into the accumulator registers)
+    f32x16 acc0, acc1;
+    auto load_hn = [&](f32x16 &acc, int a) {
 #pragma unroll
-    for (int t = 0; t < GQ; ++t) { acc0[t] = hn_w[4 * t]; acc1[t] = f32x4{kBigKey, kBigKey, kBigKey, kBigKey}; }
-    float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey;
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v4 = hn_w[8 * a + i];
+            acc[4 * i + 0] = v4.x; acc[4 * i + 1] = v4.y; acc[4 * i + 2] = v4.z; acc[4 * i + 3] = v4.w;
+        }
+    };
+    load_hn(acc0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = kBigKey;
+    float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey, kk = kBigKey;
     unsigned keymask = 0xFFFFFF00u;
     asm volatile("" : "+v"(keymask));
-    // key = (value bits & ~0xFF) | code into the sorted triple m1 <= m2 <= m3 (compared as floats).
-    // Volatile asm: callers keep it >= 8 MFMA issues behind the MFMA that wrote `v` (the hazard
-    // recogniser cannot see either side).
-    auto key_insert = [&](float v, unsigned code) {
-        float k;
-        asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
-                     "v_med3_f32 %3, %0, %2, %3\n\t"
-                     "v_med3_f32 %2, %0, %1, %2\n\t"
-                     "v_min_f32 %1, %0, %1"
-                     : "=&v"(k), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(v), "v"(keymask), "s"(code));
-    };
-    float kk = 0.0f;                                            // the same insert in two halves (one MFMA gap each)
-    auto key_half_a = [&](float v, unsigned code) {
-        asm volatile("v_and_or_b32 %0, %3, %4, %5\n\tv_med3_f32 %2, %0, %1, %2" : "=&v"(kk), "+v"(m2), "+v"(m3) : "v"(v), "v"(keymask), "s"(code));
-    };
-    auto key_half_b = [&]() {
-        asm volatile("v_med3_f32 %2, %0, %1, %2\n\tv_min_f32 %1, %0, %1" : "+v"(kk), "+v"(m1), "+v"(m2));
-    };
     auto publish = [&](int s) {                                 // triple of set s is complete (s == -1: all keys are kBigKey, a no-op)
-        __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&small[s & (kS2SmallSlots - 1)].tok[tau].best, m1, 0, 0, false);
+        __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&small[s & (kS2SmallSlots - 1)].tok[tok].best, m1, 0, 0, false);
         stash[(s & (kS2StashSlots - 1)) * 256 + tid] = f32x4{m1, m2, m3, 0.0f};
         m1 = m2 = m3 = kBigKey;
     };
-    half8 bq[3];
-    unsigned long long t_pre = 0, t_mma = 0, t_bar = 0;        // diagnostics (only when stamps are on)
-    auto end_of_iteration = [&](bool dma_issued) {
-        if (dma_issued) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");     // set it+2 has landed, it+3 stays in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    half8 bq[4];
+    unsigned long long t_vm = 0, t_bar = 0, t_top = 0;           // diagnostics (only when stamps are on)
+    auto end_of_iteration = [&]() {
+        unsigned long long e0 = 0, e1 = 0;
+        if (p.stamps) e0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // set it+2 has landed (its DMA was issued at the start of this iteration)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (p.stamps) e1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (p.stamps) { t_vm += e1 - e0; t_bar += __builtin_amdgcn_s_memtime() - e1; }
     };
+    // step of the stream at which a stage runs (positions are given for 96 steps and scaled)
+    constexpr auto at = [](int x) constexpr { return x * kSteps / 96; };
 
     // ---- main loop.  Everything except the DMA issue runs unconditionally (no per-step branches):
     // in the first iterations the "previous" keys are kBigKey, CMP / FLG are predicated off by `en`,
-    // in the last one CVT converts a stale slot nobody reads.
+    // in the last one CVT converts stale slots nobody reads.
     for (int it = 0; it < ns; ++it) {
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-        if (p.stamps) ts0 = __builtin_amdgcn_s_memtime();
-        const bool do_dma = it + 3 < ns;
+        const bool do_dma = it + 2 < ns;
         const unsigned char *fb = frag + (it & 1) * kSetFrag + lane * 16;
         bq[0] = *reinterpret_cast<const half8 *>(fb);
         bq[1] = *reinterpret_cast<const half8 *>(fb + 1024);
+        bq[2] = *reinterpret_cast<const half8 *>(fb + 2048);
         cmp_read(it - 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (p.stamps) ts1 = __builtin_amdgcn_s_memtime();
+        unsigned long long tt0 = 0;
+        if (p.stamps) tt0 = __builtin_amdgcn_s_memtime();
         static_for<kSteps>([&](auto st_c) {
             constexpr int st = decltype(st_c)::value;
-            constexpr int q = st / KS, j = st % KS;
-            if (st == KS) publish(it - 1);                           // (keys of set it-1 ended with the previous step)
-            constexpr int nh = 2 * keys_in_step(j);                  // key halves of this step, dealt to the GQ gaps in order
+            constexpr int a = st / KS, j = st % KS;
+            constexpr int pa = (a + NT - 1) % NT;                    // the tile whose accumulators are being keyed
+            if (st == KS) publish(it - 1);                           // (keys of set it-1 ended with the previous tile phase)
+            // key halves of this step: half index hi = 2 * value + (0: A, 1: B), hi -> k-step kKeyStart + hi * kKeySteps / 32
+            constexpr int lo = j < kKeyStart || j > kKeyEnd ? 0 : ((j - kKeyStart) * 32 + kKeySteps - 1) / kKeySteps;
+            constexpr int hi_end = j < kKeyStart || j > kKeyEnd ? 0 : ((j + 1 - kKeyStart) * 32 + kKeySteps - 1) / kKeySteps;
+            constexpr int n = hi_end - lo;
+            constexpr int PAT = n == 0 ? 0 : (n == 1 ? ((lo & 1) ? 2 : 1) : ((lo & 1) ? 4 : 3));
+            constexpr int va = (lo + 1) / 2;                         // the value whose half A rides with this MFMA (if any)
+            constexpr int CODE = (pa << 4) | (va & 15);
+            f32x16 &acc = (a & 1) ? acc1 : acc0;
+            f32x16 &accp = (a & 1) ? acc0 : acc1;
+            const float v = accp[va & 15];
+            if (a * KS + j < NA) s2_step<true, PAT, CODE>(acc, A[a][j], bq[st & 3], kk, m1, m2, m3, v, keymask);
+            else s2_step<false, PAT, CODE>(acc, A[a][j], bq[st & 3], kk, m1, m2, m3, v, keymask);
+            if (st + 3 < kSteps) bq[(st + 3) & 3] = *reinterpret_cast<const half8 *>(fb + ((st + 3) % KS) * 1024);
+            // further halves of this step (only the D = 192 shapes have more than two per step)
+            static_for<(n > 2 ? n - 2 : 0)>([&](auto x_c) {
+                constexpr int hx = lo + 2 + decltype(x_c)::value;
+                if constexpr (hx & 1) s2_key_b(kk, m1, m2);
+                else s2_key_a<(pa << 4) | ((hx / 2) & 15)>(kk, m2, m3, accp[(hx / 2) & 15], keymask);
+            });
+            // the buffer just keyed starts its next chain (tile a + 1) at |c|^2/2
+            if (j == kKeyEnd + 1) load_hn(accp, (a + 1) % NT);
+            // the other stages, dealt over the steps
+            if (st == at(3)) cmp_do(it - 2, it >= 2);
+            if (st == at(6) && wid == (it & 3)) win_read(it);
+            if (st == at(9) && wid == (it & 3)) win_do(it);
+            if (st == at(6) && wid == ((it + 2) & 3)) flag_read(it - 3);
+            if (st == at(9) && wid == ((it + 2) & 3)) flag_do(it - 3, it >= 3);
+            if (st == at(12) && do_dma) issue_half(2 * it + 4);
+            if (st == at(15) && do_dma) issue_half(2 * it + 5);
 #pragma unroll
-            for (int t = 0; t < GQ; ++t) {
-                const int a = q * GQ + t;
-                f32x4 &acc = q == 0 ? acc0[t] : acc1[t];
-                if (a * KS + j < NA) s2_mfma<true>(acc, A[a][j], bq[st % 3]);
-                else s2_mfma<false>(acc, A[a][j], bq[st % 3]);
-                if (t == 0 && st + 2 < kSteps) bq[(st + 2) % 3] = *reinterpret_cast<const half8 *>(fb + ((st + 2) % KS) * 1024);
-                // keys of the previous accumulator group (q == 0: group 1 of set it-1; q == 1: group 0 of this set)
+            for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
-                for (int v = 0; v < kVals; ++v) {
-                    if (key_step(v) == j) {
-                        const int vt = v >> 2, r = v & 3, ka = (1 - q) * GQ + vt;
-                        if (((2 * key_rank(v)) * GQ) / (nh > 0 ? nh : 1) == t) key_half_a(q == 0 ? acc1[vt][r] : acc0[vt][r], (unsigned)(ka << 2 | r));
-                        if (((2 * key_rank(v) + 1) * GQ) / (nh > 0 ? nh : 1) == t) key_half_b();
-                    }
+                for (int c = 0; c < kCvtPerHalf; ++c) {
+                    if (st == at(18) + (h2 * kCvtPerHalf + c) * (at(72) / (2 * kCvtPerHalf))) cvt_read(2 * it + 2 + h2, c);
+                    if (st == at(18) + (h2 * kCvtPerHalf + c) * (at(72) / (2 * kCvtPerHalf)) + 3) cvt_write(2 * it + 2 + h2, c);
                 }
-                if (t + 1 < GQ) __builtin_amdgcn_sched_barrier(0);
+                if (st == at(18) + ((h2 + 1) * kCvtPerHalf) * (at(72) / (2 * kCvtPerHalf))) cvt_norm(2 * it + 2 + h2);
             }
-            // the chain that starts KS steps from now begins at |c|^2/2: its accumulators were keyed by step kKeyEnd
-            if (j == kKeyEnd + 1) {
-#pragma unroll
-                for (int t = 0; t < GQ; ++t) {
-                    if (q == 0) acc1[t] = hn_w[4 * (GQ + t)]; else acc0[t] = hn_w[4 * t];
-                }
-            }
-            // the other stages, spread over the steps
-            if (st == 2) cmp_do(it - 2, it >= 2);
-            if (st == 3 && wid == (it & 3)) win_read(it);
-            if (st == 5 && wid == (it & 3)) win_do(it);
-            if (st == 6 && wid == ((it + 2) & 3)) flag_read(it - 3);
-            if (st == 8 && wid == ((it + 2) & 3)) flag_do(it - 3, it >= 3);
-#pragma unroll
-            for (int c = 0; c < kCvtMax; ++c) {
-                if (st == 1 + c * (kSteps / kCvtMax)) cvt_read(it + 1, c);
-                if (st == 3 + c * (kSteps / kCvtMax)) cvt_write(it + 1, c);
-            }
-            if (st == kSteps - 2) cvt_norm(it + 1);
-            if (st == KS + 1 && do_dma) issue_set(it + 3);
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (p.stamps) ts2 = __builtin_amdgcn_s_memtime();
-        end_of_iteration(do_dma);
-        if (p.stamps) { t_pre += ts1 - ts0; t_mma += ts2 - ts1; t_bar += __builtin_amdgcn_s_memtime() - ts2; }
+        if (p.stamps) t_top += __builtin_amdgcn_s_memtime() - tt0;
+        end_of_iteration();
     }
-    // ---- drain: keys of the very last group, then the compare / flag stages of the last sets
+    // ---- drain: keys of the very last tile, then the compare / flag stages of the last sets
     for (int it = ns; it < ns + 3 && ns > 0; ++it) {
         if (it == ns) {
-#pragma unroll
-            for (int v = 0; v < kVals; ++v) key_insert(acc1[v >> 2][v & 3], (unsigned)((GQ + (v >> 2)) << 2 | (v & 3)));
+            f32x16 &accl = ((NT - 1) & 1) ? acc1 : acc0;
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accl));
+            static_for<16>([&](auto r_c) {
+                constexpr int r = decltype(r_c)::value;
+                s2_key_a<((NT - 1) << 4) | r>(kk, m2, m3, accl[r], keymask);
+                s2_key_b(kk, m1, m2);
+            });
             publish(ns - 1);
         }
         if (it - 2 >= 0 && it - 2 < ns) { cmp_read(it - 2); cmp_do(it - 2, true); }
         if (it - 3 >= 0 && it - 3 < ns && wid == ((it + 2) & 3)) { flag_read(it - 3); flag_do(it - 3, true); }
-        end_of_iteration(false);
+        end_of_iteration();
     }
     stamp(p, 2, lane, wave_id);
     if (p.stamps && lane == 0) {
-        p.stamps[(size_t)wave_id * 16 + 4] = t_pre; p.stamps[(size_t)wave_id * 16 + 5] = t_mma; p.stamps[(size_t)wave_id * 16 + 6] = t_bar;
+        p.stamps[(size_t)wave_id * 16 + 4] = t_top; p.stamps[(size_t)wave_id * 16 + 5] = t_vm; p.stamps[(size_t)wave_id * 16 + 6] = t_bar;
         p.stamps[(size_t)wave_id * 16 + 7] = (unsigned long long)ns;
     }
 }
@@ -1178,7 +1213,7 @@ int device_cus()
 template <int NT, int KS>
 int launch_screen2(const AssignArgs &a, hipStream_t st)
 {
-    const size_t lds = (size_t)kS2RawSlots * KS * 2048 + (size_t)2 * KS * 1024 + kS2SmallSlots * sizeof(S2Small) + (size_t)kS2StashSlots * 256 * 16 + (size_t)4 * NT * 64;
+    const size_t lds = (size_t)kS2RawSlots * (KS / 2) * 2048 + (size_t)2 * KS * 1024 + kS2SmallSlots * sizeof(S2Small) + (size_t)kS2StashSlots * 256 * 16 + (size_t)4 * NT * 128;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)assign_screen2_kernel<NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1190,7 +1225,7 @@ int launch_screen2(const AssignArgs &a, hipStream_t st)
     sn_prof_start(0, st);
     hipLaunchKernelGGL((assign_screen2_kernel<NT, KS>), dim3(grid), dim3(256), lds, st, a);
     sn_prof_stop(0, st);
-    constexpr int NTR = KS / 2;                                             // fp64 re-rank: 64 k per lane-step
+    constexpr int NTR = KS / 4;                                             // fp64 re-rank: 64 k per lane-step
     sn_prof_start(1, st);
     const int64_t chunks = (a.n_tokens + 31) / 32;
     hipLaunchKernelGGL((assign_rerank_kernel<NTR, 1>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
@@ -1236,7 +1271,7 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)(elems / 256)), dim3(256), 0, st, codebook, M, D,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes);
     if (lay.nt2)
-        hipLaunchKernelGGL(pack_frag2_kernel, dim3((unsigned)((int64_t)64 * lay.nt2 * D / 256)), dim3(256), 0, st, codebook, M, D,
+        hipLaunchKernelGGL(pack_frag2_kernel, dim3((unsigned)((int64_t)128 * lay.nt2 * D / 256)), dim3(256), 0, st, codebook, M, D,
                            base + lay.frag2_off, (float *)(base + lay.hn2_off), lay.nt2, lay.ks2);
     hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((lay.m_pad + 3) / 4)), dim3(256), 0, st, codebook, M, D, lay.m_pad,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (double *)(base + lay.cn64_off),
@@ -1286,9 +1321,8 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.codes = ws ? ws + 32 + (size_t)n_tokens * 4 : nullptr;
     a.overflow = ws ? (int *)(ws + 32 + (size_t)n_tokens * (4 + kCodeBytes)) : nullptr;
     a.stamps = g_stamps;
-    a.flags64 = ws ? (unsigned long long *)(ws + 32) : nullptr;
-    a.codes32 = ws ? (unsigned *)(ws + 32 + (size_t)n_tokens * 8) : nullptr;
-    a.n_sets = (n_tokens + 15) / 16;
+    a.codes32 = ws ? (unsigned *)(ws + 32 + (size_t)n_tokens * 4) : nullptr;
+    a.n_sets = (n_tokens + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
     const bool screen_ok = mode == 0 && aligned && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
@@ -1302,10 +1336,10 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
         int rc = 0;
         const bool wide = screen_variant() == 1;
         const PackLayout lay = pack_layout(M, D);
-        if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 16) {
-            a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (8 + 64));
-            if (lay.ks2 == 12) rc = lay.nt2 == 8 ? launch_screen2<8, 12>(a, st) : (lay.nt2 == 4 ? launch_screen2<4, 12>(a, st) : launch_screen2<2, 12>(a, st));
-            else rc = lay.nt2 == 8 ? launch_screen2<8, 6>(a, st) : (lay.nt2 == 4 ? launch_screen2<4, 6>(a, st) : launch_screen2<2, 6>(a, st));
+        if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 32) {
+            a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + 32));
+            if (lay.ks2 == 24) rc = lay.nt2 == 4 ? launch_screen2<4, 24>(a, st) : launch_screen2<2, 24>(a, st);
+            else rc = lay.nt2 == 4 ? launch_screen2<4, 12>(a, st) : launch_screen2<2, 12>(a, st);
         } else if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st);
         else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : launch_screen<24, 4, 3>(a, st);
         else rc = launch_screen<48, 4, 3>(a, st);

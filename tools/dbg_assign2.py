@@ -21,7 +21,7 @@ for (D, M, B) in ((192, 128, 8), (384, 512, 12), (384, 100, 4)):
                                     N.ptr(o), o.stride(0), o.stride(1), N.ptr(ws), ws.numel(), mode, N.stream_ptr(dev)), "assign")
         torch.cuda.synchronize()
         if mode == 0:
-            fl = ws[32:32 + 8 * n_tok].view(torch.int64).clone()
+            fl = ws[32:32 + 4 * n_tok].view(torch.int32).clone()
     bad = (out != ex).reshape(-1).nonzero().reshape(-1)
     print(f"D={D} M={M}: {bad.numel()} / {n_tok} mismatches; flagged {(fl > 0).sum().item()} overflow {(fl < 0).sum().item()} unwritten {(out < 0).sum().item()}")
     o1, e1 = out.reshape(-1), ex.reshape(-1)

@@ -41,12 +41,8 @@ for name, tok in (("randn", tokens), ("k-means-like", tok_km)):
         v = sorted(buf)
         res[kname] = (v[n // 2] * 1e3, v[0] * 1e3)
     lib.sn_profile_enable(0)
-    if variant == 2:
-        fl = ws[32:32 + 8 * n_tok].view(torch.int64)
-        over = int((fl < 0).sum()); flagged = int((fl > 0).sum())
-    else:
-        fl = ws[32:32 + 4 * n_tok].view(torch.int32)
-        over = int((fl < 0).sum()); flagged = int((fl > 0).sum())
+    fl = ws[32:32 + 4 * n_tok].view(torch.int32)
+    over = int((fl < 0).sum()); flagged = int((fl > 0).sum())
     exact = torch.empty_like(out)
     N.check(lib.sn_assign_words(N.ptr(x), x.shape[0], x.shape[1], x.stride(0), x.stride(1), N.ptr(cb), N.ptr(packed), bench.M, bench.D,
                                 N.ptr(exact), exact.stride(0), exact.stride(1), N.ptr(ws), ws.numel(), 1, N.stream_ptr(dev)), "assign exact")
@@ -69,9 +65,10 @@ if variant == 2:      # in-kernel stamps of the register-stationary screen (shad
     torch.cuda.synchronize()
     lib.sn_debug_set_stamps(None)
     s8 = st.view(n_waves, 16).cpu().double()
+    s8 = s8[s8[:, 0] > 0]
     t0 = s8[:, 0].min()
     q = lambda v: "median %.0f max %.0f" % (v.median(), v.max())
     print("stamps (s_memtime ticks): kernel span %.0f; start skew %.0f" % (s8[:, 2].max() - t0, s8[:, 0].max() - t0))
     print("  prologue (codebook -> registers, set 0 converted): " + q(s8[:, 1] - s8[:, 0]))
     print("  loop: " + q(s8[:, 2] - s8[:, 1]) + "  sets per workgroup: " + q(s8[:, 7]))
-    print("    pre-stream stages (WIN/CMP/FLG): " + q(s8[:, 4]) + "; MFMA stream: " + q(s8[:, 5]) + "; wait+barrier: " + q(s8[:, 6]))
+    print("    MFMA stream: " + q(s8[:, 4]) + "; wait for DMA/LDS: " + q(s8[:, 5]) + "; barrier: " + q(s8[:, 6]))
