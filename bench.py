@@ -11,6 +11,10 @@ One "step" = one pass of the hot path over one batch that is already resident in
   softmax, grouping, normalise fused)--> padded instance graphs
   IR-Atlas normalise (K=100, n_max=512) --S4--> GCN on instances and on the atlas --> pred [B,100]
 Nothing is cached across steps (the atlas GCN is recomputed every step, like the reference).
+The K timed steps replay ONE captured hipGraph of the step (schema_inference.utils.graph_replay:
+same kernels, same buffers, no host launch path in the timed region; `"launch": "hipgraph"`); a
+second, untimed pass of K eager steps with HIP events on the launch stream gives the per-kernel
+durations of the roofline figure (`SN_BENCH_EAGER=1` times the eager loop instead).
 Workload = BASELINE.json configs[1]: DeiT-Small + CIFAR-100, B=256 per GPU, 512-word codebook.
 Multi-GPU: images are sharded over ranks (weak scaling, B per rank fixed), no data-path
 collective; the per-class prediction histogram + (n_seen) are all-reduced once at the end of
@@ -143,13 +147,44 @@ def main():
         torch.cuda.synchronize()
 
     votes = torch.zeros(K + 1, device=device)            # per-class prediction histogram + n_seen
+
+    def one_step():
+        pred = step(disc, sn, m, tokens, attn)
+        ops.class_votes_(pred, votes)                    # per-class vote aggregation (HIP, no host sync)
+        return pred
+
+    launch = "eager"
     with torch.no_grad():
         for _ in range(args.warmup):
-            pred = step(disc, sn, m, tokens, attn)
+            one_step()
+        graphed = None
+        if os.environ.get("SN_BENCH_EAGER", "0") != "1":
+            try:
+                from schema_inference.utils.graph_replay import GraphedStep
+                graphed = GraphedStep(one_step)          # capture (outside the timed region)
+                graphed.replay()
+                launch = "hipgraph"
+            except Exception as exc:                     # noqa: BLE001 - fall back to eager launches, and say so
+                print(f"bench: hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
+                graphed = None
+        votes.zero_()
         barrier()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            if graphed is not None:
+                graphed.replay()
+            else:
+                one_step()
+        if use_dist:
+            dist.all_reduce(votes)                       # per-class schema statistics over RCCL
+        barrier()
+        dt = time.perf_counter() - t0
+        n_voted = int(votes[K].item())
+
+        # ---- untimed instrumented pass: the same K steps launched eagerly, HIP events around the
+        # kernels (inside the library, on the launch stream) and around the stages
         lib.sn_profile_enable(args.steps)
         stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
-        t0 = time.perf_counter()
         for s in range(args.steps):
             ev = stage_ev[s]
             ev[0].record()
@@ -161,16 +196,12 @@ def main():
             ev[3].record()
             pred = m.forward_padded(g, atlas.class_dict, feat_kg=atlas)
             ev[4].record()
-            ops.class_votes_(pred, votes)                # per-class vote aggregation (HIP, no host sync)
-        if use_dist:
-            dist.all_reduce(votes)                       # per-class schema statistics over RCCL
-        barrier()
-        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
     t_max = torch.tensor([dt], device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max.item())
-    assert int(votes[K].item()) == B * args.steps * world
+    assert n_voted == B * args.steps * world, (n_voted, B * args.steps * world)
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
@@ -183,24 +214,26 @@ def main():
         alg_bytes = B * L * (D * 4 + 8)
         ach = alg_bytes / (avg["assign_screen"] * 1e-3) / 1e9 if avg["assign_screen"] else None
         graph_bytes = B * (L * L * 4 + L * 4 + L * 8) + B * (L * L * 4 + L * 12)   # attn in + padded edges/ids/weights out
+        screen_name = ("assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)" if lib.sn_assign_variant() == 2
+                       else "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen, token-stationary)")
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
                 for row in json.load(fh)["kernels"]:
-                    if row["kernel"].startswith("assign_screen_kernel<24"):
+                    if row["kernel"].startswith(screen_name.split(" ")[0].split(",")[0]):
                         traffic = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
         except (OSError, KeyError, ValueError):
             pass
         out = {
             "metric": "images/sec schema-inference (discretize+graph) DeiT-S CIFAR-100",
             "value": B * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "launch": launch,
             "vs_baseline": None, "dtype": "f32 (S1 screen: f16 MFMA + f64 re-rank; ids int64)", "data": "synthetic",
             "config": {"workload": "configs[1]: DeiT-Small + CIFAR-100, synthetic [256,197,384] tokens per GPU, "
                                    "512-word codebook, head-averaged attention logits [256,197,197], K=100, "
                                    "n_max=512, GNN E=256 x 2 layers; atlas recomputed every step",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"image-parallel x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen)",
+            "roofline": {"bound": "hbm", "kernel": screen_name,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
@@ -208,7 +241,7 @@ def main():
             "kernels_ms": avg,
             "instance_graph_GBps": (graph_bytes / (avg["instance_graph"] * 1e-3) / 1e9) if avg["instance_graph"] else None,
             "stage_ms": dict(zip(("S1_assign", "atlas_branch_enqueue", "S2S3_instance_graph", "S4_instance_gnn_join_scores"), stage_ms)),
-            "stage_note": "main-stream intervals; the class branch (atlas normalise + GNN over K graphs) runs concurrently on a side stream and is joined inside S4",
+            "stage_note": "main-stream intervals of the instrumented eager pass (slower than the timed hipGraph replays: event records + host launches); the class branch (atlas normalise + GNN over K graphs) runs concurrently on a side stream and is joined inside S4",
         }
         if not args.no_cpu_baseline and world == 1:
             cb, pred_cpu, ing_cpu = cpu_baseline(tokens, codebook, attn, sn, m)

@@ -71,6 +71,15 @@ size_t sn_codebook_pack_bytes(int M, int D);
  * factors).  Call once per codebook version; the packed image is read-only afterwards. */
 int sn_codebook_prepare(const float *codebook, int M, int D, void *packed, void *stream);
 
+/* Form of the fp16-MFMA screening kernel used by mode 0 (same results, different mapping to the chip):
+ *   0  token-stationary: a wave keeps 32 tokens in registers, the codebook streams L2 -> LDS (default)
+ *   1  the same with 8-wave workgroups
+ *   2  codebook-stationary: the fp16 codebook lives in the registers of each CU (M <= 512, D 192/384),
+ *      token sets stream HBM -> LDS once; other shapes fall back to 0
+ * Initial value: environment variable SN_ASSIGN_VARIANT (default 0). */
+int sn_assign_variant(void);
+int sn_assign_set_variant(int variant);
+
 /* Bytes of scratch sn_assign_words needs for n_tokens tokens. */
 size_t sn_assign_workspace_bytes(int64_t n_tokens);
 

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "sn_profile_elapsed_ms": (c_int, [c_int, POINTER(c_float), c_int]),
     "sn_codebook_pack_bytes": (c_size_t, [c_int, c_int]),
     "sn_codebook_prepare": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "sn_assign_variant": (c_int, []),
+    "sn_assign_set_variant": (c_int, [c_int]),
     "sn_assign_workspace_bytes": (c_size_t, [c_int64]),
     "sn_assign_words": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_int, c_void_p]),

@@ -36,6 +36,12 @@
 #ifndef SN_EXP_NODMA
 #define SN_EXP_NODMA 0
 #endif
+#ifndef SN_EXP_NOPHASEA
+#define SN_EXP_NOPHASEA 0
+#endif
+#ifndef SN_EXP_NOPHASEB
+#define SN_EXP_NOPHASEB 0
+#endif
 
 namespace {
 
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
             const unsigned f = p.flags[t];
             flag = (f >> 31) ? (1ull << 63) : (unsigned long long)f;
         }
-        unsigned long long todo = __ballot(flag != 0ull && !(flag >> 63));
+        unsigned long long todo = SN_EXP_NOPHASEA ? 0ull : __ballot(flag != 0ull && !(flag >> 63));
         for (int i = 0; todo; ++i) {
             const int tl = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
     // error window of the best, then fp64.
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     const unsigned char *tiles = p.packed + lay.tiles_off;
-    const int n_over = (int)blockIdx.x < kOverflowBlocks ? p.work[1] : 0;     // blocks 0 .. kOverflowBlocks - 1 only
+    const int n_over = ((int)blockIdx.x < kOverflowBlocks && !SN_EXP_NOPHASEB) ? p.work[1] : 0;     // blocks 0 .. kOverflowBlocks - 1 only
     for (int e = blockIdx.x; e < n_over; e += kOverflowBlocks) {
         const int64_t n = p.overflow[e];
         const float *row = token_row(p, n);
@@ -1233,14 +1239,15 @@ int launch_screen2(const AssignArgs &a, hipStream_t st)
     return 0;
 }
 
-// workgroup shape of the screen kernel: 2 (default where the shape allows it) = register-stationary
-// codebook (assign_screen2_kernel); token-stationary forms: 0 = 4 waves x 3-slot ring (two workgroups per CU),
-// 1 = 8 waves x 5-slot ring (one workgroup per CU, half the LDS-DMA traffic per token)
+// form of the screen kernel: 0 (default) = token-stationary, 4 waves x 3-slot codebook ring, two
+// workgroups per CU; 1 = token-stationary, 8 waves x 5-slot ring; 2 = register-stationary codebook
+// (assign_screen2_kernel; shapes with M <= 512, D in {192, 384}, n_inner >= 32; else falls back to 0).
+// Initialised from SN_ASSIGN_VARIANT, changed with sn_assign_set_variant().
+int g_variant = -1;
 int screen_variant()
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SN_ASSIGN_VARIANT"); v = e ? atoi(e) : 2; }
-    return v;
+    if (g_variant < 0) { const char *e = getenv("SN_ASSIGN_VARIANT"); g_variant = e ? atoi(e) : 0; }
+    return g_variant;
 }
 
 }  // namespace
@@ -1277,6 +1284,15 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (double *)(base + lay.cn64_off),
                        (unsigned *)(base + lay.scal_off), (float *)(base + lay.hn2_off), lay.nt2);
     SN_CHECK_LAUNCH("sn_codebook_prepare");
+    return SN_OK;
+}
+
+extern "C" int sn_assign_variant(void) { return screen_variant(); }
+
+extern "C" int sn_assign_set_variant(int variant)
+{
+    SN_REQUIRE(variant >= 0 && variant <= 2, SN_ERR_BAD_ARG, "sn_assign_set_variant: variant=%d", variant);
+    g_variant = variant;
     return SN_OK;
 }
 

@@ -1,0 +1,31 @@
+"""hipGraph replay of an inference step (no reference counterpart: the reference launches every op
+eagerly from Python; on MI355X the schema-inference step is ~30 short kernels on two HIP streams,
+so the launch path is captured once and replayed).
+
+Everything in the step runs without a host synchronisation (device-side extents, fixed-shape
+padded outputs, the side-stream class branch joined by an event), which is what makes it
+capturable.  `GraphedStep(fn)` warms `fn` up on a capture stream, records ONE call of it into a
+`torch.cuda.CUDAGraph` (a hipGraph on ROCm) and `replay()` re-runs the recorded kernels on the
+same buffers: inputs are read from the tensors `fn` closed over at capture time, so update them in
+place (`tensor.copy_`) between replays; the outputs are the tensors returned at capture time."""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, fn, warmup: int = 2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedStep needs a GPU (the HIP path has no CPU fallback)")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                 # first-launch work (attributes, packed codebook, workspaces) is not capturable
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.outputs = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs

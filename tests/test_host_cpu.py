@@ -31,9 +31,12 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.sn_abi_version() == N.ABI_VERSION
     assert lib.sn_last_error() is not None
     # size helpers are pure host code
-    assert lib.sn_codebook_pack_bytes(512, 384) == 16 * 25 * 1024 + 4096 + 256
+    # token-stationary tile image + norms + scalars, then the codebook-stationary fragment image + half norms
+    assert lib.sn_codebook_pack_bytes(512, 384) == (16 * 25 * 1024 + 4096 + 256) + (4 * 4 * 24 * 1024 + 4 * 4 * 128)
+    assert lib.sn_codebook_pack_bytes(1024, 384) == 32 * 25 * 1024 + 8192 + 256       # too large for the register file: no second image
     assert lib.sn_codebook_pack_bytes(512, 30) == 0
-    assert lib.sn_assign_workspace_bytes(50176) == 32 + 50176 * 32
+    assert lib.sn_assign_workspace_bytes(50176) == 32 + 50176 * 40
+    assert lib.sn_assign_variant() in (0, 1, 2)
 
 
 def test_graph_args_struct_matches_header(lib):
