@@ -96,7 +96,18 @@ class GNN(nn.Module):
             return False
         return all(isinstance(l.g_conv.linear, nn.Linear) and (l._is_relu or l._is_none) for l in self.layers)
 
-    def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor, adj=None):
+    def prepare(self):
+        """The parameter-only operands of the MFMA path: layer 1's Linear folded into the embedding
+        table ((M+1) x E GEMM) and W2 as fp16 hi/lo planes.  A forward pass embeds the instance graphs
+        AND the class graphs with the same weights (Matcher), so it computes them once and hands them
+        to both `forward(..., prepared=...)` calls; None when the MFMA path does not apply."""
+        if not self._mfma_ok() or not self.embedding.weight.is_cuda or self._differentiable():
+            return None
+        l1, l2 = self.layers
+        return {"table": torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight),
+                "w2": ops.split_planes(l2.g_conv.linear.weight)}
+
+    def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None):
         """Inference on the matrix cores: three GEMM launches per call, every elementwise step an
         epilogue (bias, pad-row mask, LayerNorm, ReLU, hi/lo split, node-weighted pooling).
             H1     = act(LN1(adj @ (Emb @ W1^T)[ids] + b1))
@@ -111,13 +122,13 @@ class GNN(nn.Module):
         ext = divisor if (divisor is not None and torch.is_tensor(divisor)) else None
         if adj is None:
             adj = ops.gcn_adjacency_planes(edges, extent=ext)                       # A  [G, n, n]
-        table = torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight)
-        zt1 = ops.gcn_gather_planes(table, ingredients, extent=ext)                 # Bt [G, E, n]
+        if prepared is None:
+            prepared = self.prepare()
+        zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext)     # Bt [G, E, n]
         h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                           layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
                           rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext)["planes"]   # [G, n, E]
-        w2 = ops.split_planes(l2.g_conv.linear.weight)                              # A  [1, E, E]
-        zt2 = ops.gcn_gemm(w2, h1, G, want_planes=n)["planes"]                      # [G, E, n]
+        zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n)["planes"]          # A = W2 planes [1, E, E] -> [G, E, n]
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
                               rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext)["pooled"]   # [G, row tiles, E]
@@ -125,7 +136,7 @@ class GNN(nn.Module):
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
                 feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
-                divisor: Optional[torch.Tensor] = None, adjacency=None) -> torch.Tensor:
+                divisor: Optional[torch.Tensor] = None, adjacency=None, prepared=None) -> torch.Tensor:
         """nodes [G, n], edges [G, n, n], ingredients [G, n] -> graph feature [G, embed_dim].
 
         feat_mask (bool [G, n], True = padding) is the reference argument (gnn.py:78-98).
@@ -136,12 +147,12 @@ class GNN(nn.Module):
         if adjacency is not None:        # prebuilt (E + E^T)/2 + I planes (SchemaNet.get_atlas(fused_adjacency=True))
             if not (nodes.is_cuda and self._mfma_ok()) or self._differentiable(nodes):
                 raise RuntimeError("adjacency planes need the inference MFMA path (embed_dim 256, 2 Linear layers, no autograd)")
-            return self._forward_mfma(nodes, None, ingredients, n_valid, divisor, adj=adjacency)
+            return self._forward_mfma(nodes, None, ingredients, n_valid, divisor, adj=adjacency, prepared=prepared)
         fused = nodes.is_cuda and not self._differentiable(nodes, edges)
         if n_valid is None and feat_mask is not None:
             n_valid = (~feat_mask).sum(dim=1).to(torch.int32)   # masks are suffix masks (match.py:48-51)
         if fused and self._mfma_ok():
-            return self._forward_mfma(nodes, edges, ingredients, n_valid, divisor)
+            return self._forward_mfma(nodes, edges, ingredients, n_valid, divisor, prepared=prepared)
         if feat_mask is None and n_valid is not None and not fused:
             feat_mask = torch.arange(nodes.shape[1], device=nodes.device)[None, :] >= n_valid[:, None]
         adj = ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges)

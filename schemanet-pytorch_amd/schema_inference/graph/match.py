@@ -14,8 +14,8 @@ from .gnn import GNN
 class _AtlasHandle:
     """Class-graph features being computed on the side stream (Matcher.atlas_features_async)."""
 
-    def __init__(self, class_dict, feat, done):
-        self.class_dict, self.feat, self.done = class_dict, feat, done
+    def __init__(self, class_dict, feat, done, prepared=None):
+        self.class_dict, self.feat, self.done, self.prepared = class_dict, feat, done, prepared
 
     def join(self) -> torch.Tensor:
         if self.done is not None:
@@ -53,13 +53,13 @@ class Matcher(nn.Module):
             return (torch.cosine_similarity(a, b, dim=-1) + 1) / 2
         return 1 / (1 + torch.linalg.vector_norm(a - b, dim=-1))
 
-    def atlas_features(self, class_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def atlas_features(self, class_dict: Dict[str, torch.Tensor], prepared=None) -> torch.Tensor:
         """GNN over the K class graphs -> [K, E]  (reference match.py:66-70)."""
         if "class_adjacency" in class_dict:          # fused atlas route (no class_edges tensor)
             return self.gnn(nodes=class_dict["class_vertices"], edges=None, ingredients=class_dict["class_ingredients"],
-                            adjacency=class_dict["class_adjacency"])
+                            adjacency=class_dict["class_adjacency"], prepared=prepared)
         return self.gnn(nodes=class_dict["class_vertices"], edges=class_dict["class_edges"],
-                        ingredients=class_dict["class_ingredients"])
+                        ingredients=class_dict["class_ingredients"], prepared=prepared)
 
     # ---- atlas branch on its own HIP stream -------------------------------------------------
     # The class-graph branch (atlas normalisation -> GNN over K graphs) depends only on parameters,
@@ -70,22 +70,29 @@ class Matcher(nn.Module):
     def atlas_features_async(self, get_class_dict):
         """Start `get_class_dict()` (e.g. `schema_net.get_atlas`) + the class-graph GNN on the side
         stream.  Returns a handle for `forward_padded(..., feat_kg=handle)`; `handle.class_dict` is
-        usable on the current stream after the join."""
+        usable on the current stream after the join.  The weight-only operands of the GNN
+        (`GNN.prepare`) are computed once, on the current stream before the fork, and shared by the
+        class branch and the instance branch of this forward pass (`handle.prepared`)."""
         dev = next(self.gnn.parameters()).device
+        prepared = self.gnn.prepare() if dev.type == "cuda" else None
         serial = os.environ.get("SN_SIDE_STREAM", "1") == "0"           # diagnostics: everything on one stream
         if serial or dev.type != "cuda" or torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters()):
             class_dict = get_class_dict()
-            return _AtlasHandle(class_dict, self.atlas_features(class_dict), None)
+            return _AtlasHandle(class_dict, self.atlas_features(class_dict, prepared), None, prepared)
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
             self._side_stream = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         self._side_stream.wait_stream(main)                 # parameters / earlier work are visible
+        for v in (prepared or {}).values():                # allocated on the current stream, also read on the side stream
+            for t in ((v.hi, v.lo) if hasattr(v, "hi") else (v,)):
+                if torch.is_tensor(t):
+                    t.record_stream(self._side_stream)
         with torch.cuda.stream(self._side_stream):
             class_dict = get_class_dict()
-            feat = self.atlas_features(class_dict)
+            feat = self.atlas_features(class_dict, prepared)
             done = torch.cuda.Event()
             done.record(self._side_stream)
-        return _AtlasHandle(class_dict, feat, done)
+        return _AtlasHandle(class_dict, feat, done, prepared)
 
     def forward_padded(self, graph: Dict[str, torch.Tensor], class_dict: Dict[str, torch.Tensor],
                        feat_kg=None) -> torch.Tensor:
@@ -94,7 +101,8 @@ class Matcher(nn.Module):
         pads to (max_i n_i, match.py:46; gnn.py:96), so the result does not depend on n_pad.
         feat_kg: precomputed class features [K, E] or a handle of `atlas_features_async`."""
         feat_instance = self.gnn(nodes=graph["vertices"], edges=graph["edges"], ingredients=graph["ids"],
-                                 n_valid=graph["n"], divisor=graph["n_max"])
+                                 n_valid=graph["n"], divisor=graph["n_max"],
+                                 prepared=feat_kg.prepared if isinstance(feat_kg, _AtlasHandle) else None)
         if isinstance(feat_kg, _AtlasHandle):
             feat_kg = feat_kg.join()
         elif feat_kg is None:
