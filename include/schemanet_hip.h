@@ -98,6 +98,22 @@ int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_
                     void *workspace, size_t workspace_bytes, int mode, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * codebook extraction: Lloyd's k-means with sn_assign_words as the E-step
+ * replaces: scipy.cluster.vq.kmeans(x, num_clusters)   scripts/extract_ingredients.py:33-36
+ * (SciPy float32 path: scipy/cluster/vq.py::_kmeans, _vq.update_cluster_means).
+ * Token grid and strides as in sn_assign_words; ids = its output (any strides).
+ * ------------------------------------------------------------------------------------------ */
+/* sums[k, :] = fp32 sum of the tokens assigned to centre k, added IN TOKEN ORDER (SciPy's order, so the
+ * result is bit-identical to it); counts[k] = number of members.  K workgroups. */
+int sn_kmeans_update(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer, int64_t x_stride_inner,
+                     const int64_t *ids, int64_t ids_stride_outer, int64_t ids_stride_inner, int K, int D,
+                     float *sums, int64_t *counts, void *stream);
+/* dist[t] = |x_t - centres[ids[t]]|_2 in fp64 (t = flat token index); its mean is SciPy's distortion. */
+int sn_kmeans_distances(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer, int64_t x_stride_inner,
+                        const int64_t *ids, int64_t ids_stride_outer, int64_t ids_stride_inner, const float *centres,
+                        int K, int D, double *dist, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * attention taps of the wrapper
  * replaces: IngredientModelWrapper.forward  schema_inference/utils/ingredient_model_wrapper.py:58-68
  * extracted [B*H, L+1, L+1] raw logits -> attn [B, L, L] (head mean, cls row/col dropped) and

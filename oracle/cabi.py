@@ -62,6 +62,23 @@ def assign_words(x, cb, return_score=False):
     return (idx, score) if return_score else idx
 
 
+def kmeans_update(x, ids, K):
+    """-> (sums f32 [K, D] added in observation order, counts i64 [K])   (SciPy's update_cluster_means before the division)"""
+    x, ids = _f32(x), _i64(ids)
+    sums = np.empty((K, x.shape[1]), np.float32)
+    counts = np.empty(K, np.int64)
+    lib().sno_kmeans_update(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1], _p(ids, _i64p), K, _p(sums, _f32p), _p(counts, _i64p))
+    return sums, counts
+
+
+def kmeans_distances(x, ids, centres):
+    x, ids, centres = _f32(x), _i64(ids), _f32(centres)
+    dist = np.empty(x.shape[0], np.float64)
+    lib().sno_kmeans_distances(_p(x, _f32p), ctypes.c_int64(x.shape[0]), x.shape[1], _p(ids, _i64p), _p(centres, _f32p),
+                               centres.shape[0], _p(dist, _f64p))
+    return dist
+
+
 def instance_v(ing, attn_cls, w, mean=True):
     """-> ids [sum n], attrs2 [sum n, 2], weights [sum n], num_v [B]  (concatenated like the
     reference's return value)."""

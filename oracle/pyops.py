@@ -241,3 +241,24 @@ def matcher_forward(params, inst_ids, inst_v, inst_e, class_vertices, class_edge
     if similarity == "euclidean":
         return 1 / (1 + np.linalg.norm(a - b, axis=-1))
     raise KeyError(similarity)
+
+
+# ------------------------------------------------------------------------------- codebook extraction
+def kmeans_lloyd(obs, guess, thresh=1e-5, max_iter=10_000):
+    """SciPy's `_kmeans(obs, guess, thresh)` (scipy/cluster/vq.py), float32 path, restated: exact nearest
+    centre (first index on ties), fp32 member sums in observation order / count, centres without members
+    dropped, stop when the mean distance changes by <= thresh.  -> (book f32 [k', D], avg distance, iterations).
+    Reference call site: scripts/extract_ingredients.py:33-36."""
+    obs = np.ascontiguousarray(obs, F32)
+    book = np.ascontiguousarray(guess, F32)
+    prev, diff, it = [np.inf], np.inf, 0
+    while diff > thresh and it < max_iter:
+        ids = cabi.assign_words(obs, book)
+        dist = cabi.kmeans_distances(obs, ids, book)
+        prev = (prev + [float(dist.sum() / dist.size)])[-2:]
+        sums, counts = cabi.kmeans_update(obs, ids, book.shape[0])
+        has = counts > 0
+        book = np.ascontiguousarray(sums[has] / counts[has].astype(F32)[:, None])
+        diff = abs(prev[0] - prev[1])
+        it += 1
+    return book, prev[1], it

@@ -79,6 +79,46 @@ void sno_assign_words(const float *x, int64_t n_tok, const float *cb, int M, int
 }
 
 /* ------------------------------------------------------------------------------------------
+ * codebook extraction: M-step and distortion of SciPy's k-means, float32 path
+ * (reference scripts/extract_ingredients.py:33-36 -> scipy.cluster.vq.kmeans;
+ *  scipy/cluster/vq.py::_kmeans, scipy/cluster/_vq.pyx::update_cluster_means: cb[label] += obs[i]
+ *  in observation order in the observations' dtype, then cb[i] /= count[i]).
+ * sums are NOT divided here (the driver divides after the cross-rank reduction).
+ * ------------------------------------------------------------------------------------------ */
+void sno_kmeans_update(const float *x, int64_t n_tok, int D, const int64_t *ids, int K, float *sums, int64_t *counts)
+{
+    memset(sums, 0, sizeof(float) * (size_t)K * (size_t)D);
+    memset(counts, 0, sizeof(int64_t) * (size_t)K);
+    for (int64_t t = 0; t < n_tok; ++t) {
+        const int64_t k = ids[t];
+        if (k < 0 || k >= K) continue;
+        float *row = sums + (size_t)k * D;
+        for (int d = 0; d < D; ++d) row[d] = row[d] + x[(size_t)t * D + d];
+        counts[k] += 1;
+    }
+}
+
+/* dist[t] = |x_t - c_ids[t]|_2, fp64, 64-way strided partial sums + xor butterfly (the HIP kernel's order) */
+void sno_kmeans_distances(const float *x, int64_t n_tok, int D, const int64_t *ids, const float *centres, int K, double *dist)
+{
+    for (int64_t t = 0; t < n_tok; ++t) {
+        int64_t k = ids[t];
+        k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+        double p[SNO_LANES], q[SNO_LANES];
+        for (int l = 0; l < SNO_LANES; ++l) p[l] = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double df = (double)x[(size_t)t * D + d] - (double)centres[(size_t)k * D + d];
+            p[d % SNO_LANES] = fma(df, df, p[d % SNO_LANES]);
+        }
+        for (int off = SNO_LANES / 2; off >= 1; off >>= 1) {
+            for (int l = 0; l < SNO_LANES; ++l) q[l] = p[l] + p[l ^ off];
+            memcpy(p, q, sizeof(p));
+        }
+        dist[t] = sqrt(p[0]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * helpers shared by the graph builders
  * ------------------------------------------------------------------------------------------ */
 

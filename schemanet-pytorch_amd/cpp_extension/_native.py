@@ -75,6 +75,10 @@ _SIGNATURES = {
     "sn_assign_workspace_bytes": (c_size_t, [c_int64]),
     "sn_assign_words": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_int, c_void_p]),
+    "sn_kmeans_update": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    "sn_kmeans_distances": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                    c_int, c_int, c_void_p, c_void_p]),
     "sn_head_mean_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_instance_graph": (c_int, [POINTER(GraphArgs), c_void_p]),
     "sn_full_vertices": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,

@@ -77,6 +77,41 @@ def assign_words(tokens, codebook, packed, out=None, mode=0):
     return out
 
 
+def kmeans_update(tokens, ids, K):
+    """M-step of Lloyd's k-means.  tokens [n_outer, n_inner, D] f32 view, ids int64 [n_outer, n_inner]
+    (the output of assign_words).  -> (sums f32 [K, D], counts int64 [K]): per-centre member sums added in
+    token order (bit-identical to SciPy's float32 update) and member counts."""
+    lib = N.require_gpu()
+    dev = _check_dev(tokens, ids)
+    if tokens.dtype != torch.float32 or tokens.stride(-1) != 1:
+        tokens = tokens.to(torch.float32).contiguous()
+    assert tokens.dim() == 3 and ids.dtype == torch.int64 and tuple(ids.shape) == tuple(tokens.shape[:2])
+    n_outer, n_inner, D = tokens.shape
+    sums = torch.empty((K, D), dtype=torch.float32, device=dev)
+    counts = torch.empty((K,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_kmeans_update(N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(ids), ids.stride(0),
+                                     ids.stride(1), K, D, N.ptr(sums), N.ptr(counts), N.stream_ptr(dev)), "sn_kmeans_update")
+    return sums, counts
+
+
+def kmeans_distances(tokens, ids, centres):
+    """-> float64 [n_outer * n_inner]: Euclidean distance of every token to its centre (fp64)."""
+    lib = N.require_gpu()
+    dev = _check_dev(tokens, ids, centres)
+    if tokens.dtype != torch.float32 or tokens.stride(-1) != 1:
+        tokens = tokens.to(torch.float32).contiguous()
+    centres = _f32c(centres)
+    n_outer, n_inner, D = tokens.shape
+    assert centres.shape[1] == D and ids.dtype == torch.int64
+    dist = torch.empty((n_outer * n_inner,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_kmeans_distances(N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(ids), ids.stride(0),
+                                        ids.stride(1), N.ptr(centres), centres.shape[0], D, N.ptr(dist), N.stream_ptr(dev)),
+                "sn_kmeans_distances")
+    return dist
+
+
 # ------------------------------------------------------------------------------- wrapper taps
 def head_mean_attention(extracted, bs):
     """extracted [bs*H, L+1, L+1] -> (attn [bs, L, L], attn_cls [bs, L])."""

@@ -259,3 +259,44 @@ def test_statistics_all_reduce_two_ranks_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)]) for r in range(2)]
     codes = [p.wait(timeout=300) for p in procs]
     assert codes == [0, 0], codes
+
+
+# ------------------------------------------------------------------ k-means driver: sharded == single process (gloo, world_size 2)
+_KM_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "schemanet-pytorch_amd"))
+from oracle import pyops, cabi
+from discretization import kmeans as km
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+rng = np.random.default_rng(5)
+k, D, N = 12, 64, 2400
+centres = (rng.normal(size=(k, D)) * 2).astype(np.float32)
+x = (centres[rng.integers(0, k, N)] + rng.normal(size=(N, D)).astype(np.float32)).astype(np.float32)
+guess = x[rng.choice(N, k, replace=False)].copy()
+# the three kernels come from the oracle here (no GPU in this container); under test: the driver's loop,
+# the all-reduce of sums / counts / distances over the shards and the empty-cluster handling
+backend = (lambda o, b: torch.from_numpy(cabi.assign_words(o.numpy(), b.numpy())),
+           lambda o, i, kk: tuple(torch.from_numpy(a) for a in cabi.kmeans_update(o.numpy(), i.numpy(), kk)),
+           lambda o, i, b: torch.from_numpy(cabi.kmeans_distances(o.numpy(), i.numpy(), b.numpy())))
+mine = torch.from_numpy(x[rank::2].copy())
+book, avg, it = km.lloyd(mine, torch.from_numpy(guess), 1e-5, None, backend)
+want, want_avg, want_it = pyops.kmeans_lloyd(x, guess, 1e-5)
+ok = book.shape == want.shape and it == want_it
+ok = ok and np.allclose(book.numpy(), want, rtol=1e-5, atol=1e-6) and abs(avg - want_avg) < 1e-9 * want_avg
+both = [torch.zeros_like(book) for _ in range(2)]
+dist.all_gather(both, book)
+ok = ok and torch.equal(both[0], both[1])               # every rank ends with the same book
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_kmeans_sharded_two_ranks_gloo(tmp_path):
+    script = tmp_path / "km_worker.py"
+    script.write_text(_KM_WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)]) for r in range(2)]
+    codes = [p.wait(timeout=300) for p in procs]
+    assert codes == [0, 0], codes

@@ -181,3 +181,28 @@ def test_properties_random(seed):
     for x2, x in zip(e2, e):
         close(x2.sum(axis=1), np.ones_like(x2.sum(axis=1)), rtol=1e-5)    # each channel row-normalised
         close(x.sum(axis=1), np.full(x.shape[0], w.sum()), rtol=1e-5)     # rows sum to w0+w1
+
+
+# ------------------------------------------------------------------------------- codebook extraction
+def _kmeans_case(seed, k, D, N, dup=False):
+    rng = np.random.default_rng(seed)
+    centres = (rng.normal(size=(k, D)) * 2).astype(np.float32)
+    x = (centres[rng.integers(0, k, N)] + rng.normal(size=(N, D)).astype(np.float32)).astype(np.float32)
+    guess = x[rng.choice(N, k, replace=False)].copy()
+    if dup:
+        guess[3] = guess[1]            # a duplicated centre never wins a tie (first index) -> no members -> dropped
+    return x, guess
+
+
+@pytest.mark.parametrize("seed,k,D,N,dup", [(0, 16, 64, 3000, False), (1, 24, 192, 4000, True)])
+def test_kmeans_oracle_equals_scipy(seed, k, D, N, dup):
+    """The k-means restatement (exact nearest centre + SciPy's fp32 in-order member sums + its stopping
+    rule) reproduces scipy.cluster.vq.kmeans - the call of the reference's extract_ingredients.py:33-36 -
+    bit for bit, including the dropped empty cluster."""
+    from scipy.cluster.vq import kmeans
+    x, guess = _kmeans_case(seed, k, D, N, dup)
+    want, want_dist = kmeans(x, guess, thresh=1e-5)
+    got, got_dist, iters = pyops.kmeans_lloyd(x, guess, thresh=1e-5)
+    assert got.dtype == np.float32 and got.shape == want.shape and (not dup or got.shape[0] == k - 1)
+    assert np.array_equal(got, want)
+    assert abs(got_dist - float(want_dist)) <= 1e-5 * float(want_dist) and iters >= 2
