@@ -17,6 +17,7 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kCellsPerLane = 4;               // 4 x 64 lanes = 256 output columns per row
 constexpr int kMaxCols = kCellsPerLane * SN_WAVE;
 constexpr int kTFloats = 512;                   // feat_h << ceil(log2(feat_w)) <= 2 L <= 392
@@ -612,6 +613,22 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
         qsidx4[k] = (int)s.flag[qq] * 4;                    // where this position's column sum is staged (sorted order)
     }
     const int tsh = grid_shift(a.feat_w) + 2;               // byte shift of a table row
+    // segment heads of the sorted position order, for the lane's four sorted indices 4 lane + e (bit e):
+    // a word's first position; indices past the kept positions are their own (empty) segments
+    const bool scan_ok = (L & 3) == 0 && L <= 4 * SN_WAVE;
+    unsigned hd = 0;
+    if (scan_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * lane + e;
+            bool head = true;
+            if (i > 0 && i < n_kept) head = s.words[s.pos_sorted[i]] != s.words[s.pos_sorted[i - 1]];
+            hd |= head ? (1u << e) : 0u;
+        }
+    }
+    float rcnt[kCellsPerLane];                             // 1 / (positions of the column's word)
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) rcnt[k] = 1.0f / (float)(cc.cnt[k] > 0 ? cc.cnt[k] : 1);
     unsigned long long dt_a = 0, dt_b = 0;                  // diagnostics (stamps on): wave 0's time in passes a / b
     for (int r = wid; r < a.n_pad; r += nw) {
         const int gi = (r < n_out && r < kMaxCols) ? s.rev[r] : -1;
@@ -656,6 +673,49 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             // an output column's word are then a contiguous run: independent, pipelined LDS reads
             char *stage = reinterpret_cast<char *>(s.A + __builtin_amdgcn_readfirstlane((int)s.pos_sorted[ia]) * L);
             float sa[kCellsPerLane], sg[kCellsPerLane];
+            if (scan_ok) {
+                // cell(gj) = sum of a contiguous run of the staged vector -> ONE segmented inclusive scan of the
+                // wave (segments = words, heads precomputed) gives every cell at the last element of its run:
+                // lane l owns the sorted indices 4l..4l+3, 6 shuffle steps across lanes.  Only additions inside
+                // a segment (no prefix differences): fp32 like the sequential sum, tree order.
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < kCellsPerLane; ++k)
+                        if (qok[k]) *reinterpret_cast<float *>(stage + qsidx4[k]) = pass ? csg[k] : csa[k];
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4 v4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (4 * lane < L) v4 = *reinterpret_cast<const f32x4 *>(stage + 16 * lane);
+                    float s0 = v4.x;
+                    float s1 = (hd & 2) ? v4.y : s0 + v4.y;
+                    float s2 = (hd & 4) ? v4.z : s1 + v4.z;
+                    float s3 = (hd & 8) ? v4.w : s2 + v4.w;
+                    float run = s3;                                 // sum since the last head of this lane (or of all four)
+                    int fl = hd != 0;
+#pragma unroll
+                    for (int d = 1; d < SN_WAVE; d <<= 1) {
+                        const float up = __shfl_up(run, d, SN_WAVE);
+                        const int fup = __shfl_up(fl, d, SN_WAVE);
+                        if (lane >= d) { run = fl ? run : run + up; fl |= fup; }
+                    }
+                    float carry = __shfl_up(run, 1, SN_WAVE);       // running sum that reaches into this lane
+                    if (lane == 0) carry = 0.0f;
+                    v4.x = (hd & 1) ? s0 : s0 + carry;
+                    v4.y = (hd & 3) ? s1 : s1 + carry;
+                    v4.z = (hd & 7) ? s2 : s2 + carry;
+                    v4.w = (hd & 15) ? s3 : s3 + carry;
+                    __builtin_amdgcn_wave_barrier();
+                    if (4 * lane < L) *reinterpret_cast<f32x4 *>(stage + 16 * lane) = v4;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < kCellsPerLane; ++k) {
+                        const int last = cc.cnt[k] > 0 ? cc.ja[k] + cc.cnt[k] - 1 : 0;
+                        const float v = *reinterpret_cast<const float *>(stage + last * 4);
+                        if (pass) sg[k] = v; else sa[k] = v;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 __builtin_amdgcn_wave_barrier();
@@ -675,6 +735,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     if (pass) sg[k] = acc; else sa[k] = acc;
                 }
             }
+            }
             if (stamps) { dt_a += ts1 - ts0; dt_b += __builtin_amdgcn_s_memtime() - ts1; }
 #pragma unroll
             for (int k = 0; k < kCellsPerLane; ++k) {
@@ -682,12 +743,13 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 c0[k] = has ? sg[k] : 0.0f;
                 c1[k] = has ? sa[k] : 0.0f;
             }
-            if (a.mean) {                                    // wave-uniform
+            if (a.mean) {                                    // wave-uniform; 1 / (rows x columns) as two reciprocals (2 ulp)
+                const float rr = 1.0f / (float)(ib - ia);
 #pragma unroll
                 for (int k = 0; k < kCellsPerLane; ++k) {
-                    const float nn = (float)((ib - ia) * (cc.cnt[k] > 0 ? cc.cnt[k] : 1));
-                    c0[k] = c0[k] / nn;
-                    c1[k] = c1[k] / nn;
+                    const float inv = rr * rcnt[k];
+                    c0[k] = c0[k] * inv;
+                    c1[k] = c1[k] * inv;
                 }
             }
         } else {                                             // padding row: zeros, nothing to normalise
