@@ -912,28 +912,31 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
         asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
         advance(d_o, d_i, 16);
     };
+    if (tid < 4 * NT * 2 * 4) hnl[tid] = *reinterpret_cast<const f32x4 *>(hn2 + tid * 4);    // |c|^2/2: LDS, re-read per accumulator chain
+    float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
+    float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
+    asm volatile("" : "+v"(C2), "+v"(C1), "+v"(CN), "+v"(CMAX));       // every ordinary load is consumed here, before ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... anything below is in flight (hipcc would drain it with vmcnt(0) at the first use)
     for (int hs = 0; hs < 4 && hs < 2 * ns; ++hs) issue_half(hs);
 
-    // ---- this wave's quarter of the codebook -> registers (stays there)
+    // ---- this wave's quarter of the codebook -> registers (stays there).  The NT KS loads are issued here,
+    // tile by tile, and NOT waited for: 400 KB per CU out of L2 takes ~15 k cycles; the first set starts
+    // on tile 0 as soon as its fragments are in and waits per tile (counted vmcnt, first iteration below).
     half8 A[NT][KS];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
-        for (int j = 0; j < KS; ++j)
-            A[a][j] = *reinterpret_cast<const half8 *>(frag2 + ((size_t)(wid * NT + a) * KS + j) * 1024 + lane * 16);
-    }
-    if (tid < 4 * NT * 2 * 4) hnl[tid] = *reinterpret_cast<const f32x4 *>(hn2 + tid * 4);    // |c|^2/2: LDS, re-read per accumulator chain
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-#pragma unroll
         for (int j = 0; j < KS; ++j) {
-            if (a * KS + j < NA) asm volatile("" : "+a"(A[a][j]));
-            else asm volatile("" : "+v"(A[a][j]));
+            const unsigned char *src = frag2 + ((size_t)(wid * NT + a) * KS + j) * 1024 + lane * 16;
+            if (a * KS + j < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(A[a][j]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(A[a][j]) : "v"(src) : "memory");
         }
     }
+    constexpr int kLoads = NT * KS;
+    // loads of tile a' <= a have landed when at most kLoads - KS (a + 1) operations are outstanding (younger
+    // operations only make this stricter); the counter saturates at 63
+    constexpr auto a_wait = [](int a) constexpr { return kLoads - KS * (a + 1) < 63 ? kLoads - KS * (a + 1) : 63; };
     const f32x4 *hn_w = hnl + (wid * NT * 2 + hh) * 4;           // tile a: hn_w[8 a + i], i = 0..3: accumulator registers 4 i .. 4 i + 3
-    const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
-    const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
 
     // ---- CVT: raw half set -> fp16 B fragments of chunks wid, wid + 4, ... (+ Gram diagonal = |x~|^2).
     // Lane (tau, g) converts the floats {4g..4g+3, 16+4g..16+4g+3} of the chunk: k-step 2 c + (g >> 1), row half g & 1.
@@ -1032,8 +1035,8 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
         }
     };
 
-    // ---- prologue: sets 0, 1 in flight, codebook in registers, set 0 converted
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue: sets 0, 1 landed (their DMA is older than the fragment loads), set 0 converted
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLoads < 63 ? kLoads : 63) : "memory");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1089,7 +1092,8 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
     // ---- main loop.  Everything except the DMA issue runs unconditionally (no per-step branches):
     // in the first iterations the "previous" keys are kBigKey, CMP / FLG are predicated off by `en`,
     // in the last one CVT converts stale slots nobody reads.
-    for (int it = 0; it < ns; ++it) {
+    auto body = [&](auto first_c, const int it) {
+        constexpr bool FIRST = decltype(first_c)::value;        // iteration 0: the fragment loads are still in flight
         const bool do_dma = it + 2 < ns;
         const unsigned char *fb = frag + (it & 1) * kSetFrag + lane * 16;
         bq[0] = *reinterpret_cast<const half8 *>(fb);
@@ -1103,6 +1107,7 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
             constexpr int st = decltype(st_c)::value;
             constexpr int a = st / KS, j = st % KS;
             constexpr int pa = (a + NT - 1) % NT;                    // the tile whose accumulators are being keyed
+            if (FIRST && j == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(a_wait(a)) : "memory");     // this tile's fragments are in
             if (st == KS) publish(it - 1);                           // (keys of set it-1 ended with the previous tile phase)
             // key halves of this step: half index hi = 2 * value + (0: A, 1: B), hi -> k-step kKeyStart + hi * kKeySteps / 32
             constexpr int lo = j < kKeyStart || j > kKeyEnd ? 0 : ((j - kKeyStart) * 32 + kKeySteps - 1) / kKeySteps;
@@ -1131,8 +1136,9 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
             if (st == at(9) && wid == (it & 3)) win_do(it);
             if (st == at(6) && wid == ((it + 2) & 3)) flag_read(it - 3);
             if (st == at(9) && wid == ((it + 2) & 3)) flag_do(it - 3, it >= 3);
-            if (st == at(12) && do_dma) issue_half(2 * it + 4);
-            if (st == at(15) && do_dma) issue_half(2 * it + 5);
+            // (first iteration: behind the last fragment wait, so that the counted waits see only fragment loads)
+            if (st == (FIRST ? (NT - 1) * KS + 1 : at(12)) && do_dma) issue_half(2 * it + 4);
+            if (st == (FIRST ? (NT - 1) * KS + 3 : at(15)) && do_dma) issue_half(2 * it + 5);
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
@@ -1146,7 +1152,10 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
         });
         if (p.stamps) t_top += __builtin_amdgcn_s_memtime() - tt0;
         end_of_iteration();
-    }
+    };
+    if (ns > 0) body(std::true_type{}, 0);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int it = 1; it < ns; ++it) body(std::false_type{}, it);
     // ---- drain: keys of the very last tile, then the compare / flag stages of the last sets
     for (int it = ns; it < ns + 3 && ns > 0; ++it) {
         if (it == ns) {
