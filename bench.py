@@ -11,8 +11,9 @@ One "step" = one pass of the hot path over one batch that is already resident in
   softmax, grouping, normalise fused)--> padded instance graphs
   IR-Atlas normalise (K=100, n_max=512) --S4--> GCN on instances and on the atlas --> pred [B,100]
 Nothing is cached across steps (the atlas GCN is recomputed every step, like the reference).
-The K timed steps replay ONE captured hipGraph of the step (schema_inference.utils.graph_replay:
-same kernels, same buffers, no host launch path in the timed region; `"launch": "hipgraph"`); a
+The K timed steps replay captured hipGraphs of the step (schema_inference.utils.graph_replay: same kernels,
+no host launch path in the timed region), two steps in flight on two streams (independent batches; each capture
+has its own buffers; `SN_BENCH_DEPTH=1` replays one graph back to back); a
 second, untimed pass of K eager steps with HIP events on the launch stream gives the per-kernel
 durations of the roofline figure (`SN_BENCH_EAGER=1` times the eager loop instead).
 Workload = BASELINE.json configs[1]: DeiT-Small + CIFAR-100, B=256 per GPU, 512-word codebook.
@@ -122,8 +123,8 @@ def cpu_baseline(tokens, codebook, attn, sn, m, n_img=B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -178,10 +179,13 @@ def main():
         graphed = None
         if os.environ.get("SN_BENCH_EAGER", "0") != "1":
             try:
-                from schema_inference.utils.graph_replay import GraphedStep
-                graphed = GraphedStep(one_step)          # capture (outside the timed region)
-                graphed.replay()
-                launch = "hipgraph"
+                from schema_inference.utils.graph_replay import PipelinedSteps
+                depth = int(os.environ.get("SN_BENCH_DEPTH", "2"))
+                graphed = PipelinedSteps(one_step, depth)   # capture (outside the timed region)
+                for _ in range(depth):
+                    graphed.submit()
+                graphed.join()
+                launch = f"hipgraph, {depth} steps in flight" if depth > 1 else "hipgraph"
             except Exception as exc:                     # noqa: BLE001 - fall back to eager launches, and say so
                 print(f"bench: hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
                 graphed = None
@@ -190,9 +194,11 @@ def main():
         t0 = time.perf_counter()
         for s in range(args.steps):
             if graphed is not None:
-                graphed.replay()
+                graphed.submit()
             else:
                 one_step()
+        if graphed is not None:
+            graphed.join()
         if use_dist:
             dist.all_reduce(votes)                       # per-class schema statistics over RCCL
         barrier()

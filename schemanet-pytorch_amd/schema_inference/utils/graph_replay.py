@@ -29,3 +29,30 @@ class GraphedStep:
     def replay(self):
         self.graph.replay()
         return self.outputs
+
+
+class PipelinedSteps:
+    """`depth` independent captures of the same step, replayed round-robin on `depth` HIP streams: batch i+1
+    starts while batch i is still in its tail (most kernels of the step fill every CU's LDS on their own, so one
+    graph alone leaves the chip idle at every kernel boundary and during the narrow kernels).  Every capture has
+    its own buffers; `fn` must only share read-only state and commutative accumulators (atomic adds) between
+    calls.  `submit()` returns the outputs of the capture it replayed - valid after `join()` or after the next
+    `submit()` on the same slot has been ordered behind a reader."""
+
+    def __init__(self, fn, depth: int = 2):
+        self.steps = [GraphedStep(fn) for _ in range(depth)]
+        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.i = 0
+
+    def submit(self):
+        k = self.i % len(self.steps)
+        self.i += 1
+        if self.i <= len(self.steps):                        # first use of the slot: behind whatever produced the inputs
+            self.streams[k].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.streams[k]):
+            self.steps[k].graph.replay()
+        return self.steps[k].outputs
+
+    def join(self):
+        for st in self.streams:
+            torch.cuda.current_stream().wait_stream(st)

@@ -45,3 +45,25 @@ with torch.no_grad():
             g.replay()
         torch.cuda.synchronize()
         print("graph replay x%d: %.3f ms/step" % (n, (time.perf_counter() - t0) / n * 1e3), flush=True)
+
+# ---- two steps in flight: two captured graphs replayed alternately on two streams
+from schema_inference.utils.graph_replay import GraphedStep
+with torch.no_grad():
+    def one():
+        p_ = bench.step(disc, sn, m, tokens, attn)
+        ops.class_votes_(p_, votes)
+        return p_
+    NG = int(os.environ.get('SN_NG', '2'))
+    gs = [GraphedStep(one) for _ in range(NG)]
+    streams = [torch.cuda.Stream() for _ in range(NG)]
+    torch.cuda.synchronize()
+    for n in (30, 100):
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        t0 = time.perf_counter()
+        for i in range(n):
+            with torch.cuda.stream(streams[i % NG]):
+                gs[i % NG].replay()
+        torch.cuda.synchronize()
+        print(f"{NG} graphs on {NG} streams " "x%d: %.3f ms/step" % (n, (time.perf_counter() - t0) / n * 1e3), flush=True)
+    print("equal:", bool(torch.equal(gs[0].outputs, pred_e)), bool(torch.equal(gs[1].outputs, pred_e)))
