@@ -53,7 +53,7 @@ constexpr int kTokPerWave = 32;
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
 constexpr int kCodeBytes = 24;          // per-token candidate record: one key code per candidate slot
-constexpr int kWsPerToken = 4 + kCodeBytes + 4;   // flag word + codes + overflow-list slot
+// workspace per token: token-stationary records = flag word + 24 code bytes + overflow-list slot (32 B)
 constexpr int kWsPerToken2 = 4 + 32 + 4;          // screen2 records: flag word + 8 code dwords + overflow-list slot
 constexpr int kMaxTilesScreen = 64;     // 6-bit tile code in the keys -> M <= 2048 on the MFMA path
 constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
