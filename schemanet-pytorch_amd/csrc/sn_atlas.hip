@@ -48,7 +48,12 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
     // lane per load, all loads of a 256-column chunk in flight before the first use
     if (!ce && (n & 3) == 0) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const int i0 = blockIdx.y * kRowsPerBlock + wid * 4;
+        // keep masks as all-ones / zero words: pruning is one v_and per element, "did anything change" one compare
+        unsigned rowk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rowk[q] = (!use_prune || (i0 + q < n && keep[i0 + q])) ? 0xFFFFFFFFu : 0u;
         float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int j0 = 0; j0 < n; j0 += 256) {
             const int j = j0 + lane * 4;
@@ -59,23 +64,21 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
                 const int i = i0 + q < n ? i0 + q : n - 1;
                 x[q] = *reinterpret_cast<const f32x4 *>(ew + ((int64_t)k * n + i) * n + (in ? j : 0));
             }
+            u32x4 colk = {0u, 0u, 0u, 0u};
+            if (in) {
+                const unsigned k4 = *reinterpret_cast<const unsigned *>(keep + j);          // four keep bytes (0 / 1)
+                colk = u32x4{(k4 & 1u) ? ~0u : 0u, (k4 & 0x100u) ? ~0u : 0u, (k4 & 0x10000u) ? ~0u : 0u, (k4 & 0x1000000u) ? ~0u : 0u};
+                if (!use_prune) colk = u32x4{~0u, ~0u, ~0u, ~0u};
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int i = i0 + q;
-                if (i >= n || !in) continue;
-                const bool keep_i = keep[i] != 0;
-                bool dirty = false;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = x[q][e];
-                    if (use_prune && !(keep_i && keep[j + e])) {
-                        dirty = dirty || v != 0.0f || v != v;
-                        v = 0.0f;
-                        x[q][e] = 0.0f;
-                    }
-                    s[q] += fmaxf(v, 0.0f);
-                }
-                if (dirty) *reinterpret_cast<f32x4 *>(ew + ((int64_t)k * n + i) * n + j) = x[q];   // masked_fill_(~mask, 0)  :164
+                const u32x4 raw = __builtin_bit_cast(u32x4, x[q]);
+                const u32x4 kept = raw & colk & rowk[q];                                    // masked_fill_(~mask, 0)  :164
+                const f32x4 v = __builtin_bit_cast(f32x4, kept);
+                s[q] += (fmaxf(v[0], 0.0f) + fmaxf(v[1], 0.0f)) + (fmaxf(v[2], 0.0f) + fmaxf(v[3], 0.0f));
+                const u32x4 diff = raw ^ kept;
+                if (in && i0 + q < n && ((diff[0] | diff[1]) | (diff[2] | diff[3])) != 0u)
+                    *reinterpret_cast<f32x4 *>(ew + ((int64_t)k * n + i0 + q) * n + j) = v;
             }
         }
 #pragma unroll
