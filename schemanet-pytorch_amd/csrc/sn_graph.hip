@@ -580,7 +580,10 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     SN_GSTAMP(4);
     // ---- edges: one wave per output row, lanes over output columns
     // (large_scale_feat_to_e.cpp:90-140)
-    const float w0 = a.w_e[0], w1 = a.w_e[1];
+    // (read into scalar registers HERE: left as pending vector loads, hipcc waits with vmcnt(0) at every use in
+    // the row loop, i.e. for the previous row's stores, before each store)
+    const float w0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.w_e[0])));
+    const float w1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.w_e[1])));
     int gcol[kCellsPerLane];
 #pragma unroll
     for (int k = 0; k < kCellsPerLane; ++k) {
@@ -624,6 +627,17 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             bool head = true;
             if (i > 0 && i < n_kept) head = s.words[s.pos_sorted[i]] != s.words[s.pos_sorted[i - 1]];
             hd |= head ? (1u << e) : 0u;
+        }
+    }
+    // step i of the cross-lane scan adds the value 2^i lanes below iff no head has been seen in between: the flag
+    // half of the segmented scan depends on the heads only, so it is run once here
+    unsigned take = 0;
+    if (scan_ok) {
+        int fl = hd != 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int fup = __shfl_up(fl, 1 << i, SN_WAVE);
+            if (lane >= (1 << i)) { take |= fl ? 0u : (1u << i); fl |= fup; }
         }
     }
     float rcnt[kCellsPerLane];                             // 1 / (positions of the column's word)
@@ -692,12 +706,10 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     float s2 = (hd & 4) ? v4.z : s1 + v4.z;
                     float s3 = (hd & 8) ? v4.w : s2 + v4.w;
                     float run = s3;                                 // sum since the last head of this lane (or of all four)
-                    int fl = hd != 0;
 #pragma unroll
-                    for (int d = 1; d < SN_WAVE; d <<= 1) {
-                        const float up = __shfl_up(run, d, SN_WAVE);
-                        const int fup = __shfl_up(fl, d, SN_WAVE);
-                        if (lane >= d) { run = fl ? run : run + up; fl |= fup; }
+                    for (int i = 0; i < 6; ++i) {                   // (which steps add is the same for every row: `take`)
+                        const float up = __shfl_up(run, 1 << i, SN_WAVE);
+                        run = ((take >> i) & 1u) ? run + up : run;
                     }
                     float carry = __shfl_up(run, 1, SN_WAVE);       // running sum that reaches into this lane
                     if (lane == 0) carry = 0.0f;
