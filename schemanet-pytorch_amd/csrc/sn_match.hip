@@ -151,12 +151,12 @@ __global__ __launch_bounds__(256) void pool_fc_kernel(const float *pooled, int p
     const int g = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int o0 = blockIdx.y * kScoreCols + wid * 4;
     if (o0 >= E_out) return;
-    const float div = div_dev ? (float)div_dev[0] : div_host;
+    const float rdiv = 1.0f / (div_dev ? (float)div_dev[0] : div_host);     // one reciprocal (the kernel is instruction-bound: 1 ulp vs a division per element)
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int c = lane; c < E; c += SN_WAVE) {
         float ps = pooled[((int64_t)g * parts) * E + c];
         for (int t = 1; t < parts; ++t) ps += pooled[((int64_t)g * parts + t) * E + c];     // fixed order
-        const float x = ps / div;
+        const float x = ps * rdiv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int o = o0 + j < E_out ? o0 + j : E_out - 1;
