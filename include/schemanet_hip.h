@@ -98,6 +98,15 @@ int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_
                     void *workspace, size_t workspace_bytes, int mode, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * training loss, sparsity terms
+ * replaces: entropy(p) = -sum(p * log(p + eps), dim=-1)   schema_inference/loss/schema_inference_loss.py:51-58
+ * p [rows, n] contiguous (class_vertices [K, n] or class_edges viewed as [K n, n]).
+ * ------------------------------------------------------------------------------------------ */
+int sn_row_entropy(const float *p, int64_t rows, int n, float eps, float *entropy, void *stream);
+/* grad_p[r][j] = -grad_entropy[r] * (log(p + eps) + p / (p + eps)); rows with grad_entropy[r] == 0 are zero-filled without reading p. */
+int sn_row_entropy_backward(const float *p, const float *grad_entropy, int64_t rows, int n, float eps, float *grad_p, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * codebook extraction: Lloyd's k-means with sn_assign_words as the E-step
  * replaces: scipy.cluster.vq.kmeans(x, num_clusters)   scripts/extract_ingredients.py:33-36
  * (SciPy float32 path: scipy/cluster/vq.py::_kmeans, _vq.update_cluster_means).

@@ -262,3 +262,27 @@ def kmeans_lloyd(obs, guess, thresh=1e-5, max_iter=10_000):
         diff = abs(prev[0] - prev[1])
         it += 1
     return book, prev[1], it
+
+
+# ------------------------------------------------------------------------------- training loss
+def row_entropy(p, eps=1.0e-7):
+    """-sum(p * log(p + eps), -1) in float64 (reference schema_inference_loss.py:51-58)."""
+    p = np.asarray(p, np.float64)
+    return -(p * np.log(p + eps)).sum(-1)
+
+
+def row_entropy_grad(p, g, eps=1.0e-7):
+    p = np.asarray(p, np.float64)
+    return -np.asarray(g, np.float64)[..., None] * (np.log(p + eps) + p / (p + eps))
+
+
+def schema_inference_loss(pred, label, class_vertices, class_edges, a_vertex=3.0, a_edge=3.0):
+    """reference SchemaInferenceLoss.forward (schema_inference_loss.py:21-47), float64."""
+    pred = np.asarray(pred, np.float64)
+    z = pred - pred.max(1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    cls = -logp[np.arange(len(label)), np.asarray(label)].mean()
+    ev = row_entropy(class_vertices).max(0)
+    ee = row_entropy(class_edges).max(1).mean()
+    rect = lambda x, a: x if x > a else a - 1 + 1.0 / (1 + a - x)  # noqa: E731
+    return {"cls": cls, "entropy_vertex": ev, "entropy_edge": ee, "re_entropy_vertex": rect(ev, a_vertex), "re_entropy_edge": rect(ee, a_edge)}

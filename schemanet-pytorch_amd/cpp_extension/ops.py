@@ -112,6 +112,46 @@ def kmeans_distances(tokens, ids, centres):
     return dist
 
 
+# ------------------------------------------------------------------------------- training loss
+class _RowEntropy(torch.autograd.Function):
+    """entropy over the last dimension, -sum(p * log(p + eps)) (reference schema_inference_loss.py:51-58), one
+    pass forward; the backward recomputes log(p + eps) instead of keeping it and skips rows whose upstream
+    gradient is zero."""
+
+    @staticmethod
+    def forward(ctx, p, eps):
+        lib = N.require_gpu()
+        dev = _check_dev(p)
+        pc = _f32c(p)
+        n = pc.shape[-1]
+        rows = pc.numel() // n
+        ent = torch.empty(pc.shape[:-1], dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_row_entropy(N.ptr(pc), rows, n, float(eps), N.ptr(ent), N.stream_ptr(dev)), "sn_row_entropy")
+        ctx.save_for_backward(pc)
+        ctx.eps = float(eps)
+        return ent
+
+    @staticmethod
+    def backward(ctx, g):
+        (pc,) = ctx.saved_tensors
+        lib = N.require_gpu()
+        dev = pc.device
+        n = pc.shape[-1]
+        rows = pc.numel() // n
+        gc = _f32c(g)
+        grad = torch.empty_like(pc)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_row_entropy_backward(N.ptr(pc), N.ptr(gc), rows, n, ctx.eps, N.ptr(grad), N.stream_ptr(dev)),
+                    "sn_row_entropy_backward")
+        return grad, None
+
+
+def row_entropy(p, eps=1.0e-7):
+    """-sum(p * log(p + eps), dim=-1) with autograd (CUDA tensors)."""
+    return _RowEntropy.apply(p, eps)
+
+
 # ------------------------------------------------------------------------------- wrapper taps
 def head_mean_attention(extracted, bs):
     """extracted [bs*H, L+1, L+1] -> (attn [bs, L, L], attn_cls [bs, L])."""

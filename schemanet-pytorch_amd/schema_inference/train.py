@@ -1,0 +1,53 @@
+"""The training step of the reference's SchemaNet trainer as a function (reference
+schema_inference/tasks/worker_schema_net.py:121-147 `train_iter`, :371-378 parameter groups), so that config 5
+(`4.train_schema_net.sh`) can be driven without the reference's launcher / logging / checkpoint loop:
+
+    optimizer.zero_grad(); schema_net.normalize(); output = predictor(x)
+    loss = sum(loss_weights[k.split(".")[0]] * v for k, v in loss_fn(output, targets).items() if the prefix has a weight)
+    loss.backward(); optimizer.step(); optimizer.zero_grad(set_to_none=True)
+
+With autograd enabled the modules of this package run their differentiable route (HIP forward of S1 and of the
+instance graph with gradients to the attribute weights, torch ops for the GCN); the sparsity terms of the loss use
+the HIP row-entropy kernels."""
+import re
+from collections import OrderedDict
+from typing import Any, Callable, Dict, Iterable, List, Tuple
+
+import torch
+import torch.nn as nn
+
+
+def param_groups(named_parameters: Iterable[Tuple[str, nn.Parameter]], groups: List[Dict[str, Any]],
+                 drop_remain: bool = False) -> List[Dict[str, Any]]:
+    """reference utils/customs_param_group.py: every group takes the not-yet-taken parameters whose name matches its
+    regular expression (re.match, sorted names) and carries its `cfg` as optimizer options; the rest form a last
+    group unless `drop_remain`."""
+    left = OrderedDict(named_parameters)
+    out = []
+    for group in groups:
+        names = [n for n in sorted(left) if re.match(group["pattern"], n)]
+        if not names:
+            raise AssertionError("no matched for pattern {}".format(group["pattern"]))
+        out.append(dict(params=[left.pop(n) for n in names], **group.get("cfg", dict())))
+    if left and not drop_remain:
+        out.append(dict(params=list(left.values())))
+    return out
+
+
+def weighted_total(loss_dict: Dict[str, torch.Tensor], loss_weights: Dict[str, float]) -> torch.Tensor:
+    return sum(v * loss_weights[k.split(".")[0]] for k, v in loss_dict.items() if k.split(".")[0] in loss_weights)
+
+
+def train_iter(forward: Callable[[], Dict[str, torch.Tensor]], schema_net, loss_fn, loss_weights: Dict[str, float],
+               optimizer: torch.optim.Optimizer, targets: Dict[str, torch.Tensor]):
+    """One optimisation step.  `forward()` runs the predictor on the batch (e.g. `lambda: predictor(x)`) and returns
+    its output dictionary (`pred`, `class_vertices`, `class_edges`, ...).  -> (total loss (detached), loss dict)."""
+    optimizer.zero_grad()
+    schema_net.normalize()
+    output = forward()
+    loss_dict = loss_fn(output, targets)
+    loss = weighted_total(loss_dict, loss_weights)
+    loss.backward()
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), OrderedDict((k, v.detach()) for k, v in loss_dict.items())

@@ -206,3 +206,17 @@ def test_kmeans_oracle_equals_scipy(seed, k, D, N, dup):
     assert got.dtype == np.float32 and got.shape == want.shape and (not dup or got.shape[0] == k - 1)
     assert np.array_equal(got, want)
     assert abs(got_dist - float(want_dist)) <= 1e-5 * float(want_dist) and iters >= 2
+
+
+def test_loss_oracle_matches_reference_fixture(golden):
+    """The loss restatement against the loss terms the real reference produced for the train-step fixture
+    (atlas = normalize() then get_atlas() of the fixture's SchemaNet state, both restated in numpy)."""
+    g = golden("train_step.npz")
+    vw = np.clip(g["sn:vertex_weights.tensor"], 0.0, None)
+    vw = np.nan_to_num(vw / vw.sum(-1, keepdims=True))                      # SchemaNet.normalize: normalize_sum_ after clamp_min(0)
+    ew = np.clip(g["sn:edge_weights.tensor"], 0.0, None)
+    ew = np.nan_to_num(ew / ew.sum(-1, keepdims=True))
+    cv, ce, _ = pyops.get_atlas(vw.astype(np.float32), ew.astype(np.float32), 0.001)
+    got = pyops.schema_inference_loss(g["pred"], g["label"], cv, ce)
+    for k, v in got.items():
+        np.testing.assert_allclose(v, g["loss:" + k], rtol=2e-5, err_msg=k)

@@ -51,9 +51,13 @@ pkg, ref = sys.argv[1] + "/schemanet-pytorch_amd", "/root/reference"
 sys.path[:0] = [pkg, ref]                                  # ours first, the reference behind (INTEGRATION.md level 2)
 import schema_inference.graph as g, discretization, cpp_extension
 assert g.__file__.startswith(pkg) and discretization.__file__.startswith(pkg) and cpp_extension.__file__.startswith(pkg)
-from schema_inference.loss.schema_inference_loss import SchemaInferenceLoss       # resolved in the reference checkout
-import schema_inference.loss as L
-assert L.__file__.startswith(ref), L.__file__
+import schema_inference.loss as L                                                 # ours (HIP row entropies), same names as the reference's
+assert L.__file__.startswith(pkg), L.__file__
+assert {"Loss", "CELoss", "SchemaInferenceLoss", "get_loss_fn"} <= set(dir(L))
+from schema_inference.loss.schema_inference_loss import SchemaInferenceLoss as RefLoss   # a submodule path still resolves in the reference checkout
+assert RefLoss.__module__ == "schema_inference.loss.schema_inference_loss" and RefLoss is not L.SchemaInferenceLoss
+import schema_inference.tasks                                                     # not re-implemented: the reference's package
+assert schema_inference.tasks.__path__[0].startswith(ref)
 from schema_inference.utils import IngredientModelWrapper
 assert sys.modules["schema_inference.utils"].__file__.startswith(pkg)
 # cv_lib-dependent helpers are resolved lazily from the reference (stub cv_lib like the oracle does)
