@@ -117,6 +117,11 @@ int sn_row_entropy_backward(const float *p, const float *grad_entropy, int64_t r
 int sn_kmeans_update(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer, int64_t x_stride_inner,
                      const int64_t *ids, int64_t ids_stride_outer, int64_t ids_stride_inner, int K, int D,
                      float *sums, int64_t *counts, void *stream);
+/* The same from a token order grouped by centre: order[offsets[k] .. offsets[k+1]) = flat token indices of centre k
+ * in token order (a stable sort of the ids), offsets int64 [K + 1].  No walk over the id stream. */
+int sn_kmeans_update_sorted(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer, int64_t x_stride_inner,
+                            const int64_t *order, const int64_t *offsets, int K, int D, float *sums, int64_t *counts,
+                            void *stream);
 /* dist[t] = |x_t - centres[ids[t]]|_2 in fp64 (t = flat token index); its mean is SciPy's distortion. */
 int sn_kmeans_distances(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer, int64_t x_stride_inner,
                         const int64_t *ids, int64_t ids_stride_outer, int64_t ids_stride_inner, const float *centres,

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "sn_row_entropy_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "sn_kmeans_update": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p]),
+    "sn_kmeans_update_sorted": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p]),
     "sn_kmeans_distances": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                     c_int, c_int, c_void_p, c_void_p]),
     "sn_head_mean_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -77,10 +77,12 @@ def assign_words(tokens, codebook, packed, out=None, mode=0):
     return out
 
 
-def kmeans_update(tokens, ids, K):
+def kmeans_update(tokens, ids, K, sorted_route=True):
     """M-step of Lloyd's k-means.  tokens [n_outer, n_inner, D] f32 view, ids int64 [n_outer, n_inner]
     (the output of assign_words).  -> (sums f32 [K, D], counts int64 [K]): per-centre member sums added in
-    token order (bit-identical to SciPy's float32 update) and member counts."""
+    token order (bit-identical to SciPy's float32 update) and member counts.  sorted_route: a stable sort of
+    the ids groups the tokens by centre first (sn_kmeans_update_sorted), otherwise every workgroup walks the id
+    stream (sn_kmeans_update); same result."""
     lib = N.require_gpu()
     dev = _check_dev(tokens, ids)
     if tokens.dtype != torch.float32 or tokens.stride(-1) != 1:
@@ -90,8 +92,16 @@ def kmeans_update(tokens, ids, K):
     sums = torch.empty((K, D), dtype=torch.float32, device=dev)
     counts = torch.empty((K,), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        N.check(lib.sn_kmeans_update(N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(ids), ids.stride(0),
-                                     ids.stride(1), K, D, N.ptr(sums), N.ptr(counts), N.stream_ptr(dev)), "sn_kmeans_update")
+        if sorted_route:
+            flat = ids.reshape(-1)
+            order = torch.sort(flat, stable=True).indices
+            offsets = torch.zeros(K + 1, dtype=torch.int64, device=dev)
+            offsets[1:] = torch.cumsum(torch.bincount(flat.clamp(0, K - 1), minlength=K), 0)
+            N.check(lib.sn_kmeans_update_sorted(N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(order),
+                                                N.ptr(offsets), K, D, N.ptr(sums), N.ptr(counts), N.stream_ptr(dev)), "sn_kmeans_update_sorted")
+        else:
+            N.check(lib.sn_kmeans_update(N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(ids), ids.stride(0),
+                                         ids.stride(1), K, D, N.ptr(sums), N.ptr(counts), N.stream_ptr(dev)), "sn_kmeans_update")
     return sums, counts
 
 

@@ -17,7 +17,8 @@ book, avg, it = km.lloyd(x, guess, 1e-5, max_iter=20)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"GPU: {it} Lloyd iterations in {dt*1e3:.1f} ms = {dt/it*1e3:.2f} ms per iteration ({x.shape[0]} tokens, k={bench.M}, D={bench.D}); avg distance {avg:.4f}")
 ids = ops.assign_words(x[None], *ops.PackedCodebook().get(guess))[0]
-for name, fn in (("update", lambda: ops.kmeans_update(x[None], ids[None], bench.M)), ("distances", lambda: ops.kmeans_distances(x[None], ids[None], guess))):
+for name, fn in (("update (stable sort + grouped sums)", lambda: ops.kmeans_update(x[None], ids[None], bench.M, sorted_route=True)),
+                 ("update (every workgroup walks the ids)", lambda: ops.kmeans_update(x[None], ids[None], bench.M, sorted_route=False)), ("distances", lambda: ops.kmeans_distances(x[None], ids[None], guess))):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): fn()
     torch.cuda.synchronize(); print(f"  {name}: {(time.perf_counter()-t0)/10*1e6:.0f} us")
