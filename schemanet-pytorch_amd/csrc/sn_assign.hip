@@ -221,14 +221,18 @@ __device__ __forceinline__ void stamp(const AssignArgs &p, int slot, int lane, i
 }
 
 static unsigned long long *g_stamps = nullptr;
+// (n_tokens < 2^31 is enforced by sn_assign_words: 32-bit quotient / remainder; a vector 64-bit divide is ~150
+// instructions and these run once per lane)
 __device__ __forceinline__ const float *token_row(const AssignArgs &p, int64_t n)
 {
-    return p.x + (n / p.n_inner) * p.xso + (n % p.n_inner) * p.xsi;
+    const unsigned ni = (unsigned)p.n_inner, o = (unsigned)n / ni, i = (unsigned)n - o * ni;
+    return p.x + (int64_t)o * p.xso + (int64_t)i * p.xsi;
 }
 
 __device__ __forceinline__ int64_t out_index(const AssignArgs &p, int64_t n)
 {
-    return (n / p.n_inner) * p.oso + (n % p.n_inner) * p.osi;
+    const unsigned ni = (unsigned)p.n_inner, o = (unsigned)n / ni, i = (unsigned)n - o * ni;
+    return (int64_t)o * p.oso + (int64_t)i * p.osi;
 }
 
 // exact fp64 scan of words [m0, m1) for one token held in x[]: returns (score, index) with
