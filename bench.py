@@ -83,6 +83,22 @@ def step(disc, sn, m, tokens, attn, class_branch_first=True):
     return m.forward_padded(g, atlas.class_dict, feat_kg=atlas)                  # S4 (instance GNN, join, scores)
 
 
+def stream_copy_GBps(device, n_bytes=1 << 30, reps=5):
+    """On-box HBM ceiling (report both denominators): device-to-device copy of 1 GiB, read + written
+    bytes per second (MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy against the 8 TB/s spec)."""
+    a = torch.empty(n_bytes // 4, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def kernel_times(lib, kid):
     n = lib.sn_profile_count(kid)
     if n == 0:
@@ -240,6 +256,7 @@ def main():
         graph_bytes = B * (L * L * 4 + L * 4 + L * 8) + B * (L * L * 4 + L * 12)   # attn in + padded edges/ids/weights out
         screen_name = ("assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)" if lib.sn_assign_variant() == 2
                        else "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen, token-stationary)")
+        copy_gbps = stream_copy_GBps(device)
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
@@ -261,7 +278,9 @@ def main():
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["assign_screen"]},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["assign_screen"],
+                         "peak_note": "peak = 8.0 TB/s HBM3E spec; copy_GBps = a 1 GiB device-to-device copy on this box (read + write)",
+                         "copy_GBps": copy_gbps, "frac_of_copy": (ach / copy_gbps) if (ach and copy_gbps) else None},
             "kernels_ms": avg,
             "instance_graph_GBps": (graph_bytes / (avg["instance_graph"] * 1e-3) / 1e9) if avg["instance_graph"] else None,
             "stage_ms": dict(zip(("S1_assign", "atlas_branch_enqueue", "S2S3_instance_graph", "S4_instance_gnn_join_scores"), stage_ms)),
