@@ -15,7 +15,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libschemanet_hip.so")
+LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
 ABI_VERSION = 1
 SN_MAX_TOKENS = 196
 _lib = None

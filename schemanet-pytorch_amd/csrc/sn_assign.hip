@@ -36,6 +36,15 @@
 #ifndef SN_EXP_NODMA
 #define SN_EXP_NODMA 0
 #endif
+#ifndef SN_S1_STAGE
+#define SN_S1_STAGE 1       // token rows through LDS in whole cache lines (0: fragment loads straight from global memory)
+#endif
+#ifndef SN_EXP_KEY1
+#define SN_EXP_KEY1 0       // one VALU per value instead of four (timing only)
+#endif
+#ifndef SN_EXP_NOLDSA
+#define SN_EXP_NOLDSA 0     // A fragments are not re-read from LDS (timing only)
+#endif
 #ifndef SN_EXP_NOPHASEA
 #define SN_EXP_NOPHASEA 0
 #endif
@@ -213,7 +222,18 @@ struct AssignArgs {
     // dwords per token (slot c: code_j << 8j, code = tile << 4 | accumulator register)
     unsigned *codes32;
     int64_t n_sets;     // ceil(n_tokens / 32)
+    // token-phase gate of the token-stationary screen (NULL = off): per CU {arrivals, waves whose tokens have
+    // landed}; zeroed before every launch.  See assign_screen_kernel.
+    unsigned *gate;
+    // token -> wave map of the token-stationary screen: waves 0 .. full_waves-1 of workgroup b own the tokens
+    // [32 full_waves b + 32 w, +32); wave `full_waves` (if the workgroup has one) owns [extra_base + 32 b, +32);
+    // waves without tokens only keep the codebook ring going.  Default: full_waves = waves per workgroup.
+    int full_waves;
+    int64_t extra_base;
 };
+
+constexpr int kGateSlots = 4096;        // (XCC_ID[3:0] << 8) | HW_ID[15:8] (CU_ID, SH_ID, SE_ID)
+constexpr size_t kGateBytes = (size_t)kGateSlots * 8;
 
 __device__ __forceinline__ void stamp(const AssignArgs &p, int slot, int lane, int wave_id)
 {
@@ -511,17 +531,33 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     // copies chunks w, w + NW, w + 2 NW, ...: kDmaMin of them, one more on the first kDmaExtra waves.
     constexpr int kDmaMin = kChunks / NW, kDmaExtra = kChunks % NW;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    // wave w copies the contiguous chunks [c0, c0 + kDmaMin (+1 on the first kDmaExtra waves)).  The instruction
+    // offset of global_load_lds moves the LDS address together with the global one, so up to four pieces
+    // (offsets 0, 1, 2, 3 KiB) share one address register pair and one M0 value: one asm statement per group.
+    const int dma_c0 = wid * kDmaMin + (wid < kDmaExtra ? wid : kDmaExtra);
     auto issue_tile = [&](int w, int slot) {
-        const unsigned char *src = tiles + (size_t)w * kTileBytes + wid * 1024 + lane * 16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + wid * 1024);
+        const unsigned char *src = tiles + (size_t)w * kTileBytes + dma_c0 * 1024 + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + dma_c0 * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
 #pragma unroll
-        for (int j = 0; j <= kDmaMin; ++j) {
-            if (j == kDmaMin && (kDmaExtra == 0 || wid >= kDmaExtra)) break;      // wave-uniform
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\t"
-                         "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src + (size_t)j * NW * 1024), "s"(dst + j * NW * 1024) : "memory");
+        for (int j = 0; j < kDmaMin; j += 4) {
+            const unsigned char *sj = src + (size_t)j * 1024;
+            const unsigned dj = dst + j * 1024;
+            if (kDmaMin - j >= 4)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072" :: "v"(sj), "s"(dj) : "memory");
+            else if (kDmaMin - j == 3)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048" :: "v"(sj), "s"(dj) : "memory");
+            else if (kDmaMin - j == 2)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024" :: "v"(sj), "s"(dj) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(sj), "s"(dj) : "memory");
         }
+        if (kDmaExtra != 0 && wid < kDmaExtra)                                    // wave-uniform
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src + (size_t)kDmaMin * 1024), "s"(dst + kDmaMin * 1024) : "memory");
+        asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
     };
     // wait until this wave's copies of all but the newest `ahead` tiles have landed (the first
     // kDmaExtra waves over-wait by up to `ahead` chunks: the immediate must be a constant)
@@ -532,17 +568,116 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     };
     static_assert(R >= 3 && R <= 5, "ring depth");
     const int wave_id = blockIdx.x * NW + wid;
+    const int64_t wave_tok0 = wid < p.full_waves ? (int64_t)blockIdx.x * (kTokPerWave * p.full_waves) + wid * kTokPerWave
+                            : (wid == p.full_waves ? p.extra_base + (int64_t)blockIdx.x * kTokPerWave : p.n_tokens);
+    const bool wave_active = wave_tok0 < p.n_tokens;                        // wave-uniform
     stamp(p, 0, lane, wave_id);
+    if (p.stamps && lane == 0) p.stamps[(size_t)wave_id * 16 + 9] = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+    // ---- token-phase gate.  The token loads are a chip-wide HBM phase during which the matrix pipe idles, and
+    // the MFMA loop afterwards leaves HBM idle.  With two workgroups per CU both phases would run in lockstep on
+    // every CU; instead the a-th workgroup to arrive on a CU loads its tokens only after the a earlier ones
+    // have theirs, so the second workgroup's HBM phase runs under the first one's MFMA loop (and the first
+    // generation gets the whole HBM bandwidth: it starts its MFMA loop earlier).  A workgroup only ever waits
+    // for workgroups that arrived before it on the same CU and those never wait for it: no deadlock.
+    unsigned *gate = nullptr;
+    unsigned arrival = 0;
+    if (p.gate) {
+        const unsigned cu = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4);      // HW_REG_HW_ID[15:8]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);    // HW_REG_XCC_ID[3:0]
+        gate = p.gate + 2 * ((xcc << 8) | cu);
+        if (tid == 0) arrival = atomicAdd(gate, 1u);
+    }
+    if (!SN_S1_STAGE) {
+#pragma unroll
+        for (int t = 0; t < R - 1; ++t)
+            if (t < n_tiles) issue_tile(t, t);
+    }
+    if (p.gate) {
+        if (tid == 0) {
+            const unsigned target = arrival * NW;
+            while (__hip_atomic_load(gate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (p.stamps && tid == 0) { p.stamps[(size_t)wave_id * 16 + 6] = arrival; p.stamps[(size_t)wave_id * 16 + 7] = (unsigned long long)(gate - p.gate) / 2; }
+        stamp(p, 8, lane, wave_id);
+    }
+
+    // ---- this wave's 32 tokens: fp32 -> fp16 B fragments, kept in registers for the whole kernel
+    const int64_t n = wave_tok0 + r;
+    const bool valid = n < p.n_tokens;
+    half8 b[NSTEPS];
+    float sumsq = 0.0f, sumabs = 0.0f, maxabs = 0.0f;
+    auto convert = [&](int u, const float (&f)[16]) {          // 16 consecutive floats of the lane's token -> k-steps 2u, 2u+1
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sumsq = fmaf(f[j], f[j], sumsq);
+            sumabs += fabsf(f[j]);
+            maxabs = fmaxf(maxabs, fabsf(f[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { b[2 * u][j] = (_Float16)f[j]; b[2 * u + 1][j] = (_Float16)f[8 + j]; }
+    };
+#if SN_S1_STAGE
+    // Loading a B fragment straight from global memory makes every wave-instruction touch 64 different cache
+    // lines for 16 bytes each (lane = token row): the L1 tag rate, one line per cycle, then bounds the token
+    // phase at ~11 B/cycle/CU.  Instead the rows come in whole 128-byte lines by LDS-DMA - one chunk = 32 floats
+    // of each of the wave's 32 rows = four 1 KiB instructions, 8 lanes per row - into a per-wave ring of 4 KiB
+    // buffers inside the (still unused) codebook ring, and are read back in fragment order.  The DMA lays lanes
+    // out linearly, so lane (row, slot) fetches piece slot ^ ((row >> 1) & 7) of its row: with that swizzle the
+    // four ds_read_b128 of a lane (row r, pieces 4h..4h+3) are bank-conflict-free.  Only this wave touches its
+    // buffers: counted vmcnt waits, no barrier.
+    constexpr int kU = NSTEPS / 2;                                            // chunks (u-steps) per token
+    constexpr int kBufsFit = (R * kTileBytes / NW) / 4096;
+    constexpr int kStageBufs = kBufsFit < 4 ? kBufsFit : 4;
+    static_assert(kStageBufs >= 2, "token staging needs two 4 KiB buffers per wave inside the codebook ring");
+    const unsigned stage_base = __builtin_amdgcn_readfirstlane(lds_base + wid * (kStageBufs * 4096));
+    const float *rowq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rq = 8 * q + (lane >> 3);
+        const int64_t nq = wave_tok0 + rq;
+        rowq[q] = token_row(p, nq < p.n_tokens ? nq : 0) + 4 * ((lane & 7) ^ ((rq >> 1) & 7));
+    }
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
+    if (wave_active) {
+    auto issue_chunk = [&](int u) {
+        const unsigned dst = stage_base + (u % kStageBufs) * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(rowq[q] + 32 * u), "s"(dst + q * 1024) : "memory");
+    };
+    const unsigned char *frag_src = smem + wid * (kStageBufs * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
+    const int sw = (r >> 1) & 7;
+#pragma unroll
+    for (int u = 0; u < kStageBufs && u < kU; ++u) issue_chunk(u);
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        constexpr int kAheadMax = kStageBufs - 1;
+        const int ahead = (kU - 1 - u) < kAheadMax ? (kU - 1 - u) : kAheadMax;        // chunks issued after chunk u
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f32x4 raw[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            raw[v] = *reinterpret_cast<const f32x4 *>(frag_src + (u % kStageBufs) * 4096 + (((4 * h + v) ^ sw) * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // in registers: the buffer may be refilled
+        if (u + kStageBufs < kU) issue_chunk(u + kStageBufs);
+        const float f[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
+                             raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
+        convert(u, f);
+    }
+    }
+    asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));
+    // the staging buffers are dead: the codebook ring can be primed once every wave is here
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int t = 0; t < R - 1; ++t)
         if (t < n_tiles) issue_tile(t, t);
-
-    // ---- this wave's 32 tokens: fp32 -> fp16 B fragments, kept in registers for the whole kernel
-    const int64_t n = (int64_t)blockIdx.x * (kTokPerWave * NW) + wid * kTokPerWave + r;
-    const bool valid = n < p.n_tokens;
+#else
     const float *row = token_row(p, valid ? n : 0);
-    half8 b[NSTEPS];
-    float sumsq = 0.0f, sumabs = 0.0f, maxabs = 0.0f;
     // all loads of a half-row are issued before the first conversion (the MFMA loop's registers are
     // not live yet, so up to 24 x 16 B per lane can be in flight), in two batches
     constexpr int kHalf = NSTEPS / 4;                 // u-steps per batch
@@ -558,21 +693,15 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int uu = 0; uu < kHalf; ++uu) {
-            const int u = batch * kHalf + uu;
             const float f[16] = {raw[uu][0].x, raw[uu][0].y, raw[uu][0].z, raw[uu][0].w, raw[uu][1].x, raw[uu][1].y,
                                  raw[uu][1].z, raw[uu][1].w, raw[uu][2].x, raw[uu][2].y, raw[uu][2].z, raw[uu][2].w,
                                  raw[uu][3].x, raw[uu][3].y, raw[uu][3].z, raw[uu][3].w};
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                sumsq = fmaf(f[j], f[j], sumsq);
-                sumabs += fabsf(f[j]);
-                maxabs = fmaxf(maxabs, fabsf(f[j]));
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { b[2 * u][j] = (_Float16)f[j]; b[2 * u + 1][j] = (_Float16)f[8 + j]; }
+            convert(batch * kHalf + uu, f);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#endif
+    if (p.gate && lane == 0) atomicAdd(gate + 1, 1u);       // this wave's tokens have landed (result unused: no wait)
     sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
     sumabs += __shfl_xor(sumabs, 32, SN_WAVE);
     maxabs = fmaxf(maxabs, __shfl_xor(maxabs, 32, SN_WAVE));
@@ -630,6 +759,10 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     // MFMA issues (> 64 cycles) after the last MFMA that wrote `v`.
     auto key_insert = [&](float v, unsigned code, int g) {
         unsigned k;
+        if (SN_EXP_KEY1) {      // valid key, best only: two VALU per value
+            asm volatile("v_and_or_b32 %0, %2, %3, %4\n\tv_min_u32 %1, %0, %1" : "=&v"(k), "+v"(m1[g]) : "v"(v), "v"(keymask), "s"(code));
+            return;
+        }
         asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
                      "v_med3_u32 %3, %0, %2, %3\n\t"
                      "v_med3_u32 %2, %0, %1, %2\n\t"
@@ -650,7 +783,8 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
             cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], cur, 0, 0, 0);
-            if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
+            if (SN_EXP_NOLDSA) asm volatile("" : "+v"(ar[s % kRingA]));
+            else if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
             else ar[s % kRingA] = frag_at(w + 1, s + kRingA - NSTEPS);      // (stale slot after the last tile: unused)
             // the 16 accumulators of tile w-1 become keys (w == 0: oth holds +inf, those keys never win)
             if (s >= kKeyStep0 && !SN_EXP_NOKEYS) {
@@ -683,6 +817,17 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (!wave_active) {                   // a wave without tokens: its share of the ring copies and the barriers, nothing else
+        for (int w = 0; w < n_tiles; ++w) {
+            int ahead = n_tiles - 2 - w;
+            ahead = ahead < 0 ? 0 : (ahead > R - 3 ? R - 3 : ahead);
+            wait_tiles(ahead);
+            if (!SN_EXP_NOBARRIER) __builtin_amdgcn_s_barrier();
+            if (w + R - 1 < n_tiles && !SN_EXP_NODMA) issue_tile(w + R - 1, (w + R - 1) % R);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < kRingA; ++q) ar[q] = frag_at(0, q);
 #pragma unroll
@@ -748,6 +893,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     const bool need_b = writer && overflow;
     const unsigned long long mask_b = __ballot(need_b);
     stamp(p, 3, lane, wave_id);
+    if (p.stamps && lane == 0) p.stamps[(size_t)wave_id * 16 + 10] = __builtin_amdgcn_s_memrealtime();
     if (mask_b) {                                          // rare: tokens the screen cannot bound
         int base = 0;
         const int leader = __ffsll((long long)mask_b) - 1;
@@ -1192,6 +1338,28 @@ int launch_exact(const AssignArgs &a, hipStream_t st)
     return 0;
 }
 
+int device_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// launch options of the token-stationary screen: [0] token-phase gate, [1] balanced token map.  -1 = take the
+// environment variable (default off: both measured slower at the bench shape); sn_debug_set_assign_options
+// overrides (A/B timing inside one process).
+int g_assign_opt[2] = {-1, -1};
+bool assign_option(int i, const char *env)
+{
+    if (g_assign_opt[i] < 0) { const char *e = getenv(env); g_assign_opt[i] = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_assign_opt[i] != 0;
+}
+
 template <int NSTEPS, int NW, int R>
 int launch_screen(const AssignArgs &a, hipStream_t st)
 {
@@ -1205,9 +1373,28 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
         attr_set = true;
     }
     const int tok_per_block = kTokPerWave * NW;
-    const unsigned grid = (unsigned)((a.n_tokens + tok_per_block - 1) / tok_per_block);
+    unsigned grid = (unsigned)((a.n_tokens + tok_per_block - 1) / tok_per_block);
+    AssignArgs ag = a;
+    ag.full_waves = NW;
+    ag.extra_base = a.n_tokens;
+    // Between one and two workgroups per CU (two fit): with 128 tokens each, some CUs get twice the bytes and
+    // twice the matrix work of the others and the launch lasts as long as they do.  Deal the tokens evenly
+    // instead: 2 x CUs workgroups of f full waves each, the remaining 32-token sets one per workgroup as wave f.
+    const bool balance_on = assign_option(1, "SN_ASSIGN_BALANCE");
+    const int cus = device_cus();
+    if (balance_on && NSTEPS <= 24 && NW == 4 && (int)grid > cus && (int)grid < 2 * cus) {
+        const int64_t G = 2 * (int64_t)cus;
+        const int f = (int)(a.n_tokens / (kTokPerWave * G));                  // 2 or 3 here
+        ag.full_waves = f;
+        ag.extra_base = G * kTokPerWave * f;
+        grid = (unsigned)G;
+    }
+    const bool gate_on = assign_option(0, "SN_ASSIGN_GATE");
+    // the gate pays when two workgroups share a CU and there is more than one workgroup per CU to stagger
+    if (!(gate_on && NSTEPS <= 24 && NW == 4 && (int)grid > cus)) ag.gate = nullptr;
+    else if (hipMemsetAsync(ag.gate, 0, kGateBytes, st) != hipSuccess) { sn_set_error("sn_assign_words: memset failed"); return SN_ERR_LAUNCH; }
     sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R>), dim3(grid), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R>), dim3(grid), dim3(64 * NW), lds, st, ag);
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
@@ -1215,18 +1402,6 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     hipLaunchKernelGGL((assign_rerank_kernel<NT, 0>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
     sn_prof_stop(1, st);
     return 0;
-}
-
-int device_cus()
-{
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        if (n <= 0) n = 256;
-    }
-    return n;
 }
 
 template <int NT, int KS>
@@ -1319,13 +1494,17 @@ extern "C" int sn_debug_screen_occupancy(int lds)
     return n;
 }
 
+/* diagnostics: token-phase gate / balanced token map of the token-stationary screen on (1), off (0), from the environment (-1) */
+extern "C" void sn_debug_set_assign_options(int gate, int balance) { g_assign_opt[0] = gate; g_assign_opt[1] = balance; }
+
 /* diagnostics: device buffer of 16 x u64 per wave of the screen kernel (NULL = off) */
 extern "C" void sn_debug_set_stamps(void *device_buffer) { g_stamps = (unsigned long long *)device_buffer; }
 
 extern "C" size_t sn_assign_workspace_bytes(int64_t n_tokens)
 {
     if (n_tokens < 0) return 0;
-    return 32 + (size_t)n_tokens * kWsPerToken2;     // header + flag words + candidate codes + overflow token ids (the larger record format)
+    // header + flag words + candidate codes + overflow token ids (the larger record format) + per-CU gate table
+    return ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15)) + kGateBytes;
 }
 
 extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
@@ -1352,6 +1531,8 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.stamps = g_stamps;
     a.codes32 = ws ? (unsigned *)(ws + 32 + (size_t)n_tokens * 4) : nullptr;
     a.n_sets = (n_tokens + 31) / 32;
+    a.full_waves = kWavesPerBlock; a.extra_base = n_tokens;
+    a.gate = ws ? (unsigned *)(ws + ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15))) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
     const bool screen_ok = mode == 0 && aligned && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);

@@ -42,7 +42,7 @@ for name, tok in (("randn tokens", tokens), ("k-means-like", None)):
 # ---- in-kernel stamps of the screen kernel (shader cycles)
 import ctypes
 lib.sn_debug_set_stamps.argtypes = [ctypes.c_void_p]; lib.sn_debug_set_stamps.restype = None
-n_waves = ((n_tok + 127) // 128) * 4
+n_waves = 4 * max((n_tok + 127) // 128, 2 * torch.cuda.get_device_properties(dev).multi_processor_count)
 st = torch.zeros(n_waves * 16, dtype=torch.int64, device=dev)
 lib.sn_debug_set_stamps(st.data_ptr())
 x = tokens[:, 1:, :]
@@ -52,6 +52,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib.sn_debug_set_stamps(None)
 s8 = st.view(n_waves, 16).cpu().double()
+s8 = s8[(s8[:, 0] > 0) & (s8[:, 1] > 0)]           # waves that ran and had tokens
 t0 = s8[:, 0].min()
 print("screen kernel stamps (cycles, 100MHz-ref memtime?):")
 print("  kernel span (first start -> last end): %.0f" % (s8[:, 3].max() - t0))
