@@ -294,6 +294,10 @@ def main():
                 n_img = pred_cpu.shape[0]
                 ing_gpu = disc.assign(tokens[:n_img, 1:, :]).cpu()
                 out["cpu_baseline"]["word_id_mismatches_vs_gpu"] = int((ing_gpu != ing_cpu).sum())
+                pred_gpu = step(disc, sn, m, tokens, attn)[:n_img].cpu()
+                scale = float(pred_cpu.abs().max())
+                out["cpu_baseline"]["pred_max_rel_err_vs_gpu"] = float((pred_gpu - pred_cpu).abs().max()) / scale
+                out["cpu_baseline"]["top1_mismatches_vs_gpu"] = int((pred_gpu.argmax(1) != pred_cpu.argmax(1)).sum())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

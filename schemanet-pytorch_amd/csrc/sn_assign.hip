@@ -39,12 +39,6 @@
 #ifndef SN_S1_STAGE
 #define SN_S1_STAGE 1       // token rows through LDS in whole cache lines (0: fragment loads straight from global memory)
 #endif
-#ifndef SN_EXP_KEY1
-#define SN_EXP_KEY1 0       // one VALU per value instead of four (timing only)
-#endif
-#ifndef SN_EXP_NOLDSA
-#define SN_EXP_NOLDSA 0     // A fragments are not re-read from LDS (timing only)
-#endif
 #ifndef SN_EXP_NOPHASEA
 #define SN_EXP_NOPHASEA 0
 #endif
@@ -759,10 +753,6 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     // MFMA issues (> 64 cycles) after the last MFMA that wrote `v`.
     auto key_insert = [&](float v, unsigned code, int g) {
         unsigned k;
-        if (SN_EXP_KEY1) {      // valid key, best only: two VALU per value
-            asm volatile("v_and_or_b32 %0, %2, %3, %4\n\tv_min_u32 %1, %0, %1" : "=&v"(k), "+v"(m1[g]) : "v"(v), "v"(keymask), "s"(code));
-            return;
-        }
         asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
                      "v_med3_u32 %3, %0, %2, %3\n\t"
                      "v_med3_u32 %2, %0, %1, %2\n\t"
@@ -783,8 +773,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
             cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], cur, 0, 0, 0);
-            if (SN_EXP_NOLDSA) asm volatile("" : "+v"(ar[s % kRingA]));
-            else if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
+            if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
             else ar[s % kRingA] = frag_at(w + 1, s + kRingA - NSTEPS);      // (stale slot after the last tile: unused)
             // the 16 accumulators of tile w-1 become keys (w == 0: oth holds +inf, those keys never win)
             if (s >= kKeyStep0 && !SN_EXP_NOKEYS) {
