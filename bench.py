@@ -99,6 +99,19 @@ def stream_copy_GBps(device, n_bytes=1 << 30, reps=5):
     return 2.0 * n_bytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def event_pair_floor_ms(n=200):
+    """What a HIP event pair reads with NOTHING between the two records on the launch stream (the two dispatch gaps
+    every `avg_launch_ms` below contains; rocprofv3's kernel trace does not): median of n pairs."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        b.record()
+    torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) for a, b in ev)
+    return v[n // 2]
+
+
 def kernel_times(lib, kid):
     n = lib.sn_profile_count(kid)
     if n == 0:
@@ -257,6 +270,7 @@ def main():
         screen_name = ("assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)" if lib.sn_assign_variant() == 2
                        else "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen, token-stationary)")
         copy_gbps = stream_copy_GBps(device)
+        ev_floor = event_pair_floor_ms()
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
@@ -279,6 +293,8 @@ def main():
                          "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["assign_screen"],
+                         "event_pair_floor_ms": ev_floor,
+                         "avg_launch_note": "avg_launch_ms = HIP event pair around the kernel on its launch stream (what achieved / frac use); an event pair with nothing between reads event_pair_floor_ms, so the kernel trace of rocprofv3 (profiles/) shows this kernel ~that much shorter",
                          "peak_note": "peak = 8.0 TB/s HBM3E spec; copy_GBps = a 1 GiB device-to-device copy on this box (read + write)",
                          "copy_GBps": copy_gbps, "frac_of_copy": (ach / copy_gbps) if (ach and copy_gbps) else None},
             "kernels_ms": avg,
