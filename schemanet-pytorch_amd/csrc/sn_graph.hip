@@ -458,7 +458,7 @@ static unsigned long long *g_graph_stamps = nullptr;      // diagnostics only (s
     } while (0)
 
 template <bool kEdges>
-__global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a, unsigned long long *stamps)
+__global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a, unsigned long long *stamps, int signed_table)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = a.L, b = blockIdx.x, tid = threadIdx.x;
@@ -572,6 +572,21 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     } else if (owner && me.group < kMaxCols) {
         s.rev[me.group] = me.group;
     }
+    // Signed grid table over the (now dead) grouping scratch: TS[(dr + feat_h - 1) * S + (dc + feat_w - 1)] =
+    // T[|dr|][|dc|], S = 2 feat_w - 1, so that the table offset of a (row position p, column position q) pair is
+    // P(p) + Q(q) - one scalar and one per-lane constant - instead of two absolute differences, a shift and an add
+    // per cell and row visit (the column-sum loop below is instruction-bound).  Same floats, same sums.
+    float *TS = nullptr;
+    const int ts_S = 2 * a.feat_w - 1;
+    if (signed_table) {                                          // kernel argument: uniform
+        __syncthreads();                                         // every thread has read its grouping results
+        TS = reinterpret_cast<float *>(s.pless);
+        const int sh = grid_shift(a.feat_w), fh = L / a.feat_w, n_ts = (2 * fh - 1) * ts_S;
+        for (int i = tid; i < n_ts; i += blockDim.x) {
+            const int dr = i / ts_S - (fh - 1), dc = i % ts_S - (a.feat_w - 1);
+            TS[i] = s.T[((dr < 0 ? -dr : dr) << sh) + (dc < 0 ? -dc : dc)];
+        }
+    }
     // s.flag is free after the grouping: it now holds the inverse of pos_sorted (position -> sorted index)
     const int n_kept = s.misc[1];
     if (tid < n_kept) s.flag[s.pos_sorted[tid]] = (unsigned char)tid;
@@ -602,17 +617,18 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     //      positions of ITS column's word: cell = sum_{q in gj} cs[q].
     // Sum order: q-major instead of the reference's p-major (large_scale_feat_to_e.cpp:99-125): equal to
     // fp32 rounding (1e-7); the init statistics keep the reference order (limited_edges_kernel).
-    int qv4[kCellsPerLane], qrow[kCellsPerLane], qcol4[kCellsPerLane], qsidx4[kCellsPerLane];
+    int qv4[kCellsPerLane], qrow[kCellsPerLane], qcol4[kCellsPerLane], qsidx4[kCellsPerLane], qts[kCellsPerLane];
     bool qok[kCellsPerLane];
 #pragma unroll
     for (int k = 0; k < kCellsPerLane; ++k) {
         const int q = lane + SN_WAVE * k;
         qok[k] = q < L;
-        const int qq = qok[k] ? q : L - 1;
+        const int qq = qok[k] ? q : L - 1;                  // (lanes past L accumulate a valid column nobody reads)
         qv4[k] = qq * 4;
         const int rc = a.geo ? 0 : (int)s.prc[qq];
         qrow[k] = rc >> 8;
         qcol4[k] = (rc & 255) * 4;
+        qts[k] = TS ? ((L / a.feat_w - 1 - (rc >> 8)) * ts_S + (a.feat_w - 1 - (rc & 255))) * 4 : 0;
         qsidx4[k] = (int)s.flag[qq] * 4;                    // where this position's column sum is staged (sorted order)
     }
     const int tsh = grid_shift(a.feat_w) + 2;               // byte shift of a table row
@@ -668,6 +684,14 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                         csa[k] += qok[k] ? av : 0.0f;
                         csg[k] += qok[k] ? gv : 0.0f;
                     }
+                } else if (TS) {
+                    const int prc = __builtin_amdgcn_readfirstlane((int)s.prc[p]);
+                    const char *tp = reinterpret_cast<const char *>(TS) + ((prc >> 8) * ts_S + (prc & 255)) * 4;
+#pragma unroll
+                    for (int k = 0; k < kCellsPerLane; ++k) {
+                        csa[k] += *reinterpret_cast<const float *>(arow + qv4[k]);
+                        csg[k] += *reinterpret_cast<const float *>(tp + qts[k]);
+                    }
                 } else {
                     const int prc = __builtin_amdgcn_readfirstlane((int)s.prc[p]);
                     const unsigned pr = prc >> 8, pc4 = (prc & 255) * 4;
@@ -677,8 +701,8 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                         const float av = *reinterpret_cast<const float *>(arow + qv4[k]);
                         const unsigned off = (__usad(pr, (unsigned)qrow[k], 0u) << tsh) + __usad(pc4, (unsigned)qcol4[k], 0u);
                         const float gv = *reinterpret_cast<const float *>(tbase + off);
-                        csa[k] += qok[k] ? av : 0.0f;
-                        csg[k] += qok[k] ? gv : 0.0f;
+                        csa[k] += av;
+                        csg[k] += gv;
                     }
                 }
             }
@@ -980,7 +1004,7 @@ int ensure_lds(const void *fn, size_t bytes, const char *name)
     static const void *done[4] = {nullptr, nullptr, nullptr, nullptr};
     for (const void *d : done) if (d == fn) return SN_OK;
     if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     // (cached per kernel: the maximum)
         if (e != hipSuccess) {
             sn_set_error("%s: cannot raise dynamic LDS to %zu: %s", name, bytes, hipGetErrorString(e));
             return SN_ERR_LAUNCH;
@@ -1024,15 +1048,24 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
     if (a.acls_stride_h == 0) a.acls_stride_h = a.L;
     hipStream_t st = (hipStream_t)stream;
     if (a.attn) {
-        const size_t lds = lds_bytes(a.L, true);
+        size_t lds = lds_bytes(a.L, true);
+        // signed grid table (see the kernel): it lies over the grouping scratch at the end of the carve and may need a
+        // few hundred bytes more; used when that still fits the CU's LDS
+        int signed_table = 0;
+        if (!a.geo) {
+            const size_t dead = up16((size_t)a.L * 2) * 2 + up16((size_t)a.L * 4) + up16(a.L);
+            const size_t need = up16((size_t)(2 * a.feat_h - 1) * (2 * a.feat_w - 1) * 4);
+            const size_t extra = need > dead ? need - dead : 0;
+            if (lds + extra <= 160 * 1024) { lds += extra; signed_table = 1; }
+        }
         int rc = ensure_lds((const void *)instance_graph_kernel<true>, lds, "sn_instance_graph");
         if (rc) return rc;
         sn_prof_start(2, st);
-        hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps);
+        hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table);
         sn_prof_stop(2, st);
     } else {
         const size_t lds = lds_bytes(a.L, false);
-        hipLaunchKernelGGL(instance_graph_kernel<false>, dim3(a.B), dim3(256), lds, st, a, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(instance_graph_kernel<false>, dim3(a.B), dim3(256), lds, st, a, (unsigned long long *)nullptr, 0);
     }
     SN_CHECK_LAUNCH("sn_instance_graph");
     return SN_OK;
