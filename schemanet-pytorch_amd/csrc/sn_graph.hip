@@ -645,15 +645,26 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             hd |= head ? (1u << e) : 0u;
         }
     }
-    // step i of the cross-lane scan adds the value 2^i lanes below iff no head has been seen in between: the flag
-    // half of the segmented scan depends on the heads only, so it is run once here
+    // Cross-lane half of the segmented scan on the DPP network (a ds_bpermute per step costs an exposed LDS round
+    // trip each, 14 per row): Hillis-Steele inside the 16-lane rows (row_shr 1, 2, 4, 8), then the last lane of row
+    // 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2, 3 (row_bcast:31).  A step adds the incoming
+    // value iff the lane has not seen a head since the sender: that flag half depends on the heads only, so it is
+    // run once here (bit i of `take`).
     unsigned take = 0;
     if (scan_ok) {
         int fl = hd != 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int fup = __shfl_up(fl, 1 << i, SN_WAVE);
-            if (lane >= (1 << i)) { take |= fl ? 0u : (1u << i); fl |= fup; }
+            if ((lane & 15) >= (1 << i)) { take |= fl ? 0u : (1u << i); fl |= fup; }
+        }
+        {
+            const int fup = __shfl(fl, (lane & 48) - 1, SN_WAVE);       // last lane of the previous row (rows 1 and 3 listen)
+            if ((lane >> 4) & 1) { take |= fl ? 0u : (1u << 4); fl |= fup; }
+        }
+        {
+            const int fup = __shfl(fl, 31, SN_WAVE);
+            if (lane >= 32) { take |= fl ? 0u : (1u << 5); fl |= fup; }
         }
     }
     float rcnt[kCellsPerLane];                             // 1 / (positions of the column's word)
@@ -730,13 +741,19 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     float s2 = (hd & 4) ? v4.z : s1 + v4.z;
                     float s3 = (hd & 8) ? v4.w : s2 + v4.w;
                     float run = s3;                                 // sum since the last head of this lane (or of all four)
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) {                   // (which steps add is the same for every row: `take`)
-                        const float up = __shfl_up(run, 1 << i, SN_WAVE);
-                        run = ((take >> i) & 1u) ? run + up : run;
-                    }
-                    float carry = __shfl_up(run, 1, SN_WAVE);       // running sum that reaches into this lane
-                    if (lane == 0) carry = 0.0f;
+                    // (which steps add is the same for every row: `take`; lanes a DPP step does not reach read 0)
+#define SN_SCAN_STEP(bit, ctrl, rows)                                                                                         \
+                    { const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(run), (ctrl), (rows), 0xF, true)); \
+                      run = ((take >> (bit)) & 1u) ? run + up : run; }
+                    SN_SCAN_STEP(0, 0x111, 0xF)                     // row_shr:1
+                    SN_SCAN_STEP(1, 0x112, 0xF)                     // row_shr:2
+                    SN_SCAN_STEP(2, 0x114, 0xF)                     // row_shr:4
+                    SN_SCAN_STEP(3, 0x118, 0xF)                     // row_shr:8
+                    SN_SCAN_STEP(4, 0x142, 0xA)                     // row_bcast:15 -> rows 1, 3
+                    SN_SCAN_STEP(5, 0x143, 0xC)                     // row_bcast:31 -> rows 2, 3
+#undef SN_SCAN_STEP
+                    // running sum that reaches into this lane = the previous lane's total (wave_shr:1; lane 0: 0)
+                    const float carry = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(run), 0x138, 0xF, 0xF, true));
                     v4.x = (hd & 1) ? s0 : s0 + carry;
                     v4.y = (hd & 3) ? s1 : s1 + carry;
                     v4.z = (hd & 7) ? s2 : s2 + carry;
