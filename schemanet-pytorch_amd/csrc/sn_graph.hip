@@ -258,22 +258,35 @@ __device__ inline PosInfo group_positions(const Lds &s, int L, int tid, bool kep
         for (int k = 0; k < 4; ++k) total += __popcll(__ballot(vq[k]));
         if (lane == 0) s.misc[1] = total;
     }
+    // The first occurrence of a word (no equal word at a smaller position) does the work for ALL positions of that
+    // word: the lanes that hold them write their own records in parallel (index inside the word = mbcnt of the
+    // equality masks); every other position stops after its four equality ballots.
+    // It also marks them (flag bit 2): a wave that comes to a marked position skips it without any ballot.  (A mark
+    // that is not visible yet only costs the ballots: the race is benign.  The phase is bound by the CU's one scalar
+    // unit - ~70 scalar instructions per visited position from 16 waves - so skipped positions are what pays.)
     for (int p = wid; p < L; p += nw) {
-        if (!__builtin_amdgcn_readfirstlane((int)s.flag[p])) continue;
+        const int fp = __builtin_amdgcn_readfirstlane((int)s.flag[p]);
+        if (fp == 0 || (fp & 4)) continue;
         const int64_t wp = s.words[p];
-        int cnt = 0, less = 0, rank = 0;
+        const int ps = __builtin_amdgcn_readfirstlane(p);         // (scalar copy: the masks below stay on the scalar unit)
         unsigned long long eq[4];
+        bool first = true;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             eq[k] = __ballot(vq[k] && wq[k] == wp);
+            const int lo = ps - SN_WAVE * k;                      // bits below position p in chunk k
+            const unsigned long long below = lo >= SN_WAVE ? ~0ull : (lo > 0 ? ((1ull << lo) - 1ull) : 0ull);
+            first = first && (eq[k] & below) == 0ull;
+        }
+        if (!first) continue;                                     // (wave-uniform)
+        int cnt = 0, less = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             less += __popcll(__ballot(vq[k] && wq[k] < wp));
             cnt += __popcll(eq[k]);
-            const int lo = p - SN_WAVE * k;                       // bits below position p in chunk k
-            const unsigned long long below = lo >= SN_WAVE ? ~0ull : (lo > 0 ? ((1ull << lo) - 1ull) : 0ull);
-            rank += __popcll(eq[k] & below);
         }
         float sum = 0.0f;
-        if (want_sum && rank == 0) {                                 // position order (utils.cpp:9)
+        if (want_sum) {                                           // position order (utils.cpp:9)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 unsigned long long m = eq[k];
@@ -284,12 +297,19 @@ __device__ inline PosInfo group_positions(const Lds &s, int L, int tid, bool kep
                 }
             }
         }
-        if (lane == 0) {
-            s.pless[p] = (unsigned short)less;
-            s.pcnt[p] = (unsigned short)cnt;
-            s.psum[p] = sum;
-            s.pos_sorted[less + rank] = (unsigned char)p;
-            s.flag[p] = (unsigned char)(1 | (rank == 0 ? 2 : 0));
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((eq[k] >> lane) & 1ull) {                         // this lane's position lane + 64 k holds the word
+                const int q = lane + SN_WAVE * k;
+                const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(eq[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)eq[k], 0u));
+                s.pless[q] = (unsigned short)less;
+                s.pcnt[q] = (unsigned short)cnt;
+                s.pos_sorted[less + idx] = (unsigned char)q;
+                s.flag[q] = (unsigned char)(1 | (idx == 0 ? 2 : 0) | 4);
+                if (idx == 0) s.psum[q] = sum;
+            }
+            base += __popcll(eq[k]);
         }
     }
     __syncthreads();
