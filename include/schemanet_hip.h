@@ -64,7 +64,7 @@ int sn_profile_elapsed_ms(int kernel_id, float *out_ms_host, int n);
  * rigorous error bound), lowest index on exact ties -- bit-identical to oracle sno_assign_words.
  * ------------------------------------------------------------------------------------------ */
 
-/* Bytes of the packed codebook image for (M, D).  M >= 1, D >= 1; the fp16 tile image is only built when D is 192, 384 or 768 and M <= 2048. */
+/* Bytes of the packed codebook image for (M, D).  M >= 1, D >= 1; the fp16-MFMA screen is used when D is 192, 384 or 768 and M <= 8192 (the exact kernel otherwise). */
 size_t sn_codebook_pack_bytes(int M, int D);
 
 /* Packs codebook [M, D] f32 into `packed` (fp16 MFMA fragments, per-word fp64 norms, scale

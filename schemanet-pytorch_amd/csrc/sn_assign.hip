@@ -57,8 +57,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
 constexpr int kCodeBytes = 24;          // per-token candidate record: one key code per candidate slot
 // workspace per token: token-stationary records = flag word + 24 code bytes + overflow-list slot (32 B)
-constexpr int kWsPerToken2 = 4 + 32 + 4;          // screen2 records: flag word + 8 code dwords + overflow-list slot
-constexpr int kMaxTilesScreen = 64;     // 6-bit tile code in the keys -> M <= 2048 on the MFMA path
+constexpr int kWsPerToken2 = 4 + 48 + 4;          // the largest record format: flag word + 24 16-bit codes + overflow-list slot
+constexpr int kMaxTilesScreen = 256;    // tile code in the keys: 6 bits (M <= 2048, byte codes) or 8 bits (M <= 8192, 16-bit codes)
+constexpr int kCodeBytesWide = 48;      // candidate record with 16-bit codes
 constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
 // fp32 accumulate of v_mfma_f32_32x32x16_f16: measured (tools/mfma_probe.hip, MI355X) total error
@@ -339,9 +340,10 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
             const unsigned long long cmask = ((unsigned long long)(unsigned)__shfl((int)(flag >> 32), tl, SN_WAVE) << 32) |
                                              (unsigned long long)(unsigned)__shfl((int)flag, tl, SN_WAVE);
             int my_word = 0;
-            if constexpr (FMT == 0) {
+            if constexpr (FMT == 0 || FMT == 2) {
                 if (lane < kMaxCand) {
-                    const unsigned code = p.codes[n * kCodeBytes + lane];
+                    const unsigned code = FMT == 0 ? (unsigned)p.codes[n * kCodeBytes + lane]
+                                                   : (unsigned)reinterpret_cast<const unsigned short *>(p.codes)[n * kMaxCand + lane];
                     const int hh = lane / 12, g = (lane % 12) / 3;
                     my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
                 }
@@ -415,13 +417,11 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
         const float e16 = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1) +
                                    2.0f * (float)(p.D + 2) * 5.9604645e-8f * vmax + 1.2e-7f * vmax);
         const bool finite = (XM <= kHugeIn) && (CMAX <= kHugeIn) && (e16 < 1.0e30f);   // false for NaN / inf / huge
-        float smin = INFINITY;
-        float sc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {                                 // two words per thread in flight
-            const int ma = tid + 256 * j, mb = ma + 256;
-            sc[j] = INFINITY; sc[j + 1] = INFINITY;
-            if (ma >= p.M || !finite) continue;
+        // fp16 score of the words ma and ma + 256 (same row i inside their 32-word tiles) from the packed tile image
+        auto score2 = [&](int ma, float &sa, float &sb) {
+            const int mb = ma + 256;
+            sa = INFINITY; sb = INFINITY;
+            if (ma >= p.M || !finite) return;
             const bool has_b = mb < p.M;
             const int i = ma & 31;                                       // (mb & 31) == i as well
             const unsigned char *ta = tiles + (size_t)(ma >> 5) * lay.tile_bytes;
@@ -449,22 +449,48 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
             }
             const int g = i >> 3, hh = (i >> 2) & 1, ee = i & 3;
             const size_t hoff = (size_t)lay.n_steps * 1024 + ((g * 2 + hh) * 4 + ee) * 4;
-            sc[j] = *reinterpret_cast<const float *>(ta + hoff) + (a0 + a1);      // dist^2/2 - |x|^2/2 (tiles hold -c)
-            smin = fminf(smin, sc[j]);
-            if (has_b) { sc[j + 1] = *reinterpret_cast<const float *>(tb + hoff) + (b0 + b1); smin = fminf(smin, sc[j + 1]); }
+            sa = *reinterpret_cast<const float *>(ta + hoff) + (a0 + a1);          // dist^2/2 - |x|^2/2 (tiles hold -c)
+            if (has_b) sb = *reinterpret_cast<const float *>(tb + hoff) + (b0 + b1);
+        };
+        const bool big = p.M > 2048;              // more words than a thread keeps scores for: two passes, nothing kept
+        float smin = INFINITY;
+        float sc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {                                 // two words per thread in flight
+            sc[j] = INFINITY; sc[j + 1] = INFINITY;
+            if (big) continue;
+            score2(tid + 256 * j, sc[j], sc[j + 1]);
+            smin = fminf(smin, fminf(sc[j], sc[j + 1]));
+        }
+        if (big) {
+            for (int m0 = tid; m0 < p.M; m0 += 512) {
+                float sa, sb;
+                score2(m0, sa, sb);
+                smin = fminf(smin, fminf(sa, sb));
+            }
         }
         smin = sn_wave_min(smin);
         __syncthreads();
         if (lane == 0) red[wid] = smin;
         __syncthreads();
         smin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-        bool too_many = p.M > 2048;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = tid + 256 * j;
-            if (m < p.M && finite && sc[j] <= smin + 2.0f * e16) {
+        bool too_many = false;
+        const float cut16 = smin + 2.0f * e16;
+        auto keep = [&](int m, float v) {
+            if (m < p.M && finite && v <= cut16) {
                 const int slot = atomicAdd(&n_surv, 1);
                 if (slot < kMaxSurvivors) surv[slot] = m;
+            }
+        };
+        if (!big) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep(tid + 256 * j, sc[j]);
+        } else {
+            for (int m0 = tid; m0 < p.M; m0 += 512) {                    // same arithmetic as the first pass: same scores
+                float sa, sb;
+                score2(m0, sa, sb);
+                keep(m0, sa);
+                keep(m0 + 256, sb);
             }
         }
         __syncthreads();
@@ -506,9 +532,13 @@ __device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c)
 }
 
 // NW waves per workgroup (32 tokens each) share one codebook-tile ring of R LDS slots.
-template <int NSTEPS, int NW, int R>
+// CB = width of the word code in a key: 8 (tile < 64: M <= 2048) or 10 (tile < 256: M <= 8192; the keys lose two
+// more mantissa bits, which the error window accounts for, and the candidate records hold 16-bit codes).
+template <int NSTEPS, int NW, int R, int CB = 8>
 __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_kernel(const AssignArgs p)
 {
+    constexpr unsigned kCodeMask = (1u << CB) - 1u, kTileMask = (1u << (CB - 2)) - 1u;
+    constexpr float kKeyTrunc = CB == 8 ? 3.1e-5f : 1.23e-4f;                 // 2^-15 / 2^-13
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kChunks = NSTEPS + 1;
     constexpr int kTileBytes = kChunks * 1024;
@@ -709,7 +739,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     const float E = 1.01f * (2.01f * kU16 * X2 * C2                           // fp16 rounding of x and c
                              + 5.96e-8f * (X1 + C1)                           // fp16 subnormal flush
                              + (float)NSTEPS * kAccUlpPerMfma * vmax          // MFMA fp32 accumulate (starts at |c|^2/2 + shift)
-                             + vmax * (3.0f * 5.96e-8f + 3.1e-5f));           // hx/hc/adds rounding + key truncation (2^-15)
+                             + vmax * (3.0f * 5.96e-8f + kKeyTrunc));         // hx/hc/adds rounding + key truncation
     const float shift = hx + 2.0f * E;                                        // keeps every key non-negative
     const float window = 2.0f * E;
     const bool bad = !(maxabs <= kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e30f);   // NaN-safe
@@ -734,7 +764,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     static_assert(kKeyStep0 + (3 + kKeysPerStep) / kKeysPerStep <= kInitStep, "group 0 must be keyed before it is re-initialised");
     half8 ar[kRingA];
     f32x16 accA, accB;
-    unsigned keymask = 0xFFFFFF00u;
+    unsigned keymask = ~kCodeMask;
     asm volatile("" : "+v"(keymask));                     // keep the mask in a VGPR (VOP3 has no literals on gfx9)
     auto frag_at = [&](int tile, int step) {
         return *reinterpret_cast<const half8 *>(smem + (tile % R) * kTileBytes + step * 1024 + lane * 16);
@@ -760,8 +790,8 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
                      : "=&v"(k), "+v"(m1[g]), "+v"(m2[g]), "+v"(m3[g]) : "v"(v), "v"(keymask), "s"(code));
     };
     auto key_value = [&](float v, int tile, int idx) {     // same thing in C++ (compiler-scheduled, hazard-checked)
-        const unsigned code = (((unsigned)tile & 63u) << 2) | (unsigned)(idx & 3);
-        const unsigned k = (__float_as_uint(v) & 0xFFFFFF00u) | code;
+        const unsigned code = (((unsigned)tile & kTileMask) << 2) | (unsigned)(idx & 3);
+        const unsigned k = (__float_as_uint(v) & ~kCodeMask) | code;
         const int g = idx >> 2;
         m3[g] = med3u(k, m2[g], m3[g]);
         m2[g] = med3u(k, m1[g], m2[g]);
@@ -769,7 +799,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     };
     unsigned long long t_sync = 0, t_dma = 0;             // diagnostics (only when stamps are on)
     auto tile_step = [&](int w, f32x16 &cur, f32x16 &oth) {
-        const unsigned code0 = (((unsigned)(w - 1)) & 63u) << 2;
+        const unsigned code0 = (((unsigned)(w - 1)) & kTileMask) << 2;
 #pragma unroll
         for (int s = 0; s < NSTEPS; ++s) {
             cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], cur, 0, 0, 0);
@@ -837,7 +867,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     unsigned kmin = min(min(m1[0], m1[1]), min(m1[2], m1[3]));
     const unsigned kmin_o = __shfl_xor(kmin, 32, SN_WAVE);
     // word of a key: tile = code >> 2, e = code & 3, row = 8g + 4h + e
-    auto word_of = [&](unsigned k, int g, int hh) { return (int)(((k & 0xFFu) >> 2) * 32 + 8 * g + 4 * hh + (k & 3u)); };
+    auto word_of = [&](unsigned k, int g, int hh) { return (int)(((k & kCodeMask) >> 2) * 32 + 8 * g + 4 * hh + (k & 3u)); };
     int gmin = 0;
 #pragma unroll
     for (int g = 1; g < 4; ++g) if (m1[g] == kmin) gmin = g;
@@ -845,12 +875,12 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     for (int g = 3; g >= 0; --g) if (m1[g] == kmin) gmin = g;      // lowest group on ties
     const int my_best = word_of(kmin, gmin, h);
     const int ot_best = __shfl_xor(my_best, 32, SN_WAVE);
-    const unsigned vmy = kmin & 0xFFFFFF00u, vot = kmin_o & 0xFFFFFF00u;
+    const unsigned vmy = kmin & ~kCodeMask, vot = kmin_o & ~kCodeMask;
     const bool mine = vmy < vot || (vmy == vot && my_best < ot_best);
     const int best_w = mine ? my_best : ot_best;
     const float vbest = __uint_as_float(mine ? vmy : vot);
     const bool any_finite = (mine ? vmy : vot) < 0x7F800000u;
-    const unsigned cutkey = __float_as_uint(vbest + window) | 0xFFu;   // key <= cutkey  <=>  value <= cut
+    const unsigned cutkey = __float_as_uint(vbest + window) | kCodeMask;   // key <= cutkey  <=>  value <= cut
     unsigned hmask = 0;                                                // 12 bits: group g -> bits 3g..3g+2
     bool hover = false;
 #pragma unroll
@@ -871,13 +901,19 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     const bool flagged = !overflow && nc > 1;
     if (writer) p.flags[n] = overflow ? 0x80000000u : (flagged ? (hmask | (omask << 12)) : 0u);
     if (valid && flagged) {                                // both half-lanes of the token write their 12 codes
-        unsigned *cd = reinterpret_cast<unsigned *>(p.codes + (int64_t)n * kCodeBytes + 12 * h);
-        const unsigned c0 = m1[0] & 0xFFu, c1 = m2[0] & 0xFFu, c2 = m3[0] & 0xFFu, c3 = m1[1] & 0xFFu;
-        const unsigned c4 = m2[1] & 0xFFu, c5 = m3[1] & 0xFFu, c6 = m1[2] & 0xFFu, c7 = m2[2] & 0xFFu;
-        const unsigned c8 = m3[2] & 0xFFu, c9 = m1[3] & 0xFFu, c10 = m2[3] & 0xFFu, c11 = m3[3] & 0xFFu;
-        cd[0] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-        cd[1] = c4 | (c5 << 8) | (c6 << 16) | (c7 << 24);
-        cd[2] = c8 | (c9 << 8) | (c10 << 16) | (c11 << 24);
+        const unsigned c0 = m1[0] & kCodeMask, c1 = m2[0] & kCodeMask, c2 = m3[0] & kCodeMask, c3 = m1[1] & kCodeMask;
+        const unsigned c4 = m2[1] & kCodeMask, c5 = m3[1] & kCodeMask, c6 = m1[2] & kCodeMask, c7 = m2[2] & kCodeMask;
+        const unsigned c8 = m3[2] & kCodeMask, c9 = m1[3] & kCodeMask, c10 = m2[3] & kCodeMask, c11 = m3[3] & kCodeMask;
+        if (CB == 8) {
+            unsigned *cd = reinterpret_cast<unsigned *>(p.codes + (int64_t)n * kCodeBytes + 12 * h);
+            cd[0] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+            cd[1] = c4 | (c5 << 8) | (c6 << 16) | (c7 << 24);
+            cd[2] = c8 | (c9 << 8) | (c10 << 16) | (c11 << 24);
+        } else {
+            unsigned *cd = reinterpret_cast<unsigned *>(p.codes + (int64_t)n * kCodeBytesWide + 24 * h);
+            cd[0] = c0 | (c1 << 16); cd[1] = c2 | (c3 << 16); cd[2] = c4 | (c5 << 16);
+            cd[3] = c6 | (c7 << 16); cd[4] = c8 | (c9 << 16); cd[5] = c10 | (c11 << 16);
+        }
     }
     const bool need_b = writer && overflow;
     const unsigned long long mask_b = __ballot(need_b);
@@ -1349,14 +1385,14 @@ bool assign_option(int i, const char *env)
     return g_assign_opt[i] != 0;
 }
 
-template <int NSTEPS, int NW, int R>
+template <int NSTEPS, int NW, int R, int CB = 8>
 int launch_screen(const AssignArgs &a, hipStream_t st)
 {
     size_t lds = (size_t)R * (NSTEPS + 1) * 1024;
     if (const char *pad = getenv("SN_ASSIGN_LDS_PAD")) lds += (size_t)atoi(pad);     // diagnostics: force 1 workgroup per CU
     static bool attr_set = false;
     if ((!attr_set || getenv("SN_ASSIGN_LDS_PAD")) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)assign_screen_kernel<NSTEPS, NW, R>,
+        hipError_t e = hipFuncSetAttribute((const void *)assign_screen_kernel<NSTEPS, NW, R, CB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sn_set_error("sn_assign_words: LDS attribute: %s", hipGetErrorString(e)); return SN_ERR_LAUNCH; }
         attr_set = true;
@@ -1383,12 +1419,12 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     if (!(gate_on && NSTEPS <= 24 && NW == 4 && (int)grid > cus)) ag.gate = nullptr;
     else if (hipMemsetAsync(ag.gate, 0, kGateBytes, st) != hipSuccess) { sn_set_error("sn_assign_words: memset failed"); return SN_ERR_LAUNCH; }
     sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R>), dim3(grid), dim3(64 * NW), lds, st, ag);
+    hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R, CB>), dim3(grid), dim3(64 * NW), lds, st, ag);
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
     const int64_t chunks = (a.n_tokens + 31) / 32;
-    hipLaunchKernelGGL((assign_rerank_kernel<NT, 0>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((assign_rerank_kernel<NT, (CB == 8 ? 0 : 2)>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, ag);
     sn_prof_stop(1, st);
     return 0;
 }
@@ -1539,6 +1575,11 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
             a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + 32));
             if (lay.ks2 == 24) rc = lay.nt2 == 4 ? launch_screen2<4, 24>(a, st) : launch_screen2<2, 24>(a, st);
             else rc = lay.nt2 == 4 ? launch_screen2<4, 12>(a, st) : launch_screen2<2, 12>(a, st);
+        } else if (M > 2048) {               // more than 64 tiles: 10-bit word codes in the keys, 16-bit codes in the records
+            a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + kCodeBytesWide));
+            if (D == 192) rc = launch_screen<12, 4, 3, 10>(a, st);
+            else if (D == 384) rc = launch_screen<24, 4, 3, 10>(a, st);
+            else rc = launch_screen<48, 4, 3, 10>(a, st);
         } else if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st);
         else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : launch_screen<24, 4, 3>(a, st);
         else rc = launch_screen<48, 4, 3>(a, st);
