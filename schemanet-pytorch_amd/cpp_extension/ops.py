@@ -464,12 +464,13 @@ def split_planes(x):
 
 
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
-             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None):
+             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
     (>= n; the extra columns are zero).  pool_w [batches, m] -> "pooled" [batches, ceil(m/128), n]:
     per-row-tile partial sums of sum_m pool_w[m] C[m, :] (add them up, or hand them to pool_fc).
+    zero_c: the fp32 result starts as zeros (row tiles beyond m_extent are never written).
     Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
     dev = _check_dev(a.hi, a.lo, b.hi, b.lo)
@@ -482,7 +483,7 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     out = {}
     keep = []
     if want_c:
-        c = torch.empty((batches, m, n), dtype=torch.float32, device=dev)
+        c = (torch.zeros if zero_c else torch.empty)((batches, m, n), dtype=torch.float32, device=dev)
         args.c, args.c_batch_stride, args.ldc = _dp(c), m * n, n
         out["c"] = c
     if want_planes:

@@ -90,9 +90,11 @@ class GNN(nn.Module):
         return any(t.requires_grad for t in tensors if t is not None) or any(p.requires_grad for p in self.parameters())
 
     def _mfma_ok(self) -> bool:
-        """The split-fp16 MFMA path (csrc/sn_gcn.hip) covers the shipped configuration: two layers
-        with a Linear projection, ReLU / no activation and embed_dim 256."""
-        if os.environ.get("SN_GCN_MFMA", "1") == "0" or self.embed_dim != 256 or len(self.layers) != 2:
+        """The split-fp16 MFMA path (csrc/sn_gcn.hip) covers two layers with a Linear projection and ReLU / no
+        activation: embed_dim 256 (the shipped CIFAR / Caltech configurations) with every elementwise step fused into
+        the GEMM epilogues, other widths that are a multiple of 16 (1024 in the ImageNet yaml) with the same GEMMs and
+        the LayerNorm / pooling kernels of the library route in between."""
+        if os.environ.get("SN_GCN_MFMA", "1") == "0" or self.embed_dim % 16 != 0 or len(self.layers) != 2:
             return False
         return all(isinstance(l.g_conv.linear, nn.Linear) and (l._is_relu or l._is_none) for l in self.layers)
 
@@ -134,6 +136,27 @@ class GNN(nn.Module):
                               rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext)["pooled"]   # [G, row tiles, E]
         return ops.pool_fc(pooled, divisor if divisor is not None else n, self.fc.weight, self.fc.bias)
 
+    def _forward_mfma_wide(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None):
+        """embed_dim != 256: a row of the result spans several 256-column tiles, so LayerNorm cannot be an epilogue of
+        the GEMM.  Same three products on the matrix cores (split fp16, fp32-GEMM accuracy), fp32 results, the
+        mask + LayerNorm + activation kernel in place, a hi/lo split for the next product, the pooling kernel."""
+        G, n = ingredients.shape
+        l1, l2 = self.layers
+        ext = divisor if (divisor is not None and torch.is_tensor(divisor)) else None
+        if adj is None:
+            adj = ops.gcn_adjacency_planes(edges, extent=ext)
+        if prepared is None:
+            prepared = self.prepare()
+        zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext)                    # Bt [G, E, n]
+        c1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias, rows_valid=n_valid, want_c=True, zero_c=ext is not None,
+                          m_extent=ext, k_extent=ext)["c"]                                           # [G, n, E]
+        ops.mask_layernorm_act_(c1, l1.norm.weight, l1.norm.bias, l1.norm.eps, n_valid=n_valid, relu=l1._is_relu)
+        zt2 = ops.gcn_gemm(prepared["w2"], ops.split_planes(c1), G, want_planes=n)["planes"]       # [G, E, n]
+        c2 = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias, rows_valid=n_valid, want_c=True, zero_c=ext is not None,
+                          m_extent=ext, k_extent=ext)["c"]
+        ops.mask_layernorm_act_(c2, l2.norm.weight, l2.norm.bias, l2.norm.eps, n_valid=n_valid, relu=l2._is_relu)
+        return self.fc(ops.weighted_pool(c2, nodes, divisor))
+
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
                 feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
                 divisor: Optional[torch.Tensor] = None, adjacency=None, prepared=None) -> torch.Tensor:
@@ -146,13 +169,15 @@ class GNN(nn.Module):
         """
         if adjacency is not None:        # prebuilt (E + E^T)/2 + I planes (SchemaNet.get_atlas(fused_adjacency=True))
             if not (nodes.is_cuda and self._mfma_ok()) or self._differentiable(nodes):
-                raise RuntimeError("adjacency planes need the inference MFMA path (embed_dim 256, 2 Linear layers, no autograd)")
-            return self._forward_mfma(nodes, None, ingredients, n_valid, divisor, adj=adjacency, prepared=prepared)
+                raise RuntimeError("adjacency planes need the inference MFMA path (2 Linear layers, embed_dim a multiple of 16, no autograd)")
+            run = self._forward_mfma if self.embed_dim == 256 else self._forward_mfma_wide
+            return run(nodes, None, ingredients, n_valid, divisor, adj=adjacency, prepared=prepared)
         fused = nodes.is_cuda and not self._differentiable(nodes, edges)
         if n_valid is None and feat_mask is not None:
             n_valid = (~feat_mask).sum(dim=1).to(torch.int32)   # masks are suffix masks (match.py:48-51)
         if fused and self._mfma_ok():
-            return self._forward_mfma(nodes, edges, ingredients, n_valid, divisor, prepared=prepared)
+            run = self._forward_mfma if self.embed_dim == 256 else self._forward_mfma_wide
+            return run(nodes, edges, ingredients, n_valid, divisor, prepared=prepared)
         if feat_mask is None and n_valid is not None and not fused:
             feat_mask = torch.arange(nodes.shape[1], device=nodes.device)[None, :] >= n_valid[:, None]
         adj = ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges)
