@@ -79,7 +79,7 @@ def step(disc, sn, m, tokens, attn, class_branch_first=True):
     else:
         ing = disc.assign(tokens[:, 1:, :])
         atlas = m.atlas_features_async(FUSED_ATLAS(sn))
-    g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False)   # S2 + S3
+    g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False, zero_padding=False)   # S2 + S3 (as SchemaNetPredictor.forward)
     return m.forward_padded(g, atlas.class_dict, feat_kg=atlas)                  # S4 (instance GNN, join, scores)
 
 
@@ -245,7 +245,7 @@ def main():
             ev[1].record()
             atlas = m.atlas_features_async(FUSED_ATLAS(sn))  # class branch on the side stream (overlaps everything below)
             ev[2].record()
-            g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False)
+            g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False, zero_padding=False)
             ev[3].record()
             pred = m.forward_padded(g, atlas.class_dict, feat_kg=atlas)
             ev[4].record()
@@ -266,7 +266,8 @@ def main():
         # B*196 tokens * (D*4 B read + 8 B index written)  (302,624 B / image)
         alg_bytes = B * L * (D * 4 + 8)
         ach = alg_bytes / (avg["assign_screen"] * 1e-3) / 1e9 if avg["assign_screen"] else None
-        graph_bytes = B * (L * L * 4 + L * 4 + L * 8) + B * (L * L * 4 + L * 12)   # attn in + padded edges/ids/weights out
+        # attn + ids + cls attention in; the images' own n_i x n_i edge corners (the zero padding is not written) + padded ids / weights out
+        graph_bytes = B * (L * L * 4 + L * 4 + L * 8) + int((g["n"].long() ** 2).sum().item()) * 4 + B * L * 12
         screen_name = ("assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)" if lib.sn_assign_variant() == 2
                        else "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen, token-stationary)")
         copy_gbps = stream_copy_GBps(device)

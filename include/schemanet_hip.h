@@ -190,6 +190,10 @@ typedef struct sn_graph_args {
     float *attn_cls_masked;       /* [B, L] logits after the clamp (the reference's in-place
                                      masked_fill_ side effect, schema_net.py:296); may alias
                                      attn_cls                                                   */
+    int skip_edge_padding;        /* 1: rows and columns >= the image's vertex count of out_e /
+                                     out_e2 are left UNWRITTEN (two thirds of the padded batch
+                                     are such zeros); the consumer must mask by out_n, as
+                                     sn_gcn_adjacency_planes_masked does                         */
 } sn_graph_args;
 
 int sn_instance_graph(const sn_graph_args *args, void *stream);
@@ -301,6 +305,11 @@ int64_t sn_gcn_plane_elems(int rows, int k);
  * extent_dev (optional, here and below): int32 on the device, e.g. the largest vertex count of the
  * batch; blocks whose rows / k lie entirely beyond it (rounded up to 32 / 16) are not produced and
  * must not be consumed - sn_gcn_gemm's m_extent / k_extent skip exactly those. */
+/* The same with a vertex count per graph: element (i, j) of graph g is taken as 0 unless i, j < n_valid[g] and is not
+ * read (edges written with sn_graph_args.skip_edge_padding); the identity still covers all n rows (gnn.py:27-30 on the
+ * zero-padded batch, match.py:48-54).  n_valid NULL = sn_gcn_adjacency_planes. */
+int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, const int32_t *n_valid, const int32_t *extent_dev,
+                                   void *adj_hi, void *adj_lo, void *stream);
 int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, void *adj_hi,
                             void *adj_lo, void *stream);
 

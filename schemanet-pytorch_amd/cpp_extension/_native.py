@@ -16,7 +16,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
-ABI_VERSION = 1
+ABI_VERSION = 2
 SN_MAX_TOKENS = 196
 _lib = None
 
@@ -42,6 +42,7 @@ class GraphArgs(Structure):
         ("out_ids", c_void_p), ("out_v2", c_void_p), ("out_v", c_void_p),
         ("out_e2", c_void_p), ("out_e", c_void_p),
         ("out_n", c_void_p), ("out_n_max", c_void_p), ("attn_cls_masked", c_void_p),
+        ("skip_edge_padding", c_int),
     ]
 
 
@@ -102,6 +103,7 @@ _SIGNATURES = {
     "sn_gcn_atlas_adjacency_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_plane_elems": (c_int64, [c_int, c_int]),
     "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sn_gcn_adjacency_planes_masked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),

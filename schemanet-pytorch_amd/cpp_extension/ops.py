@@ -204,10 +204,12 @@ def instance_graph(ingredients, attn=None, attn_cls=None, *, w_v=None, w_e=None,
                    attn_is_logits=True, attn_cls_is_logits=True, clamp_v=None, clamp_e=None,
                    geo=None, feat_h=14, feat_w=14, dist_alpha=1.0, dist_pow=2.0, mean=True,
                    remove_self_loop=False, dicts=None, want_attr2=False, want_weighted=True,
-                   attn_cls_masked_out=None):
+                   attn_cls_masked_out=None, zero_padding=True):
     """One launch of sn_instance_graph.  Returns a dict of padded tensors:
     ids [B,n_pad] i64, n [B] i32, n_max [1] i32, and (when the inputs are given)
-    v / v2 ([B,n_pad] / [B,n_pad,2]) and e / e2 ([B,n_pad,n_pad] / [...,2])."""
+    v / v2 ([B,n_pad] / [B,n_pad,2]) and e / e2 ([B,n_pad,n_pad] / [...,2]).
+    zero_padding=False leaves the rows / columns of e / e2 beyond an image's vertex count unwritten (two thirds of the
+    padded batch): only for consumers that mask by n (gcn_adjacency_planes(..., n_valid=n))."""
     lib = N.require_gpu()
     dev = _check_dev(ingredients, attn, attn_cls, w_v, w_e, geo)
     assert ingredients.dtype == torch.int64 and ingredients.dim() == 2
@@ -255,6 +257,7 @@ def instance_graph(ingredients, attn=None, attn_cls=None, *, w_v=None, w_e=None,
             keep.append(g)
             a.geo = g.data_ptr()
         a.feat_h, a.feat_w, a.dist_alpha, a.dist_pow = feat_h, feat_w, float(dist_alpha), float(dist_pow)
+        a.skip_edge_padding = int(not zero_padding)
         if want_weighted:
             out["e"] = torch.empty((B, n_pad, n_pad), **f32)
             a.out_e = out["e"].data_ptr()
@@ -418,17 +421,23 @@ def _alloc_planes(lib, dev, batches, rows, k):
     return Planes(hi, torch.empty_like(hi), batches, rows, k)
 
 
-def gcn_adjacency_planes(edges, extent=None):
+def gcn_adjacency_planes(edges, extent=None, n_valid=None):
     """(E + E^T)/2 + I of [G, n, n] edges as blocked fp16 hi/lo planes.  extent: optional int32 [1]
-    device tensor (largest vertex count of the batch): blocks beyond it are not produced."""
+    device tensor (largest vertex count of the batch): blocks beyond it are not produced.  n_valid: optional int32 [G]
+    vertex counts: edges outside a graph's own corner count as zero and are not read."""
     lib = N.require_gpu()
     dev = _check_dev(edges)
     e = _f32c(edges)
     G, n, _ = e.shape
     out = _alloc_planes(lib, dev, G, n, n)
     with torch.cuda.device(dev):
-        N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
-                "sn_gcn_adjacency_planes")
+        if n_valid is not None:
+            assert n_valid.dtype == torch.int32 and n_valid.numel() == G and n_valid.device == dev
+            N.check(lib.sn_gcn_adjacency_planes_masked(N.ptr(e), G, n, N.ptr(n_valid), N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo),
+                                                       N.stream_ptr(dev)), "sn_gcn_adjacency_planes_masked")
+        else:
+            N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+                    "sn_gcn_adjacency_planes")
     return out
 
 

@@ -88,13 +88,16 @@ __device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h
 // 64 x 64 tile would be bound by the dispatch rate (~10 ns per workgroup chip-wide), not by HBM.
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
-                                                               const int32_t *extent)
+                                                               const int32_t *extent, const int32_t *n_valid)
 {
     __shared__ float te[64][65], tt[64][65];
     __shared__ float rs_i[64], rs_j[64];
     const int g = blockIdx.y;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float *e = edges + (int64_t)g * n * n;
+    // elements outside the graph's own nv x nv corner count as 0 and are not read (their storage may be unwritten);
+    // the identity below still covers all n rows
+    const int nv = n_valid ? min(max(n_valid[g], 0), n) : n;
     int rows_lim = (n + 31) & ~31, k_lim = kb_count * 16;
     if (extent) {                                              // nothing beyond the largest graph of the batch is ever read
         const int ext = *extent;
@@ -119,10 +122,10 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
             for (int it = 0; it < 16; ++it) {
                 const int rr = ty + 4 * it;
                 const int i = bi + rr, j = bj + tx;
-                const bool ok = i < n && j < n;
+                const bool ok = i < nv && j < nv;
                 ve[it] = e[ok ? (int64_t)i * n + j : 0];                      // E[I][J] tile, [i - bi][j - bj]
                 const int i2 = bj + rr, j2 = bi + tx;
-                const bool ok2 = i2 < n && j2 < n;
+                const bool ok2 = i2 < nv && j2 < nv;
                 vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                   // E[J][I] tile, [j - bj][i - bi]
                 ve[it] = ok ? ve[it] : 0.0f;
                 vt[it] = ok2 ? vt[it] : 0.0f;
@@ -603,8 +606,24 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const i
     const int kb = (n + 15) / 16;
     const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);      // a workgroup owns row tiles x and T-1-x
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev);
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
+                       (const int32_t *)nullptr);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
+    return SN_OK;
+}
+
+extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, const int32_t *n_valid, const int32_t *extent_dev,
+                                              void *adj_hi, void *adj_lo, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_masked: bad G=%d n=%d", G, n);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(edges && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_masked: NULL pointer");
+    SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes_masked: G=%d > 65535", G);
+    const int kb = (n + 15) / 16;
+    const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);
+    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid);
+    SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
     return SN_OK;
 }
 
@@ -618,7 +637,8 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     const int kb = (n + 15) / 16;
     const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
-                       kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr);
+                       kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }

@@ -826,6 +826,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 }
             }
         } else {                                             // padding row: zeros, nothing to normalise
+            if (a.skip_edge_padding) continue;               // (the consumer masks by the vertex count)
             const int64_t rowbase0 = ((int64_t)b * a.n_pad + r) * a.n_pad;
             for (int c = lane; c < a.n_pad; c += SN_WAVE) {
                 if (a.out_e2) { a.out_e2[2 * (rowbase0 + c)] = 0.0f; a.out_e2[2 * (rowbase0 + c) + 1] = 0.0f; }
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
 #pragma unroll
         for (int k = 0; k < kCellsPerLane; ++k) {
             const int c = lane + SN_WAVE * k;
-            if (c >= a.n_pad) continue;
+            if (c >= a.n_pad || (a.skip_edge_padding && c >= n_out)) continue;
             float e0 = 0.0f, e1 = 0.0f;
             if (c < n_out) {
                 e0 = c0[k] * i0;
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 a.out_e[rowbase + c] = p0 + p1;
             }
         }
-        for (int c = kMaxCols + lane; c < a.n_pad; c += SN_WAVE) {
+        for (int c = kMaxCols + lane; c < a.n_pad && !a.skip_edge_padding; c += SN_WAVE) {
             if (a.out_e2) { a.out_e2[2 * (rowbase + c)] = 0.0f; a.out_e2[2 * (rowbase + c) + 1] = 0.0f; }
             if (a.out_e) a.out_e[rowbase + c] = 0.0f;
         }

@@ -45,7 +45,9 @@ class SchemaNetPredictor(nn.Module):
         # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
         # instance branch on the current one; joined inside forward_padded
         atlas = self.matcher.atlas_features_async(self.schema_net.get_atlas)
-        graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"])
+        # (the zero padding of the instance edges is only written when the caller asks for the graphs)
+        graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
+                                                      zero_padding=requires_graph)
         ret["pred"] = self.matcher.forward_padded(graph, atlas.class_dict, feat_kg=atlas)
         class_dict = atlas.class_dict
         ret.update(class_dict)

@@ -98,6 +98,11 @@ class GNN(nn.Module):
             return False
         return all(isinstance(l.g_conv.linear, nn.Linear) and (l._is_relu or l._is_none) for l in self.layers)
 
+    def masks_adjacency(self, edges: torch.Tensor) -> bool:
+        """True when `forward(..., n_valid=...)` never reads edges outside a graph's own corner (the MFMA routes build
+        the adjacency operand with sn_gcn_adjacency_planes_masked)."""
+        return bool(edges.is_cuda and self._mfma_ok() and not self._differentiable(edges))
+
     def prepare(self):
         """The parameter-only operands of the MFMA path: layer 1's Linear folded into the embedding
         table ((M+1) x E GEMM) and W2 as fp16 hi/lo planes.  A forward pass embeds the instance graphs
@@ -123,7 +128,7 @@ class GNN(nn.Module):
         # (rounded up to the block sizes) is produced or multiplied - no host synchronisation needed
         ext = divisor if (divisor is not None and torch.is_tensor(divisor)) else None
         if adj is None:
-            adj = ops.gcn_adjacency_planes(edges, extent=ext)                       # A  [G, n, n]
+            adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)                       # A  [G, n, n]
         if prepared is None:
             prepared = self.prepare()
         zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext)     # Bt [G, E, n]
@@ -144,7 +149,7 @@ class GNN(nn.Module):
         l1, l2 = self.layers
         ext = divisor if (divisor is not None and torch.is_tensor(divisor)) else None
         if adj is None:
-            adj = ops.gcn_adjacency_planes(edges, extent=ext)
+            adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)
         if prepared is None:
             prepared = self.prepare()
         zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext)                    # Bt [G, E, n]

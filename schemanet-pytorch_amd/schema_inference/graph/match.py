@@ -100,7 +100,12 @@ class Matcher(nn.Module):
         n_max [1] i32 (device).  The pooling divides by n_max, i.e. by the length the reference
         pads to (max_i n_i, match.py:46; gnn.py:96), so the result does not depend on n_pad.
         feat_kg: precomputed class features [K, E] or a handle of `atlas_features_async`."""
-        feat_instance = self.gnn(nodes=graph["vertices"], edges=graph["edges"], ingredients=graph["ids"],
+        edges = graph["edges"]
+        if not graph.get("edges_padded", True) and not self.gnn.masks_adjacency(edges):
+            # written without its zero padding, and this GNN route reads all of it: mask by the vertex counts here
+            valid = torch.arange(edges.shape[-1], device=edges.device)[None, :] < graph["n"][:, None]
+            edges = torch.where(valid[:, :, None] & valid[:, None, :], edges, torch.zeros((), dtype=edges.dtype, device=edges.device))
+        feat_instance = self.gnn(nodes=graph["vertices"], edges=edges, ingredients=graph["ids"],
                                  n_valid=graph["n"], divisor=graph["n_max"],
                                  prepared=feat_kg.prepared if isinstance(feat_kg, _AtlasHandle) else None)
         if isinstance(feat_kg, _AtlasHandle):

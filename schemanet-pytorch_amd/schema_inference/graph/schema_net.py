@@ -226,7 +226,7 @@ class SchemaNet(nn.Module):
         return min(L, self.num_vertices)
 
     def instance_graph_padded(self, ingredients: torch.LongTensor, attn: torch.Tensor, attn_cls: torch.Tensor,
-                              n_pad: int = None, mutate_inputs: bool = True) -> Dict[str, torch.Tensor]:
+                              n_pad: int = None, mutate_inputs: bool = True, zero_padding: bool = True) -> Dict[str, torch.Tensor]:
         """One fused launch: logits -> padded instance graphs.
 
         ingredients [bs, L] i64; attn [bs, L, L] or [bs, H, L, L] logits (head mean fused);
@@ -237,6 +237,9 @@ class SchemaNet(nn.Module):
         (reference match.py:48-54), without the .tolist() syncs.
         mutate_inputs: reproduce the reference's in-place masked_fill_ on `attn_cls`
         (schema_net.py:296) when it is a plain [bs, L] contiguous tensor.
+        zero_padding=False: the rows / columns of `edges` beyond an image's own vertex count are left unwritten
+        (about two thirds of the padded batch are such zeros) and the dict says `edges_padded: False`;
+        `Matcher.forward_padded` masks by `n` instead.  For callers that only want the scores.
         """
         dev = self._dev()
         B, L = ingredients.shape
@@ -252,11 +255,13 @@ class SchemaNet(nn.Module):
             pad_id=self.num_vertices, attn_is_logits=True, attn_cls_is_logits=True,
             clamp_v=self.clamp_vertex_attn, clamp_e=self.clamp_edge_attn, feat_h=self.feat_h, feat_w=self.feat_w,
             dist_alpha=self.dist_alpha, dist_pow=self.dist_pow, mean=True, remove_self_loop=self.remove_self_loop,
-            want_attr2=need_grad, want_weighted=not need_grad, attn_cls_masked_out=masked_out)
+            want_attr2=need_grad, want_weighted=not need_grad, attn_cls_masked_out=masked_out,
+            zero_padding=zero_padding or need_grad)
         if need_grad:   # keep `@ w` visible to autograd (the reference does it inside C++)
             g["v"] = (g["v2"] @ w_v).squeeze(-1)
             g["e"] = (g["e2"] @ w_e).squeeze(-1)
-        return {"ids": g["ids"], "vertices": g["v"], "edges": g["e"], "n": g["n"], "n_max": g["n_max"]}
+        return {"ids": g["ids"], "vertices": g["v"], "edges": g["e"], "n": g["n"], "n_max": g["n_max"],
+                "edges_padded": bool(zero_padding or need_grad)}
 
     @staticmethod
     def _as_lists(g: Dict[str, torch.Tensor]) -> Dict[str, List[torch.Tensor]]:

@@ -11,7 +11,8 @@ lib = N.load()
 with torch.no_grad():
     disc.vocabulary.weight.copy_(codebook)
     ing = disc.assign(tokens[:, 1:, :])
-    run = lambda: sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False)
+    zp = os.environ.get("SN_ZERO_PADDING", "1") != "0"
+    run = lambda: sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False, zero_padding=zp)
     for _ in range(100): run()
     torch.cuda.synchronize()
     lib.sn_profile_enable(100)
