@@ -96,6 +96,13 @@ int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_
                     int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
                     int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
                     void *workspace, size_t workspace_bytes, int mode, void *stream);
+/* The same for bfloat16 tokens (what an autocast backbone hands over; strides in bf16 elements, 16-byte aligned rows for
+ * the fast path).  The word ids are those of the tokens converted to fp32 (exact), i.e. what the reference computes after
+ * `seq.float()`; half the token bytes of sn_assign_words. */
+int sn_assign_words_bf16(const void *x_bf16, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
+                         int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
+                         int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
+                         void *workspace, size_t workspace_bytes, int mode, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * training loss, sparsity terms

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "sn_assign_workspace_bytes": (c_size_t, [c_int64]),
     "sn_assign_words": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_int, c_void_p]),
+    "sn_assign_words_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_int, c_void_p]),
     "sn_row_entropy": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "sn_row_entropy_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "sn_kmeans_update": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,

@@ -58,7 +58,8 @@ def assign_words(tokens, codebook, packed, out=None, mode=0):
     returns int64 [n_outer, n_inner] word ids (or fills `out`, any strides)."""
     lib = N.require_gpu()
     dev = _check_dev(tokens, codebook, packed, out)
-    if tokens.dtype != torch.float32 or tokens.stride(-1) != 1:
+    bf16 = tokens.dtype == torch.bfloat16 and tokens.stride(-1) == 1      # consumed in place (half the token bytes)
+    if not bf16 and (tokens.dtype != torch.float32 or tokens.stride(-1) != 1):
         tokens = tokens.to(torch.float32).contiguous()
     assert tokens.dim() == 3
     n_outer, n_inner, D = tokens.shape
@@ -71,7 +72,8 @@ def assign_words(tokens, codebook, packed, out=None, mode=0):
     ws_bytes = lib.sn_assign_workspace_bytes(n_tok)
     ws = torch.empty(max(ws_bytes, 32), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        N.check(lib.sn_assign_words(
+        fn = lib.sn_assign_words_bf16 if bf16 else lib.sn_assign_words
+        N.check(fn(
             N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(codebook), N.ptr(packed), M, D,
             N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws_bytes, int(mode), N.stream_ptr(dev)), "sn_assign_words")
     return out

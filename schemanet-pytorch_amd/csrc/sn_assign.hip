@@ -225,6 +225,7 @@ struct AssignArgs {
     // waves without tokens only keep the codebook ring going.  Default: full_waves = waves per workgroup.
     int full_waves;
     int64_t extra_base;
+    int x_bf16;         // tokens are bfloat16 (x points at 2-byte elements, strides in elements); results are defined on their fp32 values
 };
 
 constexpr int kGateSlots = 4096;        // (XCC_ID[3:0] << 8) | HW_ID[15:8] (CU_ID, SH_ID, SE_ID)
@@ -241,7 +242,14 @@ static unsigned long long *g_stamps = nullptr;
 __device__ __forceinline__ const float *token_row(const AssignArgs &p, int64_t n)
 {
     const unsigned ni = (unsigned)p.n_inner, o = (unsigned)n / ni, i = (unsigned)n - o * ni;
-    return p.x + (int64_t)o * p.xso + (int64_t)i * p.xsi;
+    const int64_t e = (int64_t)o * p.xso + (int64_t)i * p.xsi;                  // element offset of the row
+    return p.x_bf16 ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(p.x) + e) : p.x + e;
+}
+
+// element k of a token row as fp32 (bf16 -> fp32 is exact)
+__device__ __forceinline__ float token_elem(const AssignArgs &p, const float *row, int k)
+{
+    return p.x_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(row)[k] << 16) : row[k];
 }
 
 __device__ __forceinline__ int64_t out_index(const AssignArgs &p, int64_t n)
@@ -263,12 +271,12 @@ __device__ __forceinline__ void exact_scan(const double (&x)[NT], const AssignAr
 }
 
 template <int NT>
-__device__ __forceinline__ void load_token64(double (&x)[NT], const float *row, int D, int lane)
+__device__ __forceinline__ void load_token64(double (&x)[NT], const AssignArgs &p, const float *row, int D, int lane)
 {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int k = lane + SN_WAVE * t;
-        x[t] = k < D ? (double)row[k] : 0.0;
+        x[t] = k < D ? (double)token_elem(p, row, k) : 0.0;
     }
 }
 
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
     const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
     for (int64_t n = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); n < p.n_tokens; n += n_waves) {
         double x[NT];
-        load_token64<NT>(x, token_row(p, n), p.D, lane);
+        load_token64<NT>(x, p, token_row(p, n), p.D, lane);
         double best = (double)INFINITY;
         int bi = 0;
         exact_scan<NT>(x, p, cn64, 0, p.M, lane, best, bi);
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
                 }
             }
             double x[NT];
-            load_token64<NT>(x, token_row(p, n), p.D, lane);
+            load_token64<NT>(x, p, token_row(p, n), p.D, lane);
             double best = (double)INFINITY;
             int bi = 0x7fffffff;
             for (unsigned long long cm = cmask; cm;) {           // two candidates per round: their loads overlap
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
         __syncthreads();
         float sq = 0.0f, sabs = 0.0f, mabs = 0.0f;
         for (int k = tid; k < NT * SN_WAVE; k += 256) {
-            const float v = k < p.D ? row[k] : 0.0f;
+            const float v = k < p.D ? token_elem(p, row, k) : 0.0f;
             xs[k] = v;
             xh[k] = (_Float16)v;
             sq = fmaf(v, v, sq);
@@ -655,12 +663,12 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     constexpr int kStageBufs = kBufsFit < 4 ? kBufsFit : 4;
     static_assert(kStageBufs >= 2, "token staging needs two 4 KiB buffers per wave inside the codebook ring");
     const unsigned stage_base = __builtin_amdgcn_readfirstlane(lds_base + wid * (kStageBufs * 4096));
-    const float *rowq[4];
+    const unsigned char *rowq[4];                                             // (bytes: fp32 and bf16 rows alike, 128-byte chunks)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rq = 8 * q + (lane >> 3);
         const int64_t nq = wave_tok0 + rq;
-        rowq[q] = token_row(p, nq < p.n_tokens ? nq : 0) + 4 * ((lane & 7) ^ ((rq >> 1) & 7));
+        rowq[q] = reinterpret_cast<const unsigned char *>(token_row(p, nq < p.n_tokens ? nq : 0)) + 16 * ((lane & 7) ^ ((rq >> 1) & 7));
     }
     unsigned keep_m0;
     asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
@@ -669,29 +677,64 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
         const unsigned dst = stage_base + (u % kStageBufs) * 4096;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(rowq[q] + 32 * u), "s"(dst + q * 1024) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(rowq[q] + 128 * u), "s"(dst + q * 1024) : "memory");
     };
     const unsigned char *frag_src = smem + wid * (kStageBufs * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
     const int sw = (r >> 1) & 7;
-#pragma unroll
-    for (int u = 0; u < kStageBufs && u < kU; ++u) issue_chunk(u);
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-        constexpr int kAheadMax = kStageBufs - 1;
-        const int ahead = (kU - 1 - u) < kAheadMax ? (kU - 1 - u) : kAheadMax;        // chunks issued after chunk u
+    // chunk c = bytes [128 c, 128 c + 128) of every row: 32 fp32 elements (k-steps 2c, 2c+1) or 64 bf16 elements
+    // (k-steps 4c .. 4c+3).  A lane reads the four 16-byte pieces that hold its k: fp32 4h..4h+3; bf16 2h, 2h+1 of
+    // each 64-byte half.
+    auto wait_chunk = [&](int ahead) {
         if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        f32x4 raw[4];
+    };
+    constexpr int kAheadMax = kStageBufs - 1;
+    if (!p.x_bf16) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-            raw[v] = *reinterpret_cast<const f32x4 *>(frag_src + (u % kStageBufs) * 4096 + (((4 * h + v) ^ sw) * 16));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            // in registers: the buffer may be refilled
-        if (u + kStageBufs < kU) issue_chunk(u + kStageBufs);
-        const float f[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
-                             raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
-        convert(u, f);
+        for (int u = 0; u < kStageBufs && u < kU; ++u) issue_chunk(u);
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            wait_chunk((kU - 1 - u) < kAheadMax ? (kU - 1 - u) : kAheadMax);      // chunks issued after chunk u
+            f32x4 raw[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                raw[v] = *reinterpret_cast<const f32x4 *>(frag_src + (u % kStageBufs) * 4096 + (((4 * h + v) ^ sw) * 16));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // in registers: the buffer may be refilled
+            if (u + kStageBufs < kU) issue_chunk(u + kStageBufs);
+            const float f[16] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w,
+                                 raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
+            convert(u, f);
+        }
+    } else {
+        constexpr int kUB = NSTEPS / 4;                                               // 128-byte chunks of a bf16 row
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < kStageBufs && c < kUB; ++c) issue_chunk(c);
+#pragma unroll
+        for (int c = 0; c < kUB; ++c) {
+            wait_chunk((kUB - 1 - c) < kAheadMax ? (kUB - 1 - c) : kAheadMax);
+            u32x4 raw[4];                                                             // [half uu][piece e]
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                raw[v] = *reinterpret_cast<const u32x4 *>(frag_src + (c % kStageBufs) * 4096 + (((4 * (v >> 1) + 2 * h + (v & 1)) ^ sw) * 16));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (c + kStageBufs < kUB) issue_chunk(c + kStageBufs);
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                float f[16];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned w2 = raw[2 * uu + e][j];                       // two bf16: element 2j (low half), 2j + 1
+                        f[8 * e + 2 * j] = __uint_as_float(w2 << 16);
+                        f[8 * e + 2 * j + 1] = __uint_as_float(w2 & 0xFFFF0000u);
+                    }
+                convert(2 * c + uu, f);
+            }
+        }
     }
     }
     asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));
@@ -1532,11 +1575,12 @@ extern "C" size_t sn_assign_workspace_bytes(int64_t n_tokens)
     return ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15)) + kGateBytes;
 }
 
-extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
-                               int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
-                               int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
-                               void *workspace, size_t workspace_bytes, int mode, void *stream)
+static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
+                             int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
+                             int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
+                             void *workspace, size_t workspace_bytes, int mode, void *stream)
 {
+    const float *x = (const float *)x_any;
     SN_REQUIRE(n_outer >= 0 && n_inner >= 0, SN_ERR_BAD_ARG, "sn_assign_words: negative token grid");
     const int64_t n_tokens = n_outer * n_inner;
     if (n_tokens == 0) return SN_OK;
@@ -1557,10 +1601,12 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     a.codes32 = ws ? (unsigned *)(ws + 32 + (size_t)n_tokens * 4) : nullptr;
     a.n_sets = (n_tokens + 31) / 32;
     a.full_waves = kWavesPerBlock; a.extra_base = n_tokens;
+    a.x_bf16 = x_bf16;
     a.gate = ws ? (unsigned *)(ws + ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15))) : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % 4 == 0 && x_stride_inner % 4 == 0;
-    const bool screen_ok = mode == 0 && aligned && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
+    const int per16 = x_bf16 ? 8 : 4;                            // elements per 16 bytes
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % per16 == 0 && x_stride_inner % per16 == 0;
+    const bool screen_ok = mode == 0 && aligned && (SN_S1_STAGE || !x_bf16) && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
     if (screen_ok) {
         SN_REQUIRE(workspace && workspace_bytes >= sn_assign_workspace_bytes(n_tokens), SN_ERR_WORKSPACE,
                    "sn_assign_words: workspace %zu < %zu bytes", workspace_bytes, sn_assign_workspace_bytes(n_tokens));
@@ -1571,7 +1617,7 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
         int rc = 0;
         const bool wide = screen_variant() == 1;
         const PackLayout lay = pack_layout(M, D);
-        if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 32) {
+        if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 32 && !x_bf16) {
             a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + 32));
             if (lay.ks2 == 24) rc = lay.nt2 == 4 ? launch_screen2<4, 24>(a, st) : launch_screen2<2, 24>(a, st);
             else rc = lay.nt2 == 4 ? launch_screen2<4, 12>(a, st) : launch_screen2<2, 12>(a, st);
@@ -1593,4 +1639,22 @@ extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner,
     }
     SN_CHECK_LAUNCH("sn_assign_words");
     return SN_OK;
+}
+
+extern "C" int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
+                               int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
+                               int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
+                               void *workspace, size_t workspace_bytes, int mode, void *stream)
+{
+    return assign_words_impl(x, 0, n_outer, n_inner, x_stride_outer, x_stride_inner, codebook, packed, M, D, out, out_stride_outer,
+                             out_stride_inner, workspace, workspace_bytes, mode, stream);
+}
+
+extern "C" int sn_assign_words_bf16(const void *x_bf16, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
+                                    int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
+                                    int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
+                                    void *workspace, size_t workspace_bytes, int mode, void *stream)
+{
+    return assign_words_impl(x_bf16, 1, n_outer, n_inner, x_stride_outer, x_stride_inner, codebook, packed, M, D, out, out_stride_outer,
+                             out_stride_inner, workspace, workspace_bytes, mode, stream);
 }
