@@ -12,7 +12,7 @@ One "step" = one pass of the hot path over one batch that is already resident in
   IR-Atlas normalise (K=100, n_max=512) --S4--> GCN on instances and on the atlas --> pred [B,100]
 Nothing is cached across steps (the atlas GCN is recomputed every step, like the reference).
 The K timed steps replay captured hipGraphs of the step (schema_inference.utils.graph_replay: same kernels,
-no host launch path in the timed region), two steps in flight on two streams (independent batches; each capture
+no host launch path in the timed region), four steps in flight on four streams (independent batches; each capture
 has its own buffers; `SN_BENCH_DEPTH=1` replays one graph back to back); a
 second, untimed pass of K eager steps with HIP events on the launch stream gives the per-kernel
 durations of the roofline figure (`SN_BENCH_EAGER=1` times the eager loop instead).
@@ -209,7 +209,7 @@ def main():
         if os.environ.get("SN_BENCH_EAGER", "0") != "1":
             try:
                 from schema_inference.utils.graph_replay import PipelinedSteps
-                depth = int(os.environ.get("SN_BENCH_DEPTH", "2"))
+                depth = int(os.environ.get("SN_BENCH_DEPTH", "4"))
                 graphed = PipelinedSteps(one_step, depth)   # capture (outside the timed region)
                 for _ in range(depth):
                     graphed.submit()
