@@ -282,6 +282,7 @@ struct GemmArgs {
     int batches, tiles_x, tiles_y;   // logical grid (the launch is 1-D, see the XCD remap in the kernel)
     const int32_t *m_extent, *k_extent;   // device scalars (or NULL): rows / k beyond them are never consumed downstream
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
+    int nt_a, nt_b;                  // stream that operand past the caches (read once by one workgroup)
 };
 static unsigned long long *g_gemm_stamps = nullptr;
 
@@ -310,10 +311,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     // ---- LDS-DMA sources: wave w copies chunks 6w .. 6w+5 of a stage.  chunk c < 8: A row block c>>1,
     // plane c&1; c >= 8: the same for B.  A chunk is one contiguous 1 KiB block of the blocked plane.
     const _Float16 *src[kDmaPerWave];
+    unsigned nt_mask = 0;
 #pragma unroll
     for (int j = 0; j < kDmaPerWave; ++j) {
         const int c = wid * kDmaPerWave + j;
         const bool is_b = c >= kChunksA;
+        if (is_b ? p.nt_b : p.nt_a) nt_mask |= 1u << j;
         const int t = (is_b ? c - kChunksA : c) >> 1, plane = c & 1;
         const int rb_max = ((is_b ? p.n : p.m) - 1) >> 5;
         int rb = ((is_b ? tile_n : tile_m) >> 5) + t;
@@ -328,6 +331,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
         for (int j = 0; j < kDmaPerWave; ++j) {
             unsigned keep;
+            if ((nt_mask >> j) & 1u)                                  // wave-uniform
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off nt\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src[j] + (int64_t)t * kBlockElems), "s"(dst + j * 1024) : "memory");
+            else
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                          "global_load_lds_dwordx4 %1, off\n\t"
                          "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src[j] + (int64_t)t * kBlockElems), "s"(dst + j * 1024) : "memory");
@@ -702,6 +710,14 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.rows_valid = u->rows_valid; a.pool_w = u->pool_w; a.pool_w_stride = u->pool_w_stride; a.pooled = u->pooled;
     a.stamps = g_gemm_stamps;
     a.m_extent = u->m_extent; a.k_extent = u->k_extent;
+    {   // A per-graph A operand (the adjacency) is read once, by the one workgroup that owns its row tile: its copies carry
+        // the nt hint, so it does not displace what the other workgroups re-read (Bt of the graph, the atlas, the tokens of
+        // the steps in flight): +1 % on the bench step.  The once-read B of the transposed Linear (A shared) gains nothing.
+        // SN_GEMM_NT: bit 0 = A when per-graph (default), bit 1 = B when A is shared.
+        static const int nt = getenv("SN_GEMM_NT") ? atoi(getenv("SN_GEMM_NT")) : 1;
+        a.nt_a = (nt & 1) && u->a_batch_stride != 0;
+        a.nt_b = (nt & 2) && u->a_batch_stride == 0;
+    }
     const int cols = (u->c_hi && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
     a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + kTileM - 1) / kTileM;
     const int64_t n_blocks = (int64_t)8 * ((u->batches + 7) / 8) * a.tiles_x * a.tiles_y;
