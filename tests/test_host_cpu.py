@@ -202,6 +202,19 @@ def test_gnn_torch_form_matches_golden(golden):
     np.testing.assert_allclose(pred.detach().numpy(), g["pred_inner_product"], rtol=2e-5, atol=2e-6)
 
 
+def test_gnn_route_selection_on_the_host():
+    """which GNN configurations the split-fp16 MFMA routes cover (decided on the host, no GPU needed), and that CPU
+    tensors never claim the masking adjacency producer."""
+    import schema_inference.graph as graph
+    cfg = dict(num_layers=2, identity_proj=False, activation="relu")
+    assert graph.Matcher("inner_product", 64, dict(embed_dim=256, **cfg)).gnn._mfma_ok()
+    assert graph.Matcher("inner_product", 64, dict(embed_dim=1024, **cfg)).gnn._mfma_ok()        # wide route (ImageNet yaml)
+    assert not graph.Matcher("inner_product", 64, dict(embed_dim=250, **cfg)).gnn._mfma_ok()
+    assert not graph.Matcher("inner_product", 64, dict(embed_dim=256, num_layers=3, identity_proj=False, activation="relu")).gnn._mfma_ok()
+    m = graph.Matcher("inner_product", 64, dict(embed_dim=256, **cfg))
+    assert not m.gnn.masks_adjacency(torch.zeros(2, 4, 4))
+
+
 def test_shard_indices_partition():
     import schema_inference.graph as graph
     for n, w in ((10, 1), (10, 2), (257, 8), (5, 8)):
