@@ -351,6 +351,12 @@ typedef struct sn_gemm_args {
     const float *pool_w; int64_t pool_w_stride; float *pooled;
     const int32_t *m_extent, *k_extent;   /* device scalars or NULL: row tiles >= *m_extent are skipped (their
                                              pooled partial is zero), the k loop stops at *k_extent */
+    /* gathered B (optional; then b_hi / b_lo are ignored): Bt[g][f][j] = table[b_ids[g * b_ids_stride + j]][f] for
+     * j < b_ids_n, zero for other j and for ids outside [0, b_table_rows).  b_table_hi / _lo: row-major fp16 planes
+     * [b_table_rows + 1][256] of the table split as hi + lo, the last row zero.  Needs n == 256, the LayerNorm
+     * epilogue and k <= 1024.  (Layer 1 of the GNN: (Emb W1^T)[ids], gnn.py:64-66 + 30, without the gathered copy.) */
+    const void *b_table_hi, *b_table_lo;
+    const int64_t *b_ids; int64_t b_ids_stride; int b_ids_n, b_table_rows;
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 

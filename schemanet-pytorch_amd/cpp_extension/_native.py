@@ -16,7 +16,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
-ABI_VERSION = 2
+ABI_VERSION = 3
 SN_MAX_TOKENS = 196
 _lib = None
 
@@ -59,6 +59,8 @@ class GemmArgs(Structure):
         ("rows_valid", c_void_p),
         ("pool_w", c_void_p), ("pool_w_stride", c_int64), ("pooled", c_void_p),
         ("m_extent", c_void_p), ("k_extent", c_void_p),
+        ("b_table_hi", c_void_p), ("b_table_lo", c_void_p),
+        ("b_ids", c_void_p), ("b_ids_stride", c_int64), ("b_ids_n", c_int), ("b_table_rows", c_int),
     ]
 
 

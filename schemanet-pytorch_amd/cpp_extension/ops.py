@@ -474,22 +474,43 @@ def split_planes(x):
     return out
 
 
+def table_planes(table):
+    """fp32 [rows, 256] -> (hi, lo) row-major fp16 planes [rows + 1, 256] with hi + lo ~= table (22 bits, the same split as
+    split_planes) and a zero last row: the gathered-B operand of gcn_gemm."""
+    t = _f32c(table.detach())
+    hi = t.to(torch.float16)
+    lo = (t - hi.to(torch.float32)).to(torch.float16)
+    z = torch.zeros((1, t.shape[1]), dtype=torch.float16, device=t.device)
+    return torch.cat([hi, z]).contiguous(), torch.cat([lo, z]).contiguous()
+
+
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
-             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False):
+             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False, b_table=None):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
     (>= n; the extra columns are zero).  pool_w [batches, m] -> "pooled" [batches, ceil(m/128), n]:
     per-row-tile partial sums of sum_m pool_w[m] C[m, :] (add them up, or hand them to pool_fc).
     zero_c: the fp32 result starts as zeros (row tiles beyond m_extent are never written).
+    b_table = (hi, lo, ids): B is gathered inside the kernel, Bt[g, f, j] = table[ids[g, j], f] (hi, lo = table_planes(table),
+    ids int64 [batches, n_ids]); `b` is then None.  Needs the LayerNorm epilogue and 256 features.
     Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
-    dev = _check_dev(a.hi, a.lo, b.hi, b.lo)
-    assert a.kpad == b.kpad and a.batches in (1, batches) and b.batches in (1, batches)
-    m, n = a.rows, b.rows
     args = N.GemmArgs()
+    if b_table is not None:
+        t_hi, t_lo, ids = b_table
+        dev = _check_dev(a.hi, a.lo, t_hi, t_lo, ids)
+        assert b is None and a.batches in (1, batches) and ids.dtype == torch.int64 and ids.is_contiguous() and ids.shape[0] == batches
+        assert t_hi.dtype == torch.float16 and t_hi.is_contiguous() and t_lo.is_contiguous() and t_hi.shape == t_lo.shape and t_hi.shape[1] == 256
+        m, n = a.rows, 256
+        args.b_table_hi, args.b_table_lo, args.b_ids = _dp(t_hi), _dp(t_lo), _dp(ids)
+        args.b_ids_stride, args.b_ids_n, args.b_table_rows = ids.shape[1], ids.shape[1], t_hi.shape[0] - 1
+    else:
+        dev = _check_dev(a.hi, a.lo, b.hi, b.lo)
+        assert a.kpad == b.kpad and a.batches in (1, batches) and b.batches in (1, batches)
+        m, n = a.rows, b.rows
+        args.b_hi, args.b_lo, args.b_batch_stride = _dp(b.hi), _dp(b.lo), b.stride
     args.a_hi, args.a_lo, args.a_batch_stride = _dp(a.hi), _dp(a.lo), a.stride
-    args.b_hi, args.b_lo, args.b_batch_stride = _dp(b.hi), _dp(b.lo), b.stride
     args.m, args.n, args.k, args.batches = int(m), int(n), int(a.kpad), int(batches)
     out = {}
     keep = []

@@ -283,10 +283,25 @@ struct GemmArgs {
     const int32_t *m_extent, *k_extent;   // device scalars (or NULL): rows / k beyond them are never consumed downstream
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
     int nt_a, nt_b;                  // stream that operand past the caches (read once by one workgroup)
+    // gathered B (GB kernels): Bt[g][f][j] = table[ids[g][j]][f] from row-major fp16 hi/lo tables [tab_rows + 1][256]
+    // (row tab_rows is zero: it stands for j >= ids_n and for ids outside the table)
+    const _Float16 *tab_hi, *tab_lo;
+    const int64_t *ids;
+    int64_t ids_stride;
+    int ids_n, tab_rows;
 };
+constexpr int kMaxGatherK = 1024;      // nodes per graph the gathered-B form stages ids for
 static unsigned long long *g_gemm_stamps = nullptr;
 
-template <bool LN>
+// GB: the B operand is not read from blocked planes but gathered from a row-major table (the layer-1 operand
+// Zt1[f][j] = (Emb W1^T)[ids[j]][f], gnn.py:64-66 + 30, which gather_planes_kernel would otherwise write to HBM and this
+// kernel read back).  A stage of B is then 16 table rows (one per node, 512 bytes per plane) copied by LDS-DMA with
+// per-lane source addresses into a row-major [plane][node][256 features] image, and a B fragment - feature r, eight
+// consecutive nodes - is two transposing LDS reads (ds_read_b64_tr_b16: a 4-row x 16-column block per 16 lanes,
+// delivered column-major).  The 16-byte chunks of row `node` are stored at chunk ^ ((node & 3) << 2): the four rows of
+// a block then lie in four different 64-byte bank groups (conflict-free).  Same products in the same order as with the
+// gathered planes: bit-identical results.
+template <bool LN, bool GB = false>
 __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -307,6 +322,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         return;
     }
     const int kb_count = p.k / kStageK;
+    __shared__ int ids_s[GB ? kMaxGatherK : 1];
+    if constexpr (GB) {
+        for (int j = tid; j < p.k; j += kGemmThreads) {
+            const int64_t id = j < p.ids_n ? p.ids[(int64_t)batch * p.ids_stride + j] : -1;
+            ids_s[j] = (id >= 0 && id < p.tab_rows) ? (int)id : p.tab_rows;
+        }
+        __syncthreads();
+    }
 
     // ---- LDS-DMA sources: wave w copies chunks 6w .. 6w+5 of a stage.  chunk c < 8: A row block c>>1,
     // plane c&1; c >= 8: the same for B.  A chunk is one contiguous 1 KiB block of the blocked plane.
@@ -331,6 +354,15 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
         for (int j = 0; j < kDmaPerWave; ++j) {
             unsigned keep;
+            if (GB && wid * kDmaPerWave + j >= kChunksA) {            // (wave-uniform) piece = plane, node pair; lane = (node, 16-byte chunk)
+                const int pb = wid * kDmaPerWave + j - kChunksA, row = 2 * (pb & 7) + h;
+                const int id = ids_s[t * kStageK + row];
+                const _Float16 *gsrc = ((pb >> 3) ? p.tab_lo : p.tab_hi) + (int64_t)id * kTileN + ((r ^ ((row & 3) << 2)) << 3);
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, off\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst + j * 1024) : "memory");
+                continue;
+            }
             if ((nt_mask >> j) & 1u)                                  // wave-uniform
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %1, off nt\n\t"
@@ -378,8 +410,24 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nt = 4 * wn + j;
-            bh[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 0) * 1024 + lane * 16);
-            bl[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 1) * 1024 + lane * 16);
+            if constexpr (GB) {
+                // lane 4q + p of its 16-lane group addresses row (node) 8h + 4 half + q, features 32 nt + 16 rh + 4p .. + 3
+                typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+                const int q = (lane & 15) >> 2, pp = lane & 3, rh = (lane >> 4) & 1;
+                const unsigned char *base = sb + (8 * h + q) * 512 + ((4 * (nt ^ q) + 2 * rh + (pp >> 1)) << 4) + 8 * (pp & 1);
+                fp16x4 v[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)                                       // x = 2 plane + half
+                    v[x] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4 *)(base + (x >> 1) * 8192 + (x & 1) * 2048));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bh[j][e] = (_Float16)v[0][e]; bh[j][4 + e] = (_Float16)v[1][e];
+                    bl[j][e] = (_Float16)v[2][e]; bl[j][4 + e] = (_Float16)v[3][e];
+                }
+            } else {
+                bh[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 0) * 1024 + lane * 16);
+                bl[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 1) * 1024 + lane * 16);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -689,10 +737,17 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     SN_REQUIRE(u->batches >= 0 && u->m > 0 && u->n > 0 && u->k > 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: bad shape m=%d n=%d k=%d batches=%d",
                u->m, u->n, u->k, u->batches);
     if (u->batches == 0) return SN_OK;
-    SN_REQUIRE(u->a_hi && u->a_lo && u->b_hi && u->b_lo, SN_ERR_BAD_ARG, "sn_gcn_gemm: NULL operand plane");
+    const bool gathered = u->b_table_hi != nullptr;
+    SN_REQUIRE(u->a_hi && u->a_lo && (gathered || (u->b_hi && u->b_lo)), SN_ERR_BAD_ARG, "sn_gcn_gemm: NULL operand plane");
+    if (gathered) {
+        SN_REQUIRE(u->b_table_lo && u->b_ids && u->b_table_rows > 0 && u->b_ids_n >= 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: incomplete gathered-B arguments");
+        SN_REQUIRE(u->layernorm && u->n == kTileN && u->k <= kMaxGatherK, SN_ERR_UNSUPPORTED,
+                   "sn_gcn_gemm: gathered B needs n == 256, the LayerNorm epilogue and k <= %d (got n=%d k=%d)", kMaxGatherK, u->n, u->k);
+        SN_REQUIRE(((uintptr_t)u->b_table_hi | (uintptr_t)u->b_table_lo) % 16 == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: table planes must be 16-byte aligned");
+    }
     SN_REQUIRE(u->k % kStageK == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: k=%d must be a multiple of 16 (the planes' padded k)", u->k);
-    SN_REQUIRE(((uintptr_t)u->a_hi | (uintptr_t)u->a_lo | (uintptr_t)u->b_hi | (uintptr_t)u->b_lo) % 16 == 0 &&
-                   u->a_batch_stride % 8 == 0 && u->b_batch_stride % 8 == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: planes must be 16-byte aligned");
+    SN_REQUIRE(((uintptr_t)u->a_hi | (uintptr_t)u->a_lo | (gathered ? 0 : ((uintptr_t)u->b_hi | (uintptr_t)u->b_lo))) % 16 == 0 &&
+                   u->a_batch_stride % 8 == 0 && (gathered || u->b_batch_stride % 8 == 0), SN_ERR_BAD_ARG, "sn_gcn_gemm: planes must be 16-byte aligned");
     SN_REQUIRE(u->c || u->c_hi || u->pooled, SN_ERR_BAD_ARG, "sn_gcn_gemm: no output requested");
     SN_REQUIRE(!u->c_hi || (u->c_lo && u->cp_cols >= u->n && u->cp_cols % kStageK == 0), SN_ERR_BAD_ARG, "sn_gcn_gemm: bad output planes");
     SN_REQUIRE(!u->c || u->ldc >= u->n, SN_ERR_BAD_ARG, "sn_gcn_gemm: ldc=%d < n=%d", u->ldc, u->n);
@@ -710,6 +765,8 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.rows_valid = u->rows_valid; a.pool_w = u->pool_w; a.pool_w_stride = u->pool_w_stride; a.pooled = u->pooled;
     a.stamps = g_gemm_stamps;
     a.m_extent = u->m_extent; a.k_extent = u->k_extent;
+    a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
+    a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows;
     {   // A per-graph A operand (the adjacency) is read once, by the one workgroup that owns its row tile: its copies carry
         // the nt hint, so it does not displace what the other workgroups re-read (Bt of the graph, the atlas, the tokens of
         // the steps in flight): +1 % on the bench step.  The once-read B of the transposed Linear (A shared) gains nothing.
@@ -728,12 +785,15 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute((const void *)gcn_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipError_t e2 = hipFuncSetAttribute((const void *)gcn_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e3 = hipFuncSetAttribute((const void *)gcn_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e3 != hipSuccess) e1 = e3;
         if (e1 != hipSuccess || e2 != hipSuccess) { sn_set_error("sn_gcn_gemm: LDS attribute failed"); return SN_ERR_LAUNCH; }
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
     sn_prof_start(4, st);
-    if (u->layernorm) hipLaunchKernelGGL(gcn_gemm_kernel<true>, grid, dim3(kGemmThreads), lds, st, a);
+    if (gathered) hipLaunchKernelGGL((gcn_gemm_kernel<true, true>), grid, dim3(kGemmThreads), lds, st, a);
+    else if (u->layernorm) hipLaunchKernelGGL(gcn_gemm_kernel<true>, grid, dim3(kGemmThreads), lds, st, a);
     else hipLaunchKernelGGL(gcn_gemm_kernel<false>, grid, dim3(kGemmThreads), lds, st, a);
     sn_prof_stop(4, st);
     SN_CHECK_LAUNCH("sn_gcn_gemm");

@@ -111,8 +111,11 @@ class GNN(nn.Module):
         if not self._mfma_ok() or not self.embedding.weight.is_cuda or self._differentiable():
             return None
         l1, l2 = self.layers
-        return {"table": torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight),
-                "w2": ops.split_planes(l2.g_conv.linear.weight)}
+        table = torch.nn.functional.linear(self.embedding.weight, l1.g_conv.linear.weight)
+        out = {"table": table, "w2": ops.split_planes(l2.g_conv.linear.weight)}
+        if self.embed_dim == 256 and os.environ.get("SN_GCN_GATHER_FUSED", "1") != "0":
+            out["table_planes"] = ops.table_planes(table)      # layer 1 gathers its B operand inside the GEMM
+        return out
 
     def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None):
         """Inference on the matrix cores: three GEMM launches per call, every elementwise step an
@@ -131,10 +134,15 @@ class GNN(nn.Module):
             adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)                       # A  [G, n, n]
         if prepared is None:
             prepared = self.prepare()
-        zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext)     # Bt [G, E, n]
+        if "table_planes" in prepared and adj.kpad <= 1024:
+            # Bt[g, f, j] = table[ids[g, j], f] gathered inside the kernel (no [G, E, n] copy through HBM)
+            t_hi, t_lo = prepared["table_planes"]
+            zt1, b_table = None, (t_hi, t_lo, ingredients.contiguous())
+        else:
+            zt1, b_table = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext), None     # Bt [G, E, n]
         h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                           layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
-                          rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext)["planes"]   # [G, n, E]
+                          rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext, b_table=b_table)["planes"]   # [G, n, E]
         zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n)["planes"]          # A = W2 planes [1, E, E] -> [G, E, n]
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,

@@ -22,7 +22,7 @@ class _AtlasHandle:
             main = torch.cuda.current_stream(self.feat.device)
             main.wait_event(self.done)
             for v in [self.feat] + list(self.class_dict.values()):
-                for t in ((v.hi, v.lo) if hasattr(v, "hi") else (v,)):
+                for t in ((v.hi, v.lo) if hasattr(v, "hi") else (tuple(v) if isinstance(v, (tuple, list)) else (v,))):
                     if torch.is_tensor(t):
                         t.record_stream(main)                        # allocated on the side stream, consumed here
             self.done = None
@@ -84,7 +84,7 @@ class Matcher(nn.Module):
         main = torch.cuda.current_stream(dev)
         self._side_stream.wait_stream(main)                 # parameters / earlier work are visible
         for v in (prepared or {}).values():                # allocated on the current stream, also read on the side stream
-            for t in ((v.hi, v.lo) if hasattr(v, "hi") else (v,)):
+            for t in ((v.hi, v.lo) if hasattr(v, "hi") else (tuple(v) if isinstance(v, (tuple, list)) else (v,))):
                 if torch.is_tensor(t):
                     t.record_stream(self._side_stream)
         with torch.cuda.stream(self._side_stream):
