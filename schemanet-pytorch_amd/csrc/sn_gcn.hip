@@ -349,6 +349,21 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         src[j] = base + (int64_t)rb * kb_count * kBlockElems + lane * 8;
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    // GB: the table row (id) of this lane's node for each of the wave's B pieces of the NEXT stage to be issued, read from
+    // LDS one stage ahead: the LDS round trip is then off the copy-issue path
+    int next_id[kDmaPerWave];
+    auto load_ids = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < kDmaPerWave; ++j) {
+            next_id[j] = 0;
+            if (GB && wid * kDmaPerWave + j >= kChunksA) {
+                const int pb = wid * kDmaPerWave + j - kChunksA, row = 2 * (pb & 7) + h;
+                const int node = t * kStageK + row;
+                next_id[j] = ids_s[node < p.k ? node : 0];
+            }
+        }
+    };
+    if constexpr (GB) load_ids(0);
     auto issue_stage = [&](int t) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (t % kRing) * kStageBytes + wid * kDmaPerWave * 1024);
 #pragma unroll
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
             unsigned keep;
             if (GB && wid * kDmaPerWave + j >= kChunksA) {            // (wave-uniform) piece = plane, node pair; lane = (node, 16-byte chunk)
                 const int pb = wid * kDmaPerWave + j - kChunksA, row = 2 * (pb & 7) + h;
-                const int id = ids_s[t * kStageK + row];
+                const int id = next_id[j];
                 const _Float16 *gsrc = ((pb >> 3) ? p.tab_lo : p.tab_hi) + (int64_t)id * kTileN + ((r ^ ((row & 3) << 2)) << 3);
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %1, off\n\t"
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                          "global_load_lds_dwordx4 %1, off\n\t"
                          "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src[j] + (int64_t)t * kBlockElems), "s"(dst + j * 1024) : "memory");
         }
+        if constexpr (GB) load_ids(t + 1);                          // (stages are issued in order)
     };
 
     f32x16 acc[2][4];
@@ -419,11 +435,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
                 for (int x = 0; x < 4; ++x)                                       // x = 2 plane + half
                     v[x] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4 *)(base + (x >> 1) * 8192 + (x & 1) * 2048));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bh[j][e] = (_Float16)v[0][e]; bh[j][4 + e] = (_Float16)v[1][e];
-                    bl[j][e] = (_Float16)v[2][e]; bl[j][4 + e] = (_Float16)v[3][e];
-                }
+                // (two 8-byte results side by side = the 16-byte fragment: no element moves)
+                bh[j] = __builtin_bit_cast(half8, __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                bl[j] = __builtin_bit_cast(half8, __builtin_shufflevector(v[2], v[3], 0, 1, 2, 3, 4, 5, 6, 7));
             } else {
                 bh[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 0) * 1024 + lane * 16);
                 bl[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 1) * 1024 + lane * 16);
