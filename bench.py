@@ -79,7 +79,8 @@ def step(disc, sn, m, tokens, attn, class_branch_first=True):
     else:
         ing = disc.assign(tokens[:, 1:, :])
         atlas = m.atlas_features_async(FUSED_ATLAS(sn))
-    g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False, zero_padding=False)   # S2 + S3 (as SchemaNetPredictor.forward)
+    g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False,
+                                 zero_padding=os.environ.get("SN_ZERO_PADDING", "0") == "1")   # S2 + S3 (as SchemaNetPredictor.forward)
     return m.forward_padded(g, atlas.class_dict, feat_kg=atlas)                  # S4 (instance GNN, join, scores)
 
 
