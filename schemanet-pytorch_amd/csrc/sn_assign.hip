@@ -312,8 +312,10 @@ constexpr int kOverflowBlocks = 64;     // blocks reserved for phase B
 
 // FMT 0: records of assign_screen_kernel (24 code bytes per token); FMT 1: records of
 // assign_screen2_kernel (8 code dwords, slot c = 2 wave + accumulator half, key j: bit 3c + j).
+// (six waves per SIMD: phase B, compiled alone, takes 139 registers and would leave phase A - 51 registers, one block per
+// chunk, latency-bound - three waves per SIMD, i.e. less than half of its blocks resident)
 template <int NT, int FMT>
-__global__ __launch_bounds__(256) void assign_rerank_kernel(const AssignArgs p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void assign_rerank_kernel(const AssignArgs p)
 {
     __shared__ float xs[NT * SN_WAVE];
     __shared__ __attribute__((aligned(16))) _Float16 xh[NT * SN_WAVE];
