@@ -12,11 +12,15 @@ order) and ONE all-reduce(SUM) per pass over RCCL/xGMI merges the ranks; sums ar
 the result equals the single-process one up to fp32 re-association.
 
 Message sizes: pass 1 is K*M + K floats (205 KB at K=100, M=512) -> a single fused all-reduce
-(latency bound).  Pass 2 is K*n_max^2 floats (105 MB at n_max=512, 419 MB at 1024): issued as
-reduce_scatter + all_gather on the flat buffer when the backend supports it, so that on the
-fully connected xGMI mesh each rank exchanges 1/W shards with every peer directly instead of
-pushing the whole buffer around a ring.
+(latency bound).  Pass 2 is K*n_max^2 + K floats (105 MB at n_max=512, 419 MB at 1024): issued as
+reduce_scatter + all_gather on the flat buffer, so that on the fully connected xGMI mesh each rank
+exchanges 1/W shards with every peer directly instead of pushing the whole buffer around a ring.
+The flat buffers are allocated with `_SLACK` spare (zero) elements behind the logical end, so the
+collective runs on the buffer rounded up to a multiple of the world size whatever K and n_max are
+(K*n_max^2 + K is 26 214 500 at C2: not a multiple of 8) - no copy, no fallback to the ring.
+`SchemaStatistics.last_collective` says which form the last merge took.
 """
+import logging
 from typing import Optional, Tuple
 
 import torch
@@ -35,8 +39,13 @@ def _world() -> Tuple[int, int]:
     return 0, 1
 
 
+_SLACK = 256          # spare elements behind a flat buffer: any world size up to 256 divides some length in [n, n + 256)
+
+
 class SchemaStatistics:
     """Accumulates per-class vertex / edge statistics for one rank and merges ranks."""
+
+    large_bytes = 8 << 20      # flat buffers of at least this many bytes are merged by reduce_scatter + all_gather
 
     def __init__(self, num_classes: int, num_vertices: int, class_max_vertices: Optional[int] = None,
                  device: torch.device = None):
@@ -45,9 +54,12 @@ class SchemaStatistics:
         self.device = device
         f32 = dict(dtype=torch.float32, device=device)
         # one flat buffer per pass so a pass needs exactly one collective: [sums..., n_tracked]
-        self._v_flat = torch.zeros(self.K * self.M + self.K, **f32)
+        self._v_store = torch.zeros(self.K * self.M + self.K + _SLACK, **f32)
+        self._v_flat = self._v_store[: self.K * self.M + self.K]
+        self._e_store = None
         self._e_flat = None
         self._f32 = f32
+        self.last_collective = None
 
     # ----- views
     @property
@@ -60,7 +72,9 @@ class SchemaStatistics:
 
     def _edges(self) -> torch.Tensor:
         if self._e_flat is None:
-            self._e_flat = torch.zeros(self.K * self.n_max * self.n_max + self.K, **self._f32)
+            n = self.K * self.n_max * self.n_max + self.K
+            self._e_store = torch.zeros(n + _SLACK, **self._f32)
+            self._e_flat = self._e_store[:n]
         return self._e_flat
 
     @property
@@ -87,27 +101,31 @@ class SchemaStatistics:
         self._accumulate(limited_edges, label, self.edge_sum, self.edge_count)
 
     # ----- cross-rank merge
-    @staticmethod
-    def _all_reduce_flat(flat: torch.Tensor, large: bool):
+    def _all_reduce_flat(self, store: torch.Tensor, n: int, large: bool):
+        """SUM over ranks of store[:n].  `store` has >= _SLACK zero elements behind n."""
         rank, world = _world()
         if world == 1:
+            self.last_collective = None
             return
-        n = flat.numel()
-        backend = dist.get_backend()
-        if large and backend == "nccl" and n % world == 0:
-            # direct 1-hop exchange of 1/W shards on the xGMI mesh
-            shard = torch.empty(n // world, dtype=flat.dtype, device=flat.device)
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
-            dist.all_gather_into_tensor(flat, shard)
+        if large and world <= _SLACK:
+            # direct 1-hop exchange of 1/W shards on the xGMI mesh; the zero slack rounds the length up to the world size
+            padded = store[: (n + world - 1) // world * world]
+            shard = torch.empty(padded.numel() // world, dtype=store.dtype, device=store.device)
+            dist.reduce_scatter_tensor(shard, padded, op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(padded, shard)
+            self.last_collective = "reduce_scatter+all_gather"
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(store[:n], op=dist.ReduceOp.SUM)
+            self.last_collective = "all_reduce"
+        if rank == 0:
+            logging.getLogger("SchemaStatistics").debug("merged %d floats over %d ranks by %s", n, world, self.last_collective)
 
     def all_reduce_vertices(self):
-        self._all_reduce_flat(self._v_flat, large=False)
+        self._all_reduce_flat(self._v_store, self._v_flat.numel(), large=self._v_flat.numel() * 4 >= self.large_bytes)
 
     def all_reduce_edges(self):
         flat = self._edges()
-        self._all_reduce_flat(flat, large=flat.numel() * 4 >= (8 << 20))
+        self._all_reduce_flat(self._e_store, flat.numel(), large=flat.numel() * 4 >= self.large_bytes)
 
     # ----- finalisation (identical on every rank after the all-reduce)
     def class_vertices(self) -> torch.Tensor:

@@ -242,20 +242,24 @@ idx = graph.shard_indices(B, rank, 2).numpy()
 # per-image features come from the oracle here (no GPU in this container); the product computes
 # them with the HIP kernels.  What is under test: shard split + flat all-reduce + finalisation.
 stats = graph.SchemaStatistics(K, M, n_max)
+stats.large_bytes = 1024        # 99 floats of vertex sums -> all_reduce; 435 floats (odd: padded to 436) of edge sums -> reduce_scatter + all_gather
 fv = pyops.full_vertices(ing[idx], acls[idx], M, w)
 stats.vertex_sum.index_add_(0, torch.from_numpy(label[idx]), torch.from_numpy(fv))
 stats.vertex_count.index_add_(0, torch.from_numpy(label[idx]), torch.ones(len(idx)))
 stats.all_reduce_vertices()
+ok = stats.last_collective == "all_reduce"
 vals, top = stats.top_vertices()
 tab = cabi.dicts_to_slot_table([{int(k): v for v, k in enumerate(r)} for r in top.numpy()], M)
 fe = pyops.limited_edges(ing[idx], attn[idx], label[idx], tab, n_max, w, feat_h=7, feat_w=7)
 stats.edge_sum.index_add_(0, torch.from_numpy(label[idx]), torch.from_numpy(fe))
 stats.edge_count.index_add_(0, torch.from_numpy(label[idx]), torch.ones(len(idx)))
 stats.all_reduce_edges()
+ok &= stats.last_collective == "reduce_scatter+all_gather" and stats._edges().numel() % 2 == 1
+ok &= bool((stats._e_store[stats._edges().numel():] == 0).all())          # the slack stays zero
 # single-process result on the concatenated batch
 cv1, _, _ = pyops.init_class_vertices(ing, acls, label, K, M, w)
 ew1, _, n1 = pyops.init_graph(ing, attn, label, tab, K, n_max, w, feat_h=7, feat_w=7)
-ok = np.allclose(np.nan_to_num(stats.class_vertices().numpy()), np.nan_to_num(cv1), rtol=1e-6, atol=1e-8)
+ok &= np.allclose(np.nan_to_num(stats.class_vertices().numpy()), np.nan_to_num(cv1), rtol=1e-6, atol=1e-8)
 ok &= np.allclose(np.nan_to_num(stats.class_edges().numpy()), np.nan_to_num(ew1), rtol=1e-6, atol=1e-8)
 ok &= np.array_equal(stats.edge_count.numpy(), n1)
 # eval-style merge of (n_correct, n_seen): one fused all-reduce
