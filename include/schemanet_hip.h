@@ -64,7 +64,9 @@ int sn_profile_elapsed_ms(int kernel_id, float *out_ms_host, int n);
  * rigorous error bound), lowest index on exact ties -- bit-identical to oracle sno_assign_words.
  * ------------------------------------------------------------------------------------------ */
 
-/* Bytes of the packed codebook image for (M, D).  M >= 1, D >= 1; the fp16-MFMA screen is used when D is 192, 384 or 768 and M <= 8192 (the exact kernel otherwise). */
+/* Bytes of the packed codebook image for (M, D); 0 for shapes outside 1 <= M <= 65536, D a multiple of 32 with
+ * 32 <= D <= 1024 (sn_codebook_prepare / sn_assign_words return SN_ERR_UNSUPPORTED for those).  Inside that range the
+ * fp16-MFMA screen runs when D is 192, 384 or 768 and M <= 8192, the exact fp64 kernel otherwise. */
 size_t sn_codebook_pack_bytes(int M, int D);
 
 /* Packs codebook [M, D] f32 into `packed` (fp16 MFMA fragments, per-word fp64 norms, scale
@@ -359,6 +361,20 @@ typedef struct sn_gemm_args {
     const int64_t *b_ids; int64_t b_ids_stride; int b_ids_n, b_table_rows;
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Diagnostics (tools/ and the A/B parity tests; not part of the drop-in contract, no reference counterpart).
+ * None of them changes a result.
+ * ------------------------------------------------------------------------------------------ */
+/* launch options of the token-stationary S1 screen: token-phase gate, balanced token map; 1 on, 0 off, -1 = from the
+ * environment (SN_ASSIGN_GATE / SN_ASSIGN_BALANCE, default off) */
+void sn_debug_set_assign_options(int gate, int balance);
+/* resident workgroups per CU the runtime reports for the S1 screen kernel (D = 384) with `lds` bytes of dynamic LDS */
+int sn_debug_screen_occupancy(int lds);
+/* device buffers the S1 screen / instance-graph / GCN GEMM kernels write s_memtime stamps to (NULL = off): 16 x u64 per wave */
+void sn_debug_set_stamps(void *device_buffer);
+void sn_debug_set_graph_stamps(void *device_buffer);
+void sn_debug_set_gemm_stamps(void *device_buffer);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,12 @@ _SIGNATURES = {
     "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    # diagnostics (include/schemanet_hip.h, last section)
+    "sn_debug_set_assign_options": (None, [c_int, c_int]),
+    "sn_debug_screen_occupancy": (c_int, [c_int]),
+    "sn_debug_set_stamps": (None, [c_void_p]),
+    "sn_debug_set_graph_stamps": (None, [c_void_p]),
+    "sn_debug_set_gemm_stamps": (None, [c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -30,12 +30,17 @@ def _check_dev(*ts):
 # ------------------------------------------------------------------------------- S1
 class PackedCodebook:
     """fp16 MFMA-fragment image + fp64 norms of a codebook (sn_codebook_prepare).  Rebuilt when
-    the codebook tensor changes (data_ptr / _version / device)."""
+    the codebook tensor changes (data_ptr / _version / device / shape).  Writes that bypass the version
+    counter (`weight.data.copy_(...)`, raw pointer writes) are not seen: call `invalidate()` after them
+    (`Discretization.load_state_dict` / `initial_vocabulary` do)."""
 
     def __init__(self):
         self.key = None
         self.buf = None
         self.codebook = None
+
+    def invalidate(self):
+        self.key = None
 
     def get(self, codebook):
         cb = _f32c(codebook.detach())

@@ -23,29 +23,9 @@
 #include <stdlib.h>
 #include <utility>
 
-// timing experiments only (results are wrong when any of these is set)
-#ifndef SN_EXP_NOKEYS
-#define SN_EXP_NOKEYS 0
-#endif
-#ifndef SN_EXP_KEYSRC
-#define SN_EXP_KEYSRC 0
-#endif
-#ifndef SN_EXP_NOBARRIER
-#define SN_EXP_NOBARRIER 0
-#endif
-#ifndef SN_EXP_NODMA
-#define SN_EXP_NODMA 0
-#endif
 #ifndef SN_S1_STAGE
 #define SN_S1_STAGE 1       // token rows through LDS in whole cache lines (0: fragment loads straight from global memory)
 #endif
-#ifndef SN_EXP_NOPHASEA
-#define SN_EXP_NOPHASEA 0
-#endif
-#ifndef SN_EXP_NOPHASEB
-#define SN_EXP_NOPHASEB 0
-#endif
-
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -341,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             const unsigned f = p.flags[t];
             flag = (f >> 31) ? (1ull << 63) : (unsigned long long)f;
         }
-        unsigned long long todo = SN_EXP_NOPHASEA ? 0ull : __ballot(flag != 0ull && !(flag >> 63));
+        unsigned long long todo = __ballot(flag != 0ull && !(flag >> 63));
         for (int i = 0; todo; ++i) {
             const int tl = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -398,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // error window of the best, then fp64.
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     const unsigned char *tiles = p.packed + lay.tiles_off;
-    const int n_over = ((int)blockIdx.x < kOverflowBlocks && !SN_EXP_NOPHASEB) ? p.work[1] : 0;     // blocks 0 .. kOverflowBlocks - 1 only
+    const int n_over = ((int)blockIdx.x < kOverflowBlocks) ? p.work[1] : 0;     // blocks 0 .. kOverflowBlocks - 1 only
     for (int e = blockIdx.x; e < n_over; e += kOverflowBlocks) {
         const int64_t n = p.overflow[e];
         const float *row = token_row(p, n);
@@ -851,10 +831,10 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
             if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
             else ar[s % kRingA] = frag_at(w + 1, s + kRingA - NSTEPS);      // (stale slot after the last tile: unused)
             // the 16 accumulators of tile w-1 become keys (w == 0: oth holds +inf, those keys never win)
-            if (s >= kKeyStep0 && !SN_EXP_NOKEYS) {
+            if (s >= kKeyStep0) {
 #pragma unroll
                 for (int q = (s - kKeyStep0) * kKeysPerStep; q < (s - kKeyStep0 + 1) * kKeysPerStep && q < 16; ++q)
-                    key_insert(SN_EXP_KEYSRC ? shift : oth[q], code0 | (unsigned)(q & 3), q >> 2);
+                    key_insert(oth[q], code0 | (unsigned)(q & 3), q >> 2);
             }
             if (s >= kInitStep && s < kInitStep + 4) init_group(oth, w + 1, s - kInitStep);
             __builtin_amdgcn_sched_barrier(0);                              // pin: MFMA, its DS read, this gap's VALU
@@ -864,9 +844,9 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
                 unsigned long long ta = 0, tb = 0;
                 if (p.stamps) ta = __builtin_amdgcn_s_memtime();
                 wait_tiles(ahead);                                          // this wave's part of tile w+1 has landed
-                if (!SN_EXP_NOBARRIER) __builtin_amdgcn_s_barrier();        // ... everybody's; tile w-1 is no longer read
+                __builtin_amdgcn_s_barrier();        // ... everybody's; tile w-1 is no longer read
                 if (p.stamps) tb = __builtin_amdgcn_s_memtime();
-                if (w + R - 1 < n_tiles && !SN_EXP_NODMA) issue_tile(w + R - 1, (w + R - 1) % R);
+                if (w + R - 1 < n_tiles) issue_tile(w + R - 1, (w + R - 1) % R);
                 if (p.stamps) { t_sync += tb - ta; t_dma += __builtin_amdgcn_s_memtime() - tb; }
             }
         }
@@ -886,8 +866,8 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
             int ahead = n_tiles - 2 - w;
             ahead = ahead < 0 ? 0 : (ahead > R - 3 ? R - 3 : ahead);
             wait_tiles(ahead);
-            if (!SN_EXP_NOBARRIER) __builtin_amdgcn_s_barrier();
-            if (w + R - 1 < n_tiles && !SN_EXP_NODMA) issue_tile(w + R - 1, (w + R - 1) % R);
+            __builtin_amdgcn_s_barrier();
+            if (w + R - 1 < n_tiles) issue_tile(w + R - 1, (w + R - 1) % R);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;

@@ -47,6 +47,21 @@ class Discretization(nn.Module):
             vocabulary = vocabulary[torch.randperm(vocabulary.shape[0])][:self.size]
         with torch.no_grad():
             self.vocabulary.weight.copy_(vocabulary)
+        self.invalidate()
+
+    def invalidate(self):
+        """Forget the packed (fp16 fragment) image of the codebook: the next `assign` re-packs it.  Needed only after
+        writes that do not bump the tensor's version counter (`vocabulary.weight.data.copy_(...)`)."""
+        self._packed.invalidate()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        ret = super().load_state_dict(state_dict, strict, **kw)
+        self.invalidate()
+        return ret
+
+    def _load_from_state_dict(self, *args, **kw):       # also when loaded as a sub-module of a larger state dict
+        super()._load_from_state_dict(*args, **kw)
+        self._packed.invalidate()
 
     def deactivate(self):
         self._activate = False

@@ -47,7 +47,7 @@ class SchemaNetPredictor(nn.Module):
         atlas = self.matcher.atlas_features_async(self.schema_net.get_atlas)
         # (the zero padding of the instance edges is only written when the caller asks for the graphs)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
-                                                      zero_padding=requires_graph)
+                                                      zero_padding=requires_graph, return_attn_cls=requires_graph)
         ret["pred"] = self.matcher.forward_padded(graph, atlas.class_dict, feat_kg=atlas)
         class_dict = atlas.class_dict
         ret.update(class_dict)
@@ -58,5 +58,5 @@ class SchemaNetPredictor(nn.Module):
             ret["instance_vertices"] = [graph["vertices"][b, :n] for b in range(bs)]
             ret["instance_edges"] = [graph["edges"][b, :n, :n] for b in range(bs)]
             ret["ingredients"] = output["ingredients"]
-            ret["attn_cls"] = output["attn_cls"]
+            ret["attn_cls"] = graph["attn_cls"]          # [bs, L] head mean, clamp-masked (reference schema_net.py:296)
         return ret

@@ -226,7 +226,8 @@ class SchemaNet(nn.Module):
         return min(L, self.num_vertices)
 
     def instance_graph_padded(self, ingredients: torch.LongTensor, attn: torch.Tensor, attn_cls: torch.Tensor,
-                              n_pad: int = None, mutate_inputs: bool = True, zero_padding: bool = True) -> Dict[str, torch.Tensor]:
+                              n_pad: int = None, mutate_inputs: bool = True, zero_padding: bool = True,
+                              return_attn_cls: bool = False) -> Dict[str, torch.Tensor]:
         """One fused launch: logits -> padded instance graphs.
 
         ingredients [bs, L] i64; attn [bs, L, L] or [bs, H, L, L] logits (head mean fused);
@@ -240,6 +241,9 @@ class SchemaNet(nn.Module):
         zero_padding=False: the rows / columns of `edges` beyond an image's own vertex count are left unwritten
         (about two thirds of the padded batch are such zeros) and the dict says `edges_padded: False`;
         `Matcher.forward_padded` masks by `n` instead.  For callers that only want the scores.
+        return_attn_cls: also return `attn_cls` [bs, L] = the head-averaged cls-attention logits after the clamp
+        (< clamp_vertex_attn -> -inf), i.e. what the reference's `attn_cls` holds after schema_net.py:296, when the
+        input is a per-head view that cannot be masked in place.
         """
         dev = self._dev()
         B, L = ingredients.shape
@@ -250,6 +254,8 @@ class SchemaNet(nn.Module):
         if (mutate_inputs and self.clamp_vertex_attn is not None and attn_cls.dim() == 2
                 and attn_cls.is_contiguous() and attn_cls.dtype == torch.float32 and attn_cls.device == dev):
             masked_out = attn_cls
+        elif return_attn_cls:
+            masked_out = torch.empty((B, L), dtype=torch.float32, device=dev)
         g = ops.instance_graph(
             ingredients.to(dev), attn.to(dev), attn_cls.to(dev), w_v=w_v, w_e=w_e, n_pad=n_pad,
             pad_id=self.num_vertices, attn_is_logits=True, attn_cls_is_logits=True,
@@ -260,8 +266,13 @@ class SchemaNet(nn.Module):
         if need_grad:   # keep `@ w` visible to autograd (the reference does it inside C++)
             g["v"] = (g["v2"] @ w_v).squeeze(-1)
             g["e"] = (g["e2"] @ w_e).squeeze(-1)
-        return {"ids": g["ids"], "vertices": g["v"], "edges": g["e"], "n": g["n"], "n_max": g["n_max"],
-                "edges_padded": bool(zero_padding or need_grad)}
+        ret = {"ids": g["ids"], "vertices": g["v"], "edges": g["e"], "n": g["n"], "n_max": g["n_max"],
+               "edges_padded": bool(zero_padding or need_grad)}
+        if return_attn_cls:
+            if masked_out is None:          # no clamp configured: the plain head mean
+                masked_out = attn_cls.to(dev, torch.float32) if attn_cls.dim() == 2 else attn_cls.to(dev, torch.float32).mean(dim=1)
+            ret["attn_cls"] = masked_out
+        return ret
 
     @staticmethod
     def _as_lists(g: Dict[str, torch.Tensor]) -> Dict[str, List[torch.Tensor]]:
