@@ -10,16 +10,21 @@ One "step" = one pass of the hot path over one batch that is already resident in
   head-averaged attention logits [B,197,197] --S2+S3 instance graph (cls slicing, clamp,
   softmax, grouping, normalise fused)--> padded instance graphs
   IR-Atlas normalise (K=100, n_max=512) --S4--> GCN on instances and on the atlas --> pred [B,100]
-Nothing is cached across steps (the atlas GCN is recomputed every step, like the reference).
+Nothing is cached across steps (the atlas GCN is recomputed every step, like the reference; `feat_kg_cache: off`).
 The K timed steps replay captured hipGraphs of the step (schema_inference.utils.graph_replay: same kernels,
-no host launch path in the timed region), four steps in flight on four streams (independent batches; each capture
-has its own buffers; `SN_BENCH_DEPTH=1` replays one graph back to back); a
-second, untimed pass of K eager steps with HIP events on the launch stream gives the per-kernel
-durations of the roofline figure (`SN_BENCH_EAGER=1` times the eager loop instead).
+no host launch path in the timed region).  There are SN_BENCH_BATCHES (default 8) DIFFERENT input batches resident in
+HBM (8 x 117 MB: more than the 256 MB Infinity Cache), one capture per batch with its own buffers, visited in
+rotation; SN_BENCH_DEPTH (default 4) of them are in flight on as many streams = `value`; the same K steps replayed
+one at a time (depth 1) are reported as `value_depth1`.  A further, untimed pass of K eager steps with HIP events on
+the launch stream gives the per-kernel durations of the roofline figures (`SN_BENCH_EAGER=1` times the eager loop
+instead).
 Workload = BASELINE.json configs[1]: DeiT-Small + CIFAR-100, B=256 per GPU, 512-word codebook.
 Multi-GPU: images are sharded over ranks (weak scaling, B per rank fixed), no data-path
 collective; the per-class prediction histogram + (n_seen) are all-reduced once at the end of
 the timed region over RCCL (the eval-meter merge of the reference, eval/evaluation.py:95-97).
+Outside the timed region every run also times one IR-Atlas initialisation over a synthetic image shard per rank
+(`init_atlas`): with N > 1 its two merges are the RCCL collectives of the per-class schema statistics
+(reference scripts/init_schema_net.py:19-65; 105 MB of edge sums at this configuration).
 """
 import argparse
 import ctypes
@@ -40,15 +45,19 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 B, L, D, M, K, E, H = 256, 196, 384, 512, 100, 256, 6
 
 
-def make_inputs(rank, device):
-    """seeded CPU generators, then copied (same bits on every box).  Every rank
-    gets its own images (seed offset) but the same codebook / atlas / matcher."""
+def make_codebook(device):
     g = lambda s: torch.Generator().manual_seed(s)  # noqa: E731
-    tokens = torch.randn(B, L + 1, D, generator=g(1000 * rank + 0))
     pool = torch.randn(4096, D, generator=g(1))
-    codebook = pool[torch.randperm(4096, generator=g(11))[:M]] + 0.05 * torch.randn(M, D, generator=g(2))
-    attn = torch.randn(B, L + 1, L + 1, generator=g(1000 * rank + 3))
-    return tokens.to(device), codebook.to(device), attn.to(device)
+    return (pool[torch.randperm(4096, generator=g(11))[:M]] + 0.05 * torch.randn(M, D, generator=g(2))).to(device)
+
+
+def make_batch(rank, device, batch=0):
+    """seeded CPU generators, then copied (same bits on every box).  Every rank and every batch
+    index gets its own images (seed offset); batch 0 of rank 0 is the batch of SURVEY 8(d) (seeds 0 and 3)."""
+    g = lambda s: torch.Generator().manual_seed(s)  # noqa: E731
+    tokens = torch.randn(B, L + 1, D, generator=g(1000 * rank + 10 * batch + 0))
+    attn = torch.randn(B, L + 1, L + 1, generator=g(1000 * rank + 10 * batch + 3))
+    return tokens.to(device), attn.to(device)
 
 
 def make_model(device):
@@ -150,6 +159,54 @@ def cpu_baseline(tokens, codebook, attn, sn, m, n_img=B):
     }, pred, ing
 
 
+def init_atlas_leg(device, rank, world, n_img=64):
+    """One IR-Atlas initialisation (reference scripts/init_schema_net.py:105-124) over a synthetic shard of n_img
+    images per rank, on a SchemaNet of its own: pass 1 (class vertex sums) -> merge -> top vertices -> pass 2 (class edge
+    sums [K, n_max, n_max] = 105 MB) -> merge -> normalise.  With world > 1 the two merges are the RCCL collectives of
+    the per-class schema statistics; HIP events bracket them."""
+    import schema_inference.graph as graph
+    from schema_inference.graph.statistics import SchemaStatistics
+    torch.manual_seed(40)
+    sn = graph.SchemaNet(num_vertices=M, num_classes=K, dist_pow=2, feat_h=14, feat_w=14, clamp_vertex_attn=-1.0,
+                         clamp_edge_attn=-1.0, remove_self_loop=False, prune_node_threshold=0.001).to(device)
+    g = torch.Generator().manual_seed(7000 + rank)
+    ing = torch.randint(0, M, (n_img, L), generator=g).to(device)
+    attn = torch.randn(n_img, L, L, generator=g).to(device)
+    acls = torch.randn(n_img, L, generator=g).to(device)
+    label = ((torch.arange(n_img) * world + rank) % K).to(device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    with torch.no_grad():
+        for timed in (False, True):                          # first pass: warm-up (kernels, communicator buffers)
+            stats = SchemaStatistics(K, M, M, device=device)
+            torch.cuda.synchronize()
+            ev[0].record()
+            stats.add_vertices(sn.feat_to_full_vertices(ing, acls.clone()), label)
+            ev[1].record()
+            stats.all_reduce_vertices()
+            ev[2].record()
+            init_w, valid = stats.top_vertices()
+            sn.register_class_vertices(valid)
+            sn.vertex_weights.copy_(init_w)
+            stats.add_edges(sn.feat_to_limited_edges(ing, attn, label), label)
+            ev[3].record()
+            stats.all_reduce_edges()
+            ev[4].record()
+            sn.edge_weights.copy_(stats.class_edges())
+            sn.normalize()
+            ev[5].record()
+            torch.cuda.synchronize()
+    n_e = stats._edges().numel()
+    e_ms = ev[3].elapsed_time(ev[4])
+    return {
+        "images_per_rank": n_img, "world_size": world, "total_ms": ev[0].elapsed_time(ev[5]),
+        "vertex_stats_collective_ms": ev[1].elapsed_time(ev[2]), "edge_stats_collective_ms": e_ms,
+        "edge_stats_collective": stats.last_collective, "edge_stats_bytes": n_e * 4,
+        # bus bandwidth of an all-reduce: 2 (W-1)/W x bytes / time
+        "edge_stats_busbw_GBps": (2.0 * (world - 1) / world * n_e * 4 / (e_ms * 1e-3) / 1e9) if world > 1 and e_ms > 0 else None,
+        "note": "outside the timed region; reference scripts/init_schema_net.py:19-65 (two passes, one merge each)",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,11 +238,18 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dist_world = dist.get_world_size() if use_dist else 1
 
     import cpp_extension
     from cpp_extension import ops
     lib = cpp_extension.load()
-    tokens, codebook, attn = make_inputs(rank, device)
+    n_batches = max(1, int(os.environ.get("SN_BENCH_BATCHES", "8")))
+    depth = max(1, int(os.environ.get("SN_BENCH_DEPTH", "4")))
+    if n_batches % depth != 0:
+        n_batches = depth * ((n_batches + depth - 1) // depth)
+    codebook = make_codebook(device)
+    batches = [make_batch(rank, device, i) for i in range(n_batches)]     # distinct (tokens, attn) per capture
+    tokens, attn = batches[0]
     disc, sn, m = make_model(device)
     with torch.no_grad():
         disc.vocabulary.weight.copy_(codebook)
@@ -197,25 +261,30 @@ def main():
 
     votes = torch.zeros(K + 1, device=device)            # per-class prediction histogram + n_seen
 
-    def one_step():
-        pred = step(disc, sn, m, tokens, attn)
-        ops.class_votes_(pred, votes)                    # per-class vote aggregation (HIP, no host sync)
-        return pred
+    def step_on(i):
+        tk, at = batches[i]
 
+        def one_step():
+            pred = step(disc, sn, m, tk, at)
+            ops.class_votes_(pred, votes)                # per-class vote aggregation (HIP, no host sync)
+            return pred
+        return one_step
+
+    steps_fn = [step_on(i) for i in range(n_batches)]
     launch = "eager"
+    value_depth1 = None
     with torch.no_grad():
-        for _ in range(args.warmup):
-            one_step()
+        for w in range(args.warmup):
+            steps_fn[w % n_batches]()
         graphed = None
         if os.environ.get("SN_BENCH_EAGER", "0") != "1":
             try:
                 from schema_inference.utils.graph_replay import PipelinedSteps
-                depth = int(os.environ.get("SN_BENCH_DEPTH", "4"))
-                graphed = PipelinedSteps(one_step, depth)   # capture (outside the timed region)
-                for _ in range(depth):
+                graphed = PipelinedSteps(steps_fn, depth)   # one capture per batch (outside the timed region)
+                for _ in range(max(args.warmup, n_batches)):         # W untimed steps of the timed kind (replays)
                     graphed.submit()
                 graphed.join()
-                launch = f"hipgraph, {depth} steps in flight" if depth > 1 else "hipgraph"
+                launch = f"hipgraph, {n_batches} batches in rotation, {depth} steps in flight" if depth > 1 else f"hipgraph, {n_batches} batches in rotation"
             except Exception as exc:                     # noqa: BLE001 - fall back to eager launches, and say so
                 print(f"bench: hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
                 graphed = None
@@ -226,31 +295,42 @@ def main():
             if graphed is not None:
                 graphed.submit()
             else:
-                one_step()
+                steps_fn[s % n_batches]()
         if graphed is not None:
             graphed.join()
         if use_dist:
-            dist.all_reduce(votes)                       # per-class schema statistics over RCCL
+            dist.all_reduce(votes)                       # eval-meter merge over RCCL
         barrier()
         dt = time.perf_counter() - t0
         n_voted = int(votes[K].item())
+
+        # ---- the same K steps, one in flight at a time (depth 1): what a single stream of batches gets
+        if graphed is not None and depth > 1:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(args.steps):
+                graphed.steps[s % n_batches].graph.replay()
+            torch.cuda.synchronize()
+            value_depth1 = B * args.steps / (time.perf_counter() - t1)
 
         # ---- untimed instrumented pass: the same K steps launched eagerly, HIP events around the
         # kernels (inside the library, on the launch stream) and around the stages
         lib.sn_profile_enable(args.steps)
         stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
         for s in range(args.steps):
+            tk, at = batches[s % n_batches]
             ev = stage_ev[s]
             ev[0].record()
-            ing = disc.assign(tokens[:, 1:, :])              # S1 runs alone (the side stream starts behind it)
+            ing = disc.assign(tk[:, 1:, :])                  # S1 runs alone (the side stream starts behind it)
             ev[1].record()
             atlas = m.atlas_features_async(FUSED_ATLAS(sn))  # class branch on the side stream (overlaps everything below)
             ev[2].record()
-            g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False, zero_padding=False)
+            g = sn.instance_graph_padded(ing, at[:, 1:, 1:], at[:, 0, 1:], mutate_inputs=False, zero_padding=False)
             ev[3].record()
             pred = m.forward_padded(g, atlas.class_dict, feat_kg=atlas)
             ev[4].record()
         torch.cuda.synchronize()
+        atlas_leg = init_atlas_leg(device, rank, dist_world)
     t_max = torch.tensor([dt], device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -261,53 +341,86 @@ def main():
         ms_step = 1e3 * dt / args.steps
         stage_ms = [sum(stage_ev[s][i].elapsed_time(stage_ev[s][i + 1]) for s in range(args.steps)) / args.steps
                     for i in range(4)]
-        k_ms = {name: kernel_times(lib, kid) for kid, name in enumerate(("assign_screen", "assign_rerank", "instance_graph", "atlas_normalize"))}
+        k_ms = {name: kernel_times(lib, kid) for kid, name in enumerate(("assign_screen", "assign_rerank", "instance_graph", "atlas_normalize", "gcn_gemm"))}
         avg = {k_: (sum(v) / len(v) if v else None) for k_, v in k_ms.items()}
         # roofline of the assignment kernel (north_star): algorithmic bytes per launch =
         # B*196 tokens * (D*4 B read + 8 B index written)  (302,624 B / image)
         alg_bytes = B * L * (D * 4 + 8)
         ach = alg_bytes / (avg["assign_screen"] * 1e-3) / 1e9 if avg["assign_screen"] else None
-        # attn + ids + cls attention in; the images' own n_i x n_i edge corners (the zero padding is not written) + padded ids / weights out
+        s1_ms = (avg["assign_screen"] or 0.0) + (avg["assign_rerank"] or 0.0)
+        # S2+S3: attn + ids + cls attention in; the images' own n_i x n_i edge corners (the zero padding is not written) + padded ids / weights out
         graph_bytes = B * (L * L * 4 + L * 4 + L * 8) + int((g["n"].long() ** 2).sum().item()) * 4 + B * L * 12
-        screen_name = ("assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)" if lib.sn_assign_variant() == 2
-                       else "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen, token-stationary)")
+        g_ach = (graph_bytes / (avg["instance_graph"] * 1e-3) / 1e9) if avg["instance_graph"] else None
+        variant = lib.sn_assign_variant()
+        screen_name = {2: "assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)",
+                       3: "assign_screen3_kernel<8> (S1 fp16-MFMA screen, K-outer token stream)"}.get(
+                           variant, "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen, token-stationary)")
         copy_gbps = stream_copy_GBps(device)
         ev_floor = event_pair_floor_ms()
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as fh:
-                for row in json.load(fh)["kernels"]:
-                    if row["kernel"].startswith(screen_name.split(" ")[0].split(",")[0]):
-                        traffic = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_s3, traffic_src = None, None, None      # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
+        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    for row in json.load(fh)["kernels"]:
+                        if row["kernel"].startswith(screen_name.split(" ")[0].split("<")[0] + "<"):
+                            traffic = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
+                        if row["kernel"].startswith("instance_graph_kernel<true>") or row["kernel"].startswith("instance_graph_kernel<1>"):
+                            traffic_s3 = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
+                if traffic is not None:
+                    traffic_src = f"profiles/{name} (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        # whole step: bytes that must cross HBM once (tokens, attention, the atlas parameters, the ids / scores out) and the
+        # dense flops of the reference's formulation (S1 distance matrix + the six GCN products as fp32 GEMMs)
+        n_mean = float(g["n"].float().mean().item())
+        step_bytes = B * (L + 1) * D * 4 + B * (L + 1) * (L + 1) * 4 + K * M * M * 4 + K * M * 4 + B * L * 8 + B * K * 4
+        gcn_flops = 2 * (2 * K * M * M * E + K * M * E * E) + 2 * (2 * B * L * L * E + B * L * E * E)
+        s1_flops = 2 * B * L * D * M
         out = {
             "metric": "images/sec schema-inference (discretize+graph) DeiT-S CIFAR-100",
             "value": B * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "launch": launch,
-            "vs_baseline": None, "dtype": "f32 (S1 screen: f16 MFMA + f64 re-rank; ids int64)", "data": "synthetic",
+            "value_depth1": value_depth1,
+            "value_note": f"value: {depth} steps in flight on {depth} streams over {n_batches} distinct resident batches ({n_batches} x 117 MB of inputs per GPU); "
+                          "value_depth1: the same captures replayed one at a time on one stream (rank 0 only, untimed by the driver)",
+            "vs_baseline": None, "dtype": "f32 (S1 screen: f16 MFMA + f64 re-rank; GCN: split-f16 MFMA, f32 accumulate; ids int64)", "data": "synthetic",
+            "world_size": dist_world,
             "config": {"workload": "configs[1]: DeiT-Small + CIFAR-100, synthetic [256,197,384] tokens per GPU, "
                                    "512-word codebook, head-averaged attention logits [256,197,197], K=100, "
                                    "n_max=512, GNN E=256 x 2 layers; atlas recomputed every step",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"image-parallel x{world}"},
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"image-parallel x{world}",
+                       "resident_batches": n_batches, "steps_in_flight": depth, "feat_kg_cache": "off"},
             "roofline": {"bound": "hbm", "kernel": screen_name,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg["assign_screen"],
+                         "whole_assignment_ms": s1_ms,
+                         "whole_assignment_frac": (alg_bytes / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if s1_ms else None,
                          "event_pair_floor_ms": ev_floor,
-                         "avg_launch_note": "avg_launch_ms = HIP event pair around the kernel on its launch stream (what achieved / frac use); an event pair with nothing between reads event_pair_floor_ms, so the kernel trace of rocprofv3 (profiles/) shows this kernel ~that much shorter",
+                         "avg_launch_note": "avg_launch_ms = HIP event pair around the kernel on its launch stream (what achieved / frac use); an event pair with nothing between reads event_pair_floor_ms, so the kernel trace of rocprofv3 (profiles/) shows this kernel ~that much shorter; whole_assignment = screen + fp64 re-rank",
                          "peak_note": "peak = 8.0 TB/s HBM3E spec; copy_GBps = a 1 GiB device-to-device copy on this box (read + write)",
                          "copy_GBps": copy_gbps, "frac_of_copy": (ach / copy_gbps) if (ach and copy_gbps) else None},
+            "roofline_s3": {"bound": "hbm", "kernel": "instance_graph_kernel<true> (S2+S3: grouping, edge cells, normalise)",
+                            "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (g_ach / HBM_PEAK_GBS) if g_ach else None,
+                            "traffic": traffic_s3, "algorithmic_bytes_per_launch": graph_bytes, "avg_launch_ms": avg["instance_graph"],
+                            "mean_vertices_per_image": n_mean},
+            "roofline_step": {"algorithmic_bytes_per_step": step_bytes, "hbm_GBps": step_bytes / (ms_step * 1e-3) / 1e9,
+                              "hbm_frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "dense_flops_per_step": s1_flops + gcn_flops, "TFLOPs": (s1_flops + gcn_flops) / (ms_step * 1e-3) / 1e12,
+                              "mfma_frac_of_2.5PF": (s1_flops + gcn_flops) / (ms_step * 1e-3) / 2.5e15,
+                              "note": "bytes that must cross HBM once per step (tokens, attention logits, IR-Atlas parameters, ids and scores out) and the dense flops of the reference's formulation (token x codebook distances + six GCN products), over ms_per_step of the timed region; the split-f16 products issue 3 MFMAs per dense flop pair"},
             "kernels_ms": avg,
-            "instance_graph_GBps": (graph_bytes / (avg["instance_graph"] * 1e-3) / 1e9) if avg["instance_graph"] else None,
+            "instance_graph_GBps": g_ach,
             "stage_ms": dict(zip(("S1_assign", "atlas_branch_enqueue", "S2S3_instance_graph", "S4_instance_gnn_join_scores"), stage_ms)),
             "stage_note": "main-stream intervals of the instrumented eager pass (slower than the timed hipGraph replays: event records + host launches); the class branch (atlas normalise + GNN over K graphs) runs concurrently on a side stream and is joined inside S4",
+            "init_atlas": atlas_leg,
         }
         if not args.no_cpu_baseline and world == 1:
             cb, pred_cpu, ing_cpu = cpu_baseline(tokens, codebook, attn, sn, m)
             out["cpu_baseline"] = cb
-            # sanity: the CPU pipeline and the GPU path agree on the sample (not a parity test)
+            # sanity: the CPU pipeline and the GPU path agree on the sample (the parity test proper is tests/test_gpu_parity.py)
             with torch.no_grad():
                 n_img = pred_cpu.shape[0]
                 ing_gpu = disc.assign(tokens[:n_img, 1:, :]).cpu()

@@ -3,6 +3,9 @@
 
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 static thread_local char g_err[512] = "";
 
 void sn_set_error(const char *fmt, ...)
@@ -31,6 +34,49 @@ extern "C" int sn_device_ok(void)
         return 0;
     }
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-device state: dynamic-LDS opt-in of a kernel, CU count
+// ------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_dev_mutex;
+struct LdsKey { int dev; const void *fn; size_t bytes; };
+std::vector<LdsKey> g_lds_done;
+int g_cus[64] = {0};
+}  // namespace
+
+int sn_ensure_dynamic_lds(const void *fn, size_t bytes, const char *name)
+{
+    if (bytes > 160 * 1024) {
+        sn_set_error("%s: needs %zu bytes of LDS (> 160 KiB)", name, bytes);
+        return SN_ERR_UNSUPPORTED;
+    }
+    if (bytes <= 64 * 1024) return SN_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { sn_set_error("%s: hipGetDevice failed", name); return SN_ERR_LAUNCH; }
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    for (const LdsKey &k : g_lds_done)
+        if (k.dev == dev && k.fn == fn && k.bytes >= bytes) return SN_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        sn_set_error("%s: cannot raise dynamic LDS to %zu: %s", name, bytes, hipGetErrorString(e));
+        return SN_ERR_LAUNCH;
+    }
+    g_lds_done.push_back(LdsKey{dev, fn, bytes});
+    return SN_OK;
+}
+
+int sn_device_cus(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    if (g_cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        g_cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return g_cus[dev];
 }
 
 // ------------------------------------------------------------------------------------------

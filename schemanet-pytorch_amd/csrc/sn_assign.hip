@@ -1388,17 +1388,7 @@ int launch_exact(const AssignArgs &a, hipStream_t st)
     return 0;
 }
 
-int device_cus()
-{
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+int device_cus() { return sn_device_cus(); }
 
 // launch options of the token-stationary screen: [0] token-phase gate, [1] balanced token map.  -1 = take the
 // environment variable (default off: both measured slower at the bench shape); sn_debug_set_assign_options
@@ -1415,13 +1405,7 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
 {
     size_t lds = (size_t)R * (NSTEPS + 1) * 1024;
     if (const char *pad = getenv("SN_ASSIGN_LDS_PAD")) lds += (size_t)atoi(pad);     // diagnostics: force 1 workgroup per CU
-    static bool attr_set = false;
-    if ((!attr_set || getenv("SN_ASSIGN_LDS_PAD")) && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)assign_screen_kernel<NSTEPS, NW, R, CB>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sn_set_error("sn_assign_words: LDS attribute: %s", hipGetErrorString(e)); return SN_ERR_LAUNCH; }
-        attr_set = true;
-    }
+    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen_kernel<NSTEPS, NW, R, CB>, lds, "sn_assign_words")) return rc;
     const int tok_per_block = kTokPerWave * NW;
     unsigned grid = (unsigned)((a.n_tokens + tok_per_block - 1) / tok_per_block);
     AssignArgs ag = a;
@@ -1458,12 +1442,7 @@ template <int NT, int KS>
 int launch_screen2(const AssignArgs &a, hipStream_t st)
 {
     const size_t lds = (size_t)kS2RawSlots * (KS / 2) * 2048 + (size_t)2 * KS * 1024 + kS2SmallSlots * sizeof(S2Small) + (size_t)kS2StashSlots * 256 * 16 + (size_t)4 * NT * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)assign_screen2_kernel<NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { sn_set_error("sn_assign_words: LDS attribute: %s", hipGetErrorString(e)); return SN_ERR_LAUNCH; }
-        attr_set = true;
-    }
+    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen2_kernel<NT, KS>, lds, "sn_assign_words")) return rc;
     const int cus = device_cus();
     const unsigned grid = (unsigned)(a.n_sets < cus ? a.n_sets : cus);     // one persistent workgroup per CU
     sn_prof_start(0, st);

@@ -31,6 +31,14 @@ void sn_set_error(const char *fmt, ...);
         }                                                                                   \
     } while (0)
 
+// ---------------------------------------------------------------- host: per-device state
+// A process may drive several GPUs: function attributes and device properties are kept per device (and the tables
+// behind these two are guarded by a mutex: entry points may be called from several host threads).
+// Raises the dynamic-LDS limit of kernel `fn` to `bytes` on the current device, once per (device, kernel, size class).
+int sn_ensure_dynamic_lds(const void *fn, size_t bytes, const char *name);
+// Compute units of the current device.
+int sn_device_cus(void);
+
 // ---------------------------------------------------------------- host: per-kernel event timing
 void sn_prof_start(int kernel_id, hipStream_t st);
 void sn_prof_stop(int kernel_id, hipStream_t st);

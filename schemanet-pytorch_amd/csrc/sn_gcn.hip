@@ -795,14 +795,9 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     SN_REQUIRE(n_blocks <= 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: grid too large");
     const dim3 grid((unsigned)n_blocks);
     const size_t lds = (size_t)kRing * kStageBytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void *)gcn_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute((const void *)gcn_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e3 = hipFuncSetAttribute((const void *)gcn_gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e3 != hipSuccess) e1 = e3;
-        if (e1 != hipSuccess || e2 != hipSuccess) { sn_set_error("sn_gcn_gemm: LDS attribute failed"); return SN_ERR_LAUNCH; }
-        attr_set = true;
+    {
+        const void *fn = gathered ? (const void *)gcn_gemm_kernel<true, true> : (u->layernorm ? (const void *)gcn_gemm_kernel<true> : (const void *)gcn_gemm_kernel<false>);
+        if (int rc = sn_ensure_dynamic_lds(fn, lds, "sn_gcn_gemm")) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
     sn_prof_start(4, st);

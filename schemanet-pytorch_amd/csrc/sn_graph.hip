@@ -1039,17 +1039,7 @@ int ensure_lds(const void *fn, size_t bytes, const char *name)
         sn_set_error("%s: needs %zu bytes of LDS (> 160 KiB)", name, bytes);
         return SN_ERR_UNSUPPORTED;
     }
-    static const void *done[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (const void *d : done) if (d == fn) return SN_OK;
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     // (cached per kernel: the maximum)
-        if (e != hipSuccess) {
-            sn_set_error("%s: cannot raise dynamic LDS to %zu: %s", name, bytes, hipGetErrorString(e));
-            return SN_ERR_LAUNCH;
-        }
-        for (const void *&d : done) if (!d) { d = fn; break; }
-    }
-    return SN_OK;
+    return sn_ensure_dynamic_lds(fn, bytes > 64 * 1024 ? (size_t)160 * 1024 : bytes, name);      // (raised once per kernel and device: to the maximum)
 }
 
 }  // namespace

@@ -32,26 +32,34 @@ class GraphedStep:
 
 
 class PipelinedSteps:
-    """`depth` independent captures of the same step, replayed round-robin on `depth` HIP streams: batch i+1
-    starts while batch i is still in its tail (most kernels of the step fill every CU's LDS on their own, so one
-    graph alone leaves the chip idle at every kernel boundary and during the narrow kernels).  Every capture has
-    its own buffers; `fn` must only share read-only state and commutative accumulators (atomic adds) between
-    calls.  `submit()` returns the outputs of the capture it replayed - valid after `join()` or after the next
-    `submit()` on the same slot has been ordered behind a reader."""
+    """Captures of the step replayed round-robin on `depth` HIP streams: batch i+1 starts while batch i is still in
+    its tail (most kernels of the step fill every CU's LDS on their own, so one graph alone leaves the chip idle at
+    every kernel boundary and during the narrow kernels).  `fns` is one callable (captured `depth` times) or a list of
+    callables, one per batch buffer (e.g. eight closures over eight different input batches): capture j replays on
+    stream j % depth, so `depth` different batches are in flight and the captures are visited in rotation.  Every
+    capture has its own buffers; the callables must only share read-only state and commutative accumulators (atomic
+    adds) between calls.  `submit()` returns the outputs of the capture it replayed - valid after `join()` or after
+    the next `submit()` on the same stream has been ordered behind a reader."""
 
-    def __init__(self, fn, depth: int = 2):
-        self.steps = [GraphedStep(fn) for _ in range(depth)]
-        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+    def __init__(self, fns, depth: int = 2):
+        if callable(fns):
+            fns = [fns] * depth
+        self.steps = [GraphedStep(fn) for fn in fns]
+        self.depth = max(1, min(depth, len(self.steps)))
+        if len(self.steps) % self.depth != 0:               # a capture must always replay on the same stream (its buffers)
+            raise ValueError(f"{len(self.steps)} captures cannot rotate over {self.depth} streams")
+        self.streams = [torch.cuda.Stream() for _ in range(self.depth)]
         self.i = 0
 
     def submit(self):
-        k = self.i % len(self.steps)
+        j = self.i % len(self.steps)
+        k = self.i % self.depth
         self.i += 1
-        if self.i <= len(self.steps):                        # first use of the slot: behind whatever produced the inputs
+        if self.i <= self.depth:                             # first use of the stream: behind whatever produced the inputs
             self.streams[k].wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.streams[k]):
-            self.steps[k].graph.replay()
-        return self.steps[k].outputs
+            self.steps[j].graph.replay()
+        return self.steps[j].outputs
 
     def join(self):
         for st in self.streams:
