@@ -21,7 +21,7 @@ def param_groups(named_parameters: Iterable[Tuple[str, nn.Parameter]], groups: L
                  drop_remain: bool = False) -> List[Dict[str, Any]]:
     """reference utils/customs_param_group.py: every group takes the not-yet-taken parameters whose name matches its
     regular expression (re.match, sorted names) and carries its `cfg` as optimizer options; the rest form a last
-    group unless `drop_remain`."""
+    group unless `drop_remain`, in which case they are set to requires_grad False."""
     left = OrderedDict(named_parameters)
     out = []
     for group in groups:
@@ -31,6 +31,9 @@ def param_groups(named_parameters: Iterable[Tuple[str, nn.Parameter]], groups: L
         out.append(dict(params=[left.pop(n) for n in names], **group.get("cfg", dict())))
     if left and not drop_remain:
         out.append(dict(params=list(left.values())))
+    elif drop_remain:
+        for p in left.values():                 # like the reference: what no group took is frozen
+            p.requires_grad_(False)
     return out
 
 

@@ -66,3 +66,16 @@ def graph_case(B=4, L=196, M=256, seed=11):
         attn_cls[3, :] = -3.0 - np.abs(attn_cls[3, :])   # whole cls row below the clamp
         attn[3, 0, :] = -1.5 - np.abs(attn[3, 0, :])
     return ing.astype(np.int64), attn, attn_cls
+
+
+def labelled_case(B, L, M, K, seed):
+    """A labelled mini-batch for the training-trajectory fixture: image b of class c draws about two thirds of its
+    tokens from the c-th block of M // K words and the rest from all words, so there is something to learn.
+    -> ingredients i64 [B, L], attn f32 [B, L, L], attn_cls f32 [B, L], label i64 [B]"""
+    label = integers((B,), seed, K)
+    block = M // K
+    own = label[:, None] * block + integers((B, L), seed + 1, block)
+    anyw = integers((B, L), seed + 2, M)
+    pick = integers((B, L), seed + 3, 3) < 2
+    ing = np.where(pick, own, anyw).astype(np.int64)
+    return ing, bellish((B, L, L), seed + 4, 1.5), bellish((B, L), seed + 5, 1.5), label.astype(np.int64)

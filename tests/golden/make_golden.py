@@ -304,10 +304,81 @@ def train_step():
     save("train_step.npz", **rec)
 
 
+# --------------------------------------------------------------------------- config [4]: a training trajectory
+# (lr is ten times the yaml's 1e-3 and there are 30 iterations instead of 10: with the yaml's rate nothing moves in ten
+# steps and the held-out top-1 stays the all-one-class answer of the initial state - a check that cannot fail)
+TRAJ = dict(B=8, L=196, M=128, K=5, n_max=48, E=32, iters=30, seed0=500, eval_seed=990, lr=1.0e-2, wd=0.05, wd_schema_net=5.0e-4)
+
+
+def trajectory():
+    """TRAJ["iters"] iterations of the reference's SchemaNet trainer (schema_inference/tasks/worker_schema_net.py:121-147:
+    zero_grad -> schema_net.normalize() -> predictor(x) -> SchemaInferenceLoss -> weighted sum -> backward ->
+    AdamW step), with the reference's own SchemaNetPredictor, parameter groups (utils/customs_param_group.py) and
+    the optimizer / loss weights of config/caltech_101/schema_net/deit_small-l9-M_1024.yaml, on seeded labelled
+    mini-batches (tests/datagen.py: labelled_case).  Records the losses of every iteration, every parameter after
+    the last one and the scores / top-1 of a held-out batch."""
+    from schema_inference.utils.customs_param_group import customs_param_group
+    c = TRAJ
+    B, L, M, K, n_max, E = c["B"], c["L"], c["M"], c["K"], c["n_max"], c["E"]
+    sn = make_schema_net(M, K, n_max=n_max, seed=21)
+    torch.manual_seed(22)
+    sn.register_class_vertices(torch.stack([torch.randperm(M)[:n_max] for _ in range(K)]))
+    torch.manual_seed(23)
+    m = ref.graph.Matcher(similarity="inner_product", num_codes=M,
+                          gnn_cfg=dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu"))
+
+    class _Wrapper(torch.nn.Module):             # stands for IngredientModelWrapper: x already is its output dict
+        def forward(self, x):
+            return {k: v.clone() for k, v in x.items()}
+
+    predictor = ref.graph.SchemaNetPredictor(_Wrapper(), sn, m)
+    rec = dict(case=np.asarray([B, L, M, K, n_max, E, c["iters"], c["seed0"], c["eval_seed"]]),
+               hyper=np.asarray([c["lr"], c["wd"], c["wd_schema_net"]]))
+    for k, v in predictor.state_dict().items():
+        rec["init:" + k] = v.clone().numpy()
+    groups = [dict(pattern="schema_net", cfg=dict(weight_decay=c["wd_schema_net"])), dict(pattern="matcher")]
+    params = customs_param_group(predictor.named_parameters(), groups, True)
+    opt = torch.optim.AdamW(params, lr=c["lr"], weight_decay=c["wd"])
+    loss_fn = ref.SchemaInferenceLoss()
+    weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+    losses, cls_losses = [], []
+    for it in range(c["iters"]):
+        ing, attn, attn_cls, label = datagen.labelled_case(B, L, M, K, c["seed0"] + 10 * it)
+        predictor.train(); loss_fn.train()
+        opt.zero_grad()
+        sn.normalize()
+        out = predictor({"ingredients": T(ing), "attn": T(attn), "attn_cls": T(attn_cls)})
+        ld = loss_fn(out, {"label": T(label)})
+        loss = sum(v * weights[k.split(".")[0]] for k, v in ld.items() if k.split(".")[0] in weights)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss.detach())); cls_losses.append(float(ld["cls"].detach()))
+    rec["loss"] = np.asarray(losses, np.float64)
+    rec["loss_cls"] = np.asarray(cls_losses, np.float64)
+    for k, v in predictor.state_dict().items():
+        rec["final:" + k] = v.clone().numpy()
+    ing, attn, attn_cls, label = datagen.labelled_case(B, L, M, K, c["eval_seed"])
+    predictor.eval()
+    with torch.no_grad():
+        sn.normalize()
+        pred = predictor({"ingredients": T(ing), "attn": T(attn), "attn_cls": T(attn_cls)})["pred"]
+    rec["eval_pred"] = pred.numpy()
+    rec["eval_top1"] = pred.argmax(1).numpy()
+    rec["eval_label"] = label
+    print("trajectory: loss", " ".join(f"{x:.4f}" for x in losses), "| eval top-1", rec["eval_top1"].tolist(), "labels", label.tolist())
+    save("trajectory.npz", **rec)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # e.g. `make_golden.py trajectory`: regenerate one fixture
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_assign()
     ext_small()
     graph()
     matcher()
     wrapper()
     train_step()
+    trajectory()
