@@ -60,6 +60,12 @@ def make_batch(rank, device, batch=0):
     return tokens.to(device), attn.to(device)
 
 
+def make_inputs(rank, device):
+    """(tokens, codebook, attn) of batch 0 - the batch of SURVEY.md 8(d); tools/ use it"""
+    tokens, attn = make_batch(rank, device, 0)
+    return tokens, make_codebook(device), attn
+
+
 def make_model(device):
     import discretization
     import schema_inference.graph as graph
