@@ -206,6 +206,7 @@ struct AssignArgs {
     int full_waves;
     int64_t extra_base;
     int tps;            // K-outer screen (assign_screen3_kernel): tokens per set (<= 32); set i holds tokens [i tps, (i + 1) tps)
+    int64_t n_sets3;    // ... number of sets, ceil(n_tokens / tps)
     int x_bf16;         // tokens are bfloat16 (x points at 2-byte elements, strides in elements); results are defined on their fp32 values
 };
 
@@ -340,11 +341,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
                 }
             } else if constexpr (FMT == 3) {
-                // records of assign_screen3_kernel: slot c = 6 (2 q + h) + 3 t + j, code = tile << 3 | (g & 1) << 2 | e
+                // records of assign_screen3_kernel: slot c = 3 (2 q + h) + j, code = tile << 4 | accumulator register
                 if (lane < kMaxCand) {
                     const unsigned code = (unsigned)p.codes[n * kCodeBytes + lane];
-                    const int qh = lane / 6, t = (lane % 6) / 3, g = 2 * t + (int)((code >> 2) & 1u);
-                    my_word = ((qh >> 1) * (lay.n_tiles / 2) + (int)(code >> 3)) * 32 + 8 * g + 4 * (qh & 1) + (int)(code & 3u);
+                    const int qh = lane / 3, reg = (int)(code & 15u);
+                    my_word = ((qh >> 1) * (lay.n_tiles / 4) + (int)(code >> 4)) * 32 + 8 * (reg >> 2) + 4 * (qh & 1) + (reg & 3);
                 }
             } else {
                 if (lane < 24 && ((cmask >> lane) & 1ull)) {          // only slots with a candidate were written
@@ -1389,275 +1390,285 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 }
 
 // ------------------------------------------------------------------------------------------
-// mode 0, pass 1, K-outer form (M <= 512; any D the packed image supports): the token stream and the matrix
-// pipe overlap by construction.
+// mode 0, pass 1, K-outer form (codebooks of 8 or 16 tiles of 32 words: 192 < M <= 256, 448 < M <= 512): the token
+// stream and the matrix pipe overlap by construction.
 //
-// A workgroup = 8 waves = 4 token sets x 2 word halves; wave (set ps, half q) keeps the accumulators of
-// its set (<= 32 tokens) against its half of the codebook - NTW tiles of 32 words, 16 registers each - for the
-// whole kernel, and K is the OUTER loop: a 32-float chunk of every token row arrives from HBM by LDS-DMA
-// (whole 128-byte lines, piece-swizzled: the token staging of assign_screen_kernel) into a 4-deep ring per set,
-// is converted to two fp16 B fragments by both waves of the set, and is multiplied against the two k-steps of the
-// codebook image that belong to it: 2 x NTW MFMAs per wave and chunk.  Those k-steps stream L2 -> LDS through a
-// 5-slot ring (one slot = one k-step of every tile = the 1 KiB blocks the token-stationary form reads tile by
-// tile), shared by the eight waves: one barrier per k-step.  Nothing waits for a whole token: the first MFMA
-// starts when the first 128 bytes of each row are in, HBM stays busy until the last chunk, and at the end every
-// wave turns its accumulators into keys (two sorted triples per lane) and the four lanes that hold a token
-// merge through LDS (float min of the best key, or of the candidate masks) into the same flag word /
-// candidate-code record the re-rank kernel reads (format 3).
+// A workgroup = 16 waves = 4 token sets x 4 word quarters, one workgroup per CU, persistent over rounds.  Wave
+// (set ps, quarter q) keeps the accumulators of its set (<= 32 tokens) against its quarter of the codebook - NTW
+// tiles of 32 words, 16 registers each - for a whole round, and K is the OUTER loop: a 32-float chunk of every
+// token row arrives from HBM by LDS-DMA (whole 128-byte lines, piece-swizzled: the token staging of
+// assign_screen_kernel) into a 4-deep ring per set, is converted to two fp16 B fragments by the four waves of the
+// set, and is multiplied against the two k-steps of the codebook image that belong to it: 2 x NTW MFMAs per wave
+// and chunk.  Those k-steps stream L2 -> LDS through a 5-slot ring (one slot = one k-step of every tile = the 1 KiB
+// blocks the token-stationary form reads tile by tile) shared by the sixteen waves: one barrier per k-step.
+// Nothing waits for a whole token: the first MFMA starts when the first 128 bytes of each row are in, HBM stays
+// busy until the last chunk of a round, and the first chunks of the NEXT round are requested before the keys of
+// this one are formed.  Four waves per SIMD, ~85 instructions per wave and chunk: a wave issues one instruction
+// per ~4 cycles whatever it is, so a stream like this one is bound by the instructions of its heaviest wave
+// unless the SIMD has several to choose from (the 8-wave first version of this kernel, 300 instructions per chunk,
+// ran at half the rate of the matrix pipe).
+// At the end of a round every wave turns its accumulators into keys (one sorted triple per lane) and the eight
+// lanes that hold a token merge through LDS (float min of the best key, or of the candidate masks) into the
+// same flag word / candidate-code record the re-rank kernel reads (format 3).
 //
 // Values: u[word] = |c|^2/2 - x~.c~ (accumulators start at |c|^2/2; no per-token shift: keys are compared as
 // floats, as in assign_screen2_kernel), window 2E from the fp32 sum of squares of the token.
 // vmcnt bookkeeping (LDS-DMA and loads retire in issue order): per wave and chunk u the issue order is
 //   barrier(2u): A(2u+4)            barrier(2u+1): A(2u+5), tok(u+5)
-// and barrier(s) publishes A(s+1) (+ tok(u+1) when s = 2u), so the younger operations that may stay in flight
-// are 4 + 2 TPD at an even barrier and 2 + 2 TPD at an odd one (TPD = A pieces per wave and k-step).
+// one 1 KiB piece each, and barrier(s) publishes A(s+1) (+ tok(u+1) when s = 2u), so the younger operations that
+// may stay in flight are 4 at an even barrier and 3 at an odd one.
 // ------------------------------------------------------------------------------------------
-constexpr int kS3RingA = 5, kS3RingT = 4, kS3Sets = 4;
+constexpr int kS3RingA = 5, kS3RingT = 4, kS3Sets = 4, kS3Quarters = 4;
 
 template <int NTW>
-__global__ __launch_bounds__(512, 2) void assign_screen3_kernel(const AssignArgs p)
+__global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArgs p)
 {
-    constexpr int NT = 2 * NTW;                                 // tiles of the (padded) codebook: 4, 8 or 16
-    constexpr int TPD = NT >= 8 ? NT / 8 : 1;                   // 1 KiB pieces of a k-step this wave copies
+    constexpr int NT = kS3Quarters * NTW;                       // tiles of the (padded) codebook: 8 or 16
     constexpr int RG = NTW / 2;                                 // A fragments read ahead (registers)
     constexpr int kSlotA = NT * 1024;
-    static_assert(NTW == 2 || NTW == 4 || NTW == 8, "tiles per wave");
+    static_assert(NTW == 2 || NTW == 4, "tiles per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *ringA = smem;                                                    // [5][NT][1 KiB]
     unsigned char *ringT = smem + kS3RingA * kSlotA;                                // [4 sets][4][4 KiB]
     float *tbest = reinterpret_cast<float *>(ringT + kS3Sets * kS3RingT * 4096);    // [4][32] best key of a token
     unsigned *tmask = reinterpret_cast<unsigned *>(tbest + kS3Sets * 32);           // [4][32] candidate mask being assembled
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int ps = wid >> 1, q = wid & 1;
+    const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int ps = wid >> 2, q = wid & 3;
     const PackLayout lay = pack_layout(p.M, p.D);
     const unsigned char *tiles = p.packed + lay.tiles_off;
-    const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
     const int n_steps = lay.n_steps, n_chunks = n_steps >> 1;   // (D % 32 == 0)
-    const int wave_id = blockIdx.x * 8 + wid;
-    stamp(p, 0, lane, wave_id);
+    const int wave_id = blockIdx.x * 16 + wid;
+    stamp(p, 0, (int)threadIdx.x & 63, wave_id);
 
-    const int64_t set = (int64_t)blockIdx.x * kS3Sets + ps;
-    const int64_t tok0 = set * p.tps;
-    const bool set_active = tok0 < p.n_tokens;                  // wave-uniform
-    const int64_t n = tok0 + r;
-    const bool valid = r < p.tps && n < p.n_tokens;
-
-    if (tid < kS3Sets * 32) { tbest[tid] = kBigKey; tmask[tid] = 0u; }
+    if (threadIdx.x < kS3Sets * 32) { tbest[threadIdx.x] = kBigKey; tmask[threadIdx.x] = 0u; }
 
     // ---- LDS-DMA (inline asm + hand-counted vmcnt: see assign_screen_kernel)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned char *a_src[TPD];
-    unsigned a_dst[TPD];
-#pragma unroll
-    for (int j = 0; j < TPD; ++j) {
-        const int t = (wid * TPD + j) % NT;                    // (NT == 4: waves w and w + 4 copy the same piece)
-        a_src[j] = tiles + (size_t)t * lay.tile_bytes + lane * 16;
-        a_dst[j] = __builtin_amdgcn_readfirstlane(lds_base + t * 1024);
-    }
-    const unsigned char *t_src[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                               // this wave copies rows 8 x + lane / 8, x = 2 q + j, of its set
-        const int rq = 8 * (2 * q + j) + (lane >> 3);
-        const int64_t nq = tok0 + rq;
-        const bool ok = rq < p.tps && nq < p.n_tokens;
-        t_src[j] = reinterpret_cast<const unsigned char *>(token_row(p, ok ? nq : (set_active ? tok0 : 0))) + 16 * ((lane & 7) ^ ((rq >> 1) & 7));
-    }
-    const unsigned t_dst = __builtin_amdgcn_readfirstlane(lds_base + kS3RingA * kSlotA + ps * (kS3RingT * 4096) + (2 * q) * 1024);
+    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (wid % NT) * 1024);
+    const unsigned t_dst = __builtin_amdgcn_readfirstlane(lds_base + kS3RingA * kSlotA + ps * (kS3RingT * 4096) + q * 1024);
+    const unsigned char *a_src = nullptr;                       // next k-step to copy (advanced by issue_a)
+    const unsigned char *t_src = nullptr;                       // next chunk to copy (advanced by issue_tok)
     unsigned keep_m0;
     asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
-    auto issue_a = [&](int s) {
-        const unsigned slot = (unsigned)(s % kS3RingA) * kSlotA;
-#pragma unroll
-        for (int j = 0; j < TPD; ++j)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(a_src[j] + (size_t)s * 1024), "s"(a_dst[j] + slot) : "memory");
+    unsigned a_slot = 0, t_slot = 0;                            // ring positions of the next copies (wave-uniform)
+    auto issue_a = [&]() {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(a_src), "s"(a_dst + a_slot) : "memory");
+        a_src += 1024;
+        a_slot = a_slot == (kS3RingA - 1) * kSlotA ? 0u : a_slot + kSlotA;
     };
-    auto issue_tok = [&](int u) {
-        const unsigned dst = t_dst + (unsigned)(u % kS3RingT) * 4096;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(t_src[j] + 128 * u), "s"(dst + j * 1024) : "memory");
+    auto issue_tok = [&]() {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(t_src), "s"(t_dst + t_slot) : "memory");
+        t_src += 128;
+        t_slot = (t_slot + 4096) & (kS3RingT * 4096 - 1);
+    };
+    // the rows this wave copies for set group `grp`: rows 8 q + lane / 8 of its set (a row past the set: the set's first)
+    auto begin_round = [&](int64_t grp, int lane) -> bool {
+        const int64_t tok0 = (grp * kS3Sets + ps) * p.tps;
+        const bool active = tok0 < p.n_tokens;
+        const int rq = 8 * q + (lane >> 3);
+        const int64_t nq = tok0 + rq;
+        const bool ok = rq < p.tps && nq < p.n_tokens;
+        t_src = reinterpret_cast<const unsigned char *>(token_row(p, ok ? nq : (active ? tok0 : 0))) + 16 * ((lane & 7) ^ ((rq >> 1) & 7));
+        a_src = tiles + (size_t)(wid % NT) * lay.tile_bytes + lane * 16;      // (NT == 8: waves w and w + 8 copy the same piece)
+        a_slot = 0; t_slot = 0;
+        if (active)
+            for (int u = 0; u < kS3RingT && u < n_chunks; ++u) issue_tok();
+        for (int s = 0; s < kS3RingA - 1 && s < n_steps; ++s) issue_a();
+        return active;
     };
 
-    // ---- prologue: four token chunks and four k-steps in flight, everything landed before the first use
-    if (set_active)
-        for (int u = 0; u < kS3RingT && u < n_chunks; ++u) issue_tok(u);
-    for (int s = 0; s < kS3RingA - 1 && s < n_steps; ++s) issue_a(s);
-    float C2 = __uint_as_float(scal[0]), CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
-    const float C1 = __uint_as_float(scal[1]);
-    // accumulators start at |c|^2/2 (padding words: +inf in the image, kept finite here so that keys never become NaNs)
-    f32x16 acc[NTW];
+    const int64_t n_groups = (p.n_sets3 + kS3Sets - 1) / kS3Sets;
+    bool set_active = false;                                    // wave-uniform
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        // (everything that depends on the lane is formed again in every round, behind an opaque copy of the thread id:
+        // hoisted out of the round loop these values - a dozen addresses and masks - do not fit beside the accumulators
+        // and are spilled, and a spill reload waits for vmcnt(0), i.e. for the token chunks in flight)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+        if (grp == blockIdx.x) set_active = begin_round(grp, lane);
+        const unsigned char *t_frag = ringT + ps * (kS3RingT * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
+        const int sw = (r >> 1) & 7;
+        const int o0 = ((4 * h + 0) ^ sw) * 16, o1 = ((4 * h + 1) ^ sw) * 16, o2 = ((4 * h + 2) ^ sw) * 16, o3 = ((4 * h + 3) ^ sw) * 16;
+        const unsigned char *a_frag = ringA + (q * NTW) * 1024 + lane * 16;
+        // ---- accumulators start at |c|^2/2 (padding words: +inf in the image, kept finite here so that keys never become NaNs)
+        f32x16 acc[NTW];
+        const unsigned char *hcp = tiles + (size_t)(q * NTW) * lay.tile_bytes + (size_t)n_steps * 1024 + h * 16;
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const float *hc = reinterpret_cast<const float *>(tiles + (size_t)(q * NTW + i) * lay.tile_bytes + (size_t)n_steps * 1024);
+        for (int i = 0; i < NTW; ++i) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(hc + (g * 2 + h) * 4);
-            acc[i][4 * g + 0] = fminf(c4.x, kPadHalfNorm); acc[i][4 * g + 1] = fminf(c4.y, kPadHalfNorm);
-            acc[i][4 * g + 2] = fminf(c4.z, kPadHalfNorm); acc[i][4 * g + 3] = fminf(c4.w, kPadHalfNorm);
+            for (int g = 0; g < 4; ++g) {
+                const float4 c4 = *reinterpret_cast<const float4 *>(hcp + (size_t)i * lay.tile_bytes + g * 32);
+                acc[i][4 * g + 0] = fminf(c4.x, kPadHalfNorm); acc[i][4 * g + 1] = fminf(c4.y, kPadHalfNorm);
+                acc[i][4 * g + 2] = fminf(c4.z, kPadHalfNorm); acc[i][4 * g + 3] = fminf(c4.w, kPadHalfNorm);
+            }
         }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    // token chunk u of this wave's set -> the lane's 16 floats (row r, k = 32 u + 16 h + 0..15)
-    const unsigned char *t_frag = ringT + ps * (kS3RingT * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
-    const int sw = (r >> 1) & 7;
-    f32x4 raw[4];
-    auto read_raw = [&](int u) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-            raw[v] = *reinterpret_cast<const f32x4 *>(t_frag + (u % kS3RingT) * 4096 + (((4 * h + v) ^ sw) * 16));
-    };
-    float sumsq = 0.0f;
-    auto convert = [&](half8 &b0, half8 &b1) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            sumsq = fmaf(raw[v].x, raw[v].x, sumsq); sumsq = fmaf(raw[v].y, raw[v].y, sumsq);
-            sumsq = fmaf(raw[v].z, raw[v].z, sumsq); sumsq = fmaf(raw[v].w, raw[v].w, sumsq);
-        }
-        b0[0] = (_Float16)raw[0].x; b0[1] = (_Float16)raw[0].y; b0[2] = (_Float16)raw[0].z; b0[3] = (_Float16)raw[0].w;
-        b0[4] = (_Float16)raw[1].x; b0[5] = (_Float16)raw[1].y; b0[6] = (_Float16)raw[1].z; b0[7] = (_Float16)raw[1].w;
-        b1[0] = (_Float16)raw[2].x; b1[1] = (_Float16)raw[2].y; b1[2] = (_Float16)raw[2].z; b1[3] = (_Float16)raw[2].w;
-        b1[4] = (_Float16)raw[3].x; b1[5] = (_Float16)raw[3].y; b1[6] = (_Float16)raw[3].z; b1[7] = (_Float16)raw[3].w;
-    };
-    half8 bc0, bc1, bn0, bn1;
-    if (set_active) read_raw(0);
-    else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) raw[v] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    convert(bc0, bc1);
-    bn0 = bc0; bn1 = bc1;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                               // every wave has chunk 0 in registers: its buffer is free
-    asm volatile("" ::: "memory");
-    if (set_active && kS3RingT < n_chunks) issue_tok(kS3RingT);
-    stamp(p, 1, lane, wave_id);
-
-    // ---- main loop
-    const unsigned char *a_frag = ringA + (q * NTW) * 1024 + lane * 16;
-    auto frag_at = [&](int s, int i) {                          // A fragment of k-step s, this wave's tile i
-        return *reinterpret_cast<const half8 *>(a_frag + (s % kS3RingA) * kSlotA + i * 1024);
-    };
-    half8 ar[RG];
-#pragma unroll
-    for (int i = 0; i < RG; ++i) ar[i] = frag_at(0, i);
-    auto half_step = [&](int s, const half8 &b, int i0) {       // MFMAs i0 .. i0 + RG - 1 of k-step s; the ring runs RG ahead
-#pragma unroll
-        for (int i = i0; i < i0 + RG; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[i % RG], b, acc[i], 0, 0, 0);
-            ar[i % RG] = (i + RG < NTW) ? frag_at(s, i + RG) : frag_at(s + 1, i + RG - NTW);     // (past the last k-step: a stale slot, never used)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    for (int u = 0; u < n_chunks; ++u) {
-        const bool steady = set_active && (u + 4 < n_chunks);   // every operation the counted waits assume has been issued
-        const bool more = u + 1 < n_chunks;
-        // -- k-step 2u
-        half_step(2 * u, bc0, 0);
-        if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + 2 * TPD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // A(2u+1) and token chunk u+1 are in LDS for everybody; slot of A(2u-1) is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the first four chunks and k-steps of this round are in
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (2 * u + 4 < n_steps) issue_a(2 * u + 4);
-        if (set_active && more) read_raw(u + 1);
-        half_step(2 * u, bc0, RG);
-        // -- k-step 2u+1
-        if (more) convert(bn0, bn1);
-        half_step(2 * u + 1, bc1, 0);
-        if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + 2 * TPD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the raw reads of chunk u+1 are in registers: its buffer may be refilled)
-        __builtin_amdgcn_s_barrier();                           // A(2u+2) is in LDS; slot of A(2u) and the buffer of chunk u+1 are free
+
+        // token chunk of this wave's set -> the lane's 16 floats (row r, k = 32 u + 16 h + 0..15)
+        f32x4 raw[4];
+        unsigned rd_slot = 0;                                   // ring position of the next chunk to read
+        auto read_raw = [&]() {
+            const unsigned char *b = t_frag + rd_slot;
+            raw[0] = *reinterpret_cast<const f32x4 *>(b + o0); raw[1] = *reinterpret_cast<const f32x4 *>(b + o1);
+            raw[2] = *reinterpret_cast<const f32x4 *>(b + o2); raw[3] = *reinterpret_cast<const f32x4 *>(b + o3);
+            rd_slot = (rd_slot + 4096) & (kS3RingT * 4096 - 1);
+        };
+        float sumsq = 0.0f;
+        auto convert = [&](half8 &b, const f32x4 &lo, const f32x4 &hi) {
+            sumsq = fmaf(lo.x, lo.x, sumsq); sumsq = fmaf(lo.y, lo.y, sumsq); sumsq = fmaf(lo.z, lo.z, sumsq); sumsq = fmaf(lo.w, lo.w, sumsq);
+            sumsq = fmaf(hi.x, hi.x, sumsq); sumsq = fmaf(hi.y, hi.y, sumsq); sumsq = fmaf(hi.z, hi.z, sumsq); sumsq = fmaf(hi.w, hi.w, sumsq);
+            b[0] = (_Float16)lo.x; b[1] = (_Float16)lo.y; b[2] = (_Float16)lo.z; b[3] = (_Float16)lo.w;
+            b[4] = (_Float16)hi.x; b[5] = (_Float16)hi.y; b[6] = (_Float16)hi.z; b[7] = (_Float16)hi.w;
+        };
+        half8 bc0, bc1;
+        if (set_active) read_raw();
+        else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) raw[v] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        convert(bc0, raw[0], raw[1]);
+        convert(bc1, raw[2], raw[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // every wave has chunk 0 in registers: its buffer is free
         asm volatile("" ::: "memory");
-        if (2 * u + 5 < n_steps) issue_a(2 * u + 5);
-        if (set_active && u + 5 < n_chunks) issue_tok(u + 5);
-        half_step(2 * u + 1, bc1, RG);
-        bc0 = bn0; bc1 = bn1;
+        if (set_active && kS3RingT < n_chunks) issue_tok();
+        stamp(p, 1, lane, wave_id);
+
+        // ---- main loop
+        unsigned ra = 0;                                        // ring position of the k-step being multiplied
+        half8 ar[RG];
+#pragma unroll
+        for (int i = 0; i < RG; ++i) ar[i] = *reinterpret_cast<const half8 *>(a_frag + i * 1024);
+        auto half_step = [&](const half8 &b, int i0) {          // MFMAs i0 .. i0 + RG - 1 of the current k-step; the ring runs RG ahead
+            const unsigned nx = ra == (kS3RingA - 1) * kSlotA ? 0u : ra + kSlotA;
+#pragma unroll
+            for (int i = i0; i < i0 + RG; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[i % RG], b, acc[i], 0, 0, 0);
+                ar[i % RG] = (i + RG < NTW) ? *reinterpret_cast<const half8 *>(a_frag + ra + (i + RG) * 1024)
+                                            : *reinterpret_cast<const half8 *>(a_frag + nx + (i + RG - NTW) * 1024);   // (past the last k-step: a stale slot, never used)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i0 != 0) ra = nx;
+        };
+        for (int u = 0; u < n_chunks; ++u) {
+            const bool steady = set_active && (u + 4 < n_chunks);   // every operation the counted waits assume has been issued
+            const bool more = u + 1 < n_chunks;
+            // -- k-step 2u
+            half_step(bc0, 0);
+            if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // A(2u+1) and token chunk u+1 are in LDS for everybody; slot of A(2u-1) is free
+            asm volatile("" ::: "memory");
+            if (2 * u + 4 < n_steps) issue_a();
+            if (set_active && more) read_raw();
+            half_step(bc0, RG);
+            // -- k-step 2u+1
+            if (more) convert(bc0, raw[0], raw[1]);             // (bc0 of chunk u has been issued to the matrix pipe)
+            half_step(bc1, 0);
+            if (steady) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the raw reads of chunk u+1 are in registers: its buffer may be refilled)
+            __builtin_amdgcn_s_barrier();                       // A(2u+2) is in LDS; slot of A(2u) and the buffer of chunk u+1 are free
+            asm volatile("" ::: "memory");
+            if (2 * u + 5 < n_steps) issue_a();
+            if (set_active && u + 5 < n_chunks) issue_tok();
+            half_step(bc1, RG);
+            if (more) convert(bc1, raw[2], raw[3]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // nobody reads the rings any more
+        asm volatile("" ::: "memory");
+        stamp(p, 2, lane, wave_id);
+        // ---- the next round's first chunks and k-steps travel while this round's keys are formed
+        const int64_t tok0 = (grp * kS3Sets + ps) * p.tps;
+        const bool was_active = set_active;
+        if (grp + gridDim.x < n_groups) set_active = begin_round(grp + gridDim.x, lane);
+
+        // ---- keys: one sorted triple per lane; code = tile << 4 | accumulator register
+        // (volatile asm, four instructions per value: left to itself hipcc forms the three chains one after the other and
+        // keeps every intermediate minimum alive - spills.  The asm reads MFMA results behind the hazard recogniser's
+        // back: the barrier and the copies above are far more than the last MFMA's write-back.)
+        float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey;
+        unsigned keymask = 0xFFFFFF00u;
+        asm volatile("s_nop 15\n\ts_nop 15" : "+s"(keymask));
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                float k;
+                asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
+                             "v_med3_f32 %3, %0, %2, %3\n\t"
+                             "v_med3_f32 %2, %0, %1, %2\n\t"
+                             "v_min_f32 %1, %0, %1"
+                             : "=&v"(k), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(acc[i][x]), "s"(keymask), "n"((i << 4) | x));
+            }
+        }
+        sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
+        // ---- per-token error window (DESIGN.md "S1 error window"): |key - exact value| <= E
+        const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
+        const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]), CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
+        const float X2 = sqrtf(sumsq) * 1.001f + 1.0e-6f, X1 = X2 * sqrtf((float)p.D);
+        const float vmax = 0.5f * CN + X2 * C2;                               // >= |any partial sum|
+        const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
+                                 + (float)n_steps * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
+        const bool bad = !(sumsq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e28f);   // NaN-safe; |x|_2 <= 3e4 bounds every component
+        const float window = 2.0f * E;
+        const int64_t n = tok0 + r;
+        const bool valid = was_active && r < p.tps && n < p.n_tokens;
+        const float kmin = fminf(m1, __shfl_xor(m1, 32, SN_WAVE));
+        if (valid && h == 0) __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&tbest[ps * 32 + r], kmin, 0, 0, false);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float best = tbest[ps * 32 + r];
+        const bool any_finite = best < kKeyLimit;
+        const float cut = best + window;
+        const unsigned hmask = (m1 <= cut ? 1u : 0u) | (m2 <= cut ? 2u : 0u) | (m3 <= cut ? 4u : 0u);
+        const bool hover = m3 <= cut;                                         // a 4th may hide behind it
+        const unsigned contrib = (bad || !any_finite) ? 0x80000000u : ((hmask << (3 * (2 * q + h))) | (hover ? 0x80000000u : 0u));
+        if (valid && contrib) __hip_atomic_fetch_or(&tmask[ps * 32 + r], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned mk = tmask[ps * 32 + r];
+        const unsigned cand = mk & 0xFFFFFFu;
+        const bool overflow = (mk >> 31) != 0u || cand == 0u;
+        const int nc = __popc(cand);
+        if (valid && !overflow) {
+            if (nc == 1 && hmask != 0u) {                                     // the only candidate: final
+                const unsigned code = __float_as_uint(m1) & 0xFFu;
+                p.out[out_index(p, n)] = (q * NTW + (int)(code >> 4)) * 32 + 8 * (int)((code >> 2) & 3u) + 4 * h + (int)(code & 3u);
+            }
+            if (nc > 1) {                                       // the eight lanes of the token write their three codes
+                unsigned char *cd = p.codes + (int64_t)n * kCodeBytes + 3 * (2 * q + h);
+                cd[0] = (unsigned char)(__float_as_uint(m1) & 0xFFu);
+                cd[1] = (unsigned char)(__float_as_uint(m2) & 0xFFu);
+                cd[2] = (unsigned char)(__float_as_uint(m3) & 0xFFu);
+            }
+        }
+        const bool writer = valid && q == 0 && h == 0;
+        if (writer) p.flags[n] = overflow ? 0x80000000u : (nc > 1 ? cand : 0u);
+        const bool need_b = writer && overflow;
+        const unsigned long long mask_b = __ballot(need_b);
+        if (mask_b) {                                          // rare: tokens the screen cannot bound (phase B of the re-rank writes out[])
+            int base = 0;
+            const int leader = __ffsll((long long)mask_b) - 1;
+            if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
+            base = __shfl(base, leader, SN_WAVE);
+            if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // everybody has read the merged words: reset them for the next round
+        asm volatile("" ::: "memory");
+        if (q == 0 && h == 0) { tbest[ps * 32 + r] = kBigKey; tmask[ps * 32 + r] = 0u; }
+        stamp(p, 3, lane, wave_id);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may be in flight when the LDS is released
     asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));
-    stamp(p, 2, lane, wave_id);
-
-    // ---- keys: two sorted triples per lane (accumulator groups {0,1} and {2,3}); code = tile << 3 | (g & 1) << 2 | e
-    float m1[2], m2[2], m3[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) m1[t] = m2[t] = m3[t] = kBigKey;
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-#pragma unroll
-        for (int x = 0; x < 16; ++x) {
-            const int g = x >> 2, e = x & 3, t = g >> 1;
-            const unsigned code = ((unsigned)i << 3) | ((unsigned)(g & 1) << 2) | (unsigned)e;
-            const float k = __uint_as_float((__float_as_uint(acc[i][x]) & 0xFFFFFF00u) | code);
-            m3[t] = __builtin_amdgcn_fmed3f(k, m2[t], m3[t]);
-            m2[t] = __builtin_amdgcn_fmed3f(k, m1[t], m2[t]);
-            m1[t] = fminf(k, m1[t]);
-        }
-    }
-    sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
-    // ---- per-token error window (DESIGN.md "S1 error window"): |key - exact value| <= E
-    const float X2 = sqrtf(sumsq) * 1.001f + 1.0e-6f, X1 = X2 * sqrtf((float)p.D);
-    const float vmax = 0.5f * CN + X2 * C2;                                   // >= |any partial sum|
-    const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
-                             + (float)n_steps * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
-    const bool bad = !(sumsq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e28f);   // NaN-safe; |x|_2 <= 3e4 bounds every component
-    const float window = 2.0f * E;
-    float kmin = fminf(m1[0], m1[1]);
-    kmin = fminf(kmin, __shfl_xor(kmin, 32, SN_WAVE));
-    if (valid && h == 0) __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&tbest[ps * 32 + r], kmin, 0, 0, false);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const float best = tbest[ps * 32 + r];
-    const bool any_finite = best < kKeyLimit;
-    const float cut = best + window;
-    unsigned hmask = 0u;
-    bool hover = false;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (m1[t] <= cut) hmask |= 1u << (3 * t);
-        if (m2[t] <= cut) hmask |= 2u << (3 * t);
-        if (m3[t] <= cut) { hmask |= 4u << (3 * t); hover = true; }              // a 4th may hide behind it
-    }
-    const unsigned contrib = (bad || !any_finite) ? 0x80000000u : ((hmask << (6 * (2 * q + h))) | (hover ? 0x80000000u : 0u));
-    if (valid && contrib) __hip_atomic_fetch_or(&tmask[ps * 32 + r], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const unsigned mk = tmask[ps * 32 + r];
-    const unsigned cand = mk & 0xFFFFFFu;
-    const bool overflow = (mk >> 31) != 0u || cand == 0u;
-    const int nc = __popc(cand);
-    auto word_of = [&](float k, int t) {
-        const unsigned code = __float_as_uint(k) & 0xFFu;
-        const int g = 2 * t + (int)((code >> 2) & 1u);
-        return (q * NTW + (int)(code >> 3)) * 32 + 8 * g + 4 * h + (int)(code & 3u);
-    };
-    if (valid && !overflow) {
-        if (nc == 1 && hmask != 0u) p.out[out_index(p, n)] = word_of((hmask & 1u) ? m1[0] : m1[1], (hmask & 1u) ? 0 : 1);     // the only candidate: final
-        if (nc > 1) {                                           // the four lanes of the token write their six codes
-            unsigned short *cd = reinterpret_cast<unsigned short *>(p.codes + (int64_t)n * kCodeBytes + 6 * (2 * q + h));
-            cd[0] = (unsigned short)((__float_as_uint(m1[0]) & 0xFFu) | ((__float_as_uint(m2[0]) & 0xFFu) << 8));
-            cd[1] = (unsigned short)((__float_as_uint(m3[0]) & 0xFFu) | ((__float_as_uint(m1[1]) & 0xFFu) << 8));
-            cd[2] = (unsigned short)((__float_as_uint(m2[1]) & 0xFFu) | ((__float_as_uint(m3[1]) & 0xFFu) << 8));
-        }
-    }
-    const bool writer = valid && q == 0 && h == 0;
-    if (writer) p.flags[n] = overflow ? 0x80000000u : (nc > 1 ? cand : 0u);
-    const bool need_b = writer && overflow;
-    const unsigned long long mask_b = __ballot(need_b);
-    stamp(p, 3, lane, wave_id);
-    if (mask_b) {                                              // rare: tokens the screen cannot bound (phase B of the re-rank writes out[])
-        int base = 0;
-        const int leader = __ffsll((long long)mask_b) - 1;
-        if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
-        base = __shfl(base, leader, SN_WAVE);
-        if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;
-    }
 }
 
 template <int NT>
@@ -1740,21 +1751,22 @@ int launch_screen2(const AssignArgs &a, hipStream_t st)
 template <int NTW, int NTR>
 int launch_screen3(const AssignArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)kS3RingA * 2 * NTW * 1024 + (size_t)kS3Sets * kS3RingT * 4096 + 1024;
+    constexpr size_t lds = (size_t)kS3RingA * kS3Quarters * NTW * 1024 + (size_t)kS3Sets * kS3RingT * 4096 + 1024;
     if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen3_kernel<NTW>, lds, "sn_assign_words")) return rc;
     AssignArgs ag = a;
-    // tokens per set: one workgroup (4 sets) per CU and round; the rounds are made equally long, so the last one does not
-    // leave half of the chip idle (50 176 tokens on 256 CUs: 2 rounds of 25-token sets instead of 32 + 17)
+    // tokens per set: one workgroup (4 sets) per CU, persistent over rounds; the rounds are made equally long, so the last
+    // one does not leave half of the chip idle (50 176 tokens on 256 CUs: 2 rounds of 25-token sets instead of 32 + 17)
     const int64_t cus = device_cus();
     const int64_t rounds = (a.n_tokens + cus * 128 - 1) / (cus * 128);
     int64_t tps = (a.n_tokens + rounds * cus * kS3Sets - 1) / (rounds * cus * kS3Sets);
     if (const char *e = getenv("SN_ASSIGN_TPS")) tps = atoi(e);
     tps = tps < 16 ? 16 : (tps > 32 ? 32 : tps);
     ag.tps = (int)tps;
-    const int64_t n_sets = (a.n_tokens + tps - 1) / tps;
-    const unsigned grid = (unsigned)((n_sets + kS3Sets - 1) / kS3Sets);
+    ag.n_sets3 = (a.n_tokens + tps - 1) / tps;
+    const int64_t groups = (ag.n_sets3 + kS3Sets - 1) / kS3Sets;
+    const unsigned grid = (unsigned)(groups < cus ? groups : cus);
     sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen3_kernel<NTW>), dim3(grid), dim3(512), lds, st, ag);
+    hipLaunchKernelGGL((assign_screen3_kernel<NTW>), dim3(grid), dim3(1024), lds, st, ag);
     sn_prof_stop(0, st);
     sn_prof_start(1, st);
     const int64_t chunks = (a.n_tokens + 31) / 32;
@@ -1766,8 +1778,8 @@ int launch_screen3(const AssignArgs &a, hipStream_t st)
 // form of the screen kernel: 0 (default) = token-stationary, 4 waves x 3-slot codebook ring, two
 // workgroups per CU; 1 = token-stationary, 8 waves x 5-slot ring; 2 = register-stationary codebook
 // (assign_screen2_kernel; shapes with M <= 512, D in {192, 384}, n_inner >= 32; else falls back to 0);
-// 3 = K-outer token stream (assign_screen3_kernel; 4, 8 or 16 tiles of 32 words, i.e. 64 < M <= 128, 192 < M <= 256 or
-// 448 < M <= 512, fp32 tokens; else falls back to 0).
+// 3 = K-outer token stream (assign_screen3_kernel; 8 or 16 tiles of 32 words, i.e. 192 < M <= 256 or 448 < M <= 512,
+// fp32 tokens; else falls back to 0).
 // Initialised from SN_ASSIGN_VARIANT, changed with sn_assign_set_variant().
 int g_variant = -1;
 int screen_variant()
@@ -1872,7 +1884,7 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
     a.n_sets = (n_tokens + 31) / 32;
     a.full_waves = kWavesPerBlock; a.extra_base = n_tokens;
     a.x_bf16 = x_bf16;
-    a.tps = 32;
+    a.tps = 32; a.n_sets3 = 0;
     a.gate = ws ? (unsigned *)(ws + ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15))) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int per16 = x_bf16 ? 8 : 4;                            // elements per 16 bytes
@@ -1888,9 +1900,8 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
         int rc = 0;
         const bool wide = screen_variant() == 1;
         const PackLayout lay = pack_layout(M, D);
-        if (screen_variant() == 3 && !x_bf16 && (lay.n_tiles == 4 || lay.n_tiles == 8 || lay.n_tiles == 16)) {
-            if (lay.n_tiles == 16) rc = D == 192 ? launch_screen3<8, 3>(a, st) : (D == 384 ? launch_screen3<8, 6>(a, st) : launch_screen3<8, 12>(a, st));
-            else if (lay.n_tiles == 8) rc = D == 192 ? launch_screen3<4, 3>(a, st) : (D == 384 ? launch_screen3<4, 6>(a, st) : launch_screen3<4, 12>(a, st));
+        if (screen_variant() == 3 && !x_bf16 && (lay.n_tiles == 8 || lay.n_tiles == 16)) {
+            if (lay.n_tiles == 16) rc = D == 192 ? launch_screen3<4, 3>(a, st) : (D == 384 ? launch_screen3<4, 6>(a, st) : launch_screen3<4, 12>(a, st));
             else rc = D == 192 ? launch_screen3<2, 3>(a, st) : (D == 384 ? launch_screen3<2, 6>(a, st) : launch_screen3<2, 12>(a, st));
         } else if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 32 && !x_bf16) {
             a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + 32));

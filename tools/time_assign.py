@@ -75,7 +75,7 @@ if variant == 2:      # in-kernel stamps of the register-stationary screen (shad
 
 if variant == 3:      # in-kernel stamps of the K-outer screen (shader clock ticks): 0 start, 1 prologue done, 2 loop done, 3 records written
     lib.sn_debug_set_stamps.argtypes = [C.c_void_p]; lib.sn_debug_set_stamps.restype = None
-    n_waves = 8 * 1024
+    n_waves = 16 * 256
     st = torch.zeros(n_waves * 16, dtype=torch.int64, device=dev)
     lib.sn_debug_set_stamps(st.data_ptr())
     x = tokens[:, 1:, :]
@@ -89,6 +89,4 @@ if variant == 3:      # in-kernel stamps of the K-outer screen (shader clock tic
     q = lambda v: "median %.0f max %.0f" % (v.median(), v.max())
     print("stamps (s_memtime ticks): %d waves; kernel span %.0f; start: %s" % (s8.shape[0], s8[:, 3].max() - t0, q(s8[:, 0] - t0)))
     print("  prologue: " + q(s8[:, 1] - s8[:, 0]) + "   loop: " + q(s8[:, 2] - s8[:, 1]) + "   keys + records: " + q(s8[:, 3] - s8[:, 2]))
-    late = s8[s8[:, 0] - t0 > 5000]
-    if late.shape[0]:
-        print("  second round (%d waves): start %s, loop %s" % (late.shape[0], q(late[:, 0] - t0), q(late[:, 2] - late[:, 1])))
+    print("  (stamps 1-3 are those of the LAST round of a workgroup; whole workgroup: " + q(s8[:, 3] - s8[:, 0]) + ")")
