@@ -207,6 +207,7 @@ struct AssignArgs {
     int64_t extra_base;
     int tps;            // K-outer screen (assign_screen3_kernel): tokens per set (<= 32); set i holds tokens [i tps, (i + 1) tps)
     int64_t n_sets3;    // ... number of sets, ceil(n_tokens / tps)
+    int dbg;
     int x_bf16;         // tokens are bfloat16 (x points at 2-byte elements, strides in elements); results are defined on their fp32 values
 };
 
@@ -1418,18 +1419,18 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 // one 1 KiB piece each, and barrier(s) publishes A(s+1) (+ tok(u+1) when s = 2u), so the younger operations that
 // may stay in flight are 4 at an even barrier and 3 at an odd one.
 // ------------------------------------------------------------------------------------------
-constexpr int kS3RingA = 5, kS3RingT = 4, kS3Sets = 4, kS3Quarters = 4;
+constexpr int kS3RingA = 3, kS3RingT = 3, kS3Sets = 4, kS3Quarters = 4;      // ring slots: codebook chunks (2 k-steps), token chunks
 
 template <int NTW>
 __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArgs p)
 {
     constexpr int NT = kS3Quarters * NTW;                       // tiles of the (padded) codebook: 8 or 16
-    constexpr int RG = NTW / 2;                                 // A fragments read ahead (registers)
-    constexpr int kSlotA = NT * 1024;
+    constexpr int RG = 2;                                       // A fragments read ahead (registers)
+    constexpr int kSlotA = NT * 2048;                           // one chunk = two k-steps of every tile: [tile][k-step][1 KiB]
     static_assert(NTW == 2 || NTW == 4, "tiles per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *ringA = smem;                                                    // [5][NT][1 KiB]
-    unsigned char *ringT = smem + kS3RingA * kSlotA;                                // [4 sets][4][4 KiB]
+    unsigned char *ringA = smem;                                                    // [3][NT][2][1 KiB]
+    unsigned char *ringT = smem + kS3RingA * kSlotA;                                // [4 sets][3][4 KiB]
     float *tbest = reinterpret_cast<float *>(ringT + kS3Sets * kS3RingT * 4096);    // [4][32] best key of a token
     unsigned *tmask = reinterpret_cast<unsigned *>(tbest + kS3Sets * 32);           // [4][32] candidate mask being assembled
 
@@ -1445,22 +1446,23 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
 
     // ---- LDS-DMA (inline asm + hand-counted vmcnt: see assign_screen_kernel)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (wid % NT) * 1024);
+    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (wid % NT) * 2048);
     const unsigned t_dst = __builtin_amdgcn_readfirstlane(lds_base + kS3RingA * kSlotA + ps * (kS3RingT * 4096) + q * 1024);
     const unsigned char *a_src = nullptr;                       // next k-step to copy (advanced by issue_a)
     const unsigned char *t_src = nullptr;                       // next chunk to copy (advanced by issue_tok)
     unsigned keep_m0;
     asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
     unsigned a_slot = 0, t_slot = 0;                            // ring positions of the next copies (wave-uniform)
-    auto issue_a = [&]() {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(a_src), "s"(a_dst + a_slot) : "memory");
-        a_src += 1024;
+    auto issue_a = [&]() {                                      // the two k-steps of the chunk are contiguous in the image and in the slot
+        if (!(p.dbg & 2)) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                     :: "v"(a_src), "s"(a_dst + a_slot) : "memory");
+        a_src += 2048;
         a_slot = a_slot == (kS3RingA - 1) * kSlotA ? 0u : a_slot + kSlotA;
     };
     auto issue_tok = [&]() {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(t_src), "s"(t_dst + t_slot) : "memory");
+        if (!(p.dbg & 1)) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(t_src), "s"(t_dst + t_slot) : "memory");
         t_src += 128;
-        t_slot = (t_slot + 4096) & (kS3RingT * 4096 - 1);
+        t_slot = t_slot == (kS3RingT - 1) * 4096 ? 0u : t_slot + 4096;
     };
     // the rows this wave copies for set group `grp`: rows 8 q + lane / 8 of its set (a row past the set: the set's first)
     auto begin_round = [&](int64_t grp, int lane) -> bool {
@@ -1474,7 +1476,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         a_slot = 0; t_slot = 0;
         if (active)
             for (int u = 0; u < kS3RingT && u < n_chunks; ++u) issue_tok();
-        for (int s = 0; s < kS3RingA - 1 && s < n_steps; ++s) issue_a();
+        for (int u = 0; u < kS3RingA - 1 && u < n_chunks; ++u) issue_a();
         return active;
     };
 
@@ -1491,7 +1493,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         const unsigned char *t_frag = ringT + ps * (kS3RingT * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
         const int sw = (r >> 1) & 7;
         const int o0 = ((4 * h + 0) ^ sw) * 16, o1 = ((4 * h + 1) ^ sw) * 16, o2 = ((4 * h + 2) ^ sw) * 16, o3 = ((4 * h + 3) ^ sw) * 16;
-        const unsigned char *a_frag = ringA + (q * NTW) * 1024 + lane * 16;
+        const unsigned char *a_frag = ringA + (q * NTW) * 2048 + lane * 16;
         // ---- accumulators start at |c|^2/2 (padding words: +inf in the image, kept finite here so that keys never become NaNs)
         f32x16 acc[NTW];
         const unsigned char *hcp = tiles + (size_t)(q * NTW) * lay.tile_bytes + (size_t)n_steps * 1024 + h * 16;
@@ -1515,7 +1517,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
             const unsigned char *b = t_frag + rd_slot;
             raw[0] = *reinterpret_cast<const f32x4 *>(b + o0); raw[1] = *reinterpret_cast<const f32x4 *>(b + o1);
             raw[2] = *reinterpret_cast<const f32x4 *>(b + o2); raw[3] = *reinterpret_cast<const f32x4 *>(b + o3);
-            rd_slot = (rd_slot + 4096) & (kS3RingT * 4096 - 1);
+            rd_slot = rd_slot == (kS3RingT - 1) * 4096 ? 0u : rd_slot + 4096;
         };
         float sumsq = 0.0f;
         auto convert = [&](half8 &b, const f32x4 &lo, const f32x4 &hi) {
@@ -1532,51 +1534,41 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         }
         convert(bc0, raw[0], raw[1]);
         convert(bc1, raw[2], raw[3]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // every wave has chunk 0 in registers: its buffer is free
-        asm volatile("" ::: "memory");
-        if (set_active && kS3RingT < n_chunks) issue_tok();
         stamp(p, 1, lane, wave_id);
 
-        // ---- main loop
-        unsigned ra = 0;                                        // ring position of the k-step being multiplied
+        // ---- main loop: one barrier per chunk, between its two k-steps
+        unsigned ra = 0;                                        // ring position of the chunk being multiplied
         half8 ar[RG];
 #pragma unroll
-        for (int i = 0; i < RG; ++i) ar[i] = *reinterpret_cast<const half8 *>(a_frag + i * 1024);
-        auto half_step = [&](const half8 &b, int i0) {          // MFMAs i0 .. i0 + RG - 1 of the current k-step; the ring runs RG ahead
+        for (int c = 0; c < RG; ++c) ar[c] = *reinterpret_cast<const half8 *>(a_frag + ((c % NTW) * 2 + c / NTW) * 1024);
+        // MFMAs of k-step e of the current chunk; fragment c = e NTW + i of the chunk sits at (2 i + e) KiB of this wave's part
+        // of the slot; the register ring runs RG fragments ahead (the last RG of a chunk fetch the next chunk's first)
+        auto k_step = [&](const half8 &b, int e) {
             const unsigned nx = ra == (kS3RingA - 1) * kSlotA ? 0u : ra + kSlotA;
 #pragma unroll
-            for (int i = i0; i < i0 + RG; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[i % RG], b, acc[i], 0, 0, 0);
-                ar[i % RG] = (i + RG < NTW) ? *reinterpret_cast<const half8 *>(a_frag + ra + (i + RG) * 1024)
-                                            : *reinterpret_cast<const half8 *>(a_frag + nx + (i + RG - NTW) * 1024);   // (past the last k-step: a stale slot, never used)
+            for (int i = 0; i < NTW; ++i) {
+                const int c = e * NTW + i;
+                if (!(p.dbg & 8)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[c % RG], b, acc[i], 0, 0, 0);
+                const int cn = c + RG;
+                if (!(p.dbg & 16)) ar[c % RG] = cn < 2 * NTW ? *reinterpret_cast<const half8 *>(a_frag + ra + ((cn % NTW) * 2 + cn / NTW) * 1024)
+                                          : *reinterpret_cast<const half8 *>(a_frag + nx + (((cn - 2 * NTW) % NTW) * 2 + (cn - 2 * NTW) / NTW) * 1024);   // (past the last chunk: a stale slot, never used)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (i0 != 0) ra = nx;
+            if (e == 1) ra = nx;
         };
         for (int u = 0; u < n_chunks; ++u) {
-            const bool steady = set_active && (u + 4 < n_chunks);   // every operation the counted waits assume has been issued
+            const bool steady = set_active && (u + 2 < n_chunks);   // the operation the counted wait assumes (tok(u+2)) has been issued
             const bool more = u + 1 < n_chunks;
-            // -- k-step 2u
-            half_step(bc0, 0);
-            if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            k_step(bc0, 0);
+            if (steady) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                       // A(2u+1) and token chunk u+1 are in LDS for everybody; slot of A(2u-1) is free
+            if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();                       // chunk u+1 (codebook and tokens) is in LDS for everybody; slot of chunk u-1 and buffer of chunk u are free
             asm volatile("" ::: "memory");
-            if (2 * u + 4 < n_steps) issue_a();
+            if (u + 2 < n_chunks) issue_a();
+            if (set_active && u + 3 < n_chunks) issue_tok();
             if (set_active && more) read_raw();
-            half_step(bc0, RG);
-            // -- k-step 2u+1
             if (more) convert(bc0, raw[0], raw[1]);             // (bc0 of chunk u has been issued to the matrix pipe)
-            half_step(bc1, 0);
-            if (steady) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the raw reads of chunk u+1 are in registers: its buffer may be refilled)
-            __builtin_amdgcn_s_barrier();                       // A(2u+2) is in LDS; slot of A(2u) and the buffer of chunk u+1 are free
-            asm volatile("" ::: "memory");
-            if (2 * u + 5 < n_steps) issue_a();
-            if (set_active && u + 5 < n_chunks) issue_tok();
-            half_step(bc1, RG);
+            k_step(bc1, 1);
             if (more) convert(bc1, raw[2], raw[3]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1751,7 +1743,7 @@ int launch_screen2(const AssignArgs &a, hipStream_t st)
 template <int NTW, int NTR>
 int launch_screen3(const AssignArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)kS3RingA * kS3Quarters * NTW * 1024 + (size_t)kS3Sets * kS3RingT * 4096 + 1024;
+    constexpr size_t lds = (size_t)kS3RingA * kS3Quarters * NTW * 2048 + (size_t)kS3Sets * kS3RingT * 4096 + 1024;
     if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen3_kernel<NTW>, lds, "sn_assign_words")) return rc;
     AssignArgs ag = a;
     // tokens per set: one workgroup (4 sets) per CU, persistent over rounds; the rounds are made equally long, so the last
@@ -1763,6 +1755,7 @@ int launch_screen3(const AssignArgs &a, hipStream_t st)
     tps = tps < 16 ? 16 : (tps > 32 ? 32 : tps);
     ag.tps = (int)tps;
     ag.n_sets3 = (a.n_tokens + tps - 1) / tps;
+    if (const char *e = getenv("SN_S3_DBG")) ag.dbg = atoi(e);
     const int64_t groups = (ag.n_sets3 + kS3Sets - 1) / kS3Sets;
     const unsigned grid = (unsigned)(groups < cus ? groups : cus);
     sn_prof_start(0, st);
@@ -1884,7 +1877,7 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
     a.n_sets = (n_tokens + 31) / 32;
     a.full_waves = kWavesPerBlock; a.extra_base = n_tokens;
     a.x_bf16 = x_bf16;
-    a.tps = 32; a.n_sets3 = 0;
+    a.tps = 32; a.n_sets3 = 0; a.dbg = 0;
     a.gate = ws ? (unsigned *)(ws + ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15))) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int per16 = x_bf16 ? 8 : 4;                            // elements per 16 bytes
