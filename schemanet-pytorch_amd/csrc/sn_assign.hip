@@ -207,7 +207,6 @@ struct AssignArgs {
     int64_t extra_base;
     int tps;            // K-outer screen (assign_screen3_kernel): tokens per set (<= 32); set i holds tokens [i tps, (i + 1) tps)
     int64_t n_sets3;    // ... number of sets, ceil(n_tokens / tps)
-    int dbg;
     int x_bf16;         // tokens are bfloat16 (x points at 2-byte elements, strides in elements); results are defined on their fp32 values
 };
 
@@ -1391,33 +1390,35 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 }
 
 // ------------------------------------------------------------------------------------------
-// mode 0, pass 1, K-outer form (codebooks of 8 or 16 tiles of 32 words: 192 < M <= 256, 448 < M <= 512): the token
-// stream and the matrix pipe overlap by construction.
+// mode 0, pass 1, K-outer form (opt-in, sn_assign_set_variant(3); codebooks of 8 or 16 tiles of 32 words: 192 < M <= 256,
+// 448 < M <= 512): the token stream and the matrix pipe overlap by construction.
 //
 // A workgroup = 16 waves = 4 token sets x 4 word quarters, one workgroup per CU, persistent over rounds.  Wave
 // (set ps, quarter q) keeps the accumulators of its set (<= 32 tokens) against its quarter of the codebook - NTW
 // tiles of 32 words, 16 registers each - for a whole round, and K is the OUTER loop: a 32-float chunk of every
 // token row arrives from HBM by LDS-DMA (whole 128-byte lines, piece-swizzled: the token staging of
-// assign_screen_kernel) into a 4-deep ring per set, is converted to two fp16 B fragments by the four waves of the
+// assign_screen_kernel) into a 3-deep ring per set, is converted to two fp16 B fragments by the four waves of the
 // set, and is multiplied against the two k-steps of the codebook image that belong to it: 2 x NTW MFMAs per wave
-// and chunk.  Those k-steps stream L2 -> LDS through a 5-slot ring (one slot = one k-step of every tile = the 1 KiB
-// blocks the token-stationary form reads tile by tile) shared by the sixteen waves: one barrier per k-step.
-// Nothing waits for a whole token: the first MFMA starts when the first 128 bytes of each row are in, HBM stays
-// busy until the last chunk of a round, and the first chunks of the NEXT round are requested before the keys of
-// this one are formed.  Four waves per SIMD, ~85 instructions per wave and chunk: a wave issues one instruction
-// per ~4 cycles whatever it is, so a stream like this one is bound by the instructions of its heaviest wave
-// unless the SIMD has several to choose from (the 8-wave first version of this kernel, 300 instructions per chunk,
-// ran at half the rate of the matrix pipe).
+// and chunk.  Those k-steps stream L2 -> LDS through a 3-slot ring (one slot = the two k-steps of a chunk of every
+// tile = the 1 KiB blocks the token-stationary form reads tile by tile) shared by the sixteen waves: one barrier
+// per chunk.  Nothing waits for a whole token: the first MFMA starts when the first 128 bytes of each row are in,
+// HBM stays busy until the last chunk of a round, and the first chunks of the NEXT round are requested before the
+// keys of this one are formed.
 // At the end of a round every wave turns its accumulators into keys (one sorted triple per lane) and the eight
 // lanes that hold a token merge through LDS (float min of the best key, or of the candidate masks) into the
 // same flag word / candidate-code record the re-rank kernel reads (format 3).
 //
 // Values: u[word] = |c|^2/2 - x~.c~ (accumulators start at |c|^2/2; no per-token shift: keys are compared as
 // floats, as in assign_screen2_kernel), window 2E from the fp32 sum of squares of the token.
-// vmcnt bookkeeping (LDS-DMA and loads retire in issue order): per wave and chunk u the issue order is
-//   barrier(2u): A(2u+4)            barrier(2u+1): A(2u+5), tok(u+5)
-// one 1 KiB piece each, and barrier(s) publishes A(s+1) (+ tok(u+1) when s = 2u), so the younger operations that
-// may stay in flight are 4 at an even barrier and 3 at an odd one.
+// vmcnt bookkeeping (LDS-DMA and loads retire in issue order): per wave, barrier(u) - between the two k-steps of
+// chunk u - is followed by the copies A(u+2) (two pieces) and tok(u+3) (one piece), and publishes A(u+1) and
+// tok(u+1): the only younger operation that may stay in flight across it is tok(u+2).
+//
+// Measured (MI355X, 50 176 tokens): 45.8 us against 35.6 us for the token-stationary form - the stream is
+// bound by the INSTRUCTIONS the CU can issue, not by HBM, LDS or the matrix pipe: with the token copies, the codebook
+// copies, the barriers, the MFMAs and the fragment reads all compiled out the loop still takes 85 % of its time
+// (170 instructions per wave and chunk, sixteen waves, one scalar unit).  Kept as the form to build on: it is the
+// one whose floor is the HBM stream.
 // ------------------------------------------------------------------------------------------
 constexpr int kS3RingA = 3, kS3RingT = 3, kS3Sets = 4, kS3Quarters = 4;      // ring slots: codebook chunks (2 k-steps), token chunks
 
@@ -1454,13 +1455,13 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
     asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
     unsigned a_slot = 0, t_slot = 0;                            // ring positions of the next copies (wave-uniform)
     auto issue_a = [&]() {                                      // the two k-steps of the chunk are contiguous in the image and in the slot
-        if (!(p.dbg & 2)) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
                      :: "v"(a_src), "s"(a_dst + a_slot) : "memory");
         a_src += 2048;
         a_slot = a_slot == (kS3RingA - 1) * kSlotA ? 0u : a_slot + kSlotA;
     };
     auto issue_tok = [&]() {
-        if (!(p.dbg & 1)) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(t_src), "s"(t_dst + t_slot) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(t_src), "s"(t_dst + t_slot) : "memory");
         t_src += 128;
         t_slot = t_slot == (kS3RingT - 1) * 4096 ? 0u : t_slot + 4096;
     };
@@ -1506,7 +1507,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
                 acc[i][4 * g + 2] = fminf(c4.z, kPadHalfNorm); acc[i][4 * g + 3] = fminf(c4.w, kPadHalfNorm);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the first four chunks and k-steps of this round are in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the first three token chunks and two codebook chunks of this round are in
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
@@ -1548,9 +1549,9 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
                 const int c = e * NTW + i;
-                if (!(p.dbg & 8)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[c % RG], b, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[c % RG], b, acc[i], 0, 0, 0);
                 const int cn = c + RG;
-                if (!(p.dbg & 16)) ar[c % RG] = cn < 2 * NTW ? *reinterpret_cast<const half8 *>(a_frag + ra + ((cn % NTW) * 2 + cn / NTW) * 1024)
+                ar[c % RG] = cn < 2 * NTW ? *reinterpret_cast<const half8 *>(a_frag + ra + ((cn % NTW) * 2 + cn / NTW) * 1024)
                                           : *reinterpret_cast<const half8 *>(a_frag + nx + (((cn - 2 * NTW) % NTW) * 2 + (cn - 2 * NTW) / NTW) * 1024);   // (past the last chunk: a stale slot, never used)
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1562,7 +1563,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
             k_step(bc0, 0);
             if (steady) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();                       // chunk u+1 (codebook and tokens) is in LDS for everybody; slot of chunk u-1 and buffer of chunk u are free
+            __builtin_amdgcn_s_barrier();                       // chunk u+1 (codebook and tokens) is in LDS for everybody; slot of chunk u-1 and buffer of chunk u are free
             asm volatile("" ::: "memory");
             if (u + 2 < n_chunks) issue_a();
             if (set_active && u + 3 < n_chunks) issue_tok();
@@ -1755,7 +1756,6 @@ int launch_screen3(const AssignArgs &a, hipStream_t st)
     tps = tps < 16 ? 16 : (tps > 32 ? 32 : tps);
     ag.tps = (int)tps;
     ag.n_sets3 = (a.n_tokens + tps - 1) / tps;
-    if (const char *e = getenv("SN_S3_DBG")) ag.dbg = atoi(e);
     const int64_t groups = (ag.n_sets3 + kS3Sets - 1) / kS3Sets;
     const unsigned grid = (unsigned)(groups < cus ? groups : cus);
     sn_prof_start(0, st);
@@ -1877,7 +1877,7 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
     a.n_sets = (n_tokens + 31) / 32;
     a.full_waves = kWavesPerBlock; a.extra_base = n_tokens;
     a.x_bf16 = x_bf16;
-    a.tps = 32; a.n_sets3 = 0; a.dbg = 0;
+    a.tps = 32; a.n_sets3 = 0;
     a.gate = ws ? (unsigned *)(ws + ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15))) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int per16 = x_bf16 ? 8 : 4;                            // elements per 16 bytes
