@@ -553,6 +553,51 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     return out
 
 
+class _SymAdjMatmul(torch.autograd.Function):
+    """Y = adj @ X for a SYMMETRIC adj [G, n, n] (the GCN operand (E + E^T)/2 + I, reference gnn.py:27-30) on the matrix
+    cores with autograd: the training-side counterpart of the inference products.  All three
+    products are split-fp16 MFMA GEMMs (sn_gcn_gemm, fp32-GEMM accuracy):
+        forward    Y     = adj . X                 A = adj planes (shared by the layers),  Bt = planes of X^T
+        backward   dX    = adj . dY                (adj symmetric: adj^T = adj)
+                   d adj = dY . X^T                A = planes of dY [G, n, E], Bt = planes of X [G, n, E]: no transposes
+    `adj_planes` = split_planes(adj) is passed in so that the layers of one forward pass share it."""
+
+    @staticmethod
+    def forward(ctx, adj, x, adj_planes):
+        G, n, _ = adj.shape
+        xt = split_planes(x.detach().transpose(1, 2).contiguous())
+        y = gcn_gemm(adj_planes, xt, G, want_c=True)["c"]
+        ctx.save_for_backward(x)
+        ctx.adj_planes = adj_planes
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        ap = ctx.adj_planes
+        G = x.shape[0]
+        # Gradients are small (1e-3 .. 1e-8) and fp16 planes have a short exponent: below 6e-5 the hi plane is subnormal
+        # and hi + lo resolves 6e-8 ABSOLUTE, i.e. percents of such a value.  So the incoming gradient is scaled by a
+        # power of two (exact) that puts its largest magnitude near 2^10, and the products are scaled back; the scale is
+        # a device scalar (no host synchronisation).
+        dy = _f32c(dy)
+        scale = torch.exp2(torch.floor(torch.log2(1024.0 / dy.abs().amax().clamp_min(1.0e-30))))
+        dys = dy * scale
+        d_adj = d_x = None
+        if ctx.needs_input_grad[1]:
+            d_x = gcn_gemm(ap, split_planes(dys.transpose(1, 2).contiguous()), G, want_c=True)["c"] / scale
+        if ctx.needs_input_grad[0]:
+            d_adj = gcn_gemm(split_planes(dys), split_planes(x.detach()), G, want_c=True)["c"] / scale
+        return d_adj, d_x, None
+
+
+def sym_adj_matmul(adj, x, adj_planes=None):
+    """adj [G, n, n] symmetric fp32, x [G, n, E] fp32 (CUDA, E a multiple of 16) -> adj @ x, differentiable in both."""
+    if adj_planes is None:
+        adj_planes = split_planes(adj.detach())
+    return _SymAdjMatmul.apply(adj, x, adj_planes)
+
+
 def pool_fc(pooled_sum, divisor, weight, bias):
     """fc(pooled / divisor) with pooled = pooled_sum [G, E] or the sum over dim 1 of [G, parts, E]
     (the per-row-tile partial sums of gcn_gemm); divisor: int32 [1] device tensor or a number."""

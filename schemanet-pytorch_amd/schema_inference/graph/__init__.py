@@ -35,6 +35,14 @@ class SchemaNetPredictor(nn.Module):
         self.matcher = matcher
         self.num_classes = schema_net.num_classes
 
+    def train(self, mode: bool = True):
+        """eval(): the class-graph features (a function of parameters only) are cached across forwards; train(): off"""
+        super().train(mode)
+        self.matcher.cache_atlas = not mode
+        if mode:
+            self.matcher.invalidate_atlas_cache()
+        return self
+
     def forward(self, x: torch.Tensor, requires_graph: bool = False) -> Dict[str, torch.Tensor]:
         ret = collections.OrderedDict()
         with torch.no_grad():
@@ -44,7 +52,8 @@ class SchemaNetPredictor(nn.Module):
                 output = self.ingredient_wrapper(x)
         # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
         # instance branch on the current one; joined inside forward_padded
-        atlas = self.matcher.atlas_features_async(self.schema_net.get_atlas)
+        atlas = self.matcher.atlas_features_async(
+            self.schema_net.get_atlas, depends_on=(self.schema_net.vertex_weights.tensor, self.schema_net.edge_weights.tensor))
         # (the zero padding of the instance edges is only written when the caller asks for the graphs)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
                                                       zero_padding=requires_graph, return_attn_cls=requires_graph)

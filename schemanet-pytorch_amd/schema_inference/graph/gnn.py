@@ -3,10 +3,12 @@
 `embedding.weight`, `layers.{i}.g_conv.linear.{weight,bias}`, `layers.{i}.norm.{weight,bias}`,
 `fc.{weight,bias}`.
 
-Inference: adjacency symmetrisation, masked LayerNorm+ReLU and the node-weighted pooling are
-HIP kernels (csrc/sn_match.hip); the dense bmm / Linear GEMMs are plain library GEMMs
-(rocBLAS via torch), fp32 so the scores stay within the 1e-5 budget.
-Training (any input or parameter requires grad): the same maths as differentiable torch ops.
+Inference: every product runs on the matrix cores as split-fp16 MFMA GEMMs with the elementwise steps as
+epilogues (csrc/sn_gcn.hip; `_forward_mfma`, `_forward_mfma_wide`), fp32-GEMM accuracy so the scores stay
+within the 1e-5 budget; other configurations use the library GEMMs with HIP kernels in between.
+Training (any input or parameter requires grad): the same maths as differentiable torch ops, with the
+adjacency products adj @ X - forward and both gradients, the 27 GFLOP per step of the class graphs - on the
+same MFMA GEMM through `ops.sym_adj_matmul` (an autograd.Function); the Linear layers stay library GEMMs.
 """
 import os
 from typing import Callable, Optional
@@ -42,9 +44,11 @@ class GraphConv(nn.Module):
         eye = torch.eye(edges.shape[-1], dtype=edges.dtype, device=edges.device)
         return (edges + edges.transpose(1, 2)) / 2 + eye
 
-    def forward(self, edges: torch.Tensor, feat: torch.Tensor, adj: torch.Tensor = None) -> torch.Tensor:
+    def forward(self, edges: torch.Tensor, feat: torch.Tensor, adj: torch.Tensor = None, adj_planes=None) -> torch.Tensor:
         if adj is None:
             adj = self.adjacency(edges)
+        if adj_planes is not None:      # training on the matrix cores: adj @ feat and both of its gradients as split-fp16 MFMA GEMMs
+            return self.linear(ops.sym_adj_matmul(adj, feat, adj_planes))
         return self.linear(torch.bmm(adj, feat))
 
 
@@ -58,8 +62,8 @@ class Layer(nn.Module):
         self._is_none = activation == "none"
 
     def forward(self, edges: torch.Tensor, feat: torch.Tensor, feat_mask: torch.BoolTensor = None,
-                adj: torch.Tensor = None, n_valid: torch.Tensor = None, fused: bool = False):
-        feat = self.g_conv(edges, feat, adj)
+                adj: torch.Tensor = None, n_valid: torch.Tensor = None, fused: bool = False, adj_planes=None):
+        feat = self.g_conv(edges, feat, adj, adj_planes)
         if fused and (self._is_relu or self._is_none) and feat.is_contiguous():
             # pad rows -> 0, LayerNorm, ReLU in one pass (reference gnn.py:43-46)
             return ops.mask_layernorm_act_(feat, self.norm.weight, self.norm.bias, self.norm.eps,
@@ -209,8 +213,11 @@ class GNN(nn.Module):
             layers = layers[1:]
         else:
             feat = self.embedding(ingredients)
+        adj_planes = None
+        if not fused and adj.is_cuda and self.embed_dim % 16 == 0 and os.environ.get("SN_GCN_MFMA", "1") != "0":
+            adj_planes = ops.split_planes(adj.detach())      # shared by the layers (and by their backward passes)
         for layer in layers:
-            feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused)
+            feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused, adj_planes=adj_planes)
         if fused:
             pooled = ops.weighted_pool(feat, nodes, divisor)
         else:

@@ -310,13 +310,9 @@ def train_step():
 TRAJ = dict(B=8, L=196, M=128, K=5, n_max=48, E=32, iters=30, seed0=500, eval_seed=990, lr=1.0e-2, wd=0.05, wd_schema_net=5.0e-4)
 
 
-def trajectory():
-    """TRAJ["iters"] iterations of the reference's SchemaNet trainer (schema_inference/tasks/worker_schema_net.py:121-147:
-    zero_grad -> schema_net.normalize() -> predictor(x) -> SchemaInferenceLoss -> weighted sum -> backward ->
-    AdamW step), with the reference's own SchemaNetPredictor, parameter groups (utils/customs_param_group.py) and
-    the optimizer / loss weights of config/caltech_101/schema_net/deit_small-l9-M_1024.yaml, on seeded labelled
-    mini-batches (tests/datagen.py: labelled_case).  Records the losses of every iteration, every parameter after
-    the last one and the scores / top-1 of a held-out batch."""
+def _trajectory_run(perturb=0.0):
+    """-> (predictor, sn, losses, cls_losses): TRAJ["iters"] reference iterations; perturb: relative size of a random
+    perturbation of the initial GNN / attribute weights (what a different summation order does to them after one step)"""
     from schema_inference.utils.customs_param_group import customs_param_group
     c = TRAJ
     B, L, M, K, n_max, E = c["B"], c["L"], c["M"], c["K"], c["n_max"], c["E"]
@@ -332,10 +328,13 @@ def trajectory():
             return {k: v.clone() for k, v in x.items()}
 
     predictor = ref.graph.SchemaNetPredictor(_Wrapper(), sn, m)
-    rec = dict(case=np.asarray([B, L, M, K, n_max, E, c["iters"], c["seed0"], c["eval_seed"]]),
-               hyper=np.asarray([c["lr"], c["wd"], c["wd_schema_net"]]))
-    for k, v in predictor.state_dict().items():
-        rec["init:" + k] = v.clone().numpy()
+    init = {k: v.clone() for k, v in predictor.state_dict().items()}
+    if perturb:
+        torch.manual_seed(99)
+        with torch.no_grad():
+            for prm in predictor.parameters():
+                if prm.dtype.is_floating_point:
+                    prm.mul_(1 + perturb * (2 * torch.rand_like(prm) - 1))
     groups = [dict(pattern="schema_net", cfg=dict(weight_decay=c["wd_schema_net"])), dict(pattern="matcher")]
     params = customs_param_group(predictor.named_parameters(), groups, True)
     opt = torch.optim.AdamW(params, lr=c["lr"], weight_decay=c["wd"])
@@ -354,6 +353,37 @@ def trajectory():
         opt.step()
         opt.zero_grad(set_to_none=True)
         losses.append(float(loss.detach())); cls_losses.append(float(ld["cls"].detach()))
+    return predictor, sn, init, losses, cls_losses
+
+
+def trajectory():
+    """TRAJ["iters"] iterations of the reference's SchemaNet trainer (schema_inference/tasks/worker_schema_net.py:121-147:
+    zero_grad -> schema_net.normalize() -> predictor(x) -> SchemaInferenceLoss -> weighted sum -> backward ->
+    AdamW step), with the reference's own SchemaNetPredictor, parameter groups (utils/customs_param_group.py) and
+    the optimizer / loss weights of config/caltech_101/schema_net/deit_small-l9-M_1024.yaml, on seeded labelled
+    mini-batches (tests/datagen.py: labelled_case).  Records the losses of every iteration, every parameter after
+    the last one and the scores / top-1 of a held-out batch."""
+    c = TRAJ
+    B, L, M, K, n_max, E = c["B"], c["L"], c["M"], c["K"], c["n_max"], c["E"]
+    predictor, sn, init, losses, cls_losses = _trajectory_run()
+    rec = dict(case=np.asarray([B, L, M, K, n_max, E, c["iters"], c["seed0"], c["eval_seed"]]),
+               hyper=np.asarray([c["lr"], c["wd"], c["wd_schema_net"]]))
+    for k, v in init.items():
+        rec["init:" + k] = v.numpy()
+    # how far the reference parts from ITSELF when its initial weights move by one fp32 rounding (relative 6e-8): the
+    # yardstick for the parameters at the end of the trajectory (Adam turns the sign of a noise-sized gradient into a
+    # full step, so two fp32 implementations of the same mathematics part by this much)
+    twin, _, _, twin_losses, _ = _trajectory_run(perturb=6.0e-8)
+    for (k, a), (_, b) in zip(predictor.state_dict().items(), twin.state_dict().items()):
+        if a.dtype.is_floating_point:
+            d = (a - b).abs().flatten()
+            d = d[~torch.isnan(d)]
+            rec["selfdev_p99:" + k] = np.float64(torch.quantile(d.double(), 0.99)) if d.numel() else np.float64(0)
+            rec["selfdev_max:" + k] = np.float64(d.max()) if d.numel() else np.float64(0)
+    rec["selfdev_loss"] = np.abs(np.asarray(losses) - np.asarray(twin_losses)) / np.abs(np.asarray(losses))
+    print("trajectory: the reference against itself under a 6e-8 perturbation: loss drift max %.2e; parameter p99 max %.2e, max %.2e"
+          % (rec["selfdev_loss"].max(), max(float(v) for k, v in rec.items() if k.startswith("selfdev_p99:")),
+             max(float(v) for k, v in rec.items() if k.startswith("selfdev_max:"))))
     rec["loss"] = np.asarray(losses, np.float64)
     rec["loss_cls"] = np.asarray(cls_losses, np.float64)
     for k, v in predictor.state_dict().items():
