@@ -344,6 +344,108 @@ __device__ inline PosInfo group_positions(const Lds &s, int L, int tid, bool kep
     return r;
 }
 
+// The same records by ONE wave and a sort (prediction path; every position kept): the 64 lanes hold four keys each,
+// key = word << 8 | position (words below 2^24, L <= 256), a bitonic network over the 256 slots (36 compare-exchange
+// stages: the strides below 4 between a lane's own registers, the others one ds_bpermute per key) leaves them
+// ascending, i.e. grouped by word with ascending positions inside a word - the order of the reference's std::map and
+// of its position lists - and everything else is local: a word starts where the word part changes (head), its index
+// is the number of heads before it (ballots), its run ends at the next head.  ~600 wave-instructions instead of the
+// ~36 000 of the ballot form above, and the other fifteen waves spend the time on the attention rows.
+// `w4[e]` / key slot e of lane l: position l + 64 e on entry.  Returns false (nothing written) when a word does not
+// fit the key; the caller then runs group_positions.
+__device__ inline bool group_positions_sorted(const Lds &s, int L, int lane, const int64_t (&w4)[4], bool want_sum)
+{
+    unsigned key[4];
+    bool fits = true;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int q = lane + SN_WAVE * e;
+        const bool ok = q < L;
+        fits = fits && (!ok || (w4[e] >= 0 && w4[e] < (1 << 24)));
+        key[e] = ok ? (((unsigned)w4[e] << 8) | (unsigned)q) : 0xFFFFFFFFu;
+    }
+    if (__any(!fits)) return false;
+    // ---- bitonic sort, element index i = 4 lane + e
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 4) {
+                const int lj = j >> 2;
+                const bool lower = (lane & lj) == 0;
+                const bool up = k == 256 || (lane & (k >> 2)) == 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned other = (unsigned)__shfl_xor((int)key[e], lj, SN_WAVE);
+                    key[e] = (lower == up) ? min(key[e], other) : max(key[e], other);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e & j) continue;
+                    const bool up = k == 2 ? (e & 2) == 0 : (k == 4 ? (lane & 1) == 0 : (k == 256 || (lane & (k >> 2)) == 0));
+                    const unsigned lo = min(key[e], key[e | j]), hi = max(key[e], key[e | j]);
+                    key[e] = up ? lo : hi;
+                    key[e | j] = up ? hi : lo;
+                }
+            }
+        }
+    }
+    // ---- heads, group indices
+    const unsigned prevk = (unsigned)__shfl_up((int)key[3], 1, SN_WAVE);
+    bool valid[4], head[4];
+    unsigned long long hm[4];
+    int n_kept = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        valid[e] = key[e] != 0xFFFFFFFFu;
+        const unsigned pk = e == 0 ? prevk : key[e - 1];
+        head[e] = valid[e] && ((e == 0 && lane == 0) || (key[e] >> 8) != (pk >> 8));
+        hm[e] = __ballot(head[e]);
+        n_kept += __popcll(__ballot(valid[e]));
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int g[4];
+    int run = __popcll(hm[0] & below) + __popcll(hm[1] & below) + __popcll(hm[2] & below) + __popcll(hm[3] & below) - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { run += head[e] ? 1 : 0; g[e] = run; }
+    const int n_groups = __popcll(hm[0]) + __popcll(hm[1]) + __popcll(hm[2]) + __popcll(hm[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (!valid[e]) continue;
+        const int i = 4 * lane + e, pos = (int)(key[e] & 255u);
+        s.pos_sorted[i] = (unsigned char)pos;
+        if (head[e]) s.gstart[g[e]] = (unsigned short)i;
+        if (want_sum) s.psum[i] = s.acls[pos];                    // (temporarily: cls attention in sorted order)
+    }
+    if (lane == 0) { s.gstart[n_groups] = (unsigned short)n_kept; s.misc[0] = n_groups; s.misc[1] = n_kept; }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int gs[4], cnt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        gs[e] = 0; cnt[e] = 0;
+        if (!valid[e]) continue;
+        gs[e] = s.gstart[g[e]];
+        cnt[e] = (int)s.gstart[g[e] + 1] - gs[e];
+        if (want_sum && head[e])
+            for (int t = 0; t < cnt[e]; ++t) sum[e] = sum[e] + s.psum[gs[e] + t];      // position order (utils.cpp:9)
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // every sum is in registers: psum can take its final contents
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (!valid[e]) continue;
+        const int pos = (int)(key[e] & 255u);
+        s.pless[pos] = (unsigned short)gs[e];
+        s.pcnt[pos] = (unsigned short)cnt[e];
+        s.flag[pos] = (unsigned char)(1 | (head[e] ? 2 : 0) | 4);
+        if (head[e]) { s.pgroup[pos] = (unsigned char)g[e]; s.psum[pos] = sum[e]; }
+    }
+    return true;
+}
+
 // block-wide max over first-occurrence values; NaN propagates like at::max (large_scale_feat_to_v.cpp:124)
 __device__ inline float block_max_nan(const Lds &s, float v, bool valid, int tid, int wid, int nw, int lane)
 {
@@ -488,14 +590,18 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
 
     SN_GSTAMP(0);
     // ---- stream this image's attention map into LDS (the only large HBM read)
+    // The last wave groups the positions by word (one-wave sort, group_positions_sorted) while the others bring the rows in.
+    const bool sorter = nw > 1 && wid == nw - 1;                // wave-uniform
     if (kEdges) {
-        attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
-                         a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e,
-                         wid, nw, lane);
+        if (!sorter)
+            attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
+                                   a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e,
+                                   wid, nw > 1 ? nw - 1 : 1, lane);
         if (!a.geo) build_grid_table(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);
     }
     if (tid < L) s.words[tid] = a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)tid * a.ing_stride_l];
     for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;
+    if (!sorter && wid == nw - 1 && lane == 0) s.misc[2] = 0;   // misc[2] = 1: the sorter wave has written the grouping records (only ever written by the last wave)
 
     // ---- attention to the cls token: clamp / softmax / nan_to_num(0)  (schema_net.py:295-297)
     if (do_v && wid == nw - 1) {
@@ -531,11 +637,34 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if (c < L) s.acls[c] = x[k];
         }
     }
+    if (sorter) {
+        bool done = false;
+        if (L <= 4 * SN_WAVE) {
+        int64_t w4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = lane + SN_WAVE * e;
+            w4[e] = q < L ? a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)q * a.ing_stride_l] : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wave's own s.acls stores)
+        done = group_positions_sorted(s, L, lane, w4, do_v);
+        }
+        if (lane == 0) s.misc[2] = done ? 1 : 0;
+    }
     __syncthreads();
 
     SN_GSTAMP(1);
-    // ---- group positions by word
-    const PosInfo me = group_positions(s, L, tid, tid < L, do_v);
+    // ---- group positions by word (the ballot form only when the sort does not apply: words >= 2^24)
+    PosInfo me = {0, 0, 0, 0.0f};
+    if (s.misc[2] == 0) {
+        me = group_positions(s, L, tid, tid < L, do_v);
+    } else if (tid < L) {
+        me.first = (s.flag[tid] & 2) != 0;
+        me.cnt = s.pcnt[tid];
+        me.group = me.first ? s.pgroup[tid] : 0;
+        me.attn_sum = me.first ? s.psum[tid] : 0.0f;
+    }
     SN_GSTAMP(2);
     const int n_groups = s.misc[0];
     const bool owner = tid < L && me.first;
