@@ -368,9 +368,9 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     for row in json.load(fh)["kernels"]:
-                        if row["kernel"].startswith(screen_name.split(" ")[0].split("<")[0] + "<"):
+                        if "::" + screen_name.split(" ")[0].split("<")[0] + "<" in row["kernel"] or row["kernel"].startswith(screen_name.split("<")[0] + "<"):
                             traffic = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
-                        if row["kernel"].startswith("instance_graph_kernel<true>") or row["kernel"].startswith("instance_graph_kernel<1>"):
+                        if "instance_graph_kernel<true>" in row["kernel"] or "instance_graph_kernel<1>" in row["kernel"]:
                             traffic_s3 = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
                 if traffic is not None:
                     traffic_src = f"profiles/{name} (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
