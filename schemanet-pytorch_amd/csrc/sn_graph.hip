@@ -99,6 +99,34 @@ __device__ __forceinline__ void load_row4(const float *row, int L, int lane, flo
 template <bool kVec>
 __device__ __forceinline__ int col_of(int lane, int k) { return kVec ? lane * 4 + k : lane + SN_WAVE * k; }
 
+// 64-lane reductions for the prediction path: DPP-fused max / add (one instruction per step; hipcc emits a v_mov_dpp, a
+// canonicalising max and the operation for each step of sn_wave_max), four steps inside the 16-lane rows, row_bcast:15 /
+// row_bcast:31 across them, the total read from lane 63.  (s_nop 1: a DPP operand written by the previous VALU instruction
+// needs two wait states.)  The sum's tree order differs from sn_wave_sum's: fp32 rounding, prediction path only.
+__device__ __forceinline__ float wave_max_fast(float v)
+{
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return SN_READLANE_F32(v, 63);
+}
+
+__device__ __forceinline__ float wave_sum_fast(float v)
+{
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return SN_READLANE_F32(v, 63);
+}
+
 // kFast (prediction path only): v_exp_f32 on (x - m) * log2(e) and one reciprocal per row instead of
 // libm-grade expf and a correctly rounded division per element: ~1e-6 relative on the probabilities,
 // inside the 1e-5 budget of the instance graph; the init statistics (bit-exact against the reference)
@@ -113,7 +141,7 @@ __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool u
         x[k] = (ok && use_clamp && x[k] < clamp) ? -INFINITY : x[k];
         m = ok ? fmaxf(m, x[k]) : m;
     }
-    m = sn_wave_max(m);
+    m = kFast ? wave_max_fast(m) : sn_wave_max(m);
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -121,9 +149,9 @@ __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool u
         x[k] = ok ? (kFast ? __builtin_amdgcn_exp2f((x[k] - m) * 1.44269504088896340736f) : expf(x[k] - m)) : 0.0f;
         s += x[k];
     }
-    s = sn_wave_sum(s);
+    s = kFast ? wave_sum_fast(s) : sn_wave_sum(s);
     if (kFast) {
-        const float r = 1.0f / s;                    // all-clamped row: m = -inf -> x = NaN, s = NaN, like torch
+        const float r = __builtin_amdgcn_rcpf(s);    // (1 ulp; a correctly rounded 1 / s is ten instructions)  all-clamped row: m = -inf -> x = NaN, s = NaN, like torch
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[k] = x[k] * r;
     } else {
@@ -181,8 +209,9 @@ __device__ inline void attn_rows_to_lds(float *A, const float *src, int64_t stri
                                         int64_t stride_h, int L, bool is_logits, bool use_clamp,
                                         float clamp, int wid, int nw, int lane)
 {
-    const bool vec = (L % 4 == 0) && (stride_r % 4 == 0) && (stride_h % 4 == 0) &&
-                     ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    // (rows need not be 16-byte aligned in global memory: gfx950 serves a dword-aligned global_load_dwordx4 correctly,
+    // tools/unaligned_probe.hip; the slices of the backbone's [.., 197, 197] tap never are.  The LDS rows are: L % 4 == 0.)
+    const bool vec = (L % 4 == 0) && (kFast || ((stride_r % 4 == 0) && (stride_h % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)));
     if (vec) attn_rows_to_lds_impl<true, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
     else attn_rows_to_lds_impl<false, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
 }
@@ -946,7 +975,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 c1[k] = has ? sa[k] : 0.0f;
             }
             if (a.mean) {                                    // wave-uniform; 1 / (rows x columns) as two reciprocals (2 ulp)
-                const float rr = 1.0f / (float)(ib - ia);
+                const float rr = __builtin_amdgcn_rcpf((float)(ib - ia));
 #pragma unroll
                 for (int k = 0; k < kCellsPerLane; ++k) {
                     const float inv = rr * rcnt[k];
@@ -965,9 +994,9 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
         }
 #pragma unroll
         for (int k = 0; k < kCellsPerLane; ++k) { t0 += c0[k]; t1 += c1[k]; }
-        t0 = sn_wave_sum(t0);     // instance_edges.sum(1, keepdim)  :135
-        t1 = sn_wave_sum(t1);
-        const float i0 = 1.0f / t0, i1 = 1.0f / t1;          // one reciprocal per row (x * (1/t) vs x / t: 1 ulp)
+        t0 = wave_sum_fast(t0);   // instance_edges.sum(1, keepdim)  :135
+        t1 = wave_sum_fast(t1);
+        const float i0 = __builtin_amdgcn_rcpf(t0), i1 = __builtin_amdgcn_rcpf(t1);     // one v_rcp_f32 per row (x * rcp(t) vs x / t: 2 ulp; a correctly rounded 1 / t is ten instructions)
         // nan_to_num only matters when a row sum is 0 / inf / NaN (then some quotient is not finite)
         const bool plain = t0 > 0.0f && t0 < INFINITY && t1 > 0.0f && t1 < INFINITY;      // wave-uniform
         const int64_t rowbase = ((int64_t)b * a.n_pad + r) * a.n_pad;
