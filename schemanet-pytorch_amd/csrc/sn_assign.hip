@@ -1393,7 +1393,8 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 // mode 0, pass 1, K-outer form (opt-in, sn_assign_set_variant(3); codebooks of 8 or 16 tiles of 32 words: 192 < M <= 256,
 // 448 < M <= 512): the token stream and the matrix pipe overlap by construction.
 //
-// A workgroup = 16 waves = 4 token sets x 4 word quarters, one workgroup per CU, persistent over rounds.  Wave
+// A workgroup = 16 waves = 4 token sets x 4 word quarters, one workgroup per CU, persistent over rounds (sets dealt
+// round-robin over the workgroups, so a last, partial round is spread over all CUs).  Wave
 // (set ps, quarter q) keeps the accumulators of its set (<= 32 tokens) against its quarter of the codebook - NTW
 // tiles of 32 words, 16 registers each - for a whole round, and K is the OUTER loop: a 32-float chunk of every
 // token row arrives from HBM by LDS-DMA (whole 128-byte lines, piece-swizzled: the token staging of
@@ -1414,172 +1415,199 @@ __global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs
 // chunk u - is followed by the copies A(u+2) (two pieces) and tok(u+3) (one piece), and publishes A(u+1) and
 // tok(u+1): the only younger operation that may stay in flight across it is tok(u+2).
 //
-// Measured (MI355X, 50 176 tokens): 45.8 us against 35.6 us for the token-stationary form - the stream is
-// bound by the INSTRUCTIONS the CU can issue, not by HBM, LDS or the matrix pipe: with the token copies, the codebook
-// copies, the barriers, the MFMAs and the fragment reads all compiled out the loop still takes 85 % of its time
-// (170 instructions per wave and chunk, sixteen waves, one scalar unit).  Kept as the form to build on: it is the
-// one whose floor is the HBM stream.
+// Measured (MI355X, 50 176 tokens): 34.8 us against 36.2 us for the token-stationary form in isolation, but
+// 5 % fewer images/s in the replayed bench (it holds every CU's whole LDS and sixteen waves for the length of the launch):
+// opt-in.  History: with a rolled chunk loop (ring positions, wait counts and conditions computed at run time: 170
+// instructions per wave and chunk) the stream was bound by the INSTRUCTIONS the CU can issue - 45.8 us, and with the token
+// copies, the codebook copies, the barriers, the MFMAs and the fragment reads all compiled out the loop still took 85 % of
+// its time.  Fully unrolled (this version: ~70 instructions per wave and chunk, every ring position an immediate) the
+// loop is 15.9 k cycles per round against 12.3 k of matrix pipe; what bounds it now is the codebook stream (393 KB per CU
+// and round out of L2, ~27 B per cycle and CU), which a round with half of its sets missing does not shorten.
 // ------------------------------------------------------------------------------------------
 constexpr int kS3RingA = 3, kS3RingT = 3, kS3Sets = 4, kS3Quarters = 4;      // ring slots: codebook chunks (2 k-steps), token chunks
 
-template <int NTW>
+// LDS-DMA pieces of assign_screen3_kernel with every ring position an immediate: the LDS address is M0 + instruction
+// offset + 16 x lane, the global address SGPR base + 32-bit lane offset + the same instruction offset (so M0 carries
+// the slot minus that offset).
+template <int LDS_OFF, int GOFF>
+__device__ __forceinline__ void s3_dma1(unsigned voff, const void *sbase, unsigned lds_dst)
+{
+    static_assert(GOFF >= 0 && GOFF < 4096, "instruction offset");
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4"
+                 :: "v"(voff), "s"(sbase), "s"(lds_dst), "n"(LDS_OFF - GOFF), "n"(GOFF) : "memory", "scc");
+}
+template <int LDS_OFF>
+__device__ __forceinline__ void s3_dma2(unsigned voff, const void *sbase, unsigned lds_dst)     // two consecutive KiB
+{
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                 :: "v"(voff), "s"(sbase), "s"(lds_dst), "n"(LDS_OFF) : "memory", "scc");
+}
+
+template <int NTW, int NCH>
 __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArgs p)
 {
     constexpr int NT = kS3Quarters * NTW;                       // tiles of the (padded) codebook: 8 or 16
     constexpr int RG = 2;                                       // A fragments read ahead (registers)
     constexpr int kSlotA = NT * 2048;                           // one chunk = two k-steps of every tile: [tile][k-step][1 KiB]
+    constexpr int kOffT = kS3RingA * kSlotA;                    // token rings  [4 sets][3][4 KiB]
+    constexpr int kOffHc = kOffT + kS3Sets * kS3RingT * 4096;   // |c|^2/2 of every word, accumulator-row order [NT][32]
+    constexpr int kOffBest = kOffHc + NT * 128;                 // [4][32] best key of a token
+    constexpr int kOffMask = kOffBest + kS3Sets * 32 * 4;       // [4][32] candidate mask being assembled
     static_assert(NTW == 2 || NTW == 4, "tiles per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *ringA = smem;                                                    // [3][NT][2][1 KiB]
-    unsigned char *ringT = smem + kS3RingA * kSlotA;                                // [4 sets][3][4 KiB]
-    float *tbest = reinterpret_cast<float *>(ringT + kS3Sets * kS3RingT * 4096);    // [4][32] best key of a token
-    unsigned *tmask = reinterpret_cast<unsigned *>(tbest + kS3Sets * 32);           // [4][32] candidate mask being assembled
+    float *hcs = reinterpret_cast<float *>(smem + kOffHc);
+    float *tbest = reinterpret_cast<float *>(smem + kOffBest);
+    unsigned *tmask = reinterpret_cast<unsigned *>(smem + kOffMask);
 
     const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int ps = wid >> 2, q = wid & 3;
     const PackLayout lay = pack_layout(p.M, p.D);
     const unsigned char *tiles = p.packed + lay.tiles_off;
-    const int n_steps = lay.n_steps, n_chunks = n_steps >> 1;   // (D % 32 == 0)
     const int wave_id = blockIdx.x * 16 + wid;
     stamp(p, 0, (int)threadIdx.x & 63, wave_id);
 
     if (threadIdx.x < kS3Sets * 32) { tbest[threadIdx.x] = kBigKey; tmask[threadIdx.x] = 0u; }
+    if (threadIdx.x < NT * 32) {                                // (padding words: +inf in the image, kept finite here so that keys never become NaNs)
+        const int t = threadIdx.x >> 5, i = threadIdx.x & 31;
+        hcs[threadIdx.x] = fminf(reinterpret_cast<const float *>(tiles + (size_t)t * lay.tile_bytes + (size_t)lay.n_steps * 1024)[i], kPadHalfNorm);
+    }
 
-    // ---- LDS-DMA (inline asm + hand-counted vmcnt: see assign_screen_kernel)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (wid % NT) * 2048);
-    const unsigned t_dst = __builtin_amdgcn_readfirstlane(lds_base + kS3RingA * kSlotA + ps * (kS3RingT * 4096) + q * 1024);
-    const unsigned char *a_src = nullptr;                       // next k-step to copy (advanced by issue_a)
-    const unsigned char *t_src = nullptr;                       // next chunk to copy (advanced by issue_tok)
+    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (wid % NT) * 2048);            // + slot
+    const unsigned t_dst = __builtin_amdgcn_readfirstlane(lds_base + kOffT + ps * (kS3RingT * 4096) + q * 1024);    // + buffer
     unsigned keep_m0;
     asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
-    unsigned a_slot = 0, t_slot = 0;                            // ring positions of the next copies (wave-uniform)
-    auto issue_a = [&]() {                                      // the two k-steps of the chunk are contiguous in the image and in the slot
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
-                     :: "v"(a_src), "s"(a_dst + a_slot) : "memory");
-        a_src += 2048;
-        a_slot = a_slot == (kS3RingA - 1) * kSlotA ? 0u : a_slot + kSlotA;
-    };
-    auto issue_tok = [&]() {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(t_src), "s"(t_dst + t_slot) : "memory");
-        t_src += 128;
-        t_slot = t_slot == (kS3RingT - 1) * 4096 ? 0u : t_slot + 4096;
-    };
-    // the rows this wave copies for set group `grp`: rows 8 q + lane / 8 of its set (a row past the set: the set's first)
-    auto begin_round = [&](int64_t grp, int lane) -> bool {
-        const int64_t tok0 = (grp * kS3Sets + ps) * p.tps;
-        const bool active = tok0 < p.n_tokens;
-        const int rq = 8 * q + (lane >> 3);
-        const int64_t nq = tok0 + rq;
-        const bool ok = rq < p.tps && nq < p.n_tokens;
-        t_src = reinterpret_cast<const unsigned char *>(token_row(p, ok ? nq : (active ? tok0 : 0))) + 16 * ((lane & 7) ^ ((rq >> 1) & 7));
-        a_src = tiles + (size_t)(wid % NT) * lay.tile_bytes + lane * 16;      // (NT == 8: waves w and w + 8 copy the same piece)
-        a_slot = 0; t_slot = 0;
-        if (active)
-            for (int u = 0; u < kS3RingT && u < n_chunks; ++u) issue_tok();
-        for (int u = 0; u < kS3RingA - 1 && u < n_chunks; ++u) issue_a();
-        return active;
-    };
+    // Sets are dealt round-robin: in round `rnd` workgroup b's slot ps holds set (4 rnd + ps) G + b (G = workgroups), so the
+    // last round's sets spread over ALL workgroups (50 176 tokens = 1 568 sets on 256 CUs: round 1 has four sets everywhere,
+    // round 2 two or three): a slot without a set only serves the codebook ring and the barriers, and a SIMD that hosts
+    // fewer computing waves finishes its chunk sooner (the loop is bound by the matrix pipe).
+    const int64_t G = gridDim.x;
+    const int64_t n_rounds = (p.n_sets3 + kS3Sets * G - 1) / (kS3Sets * G);
 
-    const int64_t n_groups = (p.n_sets3 + kS3Sets - 1) / kS3Sets;
-    bool set_active = false;                                    // wave-uniform
-    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    for (int64_t rnd = 0; rnd < n_rounds; ++rnd) {
         // (everything that depends on the lane is formed again in every round, behind an opaque copy of the thread id:
-        // hoisted out of the round loop these values - a dozen addresses and masks - do not fit beside the accumulators
-        // and are spilled, and a spill reload waits for vmcnt(0), i.e. for the token chunks in flight)
+        // hoisted out of the round loop these values do not fit beside the accumulators and are spilled, and a spill reload
+        // waits for vmcnt(0), i.e. for the token chunks in flight)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, r = lane & 31, h = lane >> 5;
-        if (grp == blockIdx.x) set_active = begin_round(grp, lane);
-        const unsigned char *t_frag = ringT + ps * (kS3RingT * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
-        const int sw = (r >> 1) & 7;
-        const int o0 = ((4 * h + 0) ^ sw) * 16, o1 = ((4 * h + 1) ^ sw) * 16, o2 = ((4 * h + 2) ^ sw) * 16, o3 = ((4 * h + 3) ^ sw) * 16;
-        const unsigned char *a_frag = ringA + (q * NTW) * 2048 + lane * 16;
-        // ---- accumulators start at |c|^2/2 (padding words: +inf in the image, kept finite here so that keys never become NaNs)
+        // copies: codebook piece = tile (wid % NT), lane offset inside the image; token piece = rows 8 q + lane / 8 of the set
+        // (a row past the set or past the last token: the set's first row, or token 0: no wave skips a copy)
+        const unsigned a_voff = (unsigned)((wid % NT) * lay.tile_bytes + lane * 16);
+        auto set_of = [&](int64_t rd) -> int64_t { return (kS3Sets * rd + ps) * G + blockIdx.x; };
+        auto tok_voff = [&](int64_t rd) -> unsigned {
+            const int64_t tok0 = set_of(rd) * p.tps;
+            const int rq = 8 * q + (lane >> 3);
+            const int64_t nq = tok0 + rq;
+            const bool ok = rq < p.tps && nq < p.n_tokens;
+            const int64_t nn = ok ? nq : (tok0 < p.n_tokens ? tok0 : 0);
+            const unsigned ni = (unsigned)p.n_inner, o = (unsigned)nn / ni, i = (unsigned)nn - o * ni;
+            return (unsigned)(((int64_t)o * p.xso + (int64_t)i * p.xsi) * 4 + 16 * ((lane & 7) ^ ((rq >> 1) & 7)));
+        };
+        // issue order of a round's first copies: T0, A0, T1, A1, T2 (one barrier later: A2, T3, ...)
+        auto begin_round = [&](unsigned tv, bool act) {
+            if (act) s3_dma1<0 * 4096, 0>(tv, p.x, t_dst);
+            s3_dma2<0 * kSlotA>(a_voff, tiles, a_dst);
+            if (NCH > 1) { if (act) s3_dma1<1 * 4096, 128>(tv, p.x, t_dst); s3_dma2<1 * kSlotA>(a_voff, tiles + 2048, a_dst); }
+            if (NCH > 2 && act) s3_dma1<2 * 4096, 256>(tv, p.x, t_dst);
+        };
+        const bool active = set_of(rnd) < p.n_sets3;            // wave-uniform
+        unsigned t_voff = tok_voff(rnd);
+        if (rnd == 0) begin_round(t_voff, active);
+
+        // ---- accumulators start at |c|^2/2
         f32x16 acc[NTW];
-        const unsigned char *hcp = tiles + (size_t)(q * NTW) * lay.tile_bytes + (size_t)n_steps * 1024 + h * 16;
+        if (rnd == 0) __syncthreads();                          // (hcs written above)
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(hcp + (size_t)i * lay.tile_bytes + g * 32);
-                acc[i][4 * g + 0] = fminf(c4.x, kPadHalfNorm); acc[i][4 * g + 1] = fminf(c4.y, kPadHalfNorm);
-                acc[i][4 * g + 2] = fminf(c4.z, kPadHalfNorm); acc[i][4 * g + 3] = fminf(c4.w, kPadHalfNorm);
+                const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (q * NTW + i) * 32 + (g * 2 + h) * 4);
+                acc[i][4 * g + 0] = c4.x; acc[i][4 * g + 1] = c4.y; acc[i][4 * g + 2] = c4.z; acc[i][4 * g + 3] = c4.w;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the first three token chunks and two codebook chunks of this round are in
+        if (active) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH > 2 ? 4 : (NCH > 1 ? 3 : 0)) : "memory");     // T0 and A0 are in (younger: T1, A1 x 2, T2)
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH > 1 ? 2 : 0) : "memory");                           // A0 is in (younger: A1 x 2)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
         // token chunk of this wave's set -> the lane's 16 floats (row r, k = 32 u + 16 h + 0..15)
+        const unsigned char *t_frag = smem + kOffT + ps * (kS3RingT * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
+        const int sw = (r >> 1) & 7;
+        const unsigned char *tq0 = t_frag + ((4 * h + 0) ^ sw) * 16, *tq1 = t_frag + ((4 * h + 1) ^ sw) * 16;
+        const unsigned char *tq2 = t_frag + ((4 * h + 2) ^ sw) * 16, *tq3 = t_frag + ((4 * h + 3) ^ sw) * 16;
+        const unsigned char *a_frag = smem + (q * NTW) * 2048 + lane * 16;
         f32x4 raw[4];
-        unsigned rd_slot = 0;                                   // ring position of the next chunk to read
-        auto read_raw = [&]() {
-            const unsigned char *b = t_frag + rd_slot;
-            raw[0] = *reinterpret_cast<const f32x4 *>(b + o0); raw[1] = *reinterpret_cast<const f32x4 *>(b + o1);
-            raw[2] = *reinterpret_cast<const f32x4 *>(b + o2); raw[3] = *reinterpret_cast<const f32x4 *>(b + o3);
-            rd_slot = rd_slot == (kS3RingT - 1) * 4096 ? 0u : rd_slot + 4096;
-        };
         float sumsq = 0.0f;
         auto convert = [&](half8 &b, const f32x4 &lo, const f32x4 &hi) {
             sumsq = fmaf(lo.x, lo.x, sumsq); sumsq = fmaf(lo.y, lo.y, sumsq); sumsq = fmaf(lo.z, lo.z, sumsq); sumsq = fmaf(lo.w, lo.w, sumsq);
             sumsq = fmaf(hi.x, hi.x, sumsq); sumsq = fmaf(hi.y, hi.y, sumsq); sumsq = fmaf(hi.z, hi.z, sumsq); sumsq = fmaf(hi.w, hi.w, sumsq);
             b[0] = (_Float16)lo.x; b[1] = (_Float16)lo.y; b[2] = (_Float16)lo.z; b[3] = (_Float16)lo.w;
             b[4] = (_Float16)hi.x; b[5] = (_Float16)hi.y; b[6] = (_Float16)hi.z; b[7] = (_Float16)hi.w;
+            asm volatile("" : "+v"(sumsq));                     // (otherwise the whole chain of squares sinks to the epilogue and every chunk's floats are spilled until then)
         };
         half8 bc0, bc1;
-        if (set_active) read_raw();
-        else {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) raw[v] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (active) {
+            raw[0] = *reinterpret_cast<const f32x4 *>(tq0); raw[1] = *reinterpret_cast<const f32x4 *>(tq1);
+            raw[2] = *reinterpret_cast<const f32x4 *>(tq2); raw[3] = *reinterpret_cast<const f32x4 *>(tq3);
+            convert(bc0, raw[0], raw[1]);
+            convert(bc1, raw[2], raw[3]);
         }
-        convert(bc0, raw[0], raw[1]);
-        convert(bc1, raw[2], raw[3]);
         stamp(p, 1, lane, wave_id);
 
-        // ---- main loop: one barrier per chunk, between its two k-steps
-        unsigned ra = 0;                                        // ring position of the chunk being multiplied
+        // ---- main loop, fully unrolled (NCH chunks): one barrier per chunk, between its two k-steps; every ring position,
+        // wait count and condition is a constant.  Fragment c = e NTW + i of a chunk sits at (2 i + e) KiB of this wave's
+        // part of the slot; the register ring runs RG fragments ahead (the last RG of a chunk fetch the next chunk's first).
+        if (active) {
         half8 ar[RG];
 #pragma unroll
         for (int c = 0; c < RG; ++c) ar[c] = *reinterpret_cast<const half8 *>(a_frag + ((c % NTW) * 2 + c / NTW) * 1024);
-        // MFMAs of k-step e of the current chunk; fragment c = e NTW + i of the chunk sits at (2 i + e) KiB of this wave's part
-        // of the slot; the register ring runs RG fragments ahead (the last RG of a chunk fetch the next chunk's first)
-        auto k_step = [&](const half8 &b, int e) {
-            const unsigned nx = ra == (kS3RingA - 1) * kSlotA ? 0u : ra + kSlotA;
+        static_for<NCH>([&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            constexpr int slot = (u % kS3RingA) * kSlotA, nslot = ((u + 1) % kS3RingA) * kSlotA;
+            auto k_step = [&](const half8 &b, auto e_c) {
+                constexpr int e = decltype(e_c)::value;
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                const int c = e * NTW + i;
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[c % RG], b, acc[i], 0, 0, 0);
-                const int cn = c + RG;
-                ar[c % RG] = cn < 2 * NTW ? *reinterpret_cast<const half8 *>(a_frag + ra + ((cn % NTW) * 2 + cn / NTW) * 1024)
-                                          : *reinterpret_cast<const half8 *>(a_frag + nx + (((cn - 2 * NTW) % NTW) * 2 + (cn - 2 * NTW) / NTW) * 1024);   // (past the last chunk: a stale slot, never used)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (e == 1) ra = nx;
-        };
-        for (int u = 0; u < n_chunks; ++u) {
-            const bool steady = set_active && (u + 2 < n_chunks);   // the operation the counted wait assumes (tok(u+2)) has been issued
-            const bool more = u + 1 < n_chunks;
-            k_step(bc0, 0);
-            if (steady) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                for (int i = 0; i < NTW; ++i) {
+                    const int c = e * NTW + i, cn = c + RG;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[c % RG], b, acc[i], 0, 0, 0);
+                    if (cn < 2 * NTW) ar[c % RG] = *reinterpret_cast<const half8 *>(a_frag + slot + ((cn % NTW) * 2 + cn / NTW) * 1024);
+                    else if (u + 1 < NCH) ar[c % RG] = *reinterpret_cast<const half8 *>(a_frag + nslot + (((cn - 2 * NTW) % NTW) * 2 + (cn - 2 * NTW) / NTW) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            k_step(bc0, std::integral_constant<int, 0>{});
+            if constexpr (u + 2 < NCH) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // (in flight across the barrier: T(u+2))
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // chunk u+1 (codebook and tokens) is in LDS for everybody; slot of chunk u-1 and buffer of chunk u are free
             asm volatile("" ::: "memory");
-            if (u + 2 < n_chunks) issue_a();
-            if (set_active && u + 3 < n_chunks) issue_tok();
-            if (set_active && more) read_raw();
-            if (more) convert(bc0, raw[0], raw[1]);             // (bc0 of chunk u has been issued to the matrix pipe)
-            k_step(bc1, 1);
-            if (more) convert(bc1, raw[2], raw[3]);
+            if constexpr (u + 2 < NCH) s3_dma2<((u + 2) % kS3RingA) * kSlotA>(a_voff, tiles + (size_t)(u + 2) * 2048, a_dst);
+            if constexpr (u + 3 < NCH) s3_dma1<((u + 3) % kS3RingT) * 4096, 128 * (u + 3)>(t_voff, p.x, t_dst);
+            if constexpr (u + 1 < NCH) {
+                constexpr int rb = ((u + 1) % kS3RingT) * 4096;
+                raw[0] = *reinterpret_cast<const f32x4 *>(tq0 + rb); raw[1] = *reinterpret_cast<const f32x4 *>(tq1 + rb);
+                raw[2] = *reinterpret_cast<const f32x4 *>(tq2 + rb); raw[3] = *reinterpret_cast<const f32x4 *>(tq3 + rb);
+                convert(bc0, raw[0], raw[1]);                   // (bc0 of chunk u has been issued to the matrix pipe)
+            }
+            k_step(bc1, std::integral_constant<int, 1>{});
+            if constexpr (u + 1 < NCH) convert(bc1, raw[2], raw[3]);
+        });
+        } else {                                                // a slot without a set: its share of the codebook copies, and the barriers
+            static_for<NCH>([&](auto u_c) {
+                constexpr int u = decltype(u_c)::value;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (u + 2 < NCH) s3_dma2<((u + 2) % kS3RingA) * kSlotA>(a_voff, tiles + (size_t)(u + 2) * 2048, a_dst);
+            });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // nobody reads the rings any more
         asm volatile("" ::: "memory");
         stamp(p, 2, lane, wave_id);
-        // ---- the next round's first chunks and k-steps travel while this round's keys are formed
-        const int64_t tok0 = (grp * kS3Sets + ps) * p.tps;
-        const bool was_active = set_active;
-        if (grp + gridDim.x < n_groups) set_active = begin_round(grp + gridDim.x, lane);
+        // ---- the next round's first chunks travel while this round's keys are formed
+        const int64_t tok0 = set_of(rnd) * p.tps;
+        if (rnd + 1 < n_rounds) { t_voff = tok_voff(rnd + 1); begin_round(t_voff, set_of(rnd + 1) < p.n_sets3); }
 
         // ---- keys: one sorted triple per lane; code = tile << 4 | accumulator register
         // (volatile asm, four instructions per value: left to itself hipcc forms the three chains one after the other and
@@ -1588,6 +1616,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey;
         unsigned keymask = 0xFFFFFF00u;
         asm volatile("s_nop 15\n\ts_nop 15" : "+s"(keymask));
+        if (active)
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
 #pragma unroll
@@ -1607,11 +1636,11 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         const float X2 = sqrtf(sumsq) * 1.001f + 1.0e-6f, X1 = X2 * sqrtf((float)p.D);
         const float vmax = 0.5f * CN + X2 * C2;                               // >= |any partial sum|
         const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
-                                 + (float)n_steps * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
+                                 + (float)(2 * NCH) * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
         const bool bad = !(sumsq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e28f);   // NaN-safe; |x|_2 <= 3e4 bounds every component
         const float window = 2.0f * E;
         const int64_t n = tok0 + r;
-        const bool valid = was_active && r < p.tps && n < p.n_tokens;
+        const bool valid = active && r < p.tps && n < p.n_tokens;
         const float kmin = fminf(m1, __shfl_xor(m1, 32, SN_WAVE));
         if (valid && h == 0) __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&tbest[ps * 32 + r], kmin, 0, 0, false);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1741,25 +1770,25 @@ int launch_screen2(const AssignArgs &a, hipStream_t st)
     return 0;
 }
 
-template <int NTW, int NTR>
+template <int NTW, int NCH>
 int launch_screen3(const AssignArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)kS3RingA * kS3Quarters * NTW * 2048 + (size_t)kS3Sets * kS3RingT * 4096 + 1024;
-    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen3_kernel<NTW>, lds, "sn_assign_words")) return rc;
+    constexpr int NTR = (NCH + 1) / 2;                          // fp64 re-rank: 64 k per lane-step
+    constexpr size_t lds = (size_t)kS3RingA * kS3Quarters * NTW * 2048 + (size_t)kS3Sets * kS3RingT * 4096 + (size_t)kS3Quarters * NTW * 128 + 1024;
+    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen3_kernel<NTW, NCH>, lds, "sn_assign_words")) return rc;
     AssignArgs ag = a;
-    // tokens per set: one workgroup (4 sets) per CU, persistent over rounds; the rounds are made equally long, so the last
-    // one does not leave half of the chip idle (50 176 tokens on 256 CUs: 2 rounds of 25-token sets instead of 32 + 17)
     const int64_t cus = device_cus();
-    const int64_t rounds = (a.n_tokens + cus * 128 - 1) / (cus * 128);
-    int64_t tps = (a.n_tokens + rounds * cus * kS3Sets - 1) / (rounds * cus * kS3Sets);
+    // full 32-token sets whenever there is more than one round of them (the loop is bound by the matrix pipe, which a
+    // smaller set does not relieve); a single partial round is spread over all CUs with smaller sets
+    int64_t tps = 32;
+    if (a.n_tokens < cus * kS3Sets * 32) tps = (a.n_tokens + cus * kS3Sets - 1) / (cus * kS3Sets);
     if (const char *e = getenv("SN_ASSIGN_TPS")) tps = atoi(e);
     tps = tps < 16 ? 16 : (tps > 32 ? 32 : tps);
     ag.tps = (int)tps;
     ag.n_sets3 = (a.n_tokens + tps - 1) / tps;
-    const int64_t groups = (ag.n_sets3 + kS3Sets - 1) / kS3Sets;
-    const unsigned grid = (unsigned)(groups < cus ? groups : cus);
+    const unsigned grid = (unsigned)(ag.n_sets3 < cus ? ag.n_sets3 : cus);      // one persistent workgroup per CU; sets are dealt round-robin
     sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen3_kernel<NTW>), dim3(grid), dim3(1024), lds, st, ag);
+    hipLaunchKernelGGL((assign_screen3_kernel<NTW, NCH>), dim3(grid), dim3(1024), lds, st, ag);
     sn_prof_stop(0, st);
     sn_prof_start(1, st);
     const int64_t chunks = (a.n_tokens + 31) / 32;
@@ -1893,9 +1922,11 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
         int rc = 0;
         const bool wide = screen_variant() == 1;
         const PackLayout lay = pack_layout(M, D);
-        if (screen_variant() == 3 && !x_bf16 && (lay.n_tiles == 8 || lay.n_tiles == 16)) {
-            if (lay.n_tiles == 16) rc = D == 192 ? launch_screen3<4, 3>(a, st) : (D == 384 ? launch_screen3<4, 6>(a, st) : launch_screen3<4, 12>(a, st));
-            else rc = D == 192 ? launch_screen3<2, 3>(a, st) : (D == 384 ? launch_screen3<2, 6>(a, st) : launch_screen3<2, 12>(a, st));
+        // (K-outer form: fp32 tokens whose byte offsets fit 32 bits: the copies address them as base + 32-bit lane offset)
+        if (screen_variant() == 3 && !x_bf16 && (lay.n_tiles == 8 || lay.n_tiles == 16) &&
+            ((n_outer - 1) * x_stride_outer + (n_inner - 1) * x_stride_inner + D) * 4 < (int64_t)0xFFFFF000ll && x_stride_outer >= 0 && x_stride_inner >= 0) {
+            if (lay.n_tiles == 16) rc = D == 192 ? launch_screen3<4, 6>(a, st) : (D == 384 ? launch_screen3<4, 12>(a, st) : launch_screen3<4, 24>(a, st));
+            else rc = D == 192 ? launch_screen3<2, 6>(a, st) : (D == 384 ? launch_screen3<2, 12>(a, st) : launch_screen3<2, 24>(a, st));
         } else if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 32 && !x_bf16) {
             a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + 32));
             if (lay.ks2 == 24) rc = lay.nt2 == 4 ? launch_screen2<4, 24>(a, st) : launch_screen2<2, 24>(a, st);
