@@ -591,6 +591,44 @@ class _SymAdjMatmul(torch.autograd.Function):
         return d_adj, d_x, None
 
 
+class _EdgesAdjMatmul(torch.autograd.Function):
+    """Y = ((E + E^T)/2 + I) @ X straight from the edge tensor E [G, n, n] (reference gnn.py:27-31): the adjacency only ever
+    exists as the fp16 planes `adj_planes` = gcn_adjacency_planes(E) (one pass over E; no dense adjacency, no identity
+    matrix, no transpose copy), shared by the layers of one forward pass and by their backward passes.
+        backward   dX = adj . dY,      dE = (S + S^T) / 2  with  S = dY . X^T   (the chain rule through the symmetrisation)"""
+
+    @staticmethod
+    def forward(ctx, edges, x, adj_planes):
+        G = edges.shape[0]
+        y = gcn_gemm(adj_planes, split_planes(x.detach().transpose(1, 2).contiguous()), G, want_c=True)["c"]
+        ctx.save_for_backward(x)
+        ctx.adj_planes = adj_planes
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        ap = ctx.adj_planes
+        G = x.shape[0]
+        dy = _f32c(dy)
+        scale = torch.exp2(torch.floor(torch.log2(1024.0 / dy.abs().amax().clamp_min(1.0e-30))))     # (see _SymAdjMatmul.backward)
+        dys = dy * scale
+        d_e = d_x = None
+        if ctx.needs_input_grad[1]:
+            d_x = gcn_gemm(ap, split_planes(dys.transpose(1, 2).contiguous()), G, want_c=True)["c"] / scale
+        if ctx.needs_input_grad[0]:
+            s_ = gcn_gemm(split_planes(dys), split_planes(x.detach()), G, want_c=True)["c"]
+            d_e = (s_ + s_.transpose(1, 2)) * (0.5 / scale)
+        return d_e, d_x, None
+
+
+def edges_adj_matmul(edges, x, adj_planes=None):
+    """edges [G, n, n] fp32, x [G, n, E] fp32 (CUDA, E a multiple of 16) -> ((edges + edges^T)/2 + I) @ x, differentiable in both."""
+    if adj_planes is None:
+        adj_planes = gcn_adjacency_planes(edges.detach())
+    return _EdgesAdjMatmul.apply(edges, x, adj_planes)
+
+
 def sym_adj_matmul(adj, x, adj_planes=None):
     """adj [G, n, n] symmetric fp32, x [G, n, E] fp32 (CUDA, E a multiple of 16) -> adj @ x, differentiable in both."""
     if adj_planes is None:

@@ -18,6 +18,10 @@ import torch.nn as nn
 
 from cpp_extension import ops
 
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
 _ACTIVATIONS = {
     "relu": nn.ReLU, "gelu": nn.GELU, "glu": nn.GLU, "swish": nn.SiLU, "sigmoid": nn.Sigmoid,
     "hard_sigmoid": nn.Hardsigmoid, "none": nn.Identity,
@@ -45,9 +49,11 @@ class GraphConv(nn.Module):
         return (edges + edges.transpose(1, 2)) / 2 + eye
 
     def forward(self, edges: torch.Tensor, feat: torch.Tensor, adj: torch.Tensor = None, adj_planes=None) -> torch.Tensor:
-        if adj is None:
+        if adj is None and adj_planes is None:
             adj = self.adjacency(edges)
         if adj_planes is not None:      # training on the matrix cores: adj @ feat and both of its gradients as split-fp16 MFMA GEMMs
+            if adj is None:             # ... with the adjacency built straight from the edges as fp16 planes (never dense)
+                return self.linear(ops.edges_adj_matmul(edges, feat, adj_planes))
             return self.linear(ops.sym_adj_matmul(adj, feat, adj_planes))
         return self.linear(torch.bmm(adj, feat))
 
@@ -211,7 +217,9 @@ class GNN(nn.Module):
             return run(nodes, edges, ingredients, n_valid, divisor, prepared=prepared)
         if feat_mask is None and n_valid is not None and not fused:
             feat_mask = torch.arange(nodes.shape[1], device=nodes.device)[None, :] >= n_valid[:, None]
-        adj = ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges)
+        # training on the GPU: the adjacency is only ever built as fp16 planes, one pass over the edges (ops.edges_adj_matmul)
+        train_mfma = not fused and edges.is_cuda and self.embed_dim % 16 == 0 and os.environ.get("SN_GCN_MFMA", "1") != "0"
+        adj = None if train_mfma else (ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges))
         layers = list(self.layers)
         first = layers[0] if layers else None
         if fused and first is not None and isinstance(first.g_conv.linear, nn.Linear) and (first._is_relu or first._is_none):
@@ -225,9 +233,7 @@ class GNN(nn.Module):
             layers = layers[1:]
         else:
             feat = self.embedding(ingredients)
-        adj_planes = None
-        if not fused and adj.is_cuda and self.embed_dim % 16 == 0 and os.environ.get("SN_GCN_MFMA", "1") != "0":
-            adj_planes = ops.split_planes(adj.detach())      # shared by the layers (and by their backward passes)
+        adj_planes = ops.gcn_adjacency_planes(_contig(edges.detach())) if train_mfma else None      # shared by the layers (and by their backward passes)
         for layer in layers:
             feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused, adj_planes=adj_planes)
         if fused:
