@@ -1467,10 +1467,6 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
     stamp(p, 0, (int)threadIdx.x & 63, wave_id);
 
     if (threadIdx.x < kS3Sets * 32) { tbest[threadIdx.x] = kBigKey; tmask[threadIdx.x] = 0u; }
-    if (threadIdx.x < NT * 32) {                                // (padding words: +inf in the image, kept finite here so that keys never become NaNs)
-        const int t = threadIdx.x >> 5, i = threadIdx.x & 31;
-        hcs[threadIdx.x] = fminf(reinterpret_cast<const float *>(tiles + (size_t)t * lay.tile_bytes + (size_t)lay.n_steps * 1024)[i], kPadHalfNorm);
-    }
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (wid % NT) * 2048);            // + slot
@@ -1513,11 +1509,17 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         };
         const bool active = set_of(rnd) < p.n_sets3;            // wave-uniform
         unsigned t_voff = tok_voff(rnd);
-        if (rnd == 0) begin_round(t_voff, active);
+        if (rnd == 0) {
+            begin_round(t_voff, active);
+            // |c|^2/2 of every word -> LDS, once (behind the first copies: its wait is theirs).  Padding words: +inf in the
+            // image, kept finite here so that keys never become NaNs.
+            if (tid < NT * 32)
+                hcs[tid] = fminf(reinterpret_cast<const float *>(tiles + (size_t)(tid >> 5) * lay.tile_bytes + (size_t)lay.n_steps * 1024)[tid & 31], kPadHalfNorm);
+        }
 
         // ---- accumulators start at |c|^2/2
         f32x16 acc[NTW];
-        if (rnd == 0) __syncthreads();                          // (hcs written above)
+        if (rnd == 0) { stamp(p, 6, lane, wave_id); __syncthreads(); stamp(p, 7, lane, wave_id); }                          // (hcs written above)
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
 #pragma unroll
@@ -1528,8 +1530,10 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         }
         if (active) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH > 2 ? 4 : (NCH > 1 ? 3 : 0)) : "memory");     // T0 and A0 are in (younger: T1, A1 x 2, T2)
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH > 1 ? 2 : 0) : "memory");                           // A0 is in (younger: A1 x 2)
+        if (rnd == 0) stamp(p, 8, lane, wave_id);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (rnd == 0) stamp(p, 11, lane, wave_id);
 
         // token chunk of this wave's set -> the lane's 16 floats (row r, k = 32 u + 16 h + 0..15)
         const unsigned char *t_frag = smem + kOffT + ps * (kS3RingT * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
@@ -1553,7 +1557,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
             convert(bc0, raw[0], raw[1]);
             convert(bc1, raw[2], raw[3]);
         }
-        stamp(p, 1, lane, wave_id);
+        stamp(p, rnd == 0 ? 12 : 1, lane, wave_id);
 
         // ---- main loop, fully unrolled (NCH chunks): one barrier per chunk, between its two k-steps; every ring position,
         // wait count and condition is a constant.  Fragment c = e NTW + i of a chunk sits at (2 i + e) KiB of this wave's
@@ -1604,7 +1608,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // nobody reads the rings any more
         asm volatile("" ::: "memory");
-        stamp(p, 2, lane, wave_id);
+        stamp(p, rnd == 0 ? 13 : 2, lane, wave_id);
         // ---- the next round's first chunks travel while this round's keys are formed
         const int64_t tok0 = set_of(rnd) * p.tps;
         if (rnd + 1 < n_rounds) { t_voff = tok_voff(rnd + 1); begin_round(t_voff, set_of(rnd + 1) < p.n_sets3); }
@@ -1687,7 +1691,7 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
         __builtin_amdgcn_s_barrier();                           // everybody has read the merged words: reset them for the next round
         asm volatile("" ::: "memory");
         if (q == 0 && h == 0) { tbest[ps * 32 + r] = kBigKey; tmask[ps * 32 + r] = 0u; }
-        stamp(p, 3, lane, wave_id);
+        stamp(p, rnd == 0 ? 14 : 3, lane, wave_id);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may be in flight when the LDS is released
     asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));

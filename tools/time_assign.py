@@ -89,4 +89,8 @@ if variant == 3:      # in-kernel stamps of the K-outer screen (shader clock tic
     q = lambda v: "median %.0f max %.0f" % (v.median(), v.max())
     print("stamps (s_memtime ticks): %d waves; kernel span %.0f; start: %s" % (s8.shape[0], s8[:, 3].max() - t0, q(s8[:, 0] - t0)))
     print("  prologue: " + q(s8[:, 1] - s8[:, 0]) + "   loop: " + q(s8[:, 2] - s8[:, 1]) + "   keys + records: " + q(s8[:, 3] - s8[:, 2]))
+    if s8[:, 12].max() > 0:
+        print("  round 0: start -> hcs staged %s | its barrier %s | acc init + wait first chunk %s | barrier %s | read + convert %s | loop %s | keys + records %s" % (
+            q(s8[:, 6] - s8[:, 0]), q(s8[:, 7] - s8[:, 6]), q(s8[:, 8] - s8[:, 7]), q(s8[:, 11] - s8[:, 8]), q(s8[:, 12] - s8[:, 11]), q(s8[:, 13] - s8[:, 12]), q(s8[:, 14] - s8[:, 13])))
+        print("  round 1: prologue %s" % q(s8[:, 1] - s8[:, 14]))
     print("  (stamps 1-3 are those of the LAST round of a workgroup; whole workgroup: " + q(s8[:, 3] - s8[:, 0]) + ")")
