@@ -304,6 +304,45 @@ def train_step():
     save("train_step.npz", **rec)
 
 
+# --------------------------------------------------------------------------- the predictor's dictionary with requires_graph
+def predictor_graph():
+    """SchemaNetPredictor.forward(x, requires_graph=True) of the reference (schema_inference/graph/__init__.py:37-57): `pred`,
+    the class graphs, the instance graphs as Matcher leaves them (lists padded in place to the batch maximum, match.py:52-54),
+    `ingredients` and `attn_cls` as schema_net.py:296 leaves it (clamp-masked in place)."""
+    B, L, M, K, E = 3, 196, 64, 4, 32
+    ing, attn, attn_cls = datagen.graph_case(B, L, M, seed=41)
+    sn = make_schema_net(M, K, seed=42)
+    sn.register_class_vertices(torch.arange(M).repeat(K, 1))
+    torch.manual_seed(43)
+    m = ref.graph.Matcher(similarity="inner_product", num_codes=M,
+                          gnn_cfg=dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu"))
+
+    class _Wrapper(torch.nn.Module):
+        def forward(self, x):
+            return {k: v.clone() for k, v in x.items()}
+
+    predictor = ref.graph.SchemaNetPredictor(_Wrapper(), sn, m).eval()
+    with torch.no_grad():
+        out = predictor({"ingredients": T(ing), "attn": T(attn), "attn_cls": T(attn_cls)}, requires_graph=True)
+    rec = dict(case=np.asarray([B, L, M, 41, K, E]), keys=np.asarray([len(out)]))
+    for k, v in sn.state_dict().items():
+        rec["sn:" + k] = v.numpy()
+    for k, v in m.state_dict().items():
+        rec["m:" + k] = v.numpy()
+    rec["key_order"] = np.asarray([list(out.keys()).index(k) for k in ("pred", "class_vertices", "class_edges", "class_ingredients",
+                                                                          "instance_ingredients", "instance_vertices", "instance_edges",
+                                                                          "ingredients", "attn_cls")])
+    rec["pred"] = out["pred"].numpy()
+    rec["class_vertices"] = out["class_vertices"].numpy()
+    rec["class_edges"] = out["class_edges"].numpy()
+    rec["instance_ingredients"] = torch.stack(out["instance_ingredients"]).numpy()
+    rec["instance_vertices"] = torch.stack(out["instance_vertices"]).numpy()
+    rec["instance_edges"] = torch.stack(out["instance_edges"]).numpy()
+    rec["ingredients"] = out["ingredients"].numpy()
+    rec["attn_cls"] = out["attn_cls"].numpy()
+    save("predictor_graph.npz", **rec)
+
+
 # --------------------------------------------------------------------------- config [4]: a training trajectory
 # (lr is ten times the yaml's 1e-3 and there are 30 iterations instead of 10: with the yaml's rate nothing moves in ten
 # steps and the held-out top-1 stays the all-one-class answer of the initial state - a check that cannot fail)
@@ -411,4 +450,5 @@ if __name__ == "__main__":
     matcher()
     wrapper()
     train_step()
+    predictor_graph()
     trajectory()

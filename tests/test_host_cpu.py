@@ -318,3 +318,33 @@ def test_kmeans_sharded_two_ranks_gloo(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)]) for r in range(2)]
     codes = [p.wait(timeout=300) for p in procs]
     assert codes == [0, 0], codes
+
+
+# ------------------------------------------------------------------ training helpers (host logic)
+def test_param_groups_follow_the_reference_rules():
+    """schema_inference.train.param_groups = reference utils/customs_param_group.py: re.match on sorted names, first group
+    wins, options from `cfg`; what no group took forms a last group, or is frozen with drop_remain (the reference does both)."""
+    import torch
+    from schema_inference.train import param_groups
+    named = [("matcher.gnn.fc.weight", torch.nn.Parameter(torch.zeros(2))), ("schema_net.edge_weights.tensor", torch.nn.Parameter(torch.zeros(3))),
+             ("schema_net.vertex_weights.tensor", torch.nn.Parameter(torch.zeros(4))), ("backbone.w", torch.nn.Parameter(torch.zeros(5)))]
+    groups = [dict(pattern="schema_net", cfg=dict(weight_decay=5.0e-4)), dict(pattern="matcher")]
+    out = param_groups(named, groups)
+    assert [len(g["params"]) for g in out] == [2, 1, 1] and out[0]["weight_decay"] == 5.0e-4 and "weight_decay" not in out[1]
+    assert [p.numel() for p in out[0]["params"]] == [3, 4]                     # sorted by name inside a group
+    assert all(p.requires_grad for _, p in named)
+    out = param_groups(named, groups, drop_remain=True)
+    assert [len(g["params"]) for g in out] == [2, 1] and not named[3][1].requires_grad and named[0][1].requires_grad
+    with pytest.raises(AssertionError):
+        param_groups(named, [dict(pattern="no_such_prefix")])
+
+
+def test_labelled_case_is_deterministic_and_learnable():
+    import datagen
+    a = datagen.labelled_case(6, 196, 128, 5, 500)
+    b = datagen.labelled_case(6, 196, 128, 5, 500)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    ing, _, _, label = a
+    block = 128 // 5
+    own = ((ing // block) == label[:, None]).mean()
+    assert own > 0.6 and ing.min() >= 0 and ing.max() < 128 and set(label.tolist()) <= set(range(5))
