@@ -287,6 +287,10 @@ int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream);
  * vertex count) when non-NULL, else divisor_host. */
 int sn_pool_fc(const float *pooled_parts, int G, int parts, int E, const int32_t *divisor_dev, float divisor_host,
                const float *weight, const float *bias, int E_out, float *out, void *stream);
+/* The same with the weight given transposed, weight_t[E][E_out] (a weight-only operand the caller keeps across steps):
+ * thread = output, no cross-lane reduction; E <= 2048. */
+int sn_pool_fc_t(const float *pooled_parts, int G, int parts, int E, const int32_t *divisor_dev, float divisor_host,
+                 const float *weight_t, const float *bias, int E_out, float *out, void *stream);
 
 /* ---- S4 on the matrix cores: GCN layers with split-fp16 operands ----------------------------
  * Replaces torch.bmm(adj, feat) + nn.Linear + masked_fill + LayerNorm + ReLU + pooling of the

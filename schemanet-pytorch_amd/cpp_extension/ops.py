@@ -636,26 +636,31 @@ def sym_adj_matmul(adj, x, adj_planes=None):
     return _SymAdjMatmul.apply(adj, x, adj_planes)
 
 
-def pool_fc(pooled_sum, divisor, weight, bias):
+def pool_fc(pooled_sum, divisor, weight, bias, weight_t=None):
     """fc(pooled / divisor) with pooled = pooled_sum [G, E] or the sum over dim 1 of [G, parts, E]
-    (the per-row-tile partial sums of gcn_gemm); divisor: int32 [1] device tensor or a number."""
+    (the per-row-tile partial sums of gcn_gemm); divisor: int32 [1] device tensor or a number.
+    weight_t: weight.t().contiguous() kept by the caller (a weight-only operand): the faster kernel form."""
     lib = N.require_gpu()
     dev = _check_dev(pooled_sum, weight, bias)
     p = _f32c(pooled_sum)
-    w = _f32c(weight.detach())
+    transposed = weight_t is not None and p.shape[-1] <= 2048
+    w = _f32c(weight_t.detach()) if transposed else _f32c(weight.detach())
+    E_out = weight.shape[0]
+    assert not transposed or tuple(w.shape) == (weight.shape[1], E_out)
     b = None if bias is None else _f32c(bias.detach())
     if p.dim() == 2:
         p = p[:, None, :]
     G, parts, E = p.shape
-    out = torch.empty((G, w.shape[0]), dtype=torch.float32, device=dev)
+    out = torch.empty((G, E_out), dtype=torch.float32, device=dev)
     if torch.is_tensor(divisor):
         assert divisor.dtype == torch.int32 and divisor.device == dev
         ddev, dhost = N.ptr(divisor), 0.0
     else:
         ddev, dhost = None, float(divisor)
     with torch.cuda.device(dev):
-        N.check(lib.sn_pool_fc(N.ptr(p), G, parts, E, ddev, dhost, N.ptr(w), N.ptr(b), w.shape[0], N.ptr(out), N.stream_ptr(dev)),
-                "sn_pool_fc")
+        fn = lib.sn_pool_fc_t if transposed else lib.sn_pool_fc
+        N.check(fn(N.ptr(p), G, parts, E, ddev, dhost, N.ptr(w), N.ptr(b), E_out, N.ptr(out), N.stream_ptr(dev)),
+                "sn_pool_fc_t" if transposed else "sn_pool_fc")
     return out
 
 

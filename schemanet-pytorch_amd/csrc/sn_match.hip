@@ -170,6 +170,87 @@ __global__ __launch_bounds__(256) void pool_fc_kernel(const float *pooled, int p
     }
 }
 
+// The same with the weight given TRANSPOSED (Wt[e][o], a weight-only operand the caller keeps): thread = output, so a wave
+// reads whole 256-byte lines of Wt and needs no cross-lane reduction; a workgroup takes kFcGraphs graphs x 64 outputs, its four
+// waves a quarter of E each (partials added in wave order: bit-reproducible).  pool_fc_kernel above reads W rows per
+// wave and reduces every output over the lanes: 4 096 workgroups and 15 us at G = 256, E = 256, against ~3 us here.
+constexpr int kFcGraphs = 4, kFcMaxE = 2048;
+__global__ __launch_bounds__(256) void pool_fc_t_kernel(const float *pooled, int parts, int G, const int32_t *div_dev, float div_host,
+                                                        const float *Wt, const float *bias, int E, int E_out, float *out)
+{
+    __shared__ __attribute__((aligned(16))) float xs[kFcGraphs][kFcMaxE + 16];
+    __shared__ float part[4][kFcGraphs][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g0 = blockIdx.x * kFcGraphs, o = blockIdx.y * 64 + lane;
+    const int chunk = (((E + 3) / 4) + 3) & ~3;                  // a wave's share of E (multiple of 4: float4 reads of xs)
+    const int e0 = wid * chunk, e1 = min(E, e0 + chunk);
+    const float *w = Wt + (o < E_out ? o : E_out - 1);
+    // the kernel lives on memory latency: the first kFcAhead weights of the wave's share are requested before anything
+    // else (at E = 256 that is all of them: one round trip, overlapped with the staging of x)
+    constexpr int kFcAhead = 64;
+    float wreg[kFcAhead];
+#pragma unroll
+    for (int q = 0; q < kFcAhead; ++q) {                         // (clamped index + select: no branch between the loads)
+        const float v = w[(int64_t)min(e0 + q, E - 1) * E_out];
+        wreg[q] = e0 + q < e1 ? v : 0.0f;
+    }
+    const float rdiv = 1.0f / (div_dev ? (float)div_dev[0] : div_host);
+    const int Ep = 4 * chunk;                                    // <= E + 15: the tail is zero
+    for (int idx = tid; idx < kFcGraphs * Ep; idx += 256) {
+        const int gg = idx / Ep, c = idx - gg * Ep, g = g0 + gg;
+        float ps = 0.0f;
+        if (g < G && c < E) {
+            ps = pooled[((int64_t)g * parts) * E + c];
+            for (int t = 1; t < parts; ++t) ps += pooled[((int64_t)g * parts + t) * E + c];     // fixed order
+        }
+        xs[gg][c] = ps * rdiv;
+    }
+    __syncthreads();
+    float acc[kFcGraphs];
+#pragma unroll
+    for (int gg = 0; gg < kFcGraphs; ++gg) acc[gg] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kFcAhead; q += 4) {
+        if (q < chunk)                                           // (wave-uniform)
+#pragma unroll
+        for (int gg = 0; gg < kFcGraphs; ++gg) {
+            const float4 x = *reinterpret_cast<const float4 *>(&xs[gg][e0 + q]);     // same address for every lane: broadcast
+            acc[gg] = fmaf(x.x, wreg[q], acc[gg]);
+            acc[gg] = fmaf(x.y, wreg[q + 1], acc[gg]);
+            acc[gg] = fmaf(x.z, wreg[q + 2], acc[gg]);
+            acc[gg] = fmaf(x.w, wreg[q + 3], acc[gg]);
+        }
+    }
+    for (int e = e0 + kFcAhead; e < e0 + chunk; e += 16) {       // wider layers: 16 weights in flight per pass
+        float wv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float v = w[(int64_t)min(e + q, E - 1) * E_out];
+            wv[q] = e + q < e1 ? v : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            if (e + q < e0 + chunk)
+#pragma unroll
+            for (int gg = 0; gg < kFcGraphs; ++gg) {
+                const float4 x = *reinterpret_cast<const float4 *>(&xs[gg][e + q]);
+                acc[gg] = fmaf(x.x, wv[q], acc[gg]);
+                acc[gg] = fmaf(x.y, wv[q + 1], acc[gg]);
+                acc[gg] = fmaf(x.z, wv[q + 2], acc[gg]);
+                acc[gg] = fmaf(x.w, wv[q + 3], acc[gg]);
+            }
+        }
+    }
+#pragma unroll
+    for (int gg = 0; gg < kFcGraphs; ++gg) part[wid][gg][lane] = acc[gg];
+    __syncthreads();
+    {
+        const int gg = wid, g = g0 + gg;                                              // wave gg finishes graph gg
+        if (g < G && o < E_out)
+            out[(int64_t)g * E_out + o] = ((part[0][gg][lane] + part[1][gg][lane]) + (part[2][gg][lane] + part[3][gg][lane])) + (bias ? bias[o] : 0.0f);
+    }
+}
+
 // ------------------------------------------------------------------ per-class votes
 // one wave per image: argmax over the K scores (first index on ties, like torch.argmax) with
 // shuffle reductions, then one atomic add into the class's counter; votes[K] counts images.
@@ -263,6 +344,22 @@ extern "C" int sn_match_scores(const float *feat_inst, const float *feat_kg, int
     hipLaunchKernelGGL(match_scores_kernel, dim3((unsigned)B, (unsigned)((K + kScoreCols - 1) / kScoreCols)), dim3(256), 0,
                        (hipStream_t)stream, feat_inst, feat_kg, K, E, similarity, pred);
     SN_CHECK_LAUNCH("sn_match_scores");
+    return SN_OK;
+}
+
+extern "C" int sn_pool_fc_t(const float *pooled_sum, int G, int parts, int E, const int32_t *divisor_dev, float divisor_host,
+                            const float *weight_t, const float *bias, int E_out, float *out, void *stream)
+{
+    SN_REQUIRE(G >= 0 && parts > 0 && E > 0 && E_out > 0, SN_ERR_BAD_ARG, "sn_pool_fc_t: bad G=%d parts=%d E=%d E_out=%d", G, parts, E, E_out);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(pooled_sum && weight_t && out, SN_ERR_BAD_ARG, "sn_pool_fc_t: NULL pointer");
+    SN_REQUIRE(divisor_dev || divisor_host != 0.0f, SN_ERR_BAD_ARG, "sn_pool_fc_t: no divisor");
+    SN_REQUIRE(E <= kFcMaxE, SN_ERR_UNSUPPORTED, "sn_pool_fc_t: E=%d > %d (use sn_pool_fc)", E, kFcMaxE);
+    SN_REQUIRE((E_out + 63) / 64 <= 65535, SN_ERR_UNSUPPORTED, "sn_pool_fc_t: E_out=%d too large", E_out);
+    static_assert(kFcGraphs == 4, "one finishing wave per graph of the group");
+    hipLaunchKernelGGL(pool_fc_t_kernel, dim3((unsigned)((G + kFcGraphs - 1) / kFcGraphs), (unsigned)((E_out + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, pooled_sum, parts, G, divisor_dev, divisor_host, weight_t, bias, E, E_out, out);
+    SN_CHECK_LAUNCH("sn_pool_fc_t");
     return SN_OK;
 }
 
