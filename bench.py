@@ -15,7 +15,8 @@ The K timed steps replay captured hipGraphs of the step (schema_inference.utils.
 no host launch path in the timed region).  There are SN_BENCH_BATCHES (default 8) DIFFERENT input batches resident in
 HBM (8 x 117 MB: more than the 256 MB Infinity Cache), one capture per batch with its own buffers, visited in
 rotation; SN_BENCH_DEPTH (default 4) of them are in flight on as many streams = `value`; the same K steps replayed
-one at a time (depth 1) are reported as `value_depth1`.  A further, untimed pass of K eager steps with HIP events on
+one at a time (depth 1) are reported as `value_depth1` (that leg runs first: right after the captures, which are
+host work with an idle GPU, so the timed region of a short run does not start on idle clocks).  A further, untimed pass of K eager steps with HIP events on
 the launch stream gives the per-kernel durations of the roofline figures (`SN_BENCH_EAGER=1` times the eager loop
 instead).
 Workload = BASELINE.json configs[1]: DeiT-Small + CIFAR-100, B=256 per GPU, 512-word codebook.
@@ -287,7 +288,19 @@ def main():
             try:
                 from schema_inference.utils.graph_replay import PipelinedSteps
                 graphed = PipelinedSteps(steps_fn, depth)   # one capture per batch (outside the timed region)
-                for _ in range(max(args.warmup, n_batches)):         # W untimed steps of the timed kind (replays)
+                for _ in range(n_batches):                  # every captured graph replayed once (first replay = upload)
+                    graphed.steps[_].graph.replay()
+                # ---- the same K steps, one in flight at a time (depth 1): what a single stream of batches gets.
+                # This leg runs BEFORE the pipelined one: the captures above are host work with an idle GPU, and
+                # the timed region of a short run (the driver's --steps 20) would otherwise start on idle clocks
+                if depth > 1:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for s in range(args.steps):
+                        graphed.steps[s % n_batches].graph.replay()
+                    torch.cuda.synchronize()
+                    value_depth1 = B * args.steps / (time.perf_counter() - t1)
+                for _ in range(args.warmup):                # W untimed steps of the timed kind (pipelined replays)
                     graphed.submit()
                 graphed.join()
                 launch = f"hipgraph, {n_batches} batches in rotation, {depth} steps in flight" if depth > 1 else f"hipgraph, {n_batches} batches in rotation"
@@ -309,15 +322,6 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         n_voted = int(votes[K].item())
-
-        # ---- the same K steps, one in flight at a time (depth 1): what a single stream of batches gets
-        if graphed is not None and depth > 1:
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for s in range(args.steps):
-                graphed.steps[s % n_batches].graph.replay()
-            torch.cuda.synchronize()
-            value_depth1 = B * args.steps / (time.perf_counter() - t1)
 
         # ---- untimed instrumented pass: the same K steps launched eagerly, HIP events around the
         # kernels (inside the library, on the launch stream) and around the stages
