@@ -227,6 +227,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # SN_BENCH_REHEARSAL=1: every rank on device 0 over gloo - the N > 1 code path of this file (barriers, vote merge,
+    # init_atlas merges, max over ranks) on a one-GPU box, where RCCL cannot form a group; its numbers mean nothing
+    rehearsal = os.environ.get("SN_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ      # launched by torch.distributed.run
@@ -237,7 +242,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=device)           # "nccl" is RCCL on ROCm
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=device)       # "nccl" is RCCL on ROCm
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -390,7 +398,7 @@ def main():
         out = {
             "metric": "images/sec schema-inference (discretize+graph) DeiT-S CIFAR-100",
             "value": B * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "launch": launch,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "launch": launch + (" [REHEARSAL: all ranks on one GPU over gloo - not a measurement]" if rehearsal else ""),
             "value_depth1": value_depth1,
             "value_note": f"value: {depth} steps in flight on {depth} streams over {n_batches} distinct resident batches ({n_batches} x 117 MB of inputs per GPU); "
                           "value_depth1: the same captures replayed one at a time on one stream (rank 0 only, untimed by the driver)",
