@@ -15,7 +15,9 @@ The K timed steps replay captured hipGraphs of the step (schema_inference.utils.
 no host launch path in the timed region).  There are SN_BENCH_BATCHES (default 8) DIFFERENT input batches resident in
 HBM (8 x 117 MB: more than the 256 MB Infinity Cache), one capture per batch with its own buffers, visited in
 rotation; SN_BENCH_DEPTH (default 4) of them are in flight on as many streams = `value`; the same K steps replayed
-one at a time (depth 1) are reported as `value_depth1` (that leg runs first: right after the captures, which are
+one at a time (depth 1) are reported as `value_depth1` (captured with the class branch forked onto a second stream, which
+is what fills the chip when ONE step runs at a time; the pipelined captures run every step in line on its own stream, the
+better choice with several in flight - see Matcher.atlas_features_async; that leg runs first: right after the captures, which are
 host work with an idle GPU, so the timed region of a short run does not start on idle clocks).  A further, untimed pass of K eager steps with HIP events on
 the launch stream gives the per-kernel durations of the roofline figures (`SN_BENCH_EAGER=1` times the eager loop
 instead).
@@ -85,16 +87,17 @@ def FUSED_ATLAS(sn):
     return lambda: sn.get_atlas(fused_adjacency=os.environ.get("SN_FUSED_ATLAS", "1") != "0")
 
 
-def step(disc, sn, m, tokens, attn, class_branch_first=True):
+def step(disc, sn, m, tokens, attn, class_branch_first=True, side_stream=None):
     """class_branch_first: the class branch (parameters only) is forked before S1, so the replayed
     graph can fill S1's tail and the gaps of the instance chain with it (483 vs 509 us per step);
-    the instrumented pass forks it behind S1 so that the S1 kernels are timed alone on the GPU."""
+    the instrumented pass forks it behind S1 so that the S1 kernels are timed alone on the GPU.
+    side_stream: see Matcher.atlas_features_async (False = the class branch in line on the step's own stream)."""
     if class_branch_first and os.environ.get("SN_CLASS_BRANCH_FIRST", "1") != "0":
-        atlas = m.atlas_features_async(FUSED_ATLAS(sn))                          # side stream: atlas normalise + class-graph GNN
+        atlas = m.atlas_features_async(FUSED_ATLAS(sn), side_stream=side_stream)  # atlas normalise + class-graph GNN
         ing = disc.assign(tokens[:, 1:, :])                                      # S1
     else:
         ing = disc.assign(tokens[:, 1:, :])
-        atlas = m.atlas_features_async(FUSED_ATLAS(sn))
+        atlas = m.atlas_features_async(FUSED_ATLAS(sn), side_stream=side_stream)
     g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False,
                                  zero_padding=os.environ.get("SN_ZERO_PADDING", "0") == "1")   # S2 + S3 (as SchemaNetPredictor.forward)
     return m.forward_padded(g, atlas.class_dict, feat_kg=atlas)                  # S4 (instance GNN, join, scores)
@@ -276,42 +279,58 @@ def main():
 
     votes = torch.zeros(K + 1, device=device)            # per-class prediction histogram + n_seen
 
-    def step_on(i):
+    def step_on(i, side_stream):
         tk, at = batches[i]
 
         def one_step():
-            pred = step(disc, sn, m, tk, at)
+            pred = step(disc, sn, m, tk, at, side_stream=side_stream)
             ops.class_votes_(pred, votes)                # per-class vote aggregation (HIP, no host sync)
             return pred
         return one_step
 
-    steps_fn = [step_on(i) for i in range(n_batches)]
+    # Several steps in flight: each step runs in line on its own stream (the device maps streams onto four hardware
+    # queues; four independent serial steps use them without cross-queue waits: 764 k img/s against 736 k with the class
+    # branch of every step forked onto a stream of its own).  One step at a time: the fork is what fills the chip
+    # (600 k against 524 k).  SN_BENCH_FORK=0/1 forces either for the pipelined captures.
+    fork_env = os.environ.get("SN_BENCH_FORK", "")
+    pipe_fork = (fork_env == "1") if fork_env in ("0", "1") else depth == 1
+    steps_fn = [step_on(i, pipe_fork) for i in range(n_batches)]
     launch = "eager"
-    value_depth1 = None
+    value_depth1 = value_depth1_inline = None
     with torch.no_grad():
         for w in range(args.warmup):
             steps_fn[w % n_batches]()
         graphed = None
         if os.environ.get("SN_BENCH_EAGER", "0") != "1":
             try:
-                from schema_inference.utils.graph_replay import PipelinedSteps
+                from schema_inference.utils.graph_replay import GraphedStep, PipelinedSteps
                 graphed = PipelinedSteps(steps_fn, depth)   # one capture per batch (outside the timed region)
-                for _ in range(n_batches):                  # every captured graph replayed once (first replay = upload)
-                    graphed.steps[_].graph.replay()
-                # ---- the same K steps, one in flight at a time (depth 1): what a single stream of batches gets.
-                # This leg runs BEFORE the pipelined one: the captures above are host work with an idle GPU, and
-                # the timed region of a short run (the driver's --steps 20) would otherwise start on idle clocks
-                if depth > 1:
+                # captures of the same steps with the class branch forked: what ONE stream of batches should run
+                forked = graphed.steps if pipe_fork else [GraphedStep(step_on(i, True)) for i in range(n_batches)]
+                for i in range(n_batches):                  # every captured graph replayed once (first replay = upload)
+                    graphed.steps[i].graph.replay()
+                    if forked is not graphed.steps:
+                        forked[i].graph.replay()
+
+                def one_at_a_time(caps):
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     for s in range(args.steps):
-                        graphed.steps[s % n_batches].graph.replay()
+                        caps[s % n_batches].graph.replay()
                     torch.cuda.synchronize()
-                    value_depth1 = B * args.steps / (time.perf_counter() - t1)
+                    return B * args.steps / (time.perf_counter() - t1)
+                # ---- the same K steps, one in flight at a time (depth 1): what a single stream of batches gets.
+                # These legs run BEFORE the pipelined one: the captures above are host work with an idle GPU, and
+                # the timed region of a short run (the driver's --steps 20) would otherwise start on idle clocks
+                if depth > 1:
+                    value_depth1 = one_at_a_time(forked)
+                    if forked is not graphed.steps:
+                        value_depth1_inline = one_at_a_time(graphed.steps)
                 for _ in range(args.warmup):                # W untimed steps of the timed kind (pipelined replays)
                     graphed.submit()
                 graphed.join()
                 launch = f"hipgraph, {n_batches} batches in rotation, {depth} steps in flight" if depth > 1 else f"hipgraph, {n_batches} batches in rotation"
+                launch += ", class branch forked onto a second stream" if pipe_fork else ", class branch in line"
             except Exception as exc:                     # noqa: BLE001 - fall back to eager launches, and say so
                 print(f"bench: hipGraph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
                 graphed = None
@@ -399,9 +418,11 @@ def main():
             "metric": "images/sec schema-inference (discretize+graph) DeiT-S CIFAR-100",
             "value": B * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "launch": launch + (" [REHEARSAL: all ranks on one GPU over gloo - not a measurement]" if rehearsal else ""),
-            "value_depth1": value_depth1,
-            "value_note": f"value: {depth} steps in flight on {depth} streams over {n_batches} distinct resident batches ({n_batches} x 117 MB of inputs per GPU); "
-                          "value_depth1: the same captures replayed one at a time on one stream (rank 0 only, untimed by the driver)",
+            "value_depth1": value_depth1, "value_depth1_inline": value_depth1_inline,
+            "value_note": f"value: {depth} steps in flight on {depth} streams over {n_batches} distinct resident batches ({n_batches} x 117 MB of inputs per GPU), "
+                          f"every step {'with its class branch forked onto a second stream' if pipe_fork else 'in line on its own stream'}; "
+                          "value_depth1: the same steps one at a time, captured with the class branch forked onto a second stream (what one stream of "
+                          "batches should run); value_depth1_inline: the captures of `value` replayed one at a time (rank 0 only, untimed by the driver)",
             "vs_baseline": None, "dtype": "f32 (S1 screen: f16 MFMA + f64 re-rank; GCN: split-f16 MFMA, f32 accumulate; ids int64)", "data": "synthetic",
             "world_size": dist_world,
             "config": {"workload": "configs[1]: DeiT-Small + CIFAR-100, synthetic [256,197,384] tokens per GPU, "

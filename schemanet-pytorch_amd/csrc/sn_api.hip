@@ -67,6 +67,27 @@ int sn_ensure_dynamic_lds(const void *fn, size_t bytes, const char *name)
     return SN_OK;
 }
 
+namespace {
+__global__ void zero_words_kernel(unsigned *p, size_t n_words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
+int sn_zero_async(void *ptr, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return SN_OK;
+    if (!ptr || (bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(ptr) & 3) != 0) {
+        sn_set_error("sn_zero_async: pointer / size not 4-byte aligned");
+        return SN_ERR_BAD_ARG;
+    }
+    const size_t n_words = bytes / 4;
+    const unsigned blocks = (unsigned)((n_words + 255) / 256 < 1024 ? (n_words + 255) / 256 : 1024);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, st, (unsigned *)ptr, n_words);
+    SN_CHECK_LAUNCH("sn_zero_async");
+    return SN_OK;
+}
+
 int sn_device_cus(void)
 {
     int dev = 0;

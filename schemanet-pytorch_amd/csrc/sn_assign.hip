@@ -1744,7 +1744,7 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     const bool gate_on = assign_option(0, "SN_ASSIGN_GATE");
     // the gate pays when two workgroups share a CU and there is more than one workgroup per CU to stagger
     if (!(gate_on && NSTEPS <= 24 && NW == 4 && (int)grid > cus)) ag.gate = nullptr;
-    else if (hipMemsetAsync(ag.gate, 0, kGateBytes, st) != hipSuccess) { sn_set_error("sn_assign_words: memset failed"); return SN_ERR_LAUNCH; }
+    else if (int rc = sn_zero_async(ag.gate, kGateBytes, st)) return rc;
     sn_prof_start(0, st);
     hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R, CB>), dim3(grid), dim3(64 * NW), lds, st, ag);
     sn_prof_stop(0, st);
@@ -1834,10 +1834,7 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
     const PackLayout lay = pack_layout(M, D);
     hipStream_t st = (hipStream_t)stream;
     unsigned char *base = (unsigned char *)packed;
-    if (hipMemsetAsync(base + lay.scal_off, 0, 256, st) != hipSuccess) {
-        sn_set_error("sn_codebook_prepare: memset failed");
-        return SN_ERR_LAUNCH;
-    }
+    if (int rc = sn_zero_async(base + lay.scal_off, 256, st)) return rc;
     const int64_t elems = (int64_t)lay.m_pad * D;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)(elems / 256)), dim3(256), 0, st, codebook, M, D,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes);
@@ -1919,10 +1916,7 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
     if (screen_ok) {
         SN_REQUIRE(workspace && workspace_bytes >= sn_assign_workspace_bytes(n_tokens), SN_ERR_WORKSPACE,
                    "sn_assign_words: workspace %zu < %zu bytes", workspace_bytes, sn_assign_workspace_bytes(n_tokens));
-        if (hipMemsetAsync(workspace, 0, 32, st) != hipSuccess) {
-            sn_set_error("sn_assign_words: memset failed");
-            return SN_ERR_LAUNCH;
-        }
+        if (int rc0 = sn_zero_async(workspace, 32, st)) return rc0;
         int rc = 0;
         const bool wide = screen_variant() == 1;
         const PackLayout lay = pack_layout(M, D);

@@ -38,6 +38,12 @@ void sn_set_error(const char *fmt, ...);
 int sn_ensure_dynamic_lds(const void *fn, size_t bytes, const char *name);
 // Compute units of the current device.
 int sn_device_cus(void);
+// Zero `bytes` (a multiple of 4) at a 4-byte aligned device address, as a KERNEL on `st`.  Used instead of
+// hipMemsetAsync wherever a launch sequence may be captured into a hipGraph: a captured memset node was seen NOT to clear
+// its 32 bytes on replay (ROCm 7.2, a graph captured after graphs of another topology: the S1 work counters kept the
+// allocator's leftovers and the re-rank walked a garbage overflow list - a GPU memory fault); a kernel node is ordered
+// and executed like every other node of the sequence.
+int sn_zero_async(void *ptr, size_t bytes, hipStream_t st);
 
 // ---------------------------------------------------------------- host: per-kernel event timing
 void sn_prof_start(int kernel_id, hipStream_t st);

@@ -82,8 +82,14 @@ class Matcher(nn.Module):
         ts = list(depends_on) + list(self.gnn.parameters())
         return tuple((t.data_ptr(), t._version, t.device) for t in ts)
 
-    def atlas_features_async(self, get_class_dict, depends_on=None):
-        """`depends_on`: the tensors `get_class_dict()` reads (e.g. schema_net's vertex_weights / edge_weights): with
+    def atlas_features_async(self, get_class_dict, depends_on=None, side_stream=None):
+        """`side_stream`: True = the class branch is forked onto a second HIP stream and overlaps the instance chain of
+        the same forward pass (shortest latency of ONE pass: 600 k vs 524 k img/s at C2, one pass at a time); False = it
+        runs in line on the current stream - the better choice when several passes are in flight on streams of their
+        own (764 k vs 736 k img/s with four: the device maps streams onto four hardware queues, and four independent
+        serial passes use them without cross-queue waits); None = True unless SN_SIDE_STREAM=0.
+
+        `depends_on`: the tensors `get_class_dict()` reads (e.g. schema_net's vertex_weights / edge_weights): with
         `cache_atlas` on and no autograd, the previous handle is returned while they and the GNN parameters are
         unchanged (one GNN pass over the K class graphs per parameter version instead of per forward).
 
@@ -99,15 +105,15 @@ class Matcher(nn.Module):
             key = self._atlas_key(depends_on)
             if self._atlas_cache is not None and self._atlas_cache[0] == key:
                 return self._atlas_cache[1]
-            handle = self._atlas_features_async(get_class_dict, dev)
+            handle = self._atlas_features_async(get_class_dict, dev, side_stream)
             handle.join()                                   # ordered behind the side stream once; later forwards just read it
             self._atlas_cache = (key, handle)
             return handle
-        return self._atlas_features_async(get_class_dict, dev)
+        return self._atlas_features_async(get_class_dict, dev, side_stream)
 
-    def _atlas_features_async(self, get_class_dict, dev):
+    def _atlas_features_async(self, get_class_dict, dev, side_stream=None):
         prepared = self.gnn.prepare() if dev.type == "cuda" else None
-        serial = os.environ.get("SN_SIDE_STREAM", "1") == "0"           # diagnostics: everything on one stream
+        serial = (os.environ.get("SN_SIDE_STREAM", "1") == "0") if side_stream is None else not side_stream
         if serial or dev.type != "cuda" or torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters()):
             class_dict = get_class_dict()
             return _AtlasHandle(class_dict, self.atlas_features(class_dict, prepared), None, prepared)
