@@ -125,7 +125,7 @@ class GNN(nn.Module):
         # weight-only operands: kept until one of the four weights changes (data_ptr / _version, like the packed codebook
         # of S1; `p.data.copy_` writes need `invalidate_prepared()`), so a forward pass launches no library GEMM
         srcs = (self.embedding.weight, l1.g_conv.linear.weight, l2.g_conv.linear.weight, self.fc.weight)
-        fused_gather = self.embed_dim == 256 and os.environ.get("SN_GCN_GATHER_FUSED", "0") == "1"
+        fused_gather = self.embed_dim == 256 and os.environ.get("SN_GCN_GATHER_FUSED", "1") == "1"
         key = tuple((t.data_ptr(), t._version, t.device) for t in srcs) + (fused_gather,)
         if getattr(self, "_prepared", None) is not None and self._prepared[0] == key:
             return self._prepared[1]
@@ -133,8 +133,9 @@ class GNN(nn.Module):
         out = {"table": table, "w2": ops.split_planes(l2.g_conv.linear.weight),
                "fc_t": self.fc.weight.detach().t().contiguous()}                      # [E, E_out]: ops.pool_fc reads whole lines of it
         if fused_gather:
-            # layer 1 gathers its B operand inside the GEMM: 170 MB less HBM traffic and 20 us less kernel time per step,
-            # but the heavier product costs the replayed pipeline 1 %: opt-in
+            # layer 1 gathers its B operand inside the GEMM: 170 MB less HBM traffic and 20 us less kernel time per step
+            # (+4 % with four in-line steps in flight, +3 % one step at a time; SN_GCN_GATHER_FUSED=0 = the
+            # separate gather kernel)
             out["table_planes"] = ops.table_planes(table)
         self._prepared = (key, out)
         return out
