@@ -363,6 +363,13 @@ typedef struct sn_gemm_args {
      * epilogue and k <= 1024.  (Layer 1 of the GNN: (Emb W1^T)[ids], gnn.py:64-66 + 30, without the gathered copy.) */
     const void *b_table_hi, *b_table_lo;
     const int64_t *b_ids; int64_t b_ids_stride; int b_ids_n, b_table_rows;
+    /* fused next-layer product (optional; needs n == 256, the LayerNorm epilogue, c_hi / c_lo only): the epilogue result H
+     * [m, 256] is not stored; the output planes hold Zt = W . H^T as a [256, cp_cols >= m] operand (rows = output features,
+     * k = rows of H; what the stand-alone product A = W planes, Bt = H planes would write: the Linear of the next GraphConv,
+     * gnn.py:29).  next_w_hi / _lo: planes of the [256, 256] weight with its COLUMNS permuted: column kappa of the
+     * planes = column (4 (kappa >> 7) + (kappa & 3)) * 32 + ((kappa >> 2) & 31) of W (the order the kernel's accumulators
+     * hold the features in; sn_gcn.hip). */
+    const void *next_w_hi, *next_w_lo;
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 

@@ -61,6 +61,7 @@ class GemmArgs(Structure):
         ("m_extent", c_void_p), ("k_extent", c_void_p),
         ("b_table_hi", c_void_p), ("b_table_lo", c_void_p),
         ("b_ids", c_void_p), ("b_ids_stride", c_int64), ("b_ids_n", c_int), ("b_table_rows", c_int),
+        ("next_w_hi", c_void_p), ("next_w_lo", c_void_p),
     ]
 
 

@@ -489,8 +489,17 @@ def table_planes(table):
     return torch.cat([hi, z]).contiguous(), torch.cat([lo, z]).contiguous()
 
 
+def next_layer_weight_planes(weight):
+    """Planes of a [256, 256] Linear weight with its columns in the order the GEMM epilogue holds the features
+    (sn_gemm_args.next_w_*): the operand of `gcn_gemm(..., next_w=)`."""
+    assert tuple(weight.shape) == (256, 256)
+    kappa = torch.arange(256, device=weight.device)
+    col = (4 * (kappa >> 7) + (kappa & 3)) * 32 + ((kappa >> 2) & 31)
+    return split_planes(weight.detach()[:, col].contiguous())
+
+
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
-             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False, b_table=None):
+             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False, b_table=None, next_w=None):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
@@ -499,6 +508,8 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     zero_c: the fp32 result starts as zeros (row tiles beyond m_extent are never written).
     b_table = (hi, lo, ids): B is gathered inside the kernel, Bt[g, f, j] = table[ids[g, j], f] (hi, lo = table_planes(table),
     ids int64 [batches, n_ids]); `b` is then None.  Needs the LayerNorm epilogue and 256 features.
+    next_w = next_layer_weight_planes(W): the epilogue result H [m, 256] is not stored; "planes" is Zt = W . H^T as a
+    [256, want_planes >= m] operand (the next GraphConv's Linear, fused: no H round trip, one launch less).
     Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
     args = N.GemmArgs()
@@ -523,7 +534,13 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
         c = (torch.zeros if zero_c else torch.empty)((batches, m, n), dtype=torch.float32, device=dev)
         args.c, args.c_batch_stride, args.ldc = _dp(c), m * n, n
         out["c"] = c
-    if want_planes:
+    if next_w is not None:
+        assert want_planes and not want_c and pool_w is None and n == 256 and layernorm is not None and next_w.rows == 256 and next_w.kpad == 256
+        args.next_w_hi, args.next_w_lo = _dp(next_w.hi), _dp(next_w.lo)
+        cp = _alloc_planes(lib, dev, batches, 256, int(want_planes))
+        args.c_hi, args.c_lo, args.cp_batch_stride, args.cp_cols = _dp(cp.hi), _dp(cp.lo), cp.hi.shape[1], cp.kpad
+        out["planes"] = cp
+    elif want_planes:
         cp = _alloc_planes(lib, dev, batches, m, int(want_planes))
         args.c_hi, args.c_lo, args.cp_batch_stride, args.cp_cols = _dp(cp.hi), _dp(cp.lo), cp.hi.shape[1], cp.kpad
         out["planes"] = cp

@@ -289,6 +289,8 @@ struct GemmArgs {
     const int64_t *ids;
     int64_t ids_stride;
     int ids_n, tab_rows;
+    // fused second product (FL kernels): planes of W2 [256, 256] with its columns in the order the epilogue holds them
+    const _Float16 *w2_hi, *w2_lo;
 };
 constexpr int kMaxGatherK = 1024;      // nodes per graph the gathered-B form stages ids for
 static unsigned long long *g_gemm_stamps = nullptr;
@@ -301,7 +303,19 @@ static unsigned long long *g_gemm_stamps = nullptr;
 // delivered column-major).  The 16-byte chunks of row `node` are stored at chunk ^ ((node & 3) << 2): the four rows of
 // a block then lie in four different 64-byte bank groups (conflict-free).  Same products in the same order as with the
 // gathered planes: bit-identical results.
-template <bool LN, bool GB = false>
+// FL: the tile that leaves the LayerNorm epilogue - H1, 128 nodes x 256 features - is multiplied by the NEXT layer's Linear
+// weight before it leaves the workgroup: Zt2[o][node] = sum_f W2[o][f] H1[node][f] (gnn.py:29 of layer 2, computed transposed
+// like the stand-alone product so that its result is K-contiguous for the product that follows), written as blocked planes
+// [256 rows = o][k = node].  H1 itself is never stored: one launch, one H1 write and one H1 read per layer pair less.
+// The accumulators hold lane <-> feature, register <-> node, and an MFMA operand wants lane <-> node with eight
+// consecutive k per lane, so half a tile at a time (the 32-row blocks i = 0, then i = 1 of every wave: 64 nodes) goes
+// through LDS as fp16 hi / lo B fragments - 64 KB of the 72 KB ring, which is dead by then.  The contraction index may be
+// visited in any order as long as both operands agree: slot kappa = (wn * 32 + r) * 4 + j stands for feature
+// (4 wn + j) * 32 + r, i.e. the four features a lane holds (j = 0..3) are four consecutive slots, a lane stores them as ONE
+// 8-byte piece per (node, plane), and the host permutes the columns of W2 the same way once (GNN.prepare).  Wave w then
+// owns the output features [64 w, 64 w + 64) for the 64 nodes of the half: 2 x 2 accumulators, 16 k-steps of 12 MFMAs,
+// A fragments (W2, 256 KB, L2-resident) straight from global memory three k-steps ahead, B fragments from the LDS image.
+template <bool LN, bool GB = false, bool FL = false>
 __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -564,6 +578,123 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = fmaxf(acc[i][j][q], 0.0f);
     }
+    if constexpr (FL) {
+        constexpr int kFragHalf = 528, kFragBlock = 1056;       // bytes: a 32-node x 8-slot half / a (node block, k-step, plane) block;
+                                                                // the 16- and 32-byte paddings spread a wave's 8-byte stores over all banks
+        constexpr int kC8Stride = 32 * 8 + 8;                   // dwords (output staging, as in the plane stores below)
+        constexpr int kPF = 2;                                  // k-steps of W2 fragments in flight (16 % kPF == 0)
+        unsigned char *frag = smem;
+        unsigned *stg = reinterpret_cast<unsigned *>(smem + 4096) + wid * (16 * kC8Stride);
+        const int kb_out = p.cp_cols / kStageK;
+        auto load_w2 = [&](int s2, half8 (&dst)[4]) {            // [2 ob + plane]: rows 64 wid + 32 ob .., slots 16 s2 ..
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const int64_t idx = ((int64_t)(wid * 2 + ob) * (kTileN / kStageK) + s2) * kBlockElems + lane * 8;
+                dst[2 * ob] = *reinterpret_cast<const half8 *>(p.w2_hi + idx);
+                dst[2 * ob + 1] = *reinterpret_cast<const half8 *>(p.w2_lo + idx);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            half8 wq[kPF][4];
+#pragma unroll
+            for (int s2 = 0; s2 < kPF; ++s2) load_w2(s2, wq[s2]);       // in flight under the fragment stores and the barriers
+            __syncthreads();                                     // LDS free: LayerNorm scratch / the staging of the half before
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int nd = (q & 3) + 8 * (q >> 2) + 4 * h;
+                const bool keep = tile_m + (2 * wm + i) * 32 + nd < p.m;
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 hi, lo;
+                    split2(keep ? acc[i][j][q] : 0.0f, hi, lo);
+                    hw[j] = (unsigned)__builtin_bit_cast(unsigned short, hi);
+                    lw[j] = (unsigned)__builtin_bit_cast(unsigned short, lo);
+                }
+                unsigned char *dst = frag + (size_t)((wm * 16 + wn * 8 + (r >> 2)) * 2) * kFragBlock + ((r >> 1) & 1) * kFragHalf + nd * 16 + (r & 1) * 8;
+                *reinterpret_cast<uint2 *>(dst) = uint2{hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16)};
+                *reinterpret_cast<uint2 *>(dst + kFragBlock) = uint2{lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16)};
+            }
+            __syncthreads();
+            f32x16 u[2][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) u[ob][nb][q] = 0.0f;
+            for (int s0 = 0; s0 < kTileN / kStageK; s0 += kPF) {  // rolled: kPF k-steps per trip, their W2 fragments replaced as they are used
+#pragma unroll
+                for (int t = 0; t < kPF; ++t) {
+                    const int s2 = s0 + t;
+                    half8 bh[2], bl[2];
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const unsigned char *src = frag + (size_t)((nb * 16 + s2) * 2) * kFragBlock + h * kFragHalf + r * 16;
+                        bh[nb] = *reinterpret_cast<const half8 *>(src);
+                        bl[nb] = *reinterpret_cast<const half8 *>(src + kFragBlock);
+                    }
+                    half8 (&w)[4] = wq[t];
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) u[ob][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * ob + 1], bh[nb], u[ob][nb], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) u[ob][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * ob], bl[nb], u[ob][nb], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) u[ob][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * ob], bh[nb], u[ob][nb], 0, 0, 0);
+                    if (s2 + kPF < kTileN / kStageK) load_w2(s2 + kPF, wq[t]);
+                }
+            }
+            __syncthreads();                                     // every wave is done with the fragment image: the staging overlaps it
+            // u[ob][nb]: lane (r, h) = node (2 nb + i) * 32 + r of the tile, registers = output features 64 wid + 32 ob + row(q, h).
+            // Planes want eight consecutive nodes per 16-byte piece: transposed through the wave's own staging as packed
+            // (hi | lo << 16) dwords, [8-node group][row][node % 8] (the scheme of the plane stores below).
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const int rb = wid * 2 + ob;                     // 32-row block of the [256, cp_cols] result
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+                        _Float16 hi, lo;
+                        split2(u[ob][nb][q], hi, lo);
+                        const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                        stg[(nb * 4 + (r >> 3)) * kC8Stride + row * 8 + (r & 7)] = packed;
+                    }
+                // (same wave wrote what it reads: LDS operations of a wave complete in order)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {                 // (node block nb, 16-node k-block pi inside it); lane half h = 8-node half of the k-block
+                    const int nb = it >> 1, pi = it & 1;
+                    const int c8 = nb * 4 + 2 * pi + h;
+                    const int kb = (tile_m >> 4) + (2 * nb + i) * 2 + pi;
+                    const uint4 lo4 = *reinterpret_cast<const uint4 *>(stg + c8 * kC8Stride + r * 8);
+                    const uint4 hi4 = *reinterpret_cast<const uint4 *>(stg + c8 * kC8Stride + r * 8 + 4);
+                    if (kb < kb_out) {
+                        uint4 ph, pl;
+                        ph.x = __builtin_amdgcn_perm(lo4.y, lo4.x, 0x05040100u); pl.x = __builtin_amdgcn_perm(lo4.y, lo4.x, 0x07060302u);
+                        ph.y = __builtin_amdgcn_perm(lo4.w, lo4.z, 0x05040100u); pl.y = __builtin_amdgcn_perm(lo4.w, lo4.z, 0x07060302u);
+                        ph.z = __builtin_amdgcn_perm(hi4.y, hi4.x, 0x05040100u); pl.z = __builtin_amdgcn_perm(hi4.y, hi4.x, 0x07060302u);
+                        ph.w = __builtin_amdgcn_perm(hi4.w, hi4.z, 0x05040100u); pl.w = __builtin_amdgcn_perm(hi4.w, hi4.z, 0x07060302u);
+                        const int64_t o = (int64_t)batch * p.cp_batch_stride + ((int64_t)rb * kb_out + kb) * kBlockElems + lane * 8;
+                        *reinterpret_cast<uint4 *>(p.c_hi + o) = ph;
+                        *reinterpret_cast<uint4 *>(p.c_lo + o) = pl;
+                    }
+                }
+            }
+        }
+        if (p.stamps && lane == 0) {
+            unsigned long long *st = p.stamps + ((size_t)blockIdx.x * 4 + wid) * 8;
+            st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_wait; st[4] = t_issue;
+        }
+        return;
+    }
     // ---- stores
     if (p.c) {
 #pragma unroll
@@ -763,7 +894,14 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     SN_REQUIRE(((uintptr_t)u->a_hi | (uintptr_t)u->a_lo | (gathered ? 0 : ((uintptr_t)u->b_hi | (uintptr_t)u->b_lo))) % 16 == 0 &&
                    u->a_batch_stride % 8 == 0 && (gathered || u->b_batch_stride % 8 == 0), SN_ERR_BAD_ARG, "sn_gcn_gemm: planes must be 16-byte aligned");
     SN_REQUIRE(u->c || u->c_hi || u->pooled, SN_ERR_BAD_ARG, "sn_gcn_gemm: no output requested");
-    SN_REQUIRE(!u->c_hi || (u->c_lo && u->cp_cols >= u->n && u->cp_cols % kStageK == 0), SN_ERR_BAD_ARG, "sn_gcn_gemm: bad output planes");
+    const bool fused2 = u->next_w_hi != nullptr;
+    if (fused2) {
+        SN_REQUIRE(u->next_w_lo && u->layernorm && u->n == kTileN && u->c_hi && u->c_lo && !u->c && !u->pooled, SN_ERR_UNSUPPORTED,
+                   "sn_gcn_gemm: the fused next-layer product needs n == 256, the LayerNorm epilogue and output planes only");
+        SN_REQUIRE(u->cp_cols >= u->m && u->cp_cols % kStageK == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: bad output planes (fused next-layer product: [256, cp_cols >= m])");
+        SN_REQUIRE(((uintptr_t)u->next_w_hi | (uintptr_t)u->next_w_lo) % 16 == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: next_w planes must be 16-byte aligned");
+    }
+    SN_REQUIRE(fused2 || !u->c_hi || (u->c_lo && u->cp_cols >= u->n && u->cp_cols % kStageK == 0), SN_ERR_BAD_ARG, "sn_gcn_gemm: bad output planes");
     SN_REQUIRE(!u->c || u->ldc >= u->n, SN_ERR_BAD_ARG, "sn_gcn_gemm: ldc=%d < n=%d", u->ldc, u->n);
     SN_REQUIRE(!u->layernorm || (u->n == kTileN && u->gamma && u->beta), SN_ERR_UNSUPPORTED,
                "sn_gcn_gemm: the LayerNorm epilogue needs n == 256 (got %d) and gamma/beta", u->n);
@@ -781,6 +919,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.m_extent = u->m_extent; a.k_extent = u->k_extent;
     a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
     a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows;
+    a.w2_hi = (const _Float16 *)u->next_w_hi; a.w2_lo = (const _Float16 *)u->next_w_lo;
     {   // A per-graph A operand (the adjacency) is read once, by the one workgroup that owns its row tile: its copies carry
         // the nt hint, so it does not displace what the other workgroups re-read (Bt of the graph, the atlas, the tokens of
         // the steps in flight): +1 % on the bench step.  The once-read B of the transposed Linear (A shared) gains nothing.
@@ -789,19 +928,22 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
         a.nt_a = (nt & 1) && u->a_batch_stride != 0;
         a.nt_b = (nt & 2) && u->a_batch_stride == 0;
     }
-    const int cols = (u->c_hi && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
+    const int cols = (u->c_hi && !fused2 && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
     a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + kTileM - 1) / kTileM;
     const int64_t n_blocks = (int64_t)8 * ((u->batches + 7) / 8) * a.tiles_x * a.tiles_y;
     SN_REQUIRE(n_blocks <= 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: grid too large");
     const dim3 grid((unsigned)n_blocks);
     const size_t lds = (size_t)kRing * kStageBytes;
     {
-        const void *fn = gathered ? (const void *)gcn_gemm_kernel<true, true> : (u->layernorm ? (const void *)gcn_gemm_kernel<true> : (const void *)gcn_gemm_kernel<false>);
+        const void *fn = fused2 ? (gathered ? (const void *)gcn_gemm_kernel<true, true, true> : (const void *)gcn_gemm_kernel<true, false, true>)
+                                : gathered ? (const void *)gcn_gemm_kernel<true, true> : (u->layernorm ? (const void *)gcn_gemm_kernel<true> : (const void *)gcn_gemm_kernel<false>);
         if (int rc = sn_ensure_dynamic_lds(fn, lds, "sn_gcn_gemm")) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
     sn_prof_start(4, st);
-    if (gathered) hipLaunchKernelGGL((gcn_gemm_kernel<true, true>), grid, dim3(kGemmThreads), lds, st, a);
+    if (fused2 && gathered) hipLaunchKernelGGL((gcn_gemm_kernel<true, true, true>), grid, dim3(kGemmThreads), lds, st, a);
+    else if (fused2) hipLaunchKernelGGL((gcn_gemm_kernel<true, false, true>), grid, dim3(kGemmThreads), lds, st, a);
+    else if (gathered) hipLaunchKernelGGL((gcn_gemm_kernel<true, true>), grid, dim3(kGemmThreads), lds, st, a);
     else if (u->layernorm) hipLaunchKernelGGL(gcn_gemm_kernel<true>, grid, dim3(kGemmThreads), lds, st, a);
     else hipLaunchKernelGGL(gcn_gemm_kernel<false>, grid, dim3(kGemmThreads), lds, st, a);
     sn_prof_stop(4, st);

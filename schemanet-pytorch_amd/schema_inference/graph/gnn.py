@@ -126,7 +126,8 @@ class GNN(nn.Module):
         # of S1; `p.data.copy_` writes need `invalidate_prepared()`), so a forward pass launches no library GEMM
         srcs = (self.embedding.weight, l1.g_conv.linear.weight, l2.g_conv.linear.weight, self.fc.weight)
         fused_gather = self.embed_dim == 256 and os.environ.get("SN_GCN_GATHER_FUSED", "1") == "1"
-        key = tuple((t.data_ptr(), t._version, t.device) for t in srcs) + (fused_gather,)
+        fused_linear = self.embed_dim == 256 and os.environ.get("SN_GCN_FUSE_LINEAR", "1") == "1"
+        key = tuple((t.data_ptr(), t._version, t.device) for t in srcs) + (fused_gather, fused_linear)
         if getattr(self, "_prepared", None) is not None and self._prepared[0] == key:
             return self._prepared[1]
         table = ops.gcn_gemm(ops.split_planes(self.embedding.weight), ops.split_planes(l1.g_conv.linear.weight), 1, want_c=True)["c"][0]
@@ -137,6 +138,10 @@ class GNN(nn.Module):
             # (+4 % with four in-line steps in flight, +3 % one step at a time; SN_GCN_GATHER_FUSED=0 = the
             # separate gather kernel)
             out["table_planes"] = ops.table_planes(table)
+        if fused_linear:
+            # layer 2's Linear runs in the epilogue of layer 1's product (H1 never leaves the workgroup): its weight with
+            # the columns in the epilogue's feature order
+            out["w2_next"] = ops.next_layer_weight_planes(l2.g_conv.linear.weight)
         self._prepared = (key, out)
         return out
 
@@ -166,10 +171,16 @@ class GNN(nn.Module):
             zt1, b_table = None, (t_hi, t_lo, ingredients.contiguous())
         else:
             zt1, b_table = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext), None     # Bt [G, E, n]
-        h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
-                          layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
-                          rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext, b_table=b_table)["planes"]   # [G, n, E]
-        zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n)["planes"]          # A = W2 planes [1, E, E] -> [G, E, n]
+        if "w2_next" in prepared:
+            zt2 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
+                               layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
+                               rows_valid=n_valid, want_planes=n, m_extent=ext, k_extent=ext, b_table=b_table,
+                               next_w=prepared["w2_next"])["planes"]                 # W2 @ H1^T [G, E, n], H1 never stored
+        else:
+            h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
+                              layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
+                              rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext, b_table=b_table)["planes"]   # [G, n, E]
+            zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n)["planes"]      # A = W2 planes [1, E, E] -> [G, E, n]
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
                               rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext)["pooled"]   # [G, row tiles, E]
