@@ -594,6 +594,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 dst[2 * ob + 1] = *reinterpret_cast<const half8 *>(p.w2_lo + idx);
             }
         };
+        unsigned long long t_fl0 = 0, t_fl1 = 0, t_fl2 = 0, t_fl3 = 0;
+        if (p.stamps) t_fl0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             half8 wq[kPF][4];
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 *reinterpret_cast<uint2 *>(dst + kFragBlock) = uint2{lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16)};
             }
             __syncthreads();
+            if (p.stamps && i == 0) t_fl1 = __builtin_amdgcn_s_memtime();
             f32x16 u[2][2];
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob)
@@ -624,7 +627,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) u[ob][nb][q] = 0.0f;
-            for (int s0 = 0; s0 < kTileN / kStageK; s0 += kPF) {  // rolled: kPF k-steps per trip, their W2 fragments replaced as they are used
+#pragma unroll 1
+            for (int s0 = 0; s0 < kTileN / kStageK; s0 += kPF) {  // rolled (unrolled, hipcc keeps 16 x 4 fragment addresses and spills): kPF k-steps per trip
 #pragma unroll
                 for (int t = 0; t < kPF; ++t) {
                     const int s2 = s0 + t;
@@ -651,7 +655,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                     if (s2 + kPF < kTileN / kStageK) load_w2(s2 + kPF, wq[t]);
                 }
             }
+            if (p.stamps && i == 0) t_fl2 = __builtin_amdgcn_s_memtime();
             __syncthreads();                                     // every wave is done with the fragment image: the staging overlaps it
+            if (p.stamps && i == 0) t_fl3 = __builtin_amdgcn_s_memtime();
             // u[ob][nb]: lane (r, h) = node (2 nb + i) * 32 + r of the tile, registers = output features 64 wid + 32 ob + row(q, h).
             // Planes want eight consecutive nodes per 16-byte piece: transposed through the wave's own staging as packed
             // (hi | lo << 16) dwords, [8-node group][row][node % 8] (the scheme of the plane stores below).
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         }
         if (p.stamps && lane == 0) {
             unsigned long long *st = p.stamps + ((size_t)blockIdx.x * 4 + wid) * 8;
-            st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_wait; st[4] = t_issue;
+            st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_fl0; st[4] = t_fl1; st[5] = t_fl2; st[6] = t_fl3;
         }
         return;
     }
