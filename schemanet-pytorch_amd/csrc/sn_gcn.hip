@@ -88,7 +88,7 @@ __device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h
 // 64 x 64 tile would be bound by the dispatch rate (~10 ns per workgroup chip-wide), not by HBM.
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
-                                                               const int32_t *extent, const int32_t *n_valid)
+                                                               const int32_t *extent, const int32_t *n_valid, int pair_tiles)
 {
     __shared__ float te[64][65], tt[64][65];
     __shared__ float rs_i[64], rs_j[64];
@@ -105,11 +105,23 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
         k_lim = min(k_lim, (ext + 15) & ~15);
     }
     const int T = (rows_lim + 63) / 64;                        // rows_lim >= k_lim: tiles that matter, both ways
+    // Small graphs (pair_tiles > 0 = tiles per side of the padded graph, at most 4): one workgroup per tile pair I <= J
+    // instead of a walk - with 1-3 pairs per graph that matter the walk was a chain of dependent rounds, 17 us alone and
+    // 53 us beside other kernels for 34 MB (the instance side of the bench); pairs beyond the batch's extent exit at once.
+    int pair_I = -1, pair_J = -1;
+    if (pair_tiles > 0) {
+        int x = (int)blockIdx.x;
+        for (int i = 0; i < pair_tiles && pair_I < 0; ++i) {
+            if (x < pair_tiles - i) { pair_I = i; pair_J = i + x; }
+            x -= pair_tiles - i;
+        }
+        if (pair_I < 0 || pair_J >= T) return;                 // (whole workgroup, before any barrier)
+    }
     for (int half = 0; half < 2; ++half) {
-        const int I = half == 0 ? (int)blockIdx.x : T - 1 - (int)blockIdx.x;
-        if (I < 0 || I >= T || (half == 1 && I <= (int)blockIdx.x)) continue;      // (odd T: the middle tile once)
+        const int I = pair_tiles > 0 ? pair_I : (half == 0 ? (int)blockIdx.x : T - 1 - (int)blockIdx.x);
+        if (pair_tiles > 0 ? half == 1 : (I < 0 || I >= T || (half == 1 && I <= (int)blockIdx.x))) continue;      // (odd T: the middle tile once)
         const int bi = I * 64;
-        for (int J = I; J < T; ++J) {
+        for (int J = pair_tiles > 0 ? pair_J : I; J < (pair_tiles > 0 ? pair_J + 1 : T); ++J) {
             const int bj = J * 64;
             __syncthreads();                                   // previous tile pair fully consumed
             if (rowsum && threadIdx.x < 64) {
@@ -804,6 +816,14 @@ extern "C" int64_t sn_gcn_plane_elems(int rows, int k)
     return (int64_t)((rows + 31) / 32) * ((k + 15) / 16) * kBlockElems;
 }
 
+// grid of the adjacency producer: (workgroups per graph, pair_tiles).  Up to 4 tiles per side: one workgroup per tile pair.
+static void adjacency_grid(int n, unsigned &wgs, int &pair_tiles)
+{
+    const int t_full = (((n + 31) & ~31) + 63) / 64;
+    if (t_full <= 4) { pair_tiles = t_full; wgs = (unsigned)(t_full * (t_full + 1) / 2); }
+    else { pair_tiles = 0; wgs = (unsigned)((t_full + 1) / 2); }                 // a workgroup owns row tiles x and T-1-x
+}
+
 extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, void *adj_hi, void *adj_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: bad G=%d n=%d", G, n);
@@ -811,10 +831,11 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const i
     SN_REQUIRE(edges && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: NULL pointer");
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
-    const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);      // a workgroup owns row tiles x and T-1-x
+    unsigned tiles; int pair_tiles;
+    adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                        sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
-                       (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, pair_tiles);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
@@ -827,9 +848,10 @@ extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, 
     SN_REQUIRE(edges && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_masked: NULL pointer");
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes_masked: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
-    const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);
+    unsigned tiles; int pair_tiles;
+    adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid);
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
     return SN_OK;
 }
@@ -842,10 +864,11 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     SN_REQUIRE(pruned_edge_weights && row_sum && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: NULL pointer");
     SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes: K=%d > 65535", K);
     const int kb = (n + 15) / 16;
-    const unsigned tiles = (unsigned)(((((n + 31) & ~31) + 63) / 64 + 1) / 2);
+    unsigned tiles; int pair_tiles;
+    adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, pair_tiles);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }
