@@ -312,13 +312,15 @@ def main():
                     if forked is not graphed.steps:
                         forked[i].graph.replay()
 
+                n_d1 = max(args.steps, 100)                 # (a leg of 20 replays is 7 ms: too short to time well)
+
                 def one_at_a_time(caps):
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    for s in range(args.steps):
+                    for s in range(n_d1):
                         caps[s % n_batches].graph.replay()
                     torch.cuda.synchronize()
-                    return B * args.steps / (time.perf_counter() - t1)
+                    return B * n_d1 / (time.perf_counter() - t1)
                 # ---- the same K steps, one in flight at a time (depth 1): what a single stream of batches gets.
                 # These legs run BEFORE the pipelined one: the captures above are host work with an idle GPU, and
                 # the timed region of a short run (the driver's --steps 20) would otherwise start on idle clocks
@@ -421,8 +423,8 @@ def main():
             "value_depth1": value_depth1, "value_depth1_inline": value_depth1_inline,
             "value_note": f"value: {depth} steps in flight on {depth} streams over {n_batches} distinct resident batches ({n_batches} x 117 MB of inputs per GPU), "
                           f"every step {'with its class branch forked onto a second stream' if pipe_fork else 'in line on its own stream'}; "
-                          "value_depth1: the same steps one at a time, captured with the class branch forked onto a second stream (what one stream of "
-                          "batches should run); value_depth1_inline: the captures of `value` replayed one at a time (rank 0 only, untimed by the driver)",
+                          "value_depth1: the same steps one at a time (max(K, 100) replays), captured with the class branch forked onto a second stream (what one "
+                          "stream of batches should run); value_depth1_inline: the captures of `value` replayed one at a time (rank 0 only, untimed by the driver)",
             "vs_baseline": None, "dtype": "f32 (S1 screen: f16 MFMA + f64 re-rank; GCN: split-f16 MFMA, f32 accumulate; ids int64)", "data": "synthetic",
             "world_size": dist_world,
             "config": {"workload": "configs[1]: DeiT-Small + CIFAR-100, synthetic [256,197,384] tokens per GPU, "
