@@ -303,6 +303,7 @@ struct GemmArgs {
     int ids_n, tab_rows;
     // fused second product (FL kernels): planes of W2 [256, 256] with its columns in the order the epilogue holds them
     const _Float16 *w2_hi, *w2_lo;
+    int fl_twin;                     // idle row tiles take the second half of the fused epilogue (SN_GEMM_FL_TWIN=0: off)
 };
 constexpr int kMaxGatherK = 1024;      // nodes per graph the gathered-B form stages ids for
 static unsigned long long *g_gemm_stamps = nullptr;
@@ -342,7 +343,22 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int batch = (slot / per_graph) * 8 + xcd, tile = slot % per_graph;
     if (batch >= p.batches) return;                            // (whole workgroup, before any barrier)
-    const int tile_m = (tile / p.tiles_x) * kTileM, tile_n = (tile % p.tiles_x) * kTileN;
+    int tile_m_ = (tile / p.tiles_x) * kTileM;
+    // FL, small graphs: when the batch's extent leaves row tiles idle (instance graphs: padded to 196 rows = 2 tiles, the
+    // largest graph of a batch has ~125 vertices = 1 tile), idle tile t_real + t repeats the product and the LayerNorm of
+    // tile t and takes the SECOND half of its fused-Linear epilogue, tile t only the first: the two workgroups share a CU
+    // (each graph otherwise leaves half of it idle) and the serial epilogue of a tile is halved.
+    int fl_first = 0, fl_last = 2;
+    if constexpr (FL) {
+        if (p.m_extent && p.tiles_x == 1 && p.fl_twin) {
+            const int t_real = (*p.m_extent + kTileM - 1) / kTileM, ty = tile;
+            if (t_real > 0 && p.tiles_y >= 2 * t_real) {
+                if (ty < t_real) fl_last = 1;
+                else if (ty < 2 * t_real) { tile_m_ = (ty - t_real) * kTileM; fl_first = 1; }
+            }
+        }
+    }
+    const int tile_m = tile_m_, tile_n = (tile % p.tiles_x) * kTileN;
     if (p.m_extent && tile_m >= *p.m_extent) {                 // a row tile past the largest graph of the batch
         if (p.pooled && tid + tile_n < p.n) p.pooled[((int64_t)batch * p.tiles_y + tile / p.tiles_x) * p.n + tile_n + tid] = 0.0f;
         return;
@@ -610,6 +626,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         if (p.stamps) t_fl0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (i < fl_first || i >= fl_last) continue;          // (workgroup-uniform: the other half belongs to the twin workgroup)
             half8 wq[kPF][4];
 #pragma unroll
             for (int s2 = 0; s2 < kPF; ++s2) load_w2(s2, wq[s2]);       // in flight under the fragment stores and the barriers
@@ -949,6 +966,10 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
     a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows;
     a.w2_hi = (const _Float16 *)u->next_w_hi; a.w2_lo = (const _Float16 *)u->next_w_lo;
+    {
+        static const int twin = getenv("SN_GEMM_FL_TWIN") ? atoi(getenv("SN_GEMM_FL_TWIN")) : 1;
+        a.fl_twin = twin;
+    }
     {   // A per-graph A operand (the adjacency) is read once, by the one workgroup that owns its row tile: its copies carry
         // the nt hint, so it does not displace what the other workgroups re-read (Bt of the graph, the atlas, the tokens of
         // the steps in flight): +1 % on the bench step.  The once-read B of the transposed Linear (A shared) gains nothing.
