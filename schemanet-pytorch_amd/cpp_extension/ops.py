@@ -586,6 +586,7 @@ class _SymAdjMatmul(torch.autograd.Function):
         y = gcn_gemm(adj_planes, xt, G, want_c=True)["c"]
         ctx.save_for_backward(x)
         ctx.adj_planes = adj_planes
+        ctx.adj_like = torch.empty(adj.shape, dtype=adj.dtype, device="meta")
         return y
 
     @staticmethod
@@ -598,6 +599,9 @@ class _SymAdjMatmul(torch.autograd.Function):
         # power of two (exact) that puts its largest magnitude near 2^10, and the products are scaled back; the scale is
         # a device scalar (no host synchronisation).
         dy = _f32c(dy)
+        if dy.numel() == 0:                                  # G == 0 or n == 0: nothing to multiply (amax of nothing raises)
+            return (torch.zeros(ctx.adj_like.shape, dtype=ctx.adj_like.dtype, device=x.device) if ctx.needs_input_grad[0] else None,
+                    torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None)
         scale = torch.exp2(torch.floor(torch.log2(1024.0 / dy.abs().amax().clamp_min(1.0e-30))))
         dys = dy * scale
         d_adj = d_x = None
@@ -620,6 +624,7 @@ class _EdgesAdjMatmul(torch.autograd.Function):
         y = gcn_gemm(adj_planes, split_planes(x.detach().transpose(1, 2).contiguous()), G, want_c=True)["c"]
         ctx.save_for_backward(x)
         ctx.adj_planes = adj_planes
+        ctx.adj_like = torch.empty(edges.shape, dtype=edges.dtype, device="meta")
         return y
 
     @staticmethod
@@ -628,6 +633,9 @@ class _EdgesAdjMatmul(torch.autograd.Function):
         ap = ctx.adj_planes
         G = x.shape[0]
         dy = _f32c(dy)
+        if dy.numel() == 0:
+            return (torch.zeros(ctx.adj_like.shape, dtype=ctx.adj_like.dtype, device=x.device) if ctx.needs_input_grad[0] else None,
+                    torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None)
         scale = torch.exp2(torch.floor(torch.log2(1024.0 / dy.abs().amax().clamp_min(1.0e-30))))     # (see _SymAdjMatmul.backward)
         dys = dy * scale
         d_e = d_x = None

@@ -390,7 +390,7 @@ __device__ inline bool group_positions_sorted(const Lds &s, int L, int lane, con
     for (int e = 0; e < 4; ++e) {
         const int q = lane + SN_WAVE * e;
         const bool ok = q < L;
-        fits = fits && (!ok || (w4[e] >= 0 && w4[e] < (1 << 24)));
+        fits = fits && (!ok || (w4[e] >= 0 && w4[e] < (1 << 24) - 1));     // (word 2^24 - 1 at position 255 would be the empty-slot key)
         key[e] = ok ? (((unsigned)w4[e] << 8) | (unsigned)q) : 0xFFFFFFFFu;
     }
     if (__any(!fits)) return false;

@@ -2,6 +2,7 @@
 MI355X-native.  `to_networkx` (visualisation helper) is outside the hot path and not provided.
 """
 import collections
+import os
 from typing import Dict
 
 import torch
@@ -28,12 +29,21 @@ class SchemaNetPredictor(nn.Module):
     clamp + softmax + graph build in one kernel, no host synchronisation.
     """
 
+    #: replay-cache size: one captured hipGraph per distinct set of backbone tap buffers (see `forward`)
+    max_graphs = 8
+
     def __init__(self, ingredient_wrapper: nn.Module, schema_net: SchemaNet, matcher: Matcher):
         super().__init__()
         self.ingredient_wrapper = ingredient_wrapper
         self.schema_net = schema_net
         self.matcher = matcher
         self.num_classes = schema_net.num_classes
+        # eval() under torch.no_grad(): the part of `forward` behind the backbone (S1, instance graph, matcher: ~20
+        # short launches, host-bound when launched from Python) is captured into a hipGraph per tap-buffer set and
+        # replayed (DESIGN 5, "the API path").  SN_PREDICTOR_GRAPH=0 or `graph_replay = False`: eager launches.
+        self.graph_replay = os.environ.get("SN_PREDICTOR_GRAPH", "1") != "0"
+        self._graphs = collections.OrderedDict()
+        self._graph_misses = 0
 
     def train(self, mode: bool = True):
         """eval(): the class-graph features (a function of parameters only) are cached across forwards; train(): off"""
@@ -41,19 +51,22 @@ class SchemaNetPredictor(nn.Module):
         self.matcher.cache_atlas = not mode
         if mode:
             self.matcher.invalidate_atlas_cache()
+            self._graphs.clear()
         return self
 
-    def forward(self, x: torch.Tensor, requires_graph: bool = False) -> Dict[str, torch.Tensor]:
+    def invalidate_graphs(self):
+        """Forget the captured launch sequences (needed only after writes that bypass the tensors' version counters,
+        e.g. `p.data.copy_`, or after changing a scalar option of `schema_net` / `matcher`)."""
+        self._graphs.clear()
+        self._graph_misses = 0
+
+    # ---- the path behind the backbone -----------------------------------------------------------------------
+    def _after_backbone(self, output, requires_graph: bool):
         ret = collections.OrderedDict()
-        with torch.no_grad():
-            if hasattr(self.ingredient_wrapper, "taps"):
-                output = self.ingredient_wrapper.taps(x)
-            else:
-                output = self.ingredient_wrapper(x)
         # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
         # instance branch on the current one; joined inside forward_padded
         atlas = self.matcher.atlas_features_async(
-            self.schema_net.get_atlas, depends_on=(self.schema_net.vertex_weights.tensor, self.schema_net.edge_weights.tensor))
+            self.schema_net.get_atlas, depends_on=self._atlas_depends_on())
         # (the zero padding of the instance edges is only written when the caller asks for the graphs)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
                                                       zero_padding=requires_graph, return_attn_cls=requires_graph)
@@ -69,3 +82,64 @@ class SchemaNetPredictor(nn.Module):
             ret["ingredients"] = output["ingredients"]
             ret["attn_cls"] = graph["attn_cls"]          # [bs, L] head mean, clamp-masked (reference schema_net.py:296)
         return ret
+
+    def _atlas_depends_on(self):
+        """what the cached class-graph features are a function of besides the GNN weights (Matcher.cache_atlas)"""
+        sn = self.schema_net
+        return (sn.vertex_weights.tensor, sn.edge_weights.tensor, sn.class_ingredients.tensor,
+                ("prune", sn.prune_node_threshold, "self_loop", sn.remove_self_loop))
+
+    def _replay_key(self, mid_feat, extracted):
+        """A capture reads its inputs and every parameter BY ADDRESS and bakes in the operands derived from parameters
+        (packed codebook, GNN.prepare, the cached class-graph features): it stays valid while the tap buffers are the
+        same memory (the caching allocator hands a steady inference loop the same blocks every iteration) and no
+        parameter / buffer of this module has been written (version counters)."""
+        key = [(t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype) for t in (mid_feat, extracted)]
+        key += [(t.data_ptr(), t._version) for t in self.parameters()]
+        key += [(t.data_ptr(), t._version) for t in self.buffers()]
+        sn = self.schema_net
+        key.append((self.matcher.cache_atlas, sn.prune_node_threshold, sn.remove_self_loop, sn.clamp_vertex_attn, sn.clamp_edge_attn))
+        return tuple(key)
+
+    def _forward_replayed(self, x):
+        """eval + no_grad + `taps`: backbone eagerly, then the captured launch sequence of everything behind it."""
+        from ..utils.graph_replay import GraphedStep
+        wrapper = self.ingredient_wrapper
+        out_backbone = wrapper.backbone_jit(x)
+        mid_feat, extracted = out_backbone["mid_feat"], out_backbone["extracted"]
+        key = self._replay_key(mid_feat, extracted)
+        step = self._graphs.get(key)
+        if step is None:
+            if self._graph_misses >= 4 * self.max_graphs:       # tap buffers keep moving: replay cannot pay here
+                self.graph_replay = False
+                self._graphs.clear()
+                return self._after_backbone(wrapper.taps_from(out_backbone), False)
+            self._graph_misses += 1
+            try:
+                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone), False))
+            except Exception as exc:                              # noqa: BLE001 - a configuration that cannot be captured
+                self.schema_net.logger.warning("hipGraph capture of the predictor failed (%r): eager launches from now on", exc)
+                self.graph_replay = False
+                self._graphs.clear()
+                return self._after_backbone(wrapper.taps_from(out_backbone), False)
+            self._graphs[key] = step
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.popitem(last=False)
+            step.taps = (mid_feat, extracted)                      # keep the captured input buffers alive
+        else:
+            self._graphs.move_to_end(key)
+        ret = collections.OrderedDict(step.replay())
+        ret["pred"] = ret["pred"].clone()                          # the capture's own buffer is rewritten by the next replay
+        return ret
+
+    def forward(self, x: torch.Tensor, requires_graph: bool = False) -> Dict[str, torch.Tensor]:
+        wrapper = self.ingredient_wrapper
+        if (self.graph_replay and not self.training and not requires_graph and not torch.is_grad_enabled()
+                and hasattr(wrapper, "taps_from") and self.schema_net.vertex_weights.tensor.is_cuda):
+            return self._forward_replayed(x)
+        with torch.no_grad():
+            if hasattr(wrapper, "taps"):
+                output = wrapper.taps(x)
+            else:
+                output = wrapper(x)
+        return self._after_backbone(output, requires_graph)

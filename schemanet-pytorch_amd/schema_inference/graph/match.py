@@ -79,8 +79,10 @@ class Matcher(nn.Module):
         self._atlas_cache = None
 
     def _atlas_key(self, depends_on):
+        """tensors by (data_ptr, _version, device); anything else in `depends_on` (scalar options of the caller, e.g.
+        prune threshold / self-loop flag) by value"""
         ts = list(depends_on) + list(self.gnn.parameters())
-        return tuple((t.data_ptr(), t._version, t.device) for t in ts)
+        return tuple((t.data_ptr(), t._version, t.device) if torch.is_tensor(t) else ("opt", t) for t in ts)
 
     def atlas_features_async(self, get_class_dict, depends_on=None, side_stream=None):
         """`side_stream`: True = the class branch is forked onto a second HIP stream and overlaps the instance chain of
@@ -89,9 +91,12 @@ class Matcher(nn.Module):
         own (764 k vs 736 k img/s with four: the device maps streams onto four hardware queues, and four independent
         serial passes use them without cross-queue waits); None = True unless SN_SIDE_STREAM=0.
 
-        `depends_on`: the tensors `get_class_dict()` reads (e.g. schema_net's vertex_weights / edge_weights): with
-        `cache_atlas` on and no autograd, the previous handle is returned while they and the GNN parameters are
-        unchanged (one GNN pass over the K class graphs per parameter version instead of per forward).
+        `depends_on`: the tensors `get_class_dict()` reads (e.g. schema_net's vertex_weights / edge_weights /
+        class_ingredients) and the scalar options it applies (any hashable non-tensor entries): with `cache_atlas` on and
+        no autograd, the previous handle is returned while they and the GNN parameters are unchanged (one GNN pass over
+        the K class graphs per parameter version instead of per forward).  Never cached while gradients could flow: grad
+        mode on and a GNN parameter OR one of the `depends_on` tensors requiring grad (a cached handle would carry an
+        autograd graph into later forwards).
 
         Start `get_class_dict()` (e.g. `schema_net.get_atlas`) + the class-graph GNN on the side
         stream.  Returns a handle for `forward_padded(..., feat_kg=handle)`; `handle.class_dict` is
@@ -99,7 +104,8 @@ class Matcher(nn.Module):
         (`GNN.prepare`) are computed once, on the current stream before the fork, and shared by the
         class branch and the instance branch of this forward pass (`handle.prepared`)."""
         dev = next(self.gnn.parameters()).device
-        no_grad = not (torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters()))
+        grad_srcs = list(self.gnn.parameters()) + [t for t in (depends_on or ()) if torch.is_tensor(t)]
+        no_grad = not (torch.is_grad_enabled() and any(p.requires_grad for p in grad_srcs))
         use_cache = self.cache_atlas and depends_on is not None and no_grad and dev.type == "cuda"
         if use_cache:
             key = self._atlas_key(depends_on)

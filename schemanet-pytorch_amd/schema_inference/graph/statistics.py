@@ -101,6 +101,12 @@ class SchemaStatistics:
         self._accumulate(limited_edges, label, self.edge_sum, self.edge_count)
 
     # ----- cross-rank merge
+    @staticmethod
+    def collective_length(n: int, world: int) -> int:
+        """length the reduce_scatter + all_gather form runs on: n rounded up to a multiple of the world size (the
+        elements behind n are the zero slack of the flat buffer)"""
+        return (n + world - 1) // world * world
+
     def _all_reduce_flat(self, store: torch.Tensor, n: int, large: bool):
         """SUM over ranks of store[:n].  `store` has >= _SLACK zero elements behind n."""
         rank, world = _world()
@@ -109,11 +115,19 @@ class SchemaStatistics:
             return
         if large and world <= _SLACK:
             # direct 1-hop exchange of 1/W shards on the xGMI mesh; the zero slack rounds the length up to the world size
-            padded = store[: (n + world - 1) // world * world]
+            padded = store[: self.collective_length(n, world)]
             shard = torch.empty(padded.numel() // world, dtype=store.dtype, device=store.device)
-            dist.reduce_scatter_tensor(shard, padded, op=dist.ReduceOp.SUM)
-            dist.all_gather_into_tensor(padded, shard)
-            self.last_collective = "reduce_scatter+all_gather"
+            try:
+                dist.reduce_scatter_tensor(shard, padded, op=dist.ReduceOp.SUM)
+            except (RuntimeError, NotImplementedError, AttributeError) as exc:
+                # a backend / torch version without reduce_scatter_tensor (older gloo, mpi) refuses before anything is
+                # exchanged (every rank takes the same branch: the refusal does not depend on the data)
+                logging.getLogger("SchemaStatistics").warning("reduce_scatter_tensor unavailable (%r): all_reduce instead", exc)
+                dist.all_reduce(store[:n], op=dist.ReduceOp.SUM)
+                self.last_collective = "all_reduce (reduce_scatter unavailable)"
+            else:
+                dist.all_gather_into_tensor(padded, shard)
+                self.last_collective = "reduce_scatter+all_gather"
         else:
             dist.all_reduce(store[:n], op=dist.ReduceOp.SUM)
             self.last_collective = "all_reduce"

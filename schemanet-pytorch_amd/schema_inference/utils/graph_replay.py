@@ -7,7 +7,15 @@ padded outputs, the side-stream class branch joined by an event), which is what 
 capturable.  `GraphedStep(fn)` warms `fn` up on a capture stream, records ONE call of it into a
 `torch.cuda.CUDAGraph` (a hipGraph on ROCm) and `replay()` re-runs the recorded kernels on the
 same buffers: inputs are read from the tensors `fn` closed over at capture time, so update them in
-place (`tensor.copy_`) between replays; the outputs are the tensors returned at capture time."""
+place (`tensor.copy_`) between replays; the outputs are the tensors returned at capture time.
+
+Contract on weights: a capture reads every parameter by address (live values: biases, LayerNorm, the
+IR-Atlas), but the operands DERIVED from parameters are whatever existed at capture time - the packed
+codebook of S1 (`ops.PackedCodebook`), `GNN.prepare()` (the folded embedding table, the W2 planes, fc^T) and,
+with `Matcher.cache_atlas`, the cached class-graph features.  After a weight update (optimizer.step,
+load_state_dict, any in-place write) a replay would mix those stale operands with live parameters:
+RE-CAPTURE after a weight change.  `SchemaNetPredictor.forward` does this by itself (its replay cache is keyed
+on the version counters of every parameter and buffer); a hand-made `GraphedStep` must be rebuilt by its owner."""
 import torch
 
 

@@ -63,7 +63,11 @@ class IngredientModelWrapper(nn.Module):
 
     @torch.no_grad()
     def taps(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
-        out_backbone = self.backbone_jit(x)
+        return self.taps_from(self.backbone_jit(x))
+
+    @torch.no_grad()
+    def taps_from(self, out_backbone: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The part of `taps` behind the backbone (no host synchronisation: SchemaNetPredictor captures it)."""
         mid_feat = out_backbone["mid_feat"]                     # [L+1, bs, D] sequence-first
         extracted = out_backbone["extracted"]                   # [bs*H, L+1, L+1]
         Lp1, bs, _ = mid_feat.shape

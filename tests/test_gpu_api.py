@@ -1,0 +1,248 @@
+"""GPU (-m gpu): the drop-in API as the fast path, the N > 1 branch of bench.py, config [4] at its real size.
+
+  * `SchemaNetPredictor.forward` in eval() under no_grad captures the launch sequence behind the backbone by itself and
+    replays it (reference entry: schema_inference/graph/__init__.py:37-57): replayed scores == eager scores bit for bit,
+    a weight update re-captures, moving tap buffers fall back to eager launches;
+  * `bench.py --gpus 2` under torch.distributed.run in rehearsal mode (both ranks on this one GPU over gloo): the code
+    the driver runs for the scaling curve (reference scripts/init_schema_net.py:19-65, eval/evaluation.py:95-97);
+  * three training iterations at config [4]'s real size (config/caltech_101/schema_net/deit_small-l9-M_1024.yaml:22-47:
+    B = 64, M = 1024, K = 101, n_max = 1024, E = 256) against the plain-torch route of the same package.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import datagen
+from test_gpu_parity import DEV, T, _Backbone, make_schema_net, mods, scores_close  # noqa: F401  (mods: fixture)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _report(name, payload):
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as fh:
+            json.dump(payload, fh, indent=1)
+    except OSError:
+        pass
+
+
+class _Rotating(torch.nn.Module):
+    def __init__(self, batches):
+        super().__init__()
+        self.batches, self.i = batches, 0
+
+    def forward(self, x):
+        mid, ext = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        return {"mid_feat": mid, "extracted": ext}
+
+
+def _predictor(mods, batches, M, D, K, E, seed=0):
+    graph = mods["graph"]
+    disc = mods["disc"].Discretization(size=M, dim=D).to(DEV)
+    with torch.no_grad():
+        disc.vocabulary.weight.copy_(T(datagen.bellish((M, D), 303 + seed, 1.0)))
+    wrapper = mods["Wrapper"](_Rotating(batches), mods["disc"].DiscretizationModule(disc)).to(DEV).eval()
+    torch.manual_seed(seed)
+    sn = make_schema_net(mods, M, K)
+    sn.register_class_vertices(torch.arange(M, device=DEV).repeat(K, 1))
+    m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu")).to(DEV)
+    return graph.SchemaNetPredictor(wrapper, sn, m).eval(), wrapper
+
+
+# =============================================================================== the API path replays itself
+@pytest.mark.parametrize("E", [256, 32])
+def test_predictor_replays_its_own_launch_sequence(mods, E):
+    bs, H, L, D, M, K = 6, 3, 196, 192, 128, 5
+    batches = [(T(datagen.bellish((L + 1, bs, D), 400 + i, 1.0)), T(datagen.bellish((bs * H, L + 1, L + 1), 410 + i, 2.0))) for i in range(3)]
+    pred, wrapper = _predictor(mods, batches, M, D, K, E)
+    x = torch.zeros(bs, 3, 4, 4, device=DEV)
+    for cache in (True, False):                       # eval() default (class-graph features kept), and recomputed per call
+        pred.matcher.cache_atlas = cache
+        pred.matcher.invalidate_atlas_cache()
+        pred.invalidate_graphs()
+        pred.graph_replay = False
+        wrapper.backbone_jit.i = 0
+        with torch.no_grad():
+            eager = [pred(x) for _ in range(3)]
+        eager_pred = [o["pred"].clone() for o in eager]
+        pred.graph_replay = True
+        wrapper.backbone_jit.i = 0
+        with torch.no_grad():
+            first = [pred(x)["pred"] for _ in range(3)]                  # three captures (one per tap-buffer set)
+            assert len(pred._graphs) == 3
+            again = [pred(x) for _ in range(6)]                         # replays, twice around
+        assert len(pred._graphs) == 3 and pred._graph_misses == 3
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert torch.equal(first[i], eager_pred[i]), f"capture pass differs from eager (cache {cache}, batch {i})"
+            assert torch.equal(again[i]["pred"], eager_pred[i]) and torch.equal(again[3 + i]["pred"], eager_pred[i])
+        assert list(again[0].keys()) == ["pred", "class_vertices", "class_edges", "class_ingredients"]
+        assert torch.equal(again[0]["class_edges"], eager[0]["class_edges"])
+        assert again[0]["pred"].data_ptr() != again[3]["pred"].data_ptr()        # the caller owns what it gets
+    # ---- a weight update: the captures are dropped for new ones, results follow the new weights
+    with torch.no_grad():
+        pred.matcher.gnn.layers[0].g_conv.linear.weight.mul_(1.25)      # bumps the version counter (as optimizer.step does)
+        pred.schema_net.vertex_weights.tensor.mul_(0.5).add_(0.01)
+        wrapper.backbone_jit.i = 0
+        new = pred(x)["pred"]
+        pred.graph_replay = False
+        wrapper.backbone_jit.i = 0
+        want = pred(x)["pred"]
+        pred.graph_replay = True
+    assert torch.equal(new, want) and not torch.equal(new, eager_pred[0])
+    # ---- the reference's other uses stay eager: requires_graph (host-side list slicing), grad mode, train()
+    with torch.no_grad():
+        wrapper.backbone_jit.i = 0
+        n_before = len(pred._graphs)
+        full = pred(x, requires_graph=True)
+        assert len(pred._graphs) == n_before and "instance_edges" in full
+    scores_close(full["pred"], want, "requires_graph route vs replayed route")
+    pred.train()
+    assert len(pred._graphs) == 0
+
+
+def test_predictor_with_moving_taps_falls_back_to_eager(mods):
+    """a backbone that returns NEW buffers on every call: captures cannot be reused; after 4 x max_graphs misses the
+    predictor stops capturing (still correct, eager launches)"""
+    bs, H, L, D, M, K = 2, 2, 196, 192, 128, 5
+    mid, ext = T(datagen.bellish((L + 1, bs, D), 420, 1.0)), T(datagen.bellish((bs * H, L + 1, L + 1), 421, 2.0))
+    keep = []
+
+    class _Fresh(torch.nn.Module):
+        def forward(self, x):
+            keep.append((mid.clone(), ext.clone()))              # (kept alive: the allocator cannot hand the block out again)
+            return {"mid_feat": keep[-1][0], "extracted": keep[-1][1]}
+    pred, wrapper = _predictor(mods, [(mid, ext)], M, D, K, 32)
+    wrapper.backbone_jit = _Fresh()
+    pred.max_graphs = 2
+    x = torch.zeros(bs, 3, 4, 4, device=DEV)
+    with torch.no_grad():
+        outs = [pred(x)["pred"].clone() for _ in range(11)]
+    assert pred.graph_replay is False and len(pred._graphs) == 0
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+# =============================================================================== the N > 1 branch of bench.py
+def test_bench_two_ranks_rehearsal():
+    """What the driver launches for N = 2, with both ranks on this box's one GPU over gloo (SN_BENCH_REHEARSAL=1: RCCL
+    cannot form a 2-rank group on one device; the numbers mean nothing, the code path is the one of the scaling run):
+    stdout is ONE JSON line, world_size 2, every image of every region voted, the edge statistics merged by
+    reduce_scatter + all_gather."""
+    steps, port = 3, str(29600 + os.getpid() % 300)
+    env = dict(os.environ, SN_BENCH_REHEARSAL="1", SN_BENCH_BATCHES="4", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "2",
+           "--regions", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["steps"] == steps and out["regions"] == 2
+    assert out["votes_merged"] == 256 * steps * 2
+    assert out["config"]["global_batch"] == 512 and out["scaling"] == "weak"
+    assert out["init_atlas"]["world_size"] == 2 and out["init_atlas"]["edge_stats_collective"] == "reduce_scatter+all_gather"
+    assert out["value"] > 0 and abs(out["ms_per_step"] * steps * 1e-3 * out["value"] - 512 * steps) < 1e-3 * 512 * steps
+    assert "REHEARSAL" in out["launch"] and out["cpu_baseline"] is None
+
+
+# =============================================================================== config [4] at its real size
+def test_c5_real_size_training_iterations(mods):
+    """deit_small-l9-M_1024.yaml:22-47: B = 64, M = 1024, K = 101, n_max = 1024 (a 424 MB edge_weights with gradients),
+    E = 256.  Three `train_iter` steps (normalize -> forward -> SchemaInferenceLoss -> backward -> AdamW) with the
+    adjacency products on the matrix cores (ops.edges_adj_matmul / sym_adj_matmul) against the same three steps with
+    SN_GCN_MFMA=0 (library bmm: the plain-torch route of the same package) from the same initial state: losses within
+    1e-4 relative, finite gradients for w_v, w_e, edge_weights; peak memory and step time are recorded."""
+    from schema_inference import loss as loss_mod
+    from schema_inference import train as train_mod
+    graph = mods["graph"]
+    B, L, D, M, K, E = 64, 196, 384, 1024, 101, 256
+    g = lambda s: torch.Generator().manual_seed(s)  # noqa: E731
+    ing = torch.randint(0, M, (B, L), generator=g(1))
+    ing[:, ::3] = ing[:, :1]                                                 # repeated words: graphs of ~130 vertices
+    attn = torch.randn(B, L, L, generator=g(2))
+    acls = torch.randn(B, L, generator=g(3))
+    label = torch.randint(0, K, (B,), generator=g(4))
+
+    def build():
+        torch.manual_seed(11)
+        sn = graph.SchemaNet(num_vertices=M, num_classes=K, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0, prune_node_threshold=0.001).to(DEV)
+        sn.register_class_vertices(torch.arange(M, device=DEV).repeat(K, 1))
+        torch.manual_seed(12)
+        m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu")).to(DEV)
+
+        class _Model(torch.nn.Module):                                       # the part of SchemaNetPredictor behind the (frozen) wrapper
+            def __init__(self):
+                super().__init__()
+                self.schema_net, self.matcher = sn, m
+
+            def forward(self, batch):
+                inst = self.schema_net(batch["ingredients"], batch["attn"].clone(), batch["attn_cls"].clone())
+                atlas = self.schema_net.get_atlas()
+                out = {"pred": self.matcher(inst, atlas)}
+                out.update(atlas)
+                return out
+        return _Model()
+
+    def run(mfma):
+        old = os.environ.get("SN_GCN_MFMA")
+        os.environ["SN_GCN_MFMA"] = "1" if mfma else "0"
+        try:
+            model = build().train()
+            loss_fn = loss_mod.get_loss_fn({"name": "schema_inference_loss"})
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-4)
+            batch = {"ingredients": ing.to(DEV), "attn": attn.to(DEV), "attn_cls": acls.to(DEV)}
+            target = {"label": label.to(DEV)}
+            weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            # gradients of the first iteration (train_iter clears them after its optimizer step): one forward / backward by hand
+            opt.zero_grad(set_to_none=True)
+            model.schema_net.normalize()
+            train_mod.weighted_total(loss_fn(model(batch), target), weights).backward()
+            sn = model.schema_net
+            grads = {"w_v": sn.vertex_attribute_weights.tensor.grad.clone(), "w_e": sn.edge_attribute_weights.tensor.grad.clone(),
+                     "edge_weights_absmax": float(sn.edge_weights.tensor.grad.abs().max()),
+                     "edge_weights_finite": bool(torch.isfinite(sn.edge_weights.tensor.grad).all()),
+                     "vertex_weights": sn.vertex_weights.tensor.grad.clone()}
+            losses, times = [], []
+            for it in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                total, _ = train_mod.train_iter(lambda: model(batch), model.schema_net, loss_fn, weights, opt, target)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                losses.append(float(total))
+            return losses, times, grads, torch.cuda.max_memory_allocated() / 2 ** 30
+        finally:
+            if old is None:
+                os.environ.pop("SN_GCN_MFMA", None)
+            else:
+                os.environ["SN_GCN_MFMA"] = old
+
+    l_mfma, t_mfma, g_mfma, mem_mfma = run(True)
+    torch.cuda.empty_cache()
+    l_lib, t_lib, g_lib, mem_lib = run(False)
+    assert all(np.isfinite(l_mfma)) and all(np.isfinite(l_lib))
+    for a, b in zip(l_mfma, l_lib):
+        assert abs(a - b) <= 1e-4 * abs(b), (l_mfma, l_lib)
+    for k in ("w_v", "w_e", "vertex_weights"):
+        assert torch.isfinite(g_mfma[k]).all() and g_mfma[k].abs().max() > 0
+        scale = g_lib[k].abs().max()
+        assert (g_mfma[k] - g_lib[k]).abs().max() <= 1e-3 * scale, k
+    assert g_mfma["edge_weights_finite"] and g_mfma["edge_weights_absmax"] > 0
+    _report("c5_real_size_training.json", {
+        "shape": {"B": B, "M": M, "K": K, "n_max": M, "E": E, "edge_weights_MB": K * M * M * 4 / 2 ** 20},
+        "losses_mfma": l_mfma, "losses_library": l_lib, "iter_seconds_mfma": t_mfma, "iter_seconds_library": t_lib,
+        "peak_GiB_mfma": mem_mfma, "peak_GiB_library": mem_lib})

@@ -224,6 +224,52 @@ def test_shard_indices_partition():
         assert all(p.tolist() == list(range(r, n, w)) for r, p in enumerate(parts))
 
 
+def test_statistics_flat_buffers_divide_by_every_world_size():
+    """The edge statistics of C2 (K = 100, n_max = 512: 26 214 500 floats), C4 (K = 1000, n_max = 500) and C5 (K = 101,
+    n_max = 1024) are not multiples of 8; the reduce_scatter + all_gather form runs on the length rounded up to the world
+    size, which must stay inside the zero slack the flat buffers are allocated with (reference scripts/init_schema_net.py
+    :19-65 has one process, so no such length to honour)."""
+    from schema_inference.graph import statistics as st
+    for K, M, n_max in ((100, 512, 512), (1000, 1024, 500), (101, 1024, 1024), (10, 128, 128)):
+        stats = st.SchemaStatistics(K, M, n_max, device=torch.device("meta"))
+        n_e, n_v = K * n_max * n_max + K, K * M + K
+        assert stats._edges().numel() == n_e and stats._e_store.numel() >= n_e + st._SLACK
+        assert stats._v_flat.numel() == n_v and stats._v_store.numel() >= n_v + st._SLACK
+        for world in (2, 3, 4, 6, 8):
+            for n, store in ((n_e, stats._e_store), (n_v, stats._v_store)):
+                padded = st.SchemaStatistics.collective_length(n, world)
+                assert padded % world == 0 and n <= padded < n + world and padded <= store.numel()
+        assert st.SchemaStatistics.collective_length(n_e, 8) % 8 == 0
+
+
+def test_atlas_cache_key_and_grad_rule():
+    """Matcher's eval cache: scalar options and class_ingredients are part of the key; never cached while
+    a `depends_on` tensor could receive gradients."""
+    import schema_inference.graph as graph
+    m = graph.Matcher("inner_product", 16, dict(embed_dim=16, num_layers=2, identity_proj=False, activation="relu"))
+    w = torch.zeros(3, requires_grad=True)
+    ci = torch.zeros(3, dtype=torch.long)
+    k1 = m._atlas_key((w, ci, ("prune", 0.001, "self_loop", False)))
+    assert k1 == m._atlas_key((w, ci, ("prune", 0.001, "self_loop", False)))
+    assert k1 != m._atlas_key((w, ci, ("prune", 0.01, "self_loop", False)))
+    assert k1 != m._atlas_key((w, ci, ("prune", 0.001, "self_loop", True)))
+    ci.add_(1)                                               # register_class_vertices rewrites class_ingredients in place
+    assert k1 != m._atlas_key((w, ci, ("prune", 0.001, "self_loop", False)))
+    # frozen GNN, atlas weights requiring grad, grad mode on: the handle must not be kept (CPU module: the route itself
+    # is the torch form; what is checked is that nothing lands in the cache)
+    for p_ in m.gnn.parameters():
+        p_.requires_grad_(False)
+    m.cache_atlas = True
+    calls = []
+
+    def get_class_dict():
+        calls.append(1)
+        return {"class_vertices": torch.rand(2, 4), "class_edges": torch.rand(2, 4, 4) * w.sum().exp(), "class_ingredients": torch.zeros(2, 4, dtype=torch.long)}
+    m.atlas_features_async(get_class_dict, depends_on=(w,))
+    m.atlas_features_async(get_class_dict, depends_on=(w,))
+    assert len(calls) == 2 and m._atlas_cache is None
+
+
 # ------------------------------------------------------------------ N > 1: gloo, world_size 2
 _WORKER = r'''
 import os, sys
