@@ -295,7 +295,11 @@ int sn_pool_fc_t(const float *pooled_parts, int G, int parts, int E, const int32
 /* ---- S4 on the matrix cores: GCN layers with split-fp16 operands ----------------------------
  * Replaces torch.bmm(adj, feat) + nn.Linear + masked_fill + LayerNorm + ReLU + pooling of the
  * reference's GNN (schema_inference/graph/gnn.py:20-98).  Every operand is a pair of fp16 planes
- * (x = hi + lo, 22 significant bits), a product is three fp16 MFMAs accumulated in fp32.
+ * (x s = hi + lo with s a power-of-two scale kept next to the planes), a product is three fp16 MFMAs accumulated in
+ * fp32.  Precision: |x s - hi - lo| <= max(2^-22 |x s|, 2^-25) (the second term: lo is an fp16 subnormal when
+ * |x s| < 2^-3), so with s chosen to put the operand's largest possible magnitude at 2^13 .. 2^14 an element keeps 22
+ * significant bits down to 2^-17 of that maximum and errs by 2^-39 of it below; scale_dev arguments (device scalars,
+ * NULL = 1) and the *_scale fields of sn_gemm_args carry s.
  * Planes are BLOCKED in MFMA fragment order: a [rows, k] operand is ceil(rows/32) x ceil(k/16)
  * blocks of 1 KiB; element (row, kk) lives in block (row >> 5, kk >> 4) at fp16 index
  * ((kk >> 3 & 1) * 32 + (row & 31)) * 8 + (kk & 7); rows / k beyond the operand are zero. */
@@ -309,7 +313,7 @@ int sn_pool_fc_t(const float *pooled_parts, int G, int parts, int E, const int32
 int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,
                           float prune_threshold, float *class_vertices, float *row_sum, void *stream);
 int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n,
-                                  int remove_self_loop, void *adj_hi, void *adj_lo, void *stream);
+                                  int remove_self_loop, float scale, void *adj_hi, void *adj_lo, void *stream);
 
 /* fp16 elements of one plane of a [rows, k] operand (per batch entry). */
 int64_t sn_gcn_plane_elems(int rows, int k);
@@ -321,21 +325,23 @@ int64_t sn_gcn_plane_elems(int rows, int k);
 /* The same with a vertex count per graph: element (i, j) of graph g is taken as 0 unless i, j < n_valid[g] and is not
  * read (edges written with sn_graph_args.skip_edge_padding); the identity still covers all n rows (gnn.py:27-30 on the
  * zero-padded batch, match.py:48-54).  n_valid NULL = sn_gcn_adjacency_planes. */
+/* scale (here and in sn_gcn_atlas_adjacency_planes): the planes hold adj * scale, a power of two in (0, 65536] given by
+ * value; |adj| * scale must stay below 65504 (normalised graphs: adj <= 2 + |w_e|_1, scale 2^10 leaves room up to 63). */
 int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, const int32_t *n_valid, const int32_t *extent_dev,
-                                   void *adj_hi, void *adj_lo, void *stream);
-int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, void *adj_hi,
+                                   float scale, void *adj_hi, void *adj_lo, void *stream);
+int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, float scale, void *adj_hi,
                             void *adj_lo, void *stream);
 
 /* Zt[g][f][j] = table[ids[g][j]][f] as blocked planes of an [E, n] operand per graph (ids outside
  * [0, rows_table) give zero): the transposed, gathered B operand of layer 1 (gnn.py:64-66 with the
  * Linear folded into the embedding table). */
 int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int E,
-                         const int32_t *extent_dev, void *out_hi, void *out_lo, void *stream);
+                         const int32_t *extent_dev, const float *scale_dev, void *out_hi, void *out_lo, void *stream);
 
 /* hi/lo split of fp32 x [batches][rows][ld] (cols valid per row, batch stride in floats) into
  * blocked planes of a [rows, cols] operand per batch entry. */
 int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
-                    void *out_hi, void *out_lo, void *stream);
+                    const float *scale_dev, void *out_hi, void *out_lo, void *stream);
 
 /* C[b] = A[b] . Bt[b]^T for b < batches; A = planes of an [m, k] operand, Bt = planes of an [n, k]
  * operand, k % 16 == 0 (the padded k of the planes); batch strides in fp16 elements, 0 = shared
@@ -370,6 +376,14 @@ typedef struct sn_gemm_args {
      * planes = column (4 (kappa >> 7) + (kappa & 3)) * 32 + ((kappa >> 2) & 31) of W (the order the kernel's accumulators
      * hold the features in; sn_gcn.hip). */
     const void *next_w_hi, *next_w_lo;
+    /* power-of-two operand scales (device scalars; NULL = 1).  The planes of A / B hold x * (*a_scale) / x * (*b_scale)
+     * (b_scale also covers the gathered table); the accumulators are multiplied by 1 / (a_scale * b_scale) before the
+     * bias; output planes are written as result * (*out_scale) (the consumer passes that scalar as its a_scale / b_scale).
+     * Fused next-layer product: the W planes hold W * (*next_w_scale), the epilogue's H fragments are formed as
+     * H * (*next_h_scale) (a bound on |H|: 16 max|gamma| + max|beta| for a LayerNorm output), the result planes hold
+     * Zt * (*out_scale).  Every scale must be a power of two (then all of this is exact) chosen so that the largest
+     * magnitude the operand can hold lands at 2^13 .. 2^14: see "precision" above. */
+    const float *a_scale, *b_scale, *out_scale, *next_w_scale, *next_h_scale;
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 

@@ -375,8 +375,9 @@ def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, r
         N.check(lib.sn_atlas_prune_rowsum(N.ptr(vertex_weights), N.ptr(edge_weights), K, n, int(prune_threshold is not None),
                                           float(prune_threshold or 0.0), N.ptr(cv), N.ptr(rs), N.stream_ptr(dev)),
                 "sn_atlas_prune_rowsum")
-        N.check(lib.sn_gcn_atlas_adjacency_planes(N.ptr(edge_weights), N.ptr(rs), K, n, int(remove_self_loop), N.ptr(out.hi),
+        N.check(lib.sn_gcn_atlas_adjacency_planes(N.ptr(edge_weights), N.ptr(rs), K, n, int(remove_self_loop), ADJ_SCALE, N.ptr(out.hi),
                                                   N.ptr(out.lo), N.stream_ptr(dev)), "sn_gcn_atlas_adjacency_planes")
+    out.scale = const_scale(ADJ_SCALE, dev)
     return cv, out
 
 
@@ -396,15 +397,38 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
+ADJ_SCALE = 1024.0     # static scale of adjacency planes: (E + E^T)/2 + I of normalised graphs is <= 2 + |w_e|_1; room up to 63
+_PLANE_TOP = 8192.0    # a scaled operand's largest magnitude lands in [2^13, 2^14)
+_const_scales = {}
+
+
+def const_scale(value, dev):
+    """device scalar (fp32 [1]) holding a compile-time scale, one per (value, device)"""
+    key = (float(value), str(dev))
+    if key not in _const_scales:
+        _const_scales[key] = torch.full((1,), float(value), dtype=torch.float32, device=dev)
+    return _const_scales[key]
+
+
+def pow2_scale(bound):
+    """bound: tensor (its largest magnitude is taken) or 0-dim / [1] tensor holding a bound on |x| -> device scalar fp32 [1],
+    the power of two s with s * bound in [2^13, 2^14) (clamped to 2^-60 .. 2^60; a zero / non-finite bound gives 1): what
+    split-fp16 planes of x are scaled by (csrc/sn_gcn.hip, "What hi + lo holds").  No host synchronisation."""
+    b = bound.detach().abs().amax().to(torch.float32).reshape(1)
+    s = torch.exp2(torch.floor(torch.log2(_PLANE_TOP / b)).clamp(-60.0, 60.0))
+    return torch.where(torch.isfinite(s) & (b > 0), s, torch.ones_like(s))
+
+
 class Planes:
     """A [batches, rows, k] fp32 operand as two blocked fp16 planes (include/schemanet_hip.h, S4):
     hi/lo are flat [batches, plane_elems] tensors; `rows`/`k` are the logical extent, `kpad` the
-    k of the blocks (multiple of 16)."""
+    k of the blocks (multiple of 16); `scale`: None or a device scalar (fp32 [1], a power of two) - the planes hold
+    x * scale."""
 
-    __slots__ = ("hi", "lo", "batches", "rows", "k", "kpad")
+    __slots__ = ("hi", "lo", "batches", "rows", "k", "kpad", "scale")
 
-    def __init__(self, hi, lo, batches, rows, k):
-        self.hi, self.lo, self.batches, self.rows, self.k = hi, lo, batches, rows, k
+    def __init__(self, hi, lo, batches, rows, k, scale=None):
+        self.hi, self.lo, self.batches, self.rows, self.k, self.scale = hi, lo, batches, rows, k, scale
         self.kpad = (k + 15) // 16 * 16
 
     @property
@@ -419,6 +443,8 @@ class Planes:
             x = x.permute(0, 1, 4, 2, 3, 5).reshape(self.batches, rb * 32, kb * 16)
             return x
         full = un(self.hi) + un(self.lo)
+        if self.scale is not None:
+            full = full / self.scale
         return full[:, :self.rows, :self.k], full
 
 
@@ -440,16 +466,17 @@ def gcn_adjacency_planes(edges, extent=None, n_valid=None):
     with torch.cuda.device(dev):
         if n_valid is not None:
             assert n_valid.dtype == torch.int32 and n_valid.numel() == G and n_valid.device == dev
-            N.check(lib.sn_gcn_adjacency_planes_masked(N.ptr(e), G, n, N.ptr(n_valid), N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo),
+            N.check(lib.sn_gcn_adjacency_planes_masked(N.ptr(e), G, n, N.ptr(n_valid), N.ptr(extent), ADJ_SCALE, N.ptr(out.hi), N.ptr(out.lo),
                                                        N.stream_ptr(dev)), "sn_gcn_adjacency_planes_masked")
         else:
-            N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+            N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(extent), ADJ_SCALE, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                     "sn_gcn_adjacency_planes")
+    out.scale = const_scale(ADJ_SCALE, dev)
     return out
 
 
-def gcn_gather_planes(table, ids, extent=None):
-    """Zt[g, f, j] = table[ids[g, j], f] as blocked planes of a [G, E, n] operand."""
+def gcn_gather_planes(table, ids, extent=None, scale=None):
+    """Zt[g, f, j] = table[ids[g, j], f] as blocked planes of a [G, E, n] operand (times the device scalar `scale`)."""
     lib = N.require_gpu()
     dev = _check_dev(table, ids)
     t = _f32c(table.detach())
@@ -459,30 +486,39 @@ def gcn_gather_planes(table, ids, extent=None):
     rows, E = t.shape
     out = _alloc_planes(lib, dev, G, E, n)
     with torch.cuda.device(dev):
-        N.check(lib.sn_gcn_gather_planes(N.ptr(t), rows, N.ptr(ids), G, n, E, N.ptr(extent), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
-                "sn_gcn_gather_planes")
+        N.check(lib.sn_gcn_gather_planes(N.ptr(t), rows, N.ptr(ids), G, n, E, N.ptr(extent), N.ptr(scale), N.ptr(out.hi), N.ptr(out.lo),
+                                         N.stream_ptr(dev)), "sn_gcn_gather_planes")
+    out.scale = scale
     return out
 
 
-def split_planes(x):
-    """fp32 [rows, k] or [batches, rows, k] -> blocked hi/lo planes with hi + lo ~= x (22 bits)."""
+def split_planes(x, scale="auto"):
+    """fp32 [rows, k] or [batches, rows, k] -> blocked hi/lo planes with hi + lo ~= x * scale (22 significant bits down to
+    2^-17 of the largest magnitude).  scale: "auto" = pow2_scale(x) (one reduction over x, no host synchronisation), a
+    device scalar from pow2_scale(bound) when a bound on |x| is known without reading x, or None (= 1: only for operands
+    known to lie in 2^-3 .. 6e4)."""
     lib = N.require_gpu()
     dev = _check_dev(x)
     xc = _f32c(x.detach())
     if xc.dim() == 2:
         xc = xc[None]
     B_, rows, k = xc.shape
+    if isinstance(scale, str):
+        scale = pow2_scale(xc) if xc.numel() else None
     out = _alloc_planes(lib, dev, B_, rows, k)
     with torch.cuda.device(dev):
-        N.check(lib.sn_split_planes(N.ptr(xc), B_, rows, k, k, rows * k, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+        N.check(lib.sn_split_planes(N.ptr(xc), B_, rows, k, k, rows * k, N.ptr(scale), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                 "sn_split_planes")
+    out.scale = scale
     return out
 
 
-def table_planes(table):
-    """fp32 [rows, 256] -> (hi, lo) row-major fp16 planes [rows + 1, 256] with hi + lo ~= table (22 bits, the same split as
-    split_planes) and a zero last row: the gathered-B operand of gcn_gemm."""
+def table_planes(table, scale=None):
+    """fp32 [rows, 256] -> (hi, lo) row-major fp16 planes [rows + 1, 256] with hi + lo ~= table * scale (the same split as
+    split_planes) and a zero last row: the gathered-B operand of gcn_gemm (pass the same device scalar as `b_scale`)."""
     t = _f32c(table.detach())
+    if scale is not None:
+        t = t * scale
     hi = t.to(torch.float16)
     lo = (t - hi.to(torch.float32)).to(torch.float16)
     z = torch.zeros((1, t.shape[1]), dtype=torch.float16, device=t.device)
@@ -495,11 +531,12 @@ def next_layer_weight_planes(weight):
     assert tuple(weight.shape) == (256, 256)
     kappa = torch.arange(256, device=weight.device)
     col = (4 * (kappa >> 7) + (kappa & 3)) * 32 + ((kappa >> 2) & 31)
-    return split_planes(weight.detach()[:, col].contiguous())
+    return split_planes(weight.detach()[:, col].contiguous())            # (scale: from the weight's largest magnitude)
 
 
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
-             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False, b_table=None, next_w=None):
+             want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False, b_table=None, next_w=None,
+             out_scale=None, h_scale=None):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
@@ -510,11 +547,17 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     ids int64 [batches, n_ids]); `b` is then None.  Needs the LayerNorm epilogue and 256 features.
     next_w = next_layer_weight_planes(W): the epilogue result H [m, 256] is not stored; "planes" is Zt = W . H^T as a
     [256, want_planes >= m] operand (the next GraphConv's Linear, fused: no H round trip, one launch less).
+    Scales: the operands' `.scale` (b_table: an optional 4th entry) are divided out of the accumulators; out_scale
+    (device scalar from pow2_scale(bound on the result)) is what the output planes are multiplied by and carry as their
+    `.scale`; h_scale (with next_w): the bound-derived scale of the epilogue's H fragments.
     Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
     args = N.GemmArgs()
+    b_scale = None
     if b_table is not None:
-        t_hi, t_lo, ids = b_table
+        if len(b_table) == 4:
+            b_scale = b_table[3]
+        t_hi, t_lo, ids = b_table[:3]
         dev = _check_dev(a.hi, a.lo, t_hi, t_lo, ids)
         assert b is None and a.batches in (1, batches) and ids.dtype == torch.int64 and ids.is_contiguous() and ids.shape[0] == batches
         assert t_hi.dtype == torch.float16 and t_hi.is_contiguous() and t_lo.is_contiguous() and t_hi.shape == t_lo.shape and t_hi.shape[1] == 256
@@ -526,7 +569,11 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
         assert a.kpad == b.kpad and a.batches in (1, batches) and b.batches in (1, batches)
         m, n = a.rows, b.rows
         args.b_hi, args.b_lo, args.b_batch_stride = _dp(b.hi), _dp(b.lo), b.stride
+        b_scale = b.scale
     args.a_hi, args.a_lo, args.a_batch_stride = _dp(a.hi), _dp(a.lo), a.stride
+    args.a_scale, args.b_scale, args.out_scale = _dp(a.scale), _dp(b_scale), _dp(out_scale)
+    for sc in (a.scale, b_scale, out_scale, h_scale):
+        assert sc is None or (sc.dtype == torch.float32 and sc.numel() == 1 and sc.device == dev)
     args.m, args.n, args.k, args.batches = int(m), int(n), int(a.kpad), int(batches)
     out = {}
     keep = []
@@ -537,11 +584,14 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     if next_w is not None:
         assert want_planes and not want_c and pool_w is None and n == 256 and layernorm is not None and next_w.rows == 256 and next_w.kpad == 256
         args.next_w_hi, args.next_w_lo = _dp(next_w.hi), _dp(next_w.lo)
+        args.next_w_scale, args.next_h_scale = _dp(next_w.scale), _dp(h_scale)
         cp = _alloc_planes(lib, dev, batches, 256, int(want_planes))
+        cp.scale = out_scale
         args.c_hi, args.c_lo, args.cp_batch_stride, args.cp_cols = _dp(cp.hi), _dp(cp.lo), cp.hi.shape[1], cp.kpad
         out["planes"] = cp
     elif want_planes:
         cp = _alloc_planes(lib, dev, batches, m, int(want_planes))
+        cp.scale = out_scale
         args.c_hi, args.c_lo, args.cp_batch_stride, args.cp_cols = _dp(cp.hi), _dp(cp.lo), cp.hi.shape[1], cp.kpad
         out["planes"] = cp
     if bias is not None:
@@ -594,21 +644,18 @@ class _SymAdjMatmul(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         ap = ctx.adj_planes
         G = x.shape[0]
-        # Gradients are small (1e-3 .. 1e-8) and fp16 planes have a short exponent: below 6e-5 the hi plane is subnormal
-        # and hi + lo resolves 6e-8 ABSOLUTE, i.e. percents of such a value.  So the incoming gradient is scaled by a
-        # power of two (exact) that puts its largest magnitude near 2^10, and the products are scaled back; the scale is
-        # a device scalar (no host synchronisation).
+        # Gradients are small (1e-3 .. 1e-8) and fp16 planes have a short exponent: split_planes scales every operand by
+        # the power of two that puts its largest magnitude at 2^13 (a device scalar, no host synchronisation), the
+        # product divides the scales out again.
         dy = _f32c(dy)
-        if dy.numel() == 0:                                  # G == 0 or n == 0: nothing to multiply (amax of nothing raises)
+        if dy.numel() == 0:                                  # G == 0 or n == 0: nothing to multiply
             return (torch.zeros(ctx.adj_like.shape, dtype=ctx.adj_like.dtype, device=x.device) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None)
-        scale = torch.exp2(torch.floor(torch.log2(1024.0 / dy.abs().amax().clamp_min(1.0e-30))))
-        dys = dy * scale
         d_adj = d_x = None
         if ctx.needs_input_grad[1]:
-            d_x = gcn_gemm(ap, split_planes(dys.transpose(1, 2).contiguous()), G, want_c=True)["c"] / scale
+            d_x = gcn_gemm(ap, split_planes(dy.transpose(1, 2).contiguous()), G, want_c=True)["c"]
         if ctx.needs_input_grad[0]:
-            d_adj = gcn_gemm(split_planes(dys), split_planes(x.detach()), G, want_c=True)["c"] / scale
+            d_adj = gcn_gemm(split_planes(dy), split_planes(x.detach()), G, want_c=True)["c"]
         return d_adj, d_x, None
 
 
@@ -636,14 +683,12 @@ class _EdgesAdjMatmul(torch.autograd.Function):
         if dy.numel() == 0:
             return (torch.zeros(ctx.adj_like.shape, dtype=ctx.adj_like.dtype, device=x.device) if ctx.needs_input_grad[0] else None,
                     torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None)
-        scale = torch.exp2(torch.floor(torch.log2(1024.0 / dy.abs().amax().clamp_min(1.0e-30))))     # (see _SymAdjMatmul.backward)
-        dys = dy * scale
         d_e = d_x = None
         if ctx.needs_input_grad[1]:
-            d_x = gcn_gemm(ap, split_planes(dys.transpose(1, 2).contiguous()), G, want_c=True)["c"] / scale
+            d_x = gcn_gemm(ap, split_planes(dy.transpose(1, 2).contiguous()), G, want_c=True)["c"]
         if ctx.needs_input_grad[0]:
-            s_ = gcn_gemm(split_planes(dys), split_planes(x.detach()), G, want_c=True)["c"]
-            d_e = (s_ + s_.transpose(1, 2)) * (0.5 / scale)
+            s_ = gcn_gemm(split_planes(dy), split_planes(x.detach()), G, want_c=True)["c"]
+            d_e = (s_ + s_.transpose(1, 2)) * 0.5
         return d_e, d_x, None
 
 

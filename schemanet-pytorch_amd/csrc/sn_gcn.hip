@@ -3,11 +3,25 @@
 //
 // The two dense products of a layer, adj @ H and (.) @ W^T, are fp32 GEMMs in the reference and the
 // scores must stay within 1e-5 of it, so fp16/bf16 inputs alone are not enough.  Every operand is
-// therefore kept as TWO fp16 planes, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant
-// bits; v_mfma_f32_32x32x16_f16 neither flushes fp16 subnormals nor rounds the products,
-// tools/mfma_denorm_probe.hip), and a product is three MFMAs accumulated in fp32:
-//     a.b ~= hi_a.hi_b + hi_a.lo_b + lo_a.hi_b          (the dropped lo.lo term is ~2^-22 relative)
+// therefore kept as TWO fp16 planes, x s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi), s a power of two
+// (v_mfma_f32_32x32x16_f16 neither flushes fp16 subnormals nor rounds the products, tools/mfma_denorm_probe.hip),
+// and a product is three MFMAs accumulated in fp32:
+//     a.b ~= hi_a.hi_b + hi_a.lo_b + lo_a.hi_b          (the dropped lo.lo term is <= 2^-22 relative)
 // which is 3 x 2.5 PF-class instructions instead of one 157 TF-class fp32 MFMA.
+//
+// What hi + lo holds (the bound the scores rest on).  y = x s.  hi = fp16(y): |y - hi| <= 2^-11 |y|, exactly
+// representable in fp32.  lo = fp16(y - hi): relative error 2^-11 while |y - hi| >= 2^-14 (fp16 normal), else the
+// ABSOLUTE error 2^-25 of an fp16 subnormal.  So |y - hi - lo| <= max(2^-22 |y|, 2^-25): 22 significant bits for
+// |y| >= 2^-3, and an absolute floor of 2^-25 / s in x below that.  Unscaled (s = 1) a typical adjacency entry 1 / 512
+// would keep 16 bits and a 512-term row could be off by 512 x 2^-25 = 1.5e-5 of |B|.  Hence every operand carries a
+// power-of-two scale s (exact) that puts the LARGEST magnitude it can hold at 2^13 .. 2^14: an element keeps 22 bits
+// down to 2^-17 of that maximum and 2^-39 of it absolutely below - whatever the magnitudes of the weights - and
+// nothing below 65504 / 4 can overflow.  The scales are device scalars next to the planes (`*_scale`; NULL = 1): static
+// for the adjacency (entries <= 2 + |w_e|_1: s = 2^10), from the actual maximum for weight-only operands (table, W2),
+// from the LayerNorm bound 16 max|gamma| + max|beta| for operands written by an epilogue.  The accumulators are
+// multiplied by 1 / (s_a s_b) (exact) before the bias.  With da, db the representation errors above, a product row
+// errs by at most  sum_k (|da_k| |b_k| + |a_k| |db_k| + |lo_a,k lo_b,k|) <= 3.1 x 2^-22 sum_k |a_k b_k| + 2^-38 n max|a| max|b|
+// plus the fp32 accumulation of its 3 n MFMA terms - against n 2^-24 sum_k |a_k b_k| for the reference's fp32 GEMM.
 //
 // One kernel form serves every product of the layer: C[M,N] = A[M,K] . Bt[N,K]^T with BOTH operands
 // K-contiguous, so no operand is ever transposed in memory:
@@ -88,7 +102,7 @@ __device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h
 // 64 x 64 tile would be bound by the dispatch rate (~10 ns per workgroup chip-wide), not by HBM.
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
-                                                               const int32_t *extent, const int32_t *n_valid, int pair_tiles)
+                                                               const int32_t *extent, const int32_t *n_valid, int pair_tiles, float scale)
 {
     __shared__ float te[64][65], tt[64][65];
     __shared__ float rs_i[64], rs_j[64];
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
                                 x = (te[tx][pc * 8 + q] + tt[pc * 8 + q][tx]) * 0.5f;       // == / 2 exactly
                                 if (i == j) x = x + 1.0f;
                             }
-                            v[q] = x;
+                            v[q] = x * scale;
                         }
                         store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(i, j0, kb_count));
                     }
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
                                 x = (tt[tx][pc * 8 + q] + te[pc * 8 + q][tx]) * 0.5f;
                                 if (i == j) x = x + 1.0f;
                             }
-                            v[q] = x;
+                            v[q] = x * scale;
                         }
                         store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(j, i0, kb_count));
                     }
@@ -205,10 +219,12 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
 // Zt[g][f][j] = table[ids[g][j]][f] as blocked planes (rows f < E, k = j; j >= n and ids outside the
 // table give zero).  (layer 1 re-associated: adj @ Emb[ids] @ W^T == adj @ (Emb @ W^T)[ids], gnn.py:64-66 + 30)
 __global__ __launch_bounds__(256) void gather_planes_kernel(const float *table, int rows_table, const int64_t *ids, int n, int kb_count,
-                                                            int E, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l, const int32_t *extent)
+                                                            int E, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l, const int32_t *extent,
+                                                            const float *scale_dev)
 {
     __shared__ float tile[64][65];
     __shared__ int rid[64];
+    const float scale = scale_dev ? *scale_dev : 1.0f;
     const int g = blockIdx.y, j0 = blockIdx.x * 64;
     if (extent && j0 >= ((*extent + 15) & ~15)) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(256) void gather_planes_kernel(const float *table, 
                 if (f < ((E + 31) & ~31) && jj < kb_count * 16) {
                     float w[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) w[q] = f < E ? tile[pc * 8 + q][lane] : 0.0f;
+                    for (int q = 0; q < 8; ++q) w[q] = f < E ? tile[pc * 8 + q][lane] * scale : 0.0f;
                     store_piece(w, out_h, out_l, (int64_t)g * batch_stride + blocked_index(f, jj, kb_count));
                 }
             }
@@ -255,9 +271,11 @@ __global__ __launch_bounds__(256) void gather_planes_kernel(const float *table, 
 
 // fp32 [batches][rows][ld] (cols valid) -> blocked planes, zero padded to 32 rows / 16 k
 __global__ __launch_bounds__(256) void split_planes_kernel(const float *x, int rows, int cols, int64_t ld, int64_t x_batch_stride,
-                                                           int kb_count, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l)
+                                                           int kb_count, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l,
+                                                           const float *scale_dev)
 {
     const int g = blockIdx.y;
+    const float scale = scale_dev ? *scale_dev : 1.0f;
     const int rows_pad = (rows + 31) & ~31;
     const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;         // over [rows_pad][kb_count * 2]
     const int row = (int)(piece % rows_pad), pk = (int)(piece / rows_pad); // consecutive threads -> consecutive rows (16 B apart)
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float *x, int r
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int k = pk * 8 + q;
-        v[q] = (row < rows && k < cols) ? x[(int64_t)g * x_batch_stride + (int64_t)row * ld + k] : 0.0f;
+        v[q] = (row < rows && k < cols) ? x[(int64_t)g * x_batch_stride + (int64_t)row * ld + k] * scale : 0.0f;
     }
     store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(row, pk * 8, kb_count));
 }
@@ -304,6 +322,9 @@ struct GemmArgs {
     // fused second product (FL kernels): planes of W2 [256, 256] with its columns in the order the epilogue holds them
     const _Float16 *w2_hi, *w2_lo;
     int fl_twin;                     // idle row tiles take the second half of the fused epilogue (SN_GEMM_FL_TWIN=0: off)
+    // power-of-two operand scales (device scalars, NULL = 1; see the header comment): the planes of A / B hold x * scale;
+    // output planes are written as result * out_scale; FL: the W2 planes hold W * w2_scale, the H fragments H * h_scale
+    const float *a_scale, *b_scale, *out_scale, *w2_scale, *h_scale;
 };
 constexpr int kMaxGatherK = 1024;      // nodes per graph the gathered-B form stages ids for
 static unsigned long long *g_gemm_stamps = nullptr;
@@ -505,6 +526,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     // rows m = tile_m + (2wm+i)*32 + (q & 3) + 8 (q >> 2) + 4 h for q = 0..15.
     float *red = reinterpret_cast<float *>(smem);              // [2 (wn)][128 rows]
     const int nv = p.rows_valid ? p.rows_valid[batch] : p.m;
+    // (powers of two: the reciprocal and the products are exact; 1.0f when no scale is given - results bit-identical)
+    const float acc_mul = 1.0f / ((p.a_scale ? *p.a_scale : 1.0f) * (p.b_scale ? *p.b_scale : 1.0f));
+    const float out_mul = p.out_scale ? *p.out_scale : 1.0f;
     float bias[4], gam[4], bet[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
             const int m = tile_m + (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
             const bool live = m < nv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j][q] = live ? acc[i][j][q] + bias[j] : 0.0f;     // pad rows -> 0 (gnn.py:43-45)
+            for (int j = 0; j < 4; ++j) acc[i][j][q] = live ? acc[i][j][q] * acc_mul + bias[j] : 0.0f;     // pad rows -> 0 (gnn.py:43-45)
         }
     if (LN) {
         // LayerNorm over the 256 columns of a row: 4 lane-local values x 32 lanes x the two wn waves.
@@ -622,6 +646,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 dst[2 * ob + 1] = *reinterpret_cast<const half8 *>(p.w2_lo + idx);
             }
         };
+        const float h_mul = p.h_scale ? *p.h_scale : 1.0f;
+        const float u_mul = out_mul / ((p.w2_scale ? *p.w2_scale : 1.0f) * h_mul);       // Zt * out_scale from (W s_w) . (H s_h)
         unsigned long long t_fl0 = 0, t_fl1 = 0, t_fl2 = 0, t_fl3 = 0;
         if (p.stamps) t_fl0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
@@ -639,7 +665,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     _Float16 hi, lo;
-                    split2(keep ? acc[i][j][q] : 0.0f, hi, lo);
+                    split2(keep ? acc[i][j][q] * h_mul : 0.0f, hi, lo);
                     hw[j] = (unsigned)__builtin_bit_cast(unsigned short, hi);
                     lw[j] = (unsigned)__builtin_bit_cast(unsigned short, lo);
                 }
@@ -699,7 +725,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                     for (int q = 0; q < 16; ++q) {
                         const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
                         _Float16 hi, lo;
-                        split2(u[ob][nb][q], hi, lo);
+                        split2(u[ob][nb][q] * u_mul, hi, lo);
                         const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
                         stg[(nb * 4 + (r >> 3)) * kC8Stride + row * 8 + (r & 7)] = packed;
                     }
@@ -765,7 +791,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                     const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
                     const bool keep = rb * 32 + row < p.m && n < p.n;
                     _Float16 hi, lo;
-                    split2(keep ? acc[i][j][q] : 0.0f, hi, lo);
+                    split2(keep ? acc[i][j][q] * out_mul : 0.0f, hi, lo);
                     const unsigned packed = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
                     stg[(j * 4 + (r >> 3)) * kC8Stride + row * 8 + (r & 7)] = packed;
                 }
@@ -841,57 +867,60 @@ static void adjacency_grid(int n, unsigned &wgs, int &pair_tiles)
     else { pair_tiles = 0; wgs = (unsigned)((t_full + 1) / 2); }                 // a workgroup owns row tiles x and T-1-x
 }
 
-extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, void *adj_hi, void *adj_lo, void *stream)
+extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, float scale, void *adj_hi, void *adj_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: bad G=%d n=%d", G, n);
     if (G == 0) return SN_OK;
     SN_REQUIRE(edges && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: NULL pointer");
+    SN_REQUIRE(scale > 0.0f && scale <= 65536.0f, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: scale %g (a power of two in (0, 65536])", (double)scale);
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                        sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
-                       (const int32_t *)nullptr, pair_tiles);
+                       (const int32_t *)nullptr, pair_tiles, scale);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
 
 extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, const int32_t *n_valid, const int32_t *extent_dev,
-                                              void *adj_hi, void *adj_lo, void *stream)
+                                              float scale, void *adj_hi, void *adj_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_masked: bad G=%d n=%d", G, n);
     if (G == 0) return SN_OK;
     SN_REQUIRE(edges && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_masked: NULL pointer");
+    SN_REQUIRE(scale > 0.0f && scale <= 65536.0f, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_masked: scale %g (a power of two in (0, 65536])", (double)scale);
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes_masked: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles);
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
     return SN_OK;
 }
 
 extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n, int remove_self_loop,
-                                             void *adj_hi, void *adj_lo, void *stream)
+                                             float scale, void *adj_hi, void *adj_lo, void *stream)
 {
     SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: bad K=%d n=%d", K, n);
     if (K == 0) return SN_OK;
     SN_REQUIRE(pruned_edge_weights && row_sum && adj_hi && adj_lo, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: NULL pointer");
+    SN_REQUIRE(scale > 0.0f && scale <= 65536.0f, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: scale %g (a power of two in (0, 65536])", (double)scale);
     SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes: K=%d > 65535", K);
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, pair_tiles);
+                       (const int32_t *)nullptr, pair_tiles, scale);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }
 
 extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int E,
-                                    const int32_t *extent_dev, void *out_hi, void *out_lo, void *stream)
+                                    const int32_t *extent_dev, const float *scale_dev, void *out_hi, void *out_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0 && E > 0 && rows_table > 0, SN_ERR_BAD_ARG, "sn_gcn_gather_planes: bad G=%d n=%d E=%d", G, n, E);
     if (G == 0) return SN_OK;
@@ -899,13 +928,13 @@ extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const in
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_gather_planes: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
     hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)((kb * 16 + 63) / 64), (unsigned)G), dim3(256), 0, (hipStream_t)stream, table,
-                       rows_table, ids, n, kb, E, sn_gcn_plane_elems(E, n), (_Float16 *)out_hi, (_Float16 *)out_lo, extent_dev);
+                       rows_table, ids, n, kb, E, sn_gcn_plane_elems(E, n), (_Float16 *)out_hi, (_Float16 *)out_lo, extent_dev, scale_dev);
     SN_CHECK_LAUNCH("sn_gcn_gather_planes");
     return SN_OK;
 }
 
-extern "C" int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride, void *out_hi,
-                               void *out_lo, void *stream)
+extern "C" int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
+                               const float *scale_dev, void *out_hi, void *out_lo, void *stream)
 {
     SN_REQUIRE(batches >= 0 && rows > 0 && cols > 0 && ld >= cols, SN_ERR_BAD_ARG, "sn_split_planes: bad shape");
     if (batches == 0) return SN_OK;
@@ -914,7 +943,7 @@ extern "C" int sn_split_planes(const float *x, int batches, int rows, int cols, 
     const int kb = (cols + 15) / 16;
     const int64_t pieces = (int64_t)((rows + 31) & ~31) * kb * 2;
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((pieces + 255) / 256), (unsigned)batches), dim3(256), 0, (hipStream_t)stream, x,
-                       rows, cols, ld, batch_stride, kb, sn_gcn_plane_elems(rows, cols), (_Float16 *)out_hi, (_Float16 *)out_lo);
+                       rows, cols, ld, batch_stride, kb, sn_gcn_plane_elems(rows, cols), (_Float16 *)out_hi, (_Float16 *)out_lo, scale_dev);
     SN_CHECK_LAUNCH("sn_split_planes");
     return SN_OK;
 }
@@ -966,6 +995,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
     a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows;
     a.w2_hi = (const _Float16 *)u->next_w_hi; a.w2_lo = (const _Float16 *)u->next_w_lo;
+    a.a_scale = u->a_scale; a.b_scale = u->b_scale; a.out_scale = u->out_scale; a.w2_scale = u->next_w_scale; a.h_scale = u->next_h_scale;
     {
         static const int twin = getenv("SN_GEMM_FL_TWIN") ? atoi(getenv("SN_GEMM_FL_TWIN")) : 1;
         a.fl_twin = twin;

@@ -124,20 +124,32 @@ class GNN(nn.Module):
         l1, l2 = self.layers
         # weight-only operands: kept until one of the four weights changes (data_ptr / _version, like the packed codebook
         # of S1; `p.data.copy_` writes need `invalidate_prepared()`), so a forward pass launches no library GEMM
-        srcs = (self.embedding.weight, l1.g_conv.linear.weight, l2.g_conv.linear.weight, self.fc.weight)
+        srcs = (self.embedding.weight, l1.g_conv.linear.weight, l2.g_conv.linear.weight, self.fc.weight,
+                l1.norm.weight, l1.norm.bias, l2.norm.weight, l2.norm.bias)       # (the LayerNorm parameters: the operand scales)
         fused_gather = self.embed_dim == 256 and os.environ.get("SN_GCN_GATHER_FUSED", "1") == "1"
         fused_linear = self.embed_dim == 256 and os.environ.get("SN_GCN_FUSE_LINEAR", "1") == "1"
         key = tuple((t.data_ptr(), t._version, t.device) for t in srcs) + (fused_gather, fused_linear)
         if getattr(self, "_prepared", None) is not None and self._prepared[0] == key:
             return self._prepared[1]
         table = ops.gcn_gemm(ops.split_planes(self.embedding.weight), ops.split_planes(l1.g_conv.linear.weight), 1, want_c=True)["c"][0]
-        out = {"table": table, "w2": ops.split_planes(l2.g_conv.linear.weight),
+        # Power-of-two scales of the split-fp16 operands (csrc/sn_gcn.hip, "What hi + lo holds"): device scalars, computed
+        # here once per weight version without a host synchronisation.  Weight-only operands: from their largest
+        # magnitude.  Operands written by a GEMM epilogue: from a BOUND on what the epilogue can produce - a LayerNorm
+        # output is at most sqrt(255) < 16 standard deviations from its mean, so |H| <= 16 max|gamma| + max|beta|, and
+        # |W2 . H^T| <= max_o |W2[o, :]|_1 x that.
+        def ln_bound(norm):
+            return 16.0 * norm.weight.detach().abs().amax() + norm.bias.detach().abs().amax()
+        w2 = l2.g_conv.linear.weight.detach()
+        h1_bound = ln_bound(l1.norm)
+        out = {"table": table, "table_scale": ops.pow2_scale(table), "w2": ops.split_planes(w2),
+               "h1_scale": ops.pow2_scale(h1_bound), "h2_scale": ops.pow2_scale(ln_bound(l2.norm)),
+               "zt2_scale": ops.pow2_scale(h1_bound * w2.abs().sum(dim=1).amax()),
                "fc_t": self.fc.weight.detach().t().contiguous()}                      # [E, E_out]: ops.pool_fc reads whole lines of it
         if fused_gather:
             # layer 1 gathers its B operand inside the GEMM: 170 MB less HBM traffic and 20 us less kernel time per step
             # (+4 % with four in-line steps in flight, +3 % one step at a time; SN_GCN_GATHER_FUSED=0 = the
             # separate gather kernel)
-            out["table_planes"] = ops.table_planes(table)
+            out["table_planes"] = ops.table_planes(table, out["table_scale"])
         if fused_linear:
             # layer 2's Linear runs in the epilogue of layer 1's product (H1 never leaves the workgroup): its weight with
             # the columns in the epilogue's feature order
@@ -168,19 +180,21 @@ class GNN(nn.Module):
         if "table_planes" in prepared and adj.kpad <= 1024:
             # Bt[g, f, j] = table[ids[g, j], f] gathered inside the kernel (no [G, E, n] copy through HBM)
             t_hi, t_lo = prepared["table_planes"]
-            zt1, b_table = None, (t_hi, t_lo, ingredients.contiguous())
+            zt1, b_table = None, (t_hi, t_lo, ingredients.contiguous(), prepared["table_scale"])
         else:
-            zt1, b_table = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext), None     # Bt [G, E, n]
+            zt1, b_table = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext, scale=prepared["table_scale"]), None     # Bt [G, E, n]
         if "w2_next" in prepared:
             zt2 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                                layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
                                rows_valid=n_valid, want_planes=n, m_extent=ext, k_extent=ext, b_table=b_table,
-                               next_w=prepared["w2_next"])["planes"]                 # W2 @ H1^T [G, E, n], H1 never stored
+                               next_w=prepared["w2_next"], h_scale=prepared["h1_scale"],
+                               out_scale=prepared["zt2_scale"])["planes"]            # W2 @ H1^T [G, E, n], H1 never stored
         else:
             h1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                               layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
-                              rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext, b_table=b_table)["planes"]   # [G, n, E]
-            zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n)["planes"]      # A = W2 planes [1, E, E] -> [G, E, n]
+                              rows_valid=n_valid, want_planes=E, m_extent=ext, k_extent=ext, b_table=b_table,
+                              out_scale=prepared["h1_scale"])["planes"]             # [G, n, E]
+            zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n, out_scale=prepared["zt2_scale"])["planes"]      # A = W2 planes [1, E, E] -> [G, E, n]
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
                               rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext)["pooled"]   # [G, row tiles, E]
@@ -197,11 +211,12 @@ class GNN(nn.Module):
             adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)
         if prepared is None:
             prepared = self.prepare()
-        zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext)                    # Bt [G, E, n]
+        zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext, scale=prepared["table_scale"])   # Bt [G, E, n]
         c1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias, rows_valid=n_valid, want_c=True, zero_c=ext is not None,
                           m_extent=ext, k_extent=ext)["c"]                                           # [G, n, E]
         ops.mask_layernorm_act_(c1, l1.norm.weight, l1.norm.bias, l1.norm.eps, n_valid=n_valid, relu=l1._is_relu)
-        zt2 = ops.gcn_gemm(prepared["w2"], ops.split_planes(c1), G, want_planes=n)["planes"]       # [G, E, n]
+        zt2 = ops.gcn_gemm(prepared["w2"], ops.split_planes(c1, scale=prepared["h1_scale"]), G, want_planes=n,
+                           out_scale=prepared["zt2_scale"])["planes"]                                # [G, E, n]
         c2 = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias, rows_valid=n_valid, want_c=True, zero_c=ext is not None,
                           m_extent=ext, k_extent=ext)["c"]
         ops.mask_layernorm_act_(c2, l2.norm.weight, l2.norm.bias, l2.norm.eps, n_valid=n_valid, relu=l2._is_relu)
