@@ -534,7 +534,14 @@ __device__ __forceinline__ unsigned med3u(unsigned a, unsigned b, unsigned c)
 // NW waves per workgroup (32 tokens each) share one codebook-tile ring of R LDS slots.
 // CB = width of the word code in a key: 8 (tile < 64: M <= 2048) or 10 (tile < 256: M <= 8192; the keys lose two
 // more mantissa bits, which the error window accounts for, and the candidate records hold 16-bit codes).
-template <int NSTEPS, int NW, int R, int CB = 8>
+// DUAL: the k-steps of a tile alternate between TWO accumulator chains (even steps: `cur`, initialised with |c|^2/2 +
+// shift; odd steps: `accQ`, started from C = 0), summed once per tile before the keys are formed.  A wave alone on its
+// SIMD issues a dependent chain at one v_mfma_f32_32x32x16_f16 per 46 cycles, two independent chains at one per 32
+// (tools/mfma_loop_probe.hip): with the token-phase gate a workgroup is alone on its CU for most of its main loop.
+// Program order of the steps: 0, 2, [sum of the previous tile], 1, 4, 3, 6, 5, ... - the odd chain lags by one step so
+// that the sum (which reads accQ) sits two MFMA issues behind the previous tile's last odd step and ahead of the new
+// tile's first one.
+template <int NSTEPS, int NW, int R, int CB = 8, bool DUAL = false>
 __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen_kernel(const AssignArgs p)
 {
     constexpr unsigned kCodeMask = (1u << CB) - 1u, kTileMask = (1u << (CB - 2)) - 1u;
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     const float E = 1.01f * (2.01f * kU16 * X2 * C2                           // fp16 rounding of x and c
                              + 5.96e-8f * (X1 + C1)                           // fp16 subnormal flush
                              + (float)NSTEPS * kAccUlpPerMfma * vmax          // MFMA fp32 accumulate (starts at |c|^2/2 + shift)
-                             + vmax * (3.0f * 5.96e-8f + kKeyTrunc));         // hx/hc/adds rounding + key truncation
+                             + vmax * ((DUAL ? 4.0f : 3.0f) * 5.96e-8f + kKeyTrunc));         // hx/hc/adds rounding (DUAL: + the chain sum) + key truncation
     const float shift = hx + 2.0f * E;                                        // keeps every key non-negative
     const float window = 2.0f * E;
     const bool bad = !(maxabs <= kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e30f);   // NaN-safe
@@ -793,12 +800,13 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     // first fragments and initialises its accumulators (|c|^2/2 + shift).  One barrier per tile.
     constexpr int kRingA = (NSTEPS % 8 == 0) ? 8 : 4;
     static_assert(NSTEPS % kRingA == 0 && NSTEPS >= 2 * kRingA, "ring phase must repeat every tile");
-    constexpr int kInitStep = NSTEPS - kRingA;            // first step that touches tile w+1
-    constexpr int kKeyStep0 = 2;                          // first gap with a key (see key_insert)
+    constexpr int kInitStep = NSTEPS - kRingA;            // first position that touches tile w+1
+    constexpr int kKeyStep0 = DUAL ? 3 : 2;               // first gap with a key (see key_insert; DUAL: behind the chain sum)
     constexpr int kKeysPerStep = (16 + (NSTEPS - kKeyStep0) - 1) / (NSTEPS - kKeyStep0);
     static_assert(kKeyStep0 + (3 + kKeysPerStep) / kKeysPerStep <= kInitStep, "group 0 must be keyed before it is re-initialised");
+    static_assert(!DUAL || (NSTEPS % 2 == 0 && kInitStep >= 4), "two chains need an even number of k-steps");
     half8 ar[kRingA];
-    f32x16 accA, accB;
+    f32x16 accA, accB, accQ;
     unsigned keymask = ~kCodeMask;
     asm volatile("" : "+v"(keymask));                     // keep the mask in a VGPR (VOP3 has no literals on gfx9)
     auto frag_at = [&](int tile, int step) {
@@ -815,7 +823,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     // Written as volatile asm because hipcc otherwise gathers all key arithmetic of a tile pair in
     // the loop latch (the matrix pipe idles meanwhile and the accumulators get copied).  The asm
     // reads MFMA results the compiler's hazard recogniser cannot see: callers place it at least two
-    // MFMA issues (> 64 cycles) after the last MFMA that wrote `v`.
+    // MFMA issues (> 64 cycles) after the last MFMA that wrote `v` (DUAL: `v` comes out of the chain sum, a VALU result).
     auto key_insert = [&](float v, unsigned code, int g) {
         unsigned k;
         asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
@@ -836,19 +844,44 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     auto tile_step = [&](int w, f32x16 &cur, f32x16 &oth) {
         const unsigned code0 = (((unsigned)(w - 1)) & kTileMask) << 2;
 #pragma unroll
-        for (int s = 0; s < NSTEPS; ++s) {
-            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], cur, 0, 0, 0);
+        for (int pos = 0; pos < NSTEPS; ++pos) {
+            // k-step issued at this position (DUAL: 0, 2, 1, 4, 3, ..., NSTEPS-2, NSTEPS-3, NSTEPS-1)
+            const int s = !DUAL ? pos : (pos == 0 ? 0 : (pos == NSTEPS - 1 ? NSTEPS - 1 : ((pos & 1) ? pos + 1 : pos - 1)));
+            if (DUAL && pos == 2) {
+                // the previous tile's two chains become one value per word; accQ is free for this tile's odd chain
+#pragma unroll
+                for (int q = 0; q < 16; ++q) oth[q] += accQ[q];
+            }
+            if (!DUAL || (s & 1) == 0) cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], cur, 0, 0, 0);
+            else if (s == 1) {
+                f32x16 zero;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) zero[q] = 0.0f;                  // (an inline constant as the C operand: no registers)
+                accQ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], zero, 0, 0, 0);
+            } else accQ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[s % kRingA], b[s], accQ, 0, 0, 0);
+            if (DUAL && pos == kInitStep - 2) {
+                // (the position after this one prefetches tile w+1's first fragments: the ring barrier comes first)
+                int ahead = n_tiles - 2 - w;
+                ahead = ahead < 0 ? 0 : (ahead > R - 3 ? R - 3 : ahead);
+                unsigned long long ta = 0, tb = 0;
+                if (p.stamps) ta = __builtin_amdgcn_s_memtime();
+                wait_tiles(ahead);
+                __builtin_amdgcn_s_barrier();
+                if (p.stamps) tb = __builtin_amdgcn_s_memtime();
+                if (w + R - 1 < n_tiles) issue_tile(w + R - 1, (w + R - 1) % R);
+                if (p.stamps) { t_sync += tb - ta; t_dma += __builtin_amdgcn_s_memtime() - tb; }
+            }
             if (s + kRingA < NSTEPS) ar[s % kRingA] = frag_at(w, s + kRingA);
             else ar[s % kRingA] = frag_at(w + 1, s + kRingA - NSTEPS);      // (stale slot after the last tile: unused)
             // the 16 accumulators of tile w-1 become keys (w == 0: oth holds +inf, those keys never win)
-            if (s >= kKeyStep0) {
+            if (pos >= kKeyStep0) {
 #pragma unroll
-                for (int q = (s - kKeyStep0) * kKeysPerStep; q < (s - kKeyStep0 + 1) * kKeysPerStep && q < 16; ++q)
+                for (int q = (pos - kKeyStep0) * kKeysPerStep; q < (pos - kKeyStep0 + 1) * kKeysPerStep && q < 16; ++q)
                     key_insert(oth[q], code0 | (unsigned)(q & 3), q >> 2);
             }
-            if (s >= kInitStep && s < kInitStep + 4) init_group(oth, w + 1, s - kInitStep);
+            if (pos >= kInitStep && pos < kInitStep + 4) init_group(oth, w + 1, pos - kInitStep);
             __builtin_amdgcn_sched_barrier(0);                              // pin: MFMA, its DS read, this gap's VALU
-            if (s == kInitStep - 1) {
+            if (!DUAL && pos == kInitStep - 1) {
                 int ahead = n_tiles - 2 - w;                                 // tiles in flight beyond w+1
                 ahead = ahead < 0 ? 0 : (ahead > R - 3 ? R - 3 : ahead);
                 unsigned long long ta = 0, tb = 0;
@@ -887,14 +920,14 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
 #pragma unroll
     for (int g = 0; g < 4; ++g) init_group(accA, 0, g);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) accB[q] = INFINITY;
+    for (int q = 0; q < 16; ++q) { accB[q] = INFINITY; accQ[q] = 0.0f; }
     for (int w = 0; w < n_tiles; w += 2) {                    // n_tiles is even (pack_layout)
         tile_step(w, accA, accB);
         tile_step(w + 1, accB, accA);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may be in flight when the LDS is released
 #pragma unroll
-    for (int q = 0; q < 16; ++q) key_value(accB[q], n_tiles - 1, q);      // keys of the last tile
+    for (int q = 0; q < 16; ++q) key_value(DUAL ? accB[q] + accQ[q] : accB[q], n_tiles - 1, q);      // keys of the last tile
 
     stamp(p, 2, lane, wave_id);
     if (p.stamps && lane == 0) { p.stamps[(size_t)wave_id * 16 + 4] = t_sync; p.stamps[(size_t)wave_id * 16 + 5] = t_dma; }
@@ -1712,18 +1745,23 @@ int device_cus() { return sn_device_cus(); }
 // environment variable (default off: both measured slower at the bench shape); sn_debug_set_assign_options
 // overrides (A/B timing inside one process).
 int g_assign_opt[2] = {-1, -1};
+bool assign_dual()          // two accumulator chains per tile in the token-stationary screen (D = 384): SN_ASSIGN_DUAL
+{
+    static const int v = getenv("SN_ASSIGN_DUAL") ? atoi(getenv("SN_ASSIGN_DUAL")) : 0;
+    return v != 0;
+}
 bool assign_option(int i, const char *env)
 {
     if (g_assign_opt[i] < 0) { const char *e = getenv(env); g_assign_opt[i] = (e && atoi(e) != 0) ? 1 : 0; }
     return g_assign_opt[i] != 0;
 }
 
-template <int NSTEPS, int NW, int R, int CB = 8>
+template <int NSTEPS, int NW, int R, int CB = 8, bool DUAL = false>
 int launch_screen(const AssignArgs &a, hipStream_t st)
 {
     size_t lds = (size_t)R * (NSTEPS + 1) * 1024;
     if (const char *pad = getenv("SN_ASSIGN_LDS_PAD")) lds += (size_t)atoi(pad);     // diagnostics: force 1 workgroup per CU
-    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen_kernel<NSTEPS, NW, R, CB>, lds, "sn_assign_words")) return rc;
+    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen_kernel<NSTEPS, NW, R, CB, DUAL>, lds, "sn_assign_words")) return rc;
     const int tok_per_block = kTokPerWave * NW;
     unsigned grid = (unsigned)((a.n_tokens + tok_per_block - 1) / tok_per_block);
     AssignArgs ag = a;
@@ -1746,7 +1784,7 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     if (!(gate_on && NSTEPS <= 24 && NW == 4 && (int)grid > cus)) ag.gate = nullptr;
     else if (int rc = sn_zero_async(ag.gate, kGateBytes, st)) return rc;
     sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R, CB>), dim3(grid), dim3(64 * NW), lds, st, ag);
+    hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R, CB, DUAL>), dim3(grid), dim3(64 * NW), lds, st, ag);
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
     sn_prof_start(1, st);
@@ -1935,7 +1973,7 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
             else if (D == 384) rc = launch_screen<24, 4, 3, 10>(a, st);
             else rc = launch_screen<48, 4, 3, 10>(a, st);
         } else if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st);
-        else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : launch_screen<24, 4, 3>(a, st);
+        else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : (assign_dual() ? launch_screen<24, 4, 3, 8, true>(a, st) : launch_screen<24, 4, 3>(a, st));
         else rc = launch_screen<48, 4, 3>(a, st);
         if (rc) return rc;
     } else {
