@@ -156,7 +156,25 @@ def cpp_feat_to_instance_e(
         o += len(ks)
     n_out = max(ln) if ln else 0
     if n_out > 256:
-        raise RuntimeError(f"dictionary with {n_out} > 256 entries is not supported")
+        # The kernel addresses at most 256 output slots per image (an image holds at most L <= 196 distinct words); the
+        # reference takes dictionaries of any size (large_scale_feat_to_e.cpp:58-60: n = dictionary size).  An image
+        # only ever touches the slots of ITS words (a word the dictionary lacks goes to slot 0, :117-118), so run on the
+        # compacted slots and scatter the [n', n'] corner into the [n, n] zeros the reference returns elsewhere.
+        words = ingredients.tolist()
+        small, slots = [], []
+        for b, d in enumerate(batch_ingredient_dict):
+            used = sorted({d.get(w_, 0) for w_ in set(words[b])})
+            compact = {v: i for i, v in enumerate(used)}
+            small.append({w_: compact[d.get(w_, 0)] for w_ in set(words[b])})
+            slots.append(used)
+        parts = cpp_feat_to_instance_e(ingredients, attn, geo_sim, small, edge_attribute_weights, mean, remove_self_loop)
+        out = []
+        for b, d in enumerate(batch_ingredient_dict):
+            full = torch.zeros((len(d), len(d)), dtype=parts[b].dtype, device=parts[b].device)
+            idx = torch.tensor(slots[b], dtype=torch.int64, device=parts[b].device)
+            full[idx[:, None], idx[None, :]] = parts[b]
+            out.append(full)
+        return out
     i64 = dict(dtype=torch.int64, device=dev)
     dicts = (torch.tensor(keys + [0], **i64), torch.tensor(vals + [0], **i64),
              torch.tensor(off, **i64), torch.tensor(ln, **i64))

@@ -331,3 +331,31 @@ def test_split_fp16_gcn_is_as_good_as_the_fp32_reference(mods, name):
                                         "max_err_fp32_reference_over_scale": err_ref.max().item() / scale,
                                         "max_excess_over_reference_error_over_scale": worst / scale})
     assert (err_hip <= err_ref + 1e-6 * scale).all(), (name, err_hip.max().item() / scale, err_ref.max().item() / scale, worst / scale)
+
+
+# =============================================================================== dictionaries beyond the kernel's 256 output slots
+def test_instance_e_with_a_dictionary_of_more_than_256_entries(mods):
+    """`cpp_feat_to_instance_e` with the dictionary of a whole class graph (600 words -> slots, most of them absent from
+    the image; one word of the image missing from it: slot 0, large_scale_feat_to_e.cpp:117-118): the reference has no
+    size limit (:58-60), the kernel addresses 256 slots - the shim compacts and scatters.  Against the C oracle."""
+    from oracle import cabi, pyops
+    cx = mods["cx"]
+    rng = np.random.default_rng(5)
+    B, L, n_dict = 3, 196, 600
+    ing = rng.integers(0, 700, (B, L)).astype(np.int64)
+    attn = rng.normal(size=(B, L, L)).astype(np.float32)
+    p_attn = np.exp(attn - attn.max(-1, keepdims=True))
+    p_attn = (p_attn / p_attn.sum(-1, keepdims=True)).astype(np.float32)
+    geo = pyops.pair_wise_point_sim(14, 14)
+    w = np.asarray([[0.4], [0.6]], np.float32)
+    dicts = []
+    for b in range(B):
+        keys = rng.permutation(700)[:n_dict]
+        d = {int(k): int(v) for k, v in zip(keys, rng.permutation(n_dict))}
+        d.pop(int(ing[b, 0]), None)                     # a word of the image the dictionary lacks -> slot 0
+        dicts.append(d)
+    _, want = cabi.instance_e(ing, p_attn, geo, dicts, w, mean=True)
+    got = cx.cpp_feat_to_instance_e(torch.from_numpy(ing), torch.from_numpy(p_attn), torch.from_numpy(geo), dicts, T(w), True, False)
+    for g_, w_, d in zip(got, want, dicts):
+        assert tuple(g_.shape) == (len(d), len(d))
+        np.testing.assert_allclose(g_.cpu().numpy(), w_, rtol=5e-6, atol=1e-7)
