@@ -309,11 +309,15 @@ int sn_pool_fc_t(const float *pooled_parts, int G, int parts, int E, const int32
  *    and row_sum[k][i] = 1 / sum_j max(pruned edge_weights[k][i][j], 0) (0 when that sum is 0, inf or NaN);
  *  sn_gcn_atlas_adjacency_planes: adj = (E + E^T)/2 + I with E[i][j] = nan_to_num(max(w_ij, 0) *
  *    row_sum[i]) (diagonal zero when remove_self_loop) - the same values sn_atlas_normalize followed
- *    by sn_gcn_adjacency_planes produce, without writing and re-reading the [K, n, n] atlas. */
+ *    by sn_gcn_adjacency_planes produce, without writing and re-reading the [K, n, n] atlas.  class_edges_out
+ *    (optional, [K, n, n] fp32): E itself as a by-product of the same pass, for callers that hand `class_edges` on
+ *    (schema_inference/graph/__init__.py:52-54 of the reference returns it next to the scores); E = w * (1 / row sum),
+ *    i.e. within one rounding of sn_atlas_normalize's w / row sum. */
 int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,
                           float prune_threshold, float *class_vertices, float *row_sum, void *stream);
 int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n,
-                                  int remove_self_loop, float scale, void *adj_hi, void *adj_lo, void *stream);
+                                  int remove_self_loop, float scale, void *adj_hi, void *adj_lo, float *class_edges_out,
+                                  void *stream);
 
 /* fp16 elements of one plane of a [rows, k] operand (per batch entry). */
 int64_t sn_gcn_plane_elems(int rows, int k);

@@ -172,7 +172,7 @@ def cpp_feat_to_instance_e(
         for b, d in enumerate(batch_ingredient_dict):
             full = torch.zeros((len(d), len(d)), dtype=parts[b].dtype, device=parts[b].device)
             idx = torch.tensor(slots[b], dtype=torch.int64, device=parts[b].device)
-            full[idx[:, None], idx[None, :]] = parts[b]
+            full[idx[:, None], idx[None, :]] = parts[b][:idx.numel(), :idx.numel()]       # (the compact result is sized by its dictionary)
             out.append(full)
         return out
     i64 = dict(dtype=torch.int64, device=dev)

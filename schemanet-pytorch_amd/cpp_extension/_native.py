@@ -107,7 +107,7 @@ _SIGNATURES = {
     "sn_pool_fc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sn_pool_fc_t": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sn_atlas_prune_rowsum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
-    "sn_gcn_atlas_adjacency_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "sn_gcn_atlas_adjacency_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_plane_elems": (c_int64, [c_int, c_int]),
     "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_adjacency_planes_masked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),

@@ -361,9 +361,10 @@ def atlas_normalize(vertex_weights, edge_weights, prune_threshold=None, remove_s
     return cv, ce
 
 
-def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, remove_self_loop=False):
+def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, remove_self_loop=False, want_edges=False):
     """Fused atlas route: -> (class_vertices [K,n], Planes of (E + E^T)/2 + I with E the normalised
-    class edges); edge_weights is pruned IN PLACE; the [K,n,n] class_edges tensor is never written."""
+    class edges); edge_weights is pruned IN PLACE; the [K,n,n] class_edges tensor is never written - unless
+    want_edges: then it is a by-product of the same pass and a third result."""
     lib = N.require_gpu()
     dev = _check_dev(vertex_weights, edge_weights)
     K, n = vertex_weights.shape
@@ -375,10 +376,11 @@ def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, r
         N.check(lib.sn_atlas_prune_rowsum(N.ptr(vertex_weights), N.ptr(edge_weights), K, n, int(prune_threshold is not None),
                                           float(prune_threshold or 0.0), N.ptr(cv), N.ptr(rs), N.stream_ptr(dev)),
                 "sn_atlas_prune_rowsum")
+        ce = torch.empty((K, n, n), dtype=torch.float32, device=dev) if want_edges else None
         N.check(lib.sn_gcn_atlas_adjacency_planes(N.ptr(edge_weights), N.ptr(rs), K, n, int(remove_self_loop), ADJ_SCALE, N.ptr(out.hi),
-                                                  N.ptr(out.lo), N.stream_ptr(dev)), "sn_gcn_atlas_adjacency_planes")
+                                                  N.ptr(out.lo), N.ptr(ce), N.stream_ptr(dev)), "sn_gcn_atlas_adjacency_planes")
     out.scale = const_scale(ADJ_SCALE, dev)
-    return cv, out
+    return (cv, out, ce) if want_edges else (cv, out)
 
 
 # ------------------------------------------------------------------------------- S4

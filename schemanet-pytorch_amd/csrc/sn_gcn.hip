@@ -102,7 +102,8 @@ __device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h
 // 64 x 64 tile would be bound by the dispatch rate (~10 ns per workgroup chip-wide), not by HBM.
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
-                                                               const int32_t *extent, const int32_t *n_valid, int pair_tiles, float scale)
+                                                               const int32_t *extent, const int32_t *n_valid, int pair_tiles, float scale,
+                                                               float *edges_out)
 {
     __shared__ float te[64][65], tt[64][65];
     __shared__ float rs_i[64], rs_j[64];
@@ -173,6 +174,18 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
             for (int it = 0; it < 16; ++it) {
                 te[ty + 4 * it][tx] = ve[it];
                 tt[ty + 4 * it][tx] = vt[it];
+            }
+            if (edges_out) {
+                // by-product (atlas form only): the normalised class edges themselves, [n, n] fp32 per graph - what
+                // atlas_normalize_kernel writes (schema_net.py:152-175), for callers that return `class_edges` next to
+                // the scores (SchemaNetPredictor's dictionary) without a second pass over the atlas
+                float *eo = edges_out + (int64_t)g * n * n;
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int rr = ty + 4 * it;
+                    if (bi + rr < n && bj + tx < n) eo[(int64_t)(bi + rr) * n + bj + tx] = ve[it];
+                    if (J != I && bj + rr < n && bi + tx < n) eo[(int64_t)(bj + rr) * n + bi + tx] = vt[it];
+                }
             }
             __syncthreads();
             // pieces: 64 rows x 8 (k / 8) per output tile; thread -> row tx, pieces ty, ty + 4
@@ -879,7 +892,7 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const i
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                        sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
-                       (const int32_t *)nullptr, pair_tiles, scale);
+                       (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
@@ -896,13 +909,13 @@ extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, 
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale);
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
     return SN_OK;
 }
 
 extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n, int remove_self_loop,
-                                             float scale, void *adj_hi, void *adj_lo, void *stream)
+                                             float scale, void *adj_hi, void *adj_lo, float *class_edges_out, void *stream)
 {
     SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes: bad K=%d n=%d", K, n);
     if (K == 0) return SN_OK;
@@ -914,7 +927,7 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, pair_tiles, scale);
+                       (const int32_t *)nullptr, pair_tiles, scale, class_edges_out);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }

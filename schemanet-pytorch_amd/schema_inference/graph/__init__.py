@@ -65,14 +65,17 @@ class SchemaNetPredictor(nn.Module):
         ret = collections.OrderedDict()
         # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
         # instance branch on the current one; joined inside forward_padded
-        atlas = self.matcher.atlas_features_async(
-            self.schema_net.get_atlas, depends_on=self._atlas_depends_on())
+        get_atlas = self.schema_net.get_atlas
+        if not torch.is_grad_enabled() and self.matcher.gnn.masks_adjacency(self.schema_net.edge_weights.tensor):
+            # no autograd, MFMA GNN: the GCN operand and `class_edges` from ONE pass over the IR-Atlas
+            get_atlas = lambda: self.schema_net.get_atlas(fused_adjacency="with_edges")       # noqa: E731
+        atlas = self.matcher.atlas_features_async(get_atlas, depends_on=self._atlas_depends_on())
         # (the zero padding of the instance edges is only written when the caller asks for the graphs)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
                                                       zero_padding=requires_graph, return_attn_cls=requires_graph)
         ret["pred"] = self.matcher.forward_padded(graph, atlas.class_dict, feat_kg=atlas)
-        class_dict = atlas.class_dict
-        ret.update(class_dict)
+        for k in ("class_vertices", "class_edges", "class_ingredients"):                  # (the reference's keys, in its order)
+            ret[k] = atlas.class_dict[k]
         if requires_graph:
             n = int(graph["n_max"].item())
             bs = graph["ids"].shape[0]

@@ -167,9 +167,15 @@ class SchemaNet(nn.Module):
         fused_adjacency=True (inference only) skips the [K, n, n] `class_edges` tensor: the dict
         then carries `class_adjacency` = the GCN operand (E + E^T)/2 + I as split-fp16 planes, built
         straight from the pruned parameters (same values, one pass less over the atlas); `Matcher`
-        consumes it directly."""
+        consumes it directly.  fused_adjacency="with_edges": both - `class_edges` is written by the same pass (within
+        one rounding of the unfused route: w * (1 / row sum) instead of w / row sum); what SchemaNetPredictor uses."""
         vw, ew = self.vertex_weights.tensor, self.edge_weights.tensor
         if fused_adjacency and vw.is_cuda and (detach or not self._needs_grad(vw, ew)):
+            if fused_adjacency == "with_edges":      # the reference's dictionary AND the GCN operand from one pass over the atlas
+                cv, adj, ce = ops.atlas_adjacency_planes(vw.detach(), ew.detach(), self.prune_node_threshold, self.remove_self_loop,
+                                                         want_edges=True)
+                return {"class_vertices": cv, "class_edges": ce, "class_ingredients": self.class_ingredients.tensor,
+                        "class_adjacency": adj}
             cv, adj = ops.atlas_adjacency_planes(vw.detach(), ew.detach(), self.prune_node_threshold, self.remove_self_loop)
             return {"class_vertices": cv, "class_adjacency": adj, "class_ingredients": self.class_ingredients.tensor}
         if vw.is_cuda and (detach or not self._needs_grad(vw, ew)):

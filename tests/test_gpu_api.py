@@ -350,12 +350,33 @@ def test_instance_e_with_a_dictionary_of_more_than_256_entries(mods):
     w = np.asarray([[0.4], [0.6]], np.float32)
     dicts = []
     for b in range(B):
-        keys = rng.permutation(700)[:n_dict]
-        d = {int(k): int(v) for k, v in zip(keys, rng.permutation(n_dict))}
-        d.pop(int(ing[b, 0]), None)                     # a word of the image the dictionary lacks -> slot 0
-        dicts.append(d)
+        pool = rng.permutation(700)
+        keys = pool[pool != ing[b, 0]][:n_dict]         # a word of the image the dictionary lacks -> slot 0
+        dicts.append({int(k): int(v) for k, v in zip(keys, rng.permutation(n_dict))})
     _, want = cabi.instance_e(ing, p_attn, geo, dicts, w, mean=True)
     got = cx.cpp_feat_to_instance_e(torch.from_numpy(ing), torch.from_numpy(p_attn), torch.from_numpy(geo), dicts, T(w), True, False)
     for g_, w_, d in zip(got, want, dicts):
         assert tuple(g_.shape) == (len(d), len(d))
         np.testing.assert_allclose(g_.cpu().numpy(), w_, rtol=5e-6, atol=1e-7)
+
+
+def test_atlas_pass_writes_class_edges_as_a_by_product(mods):
+    """get_atlas(fused_adjacency="with_edges") (what the predictor uses without autograd): the GCN operand is the one of the
+    plain fused route bit for bit, and `class_edges` is what sn_atlas_normalize writes to within one rounding (w x (1 / row
+    sum) against w / row sum; reference schema_net.py:152-175) - NaN / negative / pruned / infinite weights included."""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(33)
+    K, n = 5, 200
+    vw = torch.rand(K, n, generator=g); vw[:, ::7] = 0.0
+    ew = torch.randn(K, n, n, generator=g)
+    ew[0, 3, 5] = float("nan"); ew[1, 4, :] = -1.0; ew[2, 6, 7] = float("inf")
+    for rsl in (False, True):
+        a, b, c = (ew.clone().to(DEV) for _ in range(3))
+        cv0, ce0 = ops.atlas_normalize(vw.to(DEV), a, 0.004, rsl)
+        cv1, adj1 = ops.atlas_adjacency_planes(vw.to(DEV), b, 0.004, rsl)
+        cv2, adj2, ce2 = ops.atlas_adjacency_planes(vw.to(DEV), c, 0.004, rsl, want_edges=True)
+        assert torch.equal(cv0, cv2) and torch.equal(cv1, cv2)
+        assert torch.equal(a.nan_to_num(7.0), c.nan_to_num(7.0))                        # the same in-place pruning
+        assert torch.equal(adj1.hi, adj2.hi) and torch.equal(adj1.lo, adj2.lo)
+        assert torch.isfinite(ce2).all() and torch.equal(ce0 == 0, ce2 == 0)
+        np.testing.assert_allclose(ce2.cpu().numpy(), ce0.cpu().numpy(), rtol=4e-7, atol=0)             # (two roundings instead of one: <= 2 ulp)
