@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <utility>
 
+#ifndef SN_S1_EXACT_LOSS
+#define SN_S1_EXACT_LOSS 1  // window from the token's measured fp16 rounding loss |x - fp16(x)|_2 (0: from its bound u |x|_2: two VALU per pair less in the token phase, 1.4 x as many tokens to re-rank)
+#endif
 #ifndef SN_S1_STAGE
 #define SN_S1_STAGE 1       // token rows through LDS in whole cache lines (0: fragment loads straight from global memory)
 #endif
@@ -52,7 +55,7 @@ constexpr float kAccUlpPerMfma = 8.0f * 5.9604645e-8f;
 //                                           holding -c (negated), then one chunk whose first 128 B
 //                                           are |c|^2 / 2 (fp32) in accumulator-row order
 //   cn64    [M_pad] f64  |c|^2 (oracle summation order)
-//   scal    [0] max |c|_2  [1] max |c|_1  [2] max |c|^2  [3] max |c_mk|   (uint bits of floats)
+//   scal    [0] max |c|_2  [1] max |c|_1  [2] max |c|^2  [3] max |c_mk|  [4] max |c - fp16(c)|_2   (uint bits of floats)
 //   frag2   [4 waves][nt2 tiles][ks2 k-steps][1 KiB]   (register-stationary screen, see assign_screen2_kernel)
 //                                           v_mfma_f32_32x32x16_f16 A-fragments of -c: wave q owns words
 //                                           [32 nt2 q, 32 nt2 (q+1)), tile a = 32 of them, lane (r, h) of k-step js
@@ -153,15 +156,18 @@ __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, 
         return;
     }
     const float *c = cb + (int64_t)m * D;
-    double p = 0.0;
+    double p = 0.0, dq = 0.0;
     float l1 = 0.0f, mx = 0.0f;
     for (int k = lane; k < D; k += SN_WAVE) {
         const float v = c[k];
         p = fma((double)v, (double)v, p);
         l1 += fabsf(v);
         mx = fmaxf(mx, fabsf(v));
+        const double dv = (double)v - (double)(float)(_Float16)v;        // what the fp16 image of the word loses (exact)
+        dq = fma(dv, dv, dq);
     }
     p = sn_wave_sum_f64(p);
+    dq = sn_wave_sum_f64(dq);
     l1 = sn_wave_sum(l1);
     mx = sn_wave_max(mx);
     if (lane == 0) {
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, 
         atomicMax(&scal[1], __float_as_uint(l1 * (1.0f + 1.0e-4f)));
         atomicMax(&scal[2], __float_as_uint((float)p * up));
         atomicMax(&scal[3], __float_as_uint(mx));
+        atomicMax(&scal[4], __float_as_uint((float)sqrt(dq) * up + 1.0e-30f));      // max_m |c_m - fp16(c_m)|_2
     }
 }
 
@@ -637,16 +644,27 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     const int64_t n = wave_tok0 + r;
     const bool valid = n < p.n_tokens;
     half8 b[NSTEPS];
-    float sumsq = 0.0f, sumabs = 0.0f, maxabs = 0.0f;
+    float sumsq = 0.0f, sumd = 0.0f;
+    // sumd = |x - fp16(x)|^2, what the fp16 fragments lose (exact differences, fp32 sum): with the codebook's own loss
+    // (scal[4]) it replaces the worst-case rounding term 2.01 u |x| |c| of the window by |x| |dc| + |dx| |c~| - 2.5 x
+    // tighter on ordinary data, so 2-3 x fewer tokens go to the fp64 re-rank
+    // (packed fp32 arithmetic - v_pk_fma_f32 / v_pk_add_f32, two elements per instruction - keeps the VALU count of the
+    // token phase where it was before the loss was measured: sumsq and sumd are then two partial sums each)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 half2s __attribute__((ext_vector_type(2)));
+    f32x2 sq2 = {0.0f, 0.0f}, sd2 = {0.0f, 0.0f};
     auto convert = [&](int u, const float (&f)[16]) {          // 16 consecutive floats of the lane's token -> k-steps 2u, 2u+1
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            sumsq = fmaf(f[j], f[j], sumsq);
-            sumabs += fabsf(f[j]);
-            maxabs = fmaxf(maxabs, fabsf(f[j]));
+        for (int j = 0; j < 16; j += 2) {                      // (neighbours: the pair is a register pair as loaded, no copies)
+            const f32x2 v = {f[j], f[j + 1]};
+            sq2 = __builtin_elementwise_fma(v, v, sq2);
+            const half2s hp = __builtin_convertvector(v, half2s);                       // v_cvt_pk_f16_f32 (round to nearest)
+            b[2 * u + (j >> 3)][j & 7] = hp.x; b[2 * u + (j >> 3)][(j & 7) + 1] = hp.y;
+#if SN_S1_EXACT_LOSS
+            const f32x2 d = v - __builtin_convertvector(hp, f32x2);                     // from the SAME converted pair
+            sd2 = __builtin_elementwise_fma(d, d, sd2);
+#endif
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { b[2 * u][j] = (_Float16)f[j]; b[2 * u + 1][j] = (_Float16)f[8 + j]; }
     };
 #if SN_S1_STAGE
     // Loading a B fragment straight from global memory makes every wave-instruction touch 64 different cache
@@ -768,23 +786,32 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     }
 #endif
     if (p.gate && lane == 0) atomicAdd(gate + 1, 1u);       // this wave's tokens have landed (result unused: no wait)
+    sumsq = sq2.x + sq2.y;
+    sumd = sd2.x + sd2.y;
     sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
-    sumabs += __shfl_xor(sumabs, 32, SN_WAVE);
-    maxabs = fmaxf(maxabs, __shfl_xor(maxabs, 32, SN_WAVE));
+    sumd += __shfl_xor(sumd, 32, SN_WAVE);
 
     // ---- per-token error window (DESIGN.md "S1 error window"): |v_key - v_exact| <= E
     const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
     const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
-    const float X2 = sqrtf(sumsq) * 1.001f, X1 = sumabs * 1.001f;
+    const float DC = __uint_as_float(scal[4]);                                // max |c - fp16(c)|_2
+    const float X2 = sqrtf(sumsq) * 1.001f, X1 = X2 * sqrtf((float)p.D);      // (|x|_1 <= sqrt(D) |x|_2)
+#if SN_S1_EXACT_LOSS
+    const float DX = sqrtf(sumd) * 1.001f + 1.0e-30f;                         // |x - fp16(x)|_2 (inf / NaN tokens: `bad` below)
+#else
+    const float DX = kU16 * X2 + 1.0e-30f;                                    // |x_k - fp16(x_k)| <= u |x_k| (+ the subnormal term below)
+#endif
     const float hx = 0.5f * sumsq;
     const float vmax = 0.5f * CN + 0.5f * X2 * X2 + X2 * C2;                 // >= any v (before the shift)
-    const float E = 1.01f * (2.01f * kU16 * X2 * C2                           // fp16 rounding of x and c
+    // x.c - x~.c~ = x.(c - c~) + (x - x~).c~  (exactly), each term by Cauchy-Schwarz; |c~| <= (1 + u) |c|
+    const float E = 1.01f * (1.001f * (X2 * DC + DX * C2 * 1.0005f)            // fp16 rounding of x and c
                              + 5.96e-8f * (X1 + C1)                           // fp16 subnormal flush
                              + (float)NSTEPS * kAccUlpPerMfma * vmax          // MFMA fp32 accumulate (starts at |c|^2/2 + shift)
                              + vmax * ((DUAL ? 4.0f : 3.0f) * 5.96e-8f + kKeyTrunc));         // hx/hc/adds rounding (DUAL: + the chain sum) + key truncation
     const float shift = hx + 2.0f * E;                                        // keeps every key non-negative
     const float window = 2.0f * E;
-    const bool bad = !(maxabs <= kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e30f);   // NaN-safe
+    // (|x|_2 <= kHugeIn bounds every component; inf / NaN components make the sum of squares inf / NaN)
+    const bool bad = !(sumsq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e30f);   // NaN-safe
 
     stamp(p, 1, lane, wave_id);
     unsigned m1[4], m2[4], m3[4];
