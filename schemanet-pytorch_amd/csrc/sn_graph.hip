@@ -15,6 +15,8 @@
 //   scripts/init_schema_net.py:33-35, 59-61 (per-class sums)
 #include "sn_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -165,29 +167,62 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
                                                       int64_t stride_h, int L, bool is_logits, bool use_clamp,
                                                       float clamp, int wid, int nw, int lane)
 {
-    constexpr int kRowsInFlight = 4;        // HBM latency: 4 rows (x heads) of loads in flight per wave
+    constexpr int kRowsInFlight = 4;        // HBM latency: 4 rows of loads in flight per wave
+    if (heads > 1) {
+        // Head mean fused (the backbone's [bs, H, L+1, L+1] tap): the loads of ALL heads of a pair of rows are issued before
+        // the first add - up to 6 heads x 2 rows = 12 row loads in flight per wave (one head after the other was a chain
+        // of H dependent HBM round trips per row batch: 6 heads, 931 KB per image).  Heads are added in order 0, 1, 2, ...
+        // as before (same sums bit for bit).
+        constexpr int kHB = 6, kRB = 2;
+        for (int r0 = wid; r0 < L; r0 += nw * kRB) {
+            float x[kRB][4];
+            for (int h0 = 0; h0 < heads; h0 += kHB) {
+                float y[kHB][kRB][4];
+#pragma unroll
+                for (int hh = 0; hh < kHB; ++hh) {
+                    const int hc = min(h0 + hh, heads - 1);         // (past the last head: a repeated load nobody adds)
+#pragma unroll
+                    for (int i = 0; i < kRB; ++i)
+                        load_row4<kVec>(src + hc * stride_h + (int64_t)min(r0 + nw * i, L - 1) * stride_r, L, lane, y[hh][i]);
+                }
+#pragma unroll
+                for (int hh = 0; hh < kHB; ++hh) {
+                    if (h0 + hh >= heads) break;                     // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < kRB; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) x[i][k] = (h0 + hh == 0) ? y[hh][i][k] : x[i][k] + y[hh][i][k];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kRB; ++i) {
+                const int r = r0 + nw * i;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[i][k] = x[i][k] / (float)heads;
+                if (is_logits) softmax_row4<kVec, kFast>(x[i], L, lane, use_clamp, clamp);
+                if (r < L) {                                   // wave-uniform
+                    if (kVec) {
+                        if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int c = lane + SN_WAVE * k;
+                            if (c < L) A[r * L + c] = x[i][k];
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int r0 = wid; r0 < L; r0 += nw * kRowsInFlight) {
         float x[kRowsInFlight][4];
 #pragma unroll
         for (int i = 0; i < kRowsInFlight; ++i)
             load_row4<kVec>(src + (int64_t)min(r0 + nw * i, L - 1) * stride_r, L, lane, x[i]);
-        for (int h = 1; h < heads; ++h) {
-            float y[kRowsInFlight][4];
-#pragma unroll
-            for (int i = 0; i < kRowsInFlight; ++i)
-                load_row4<kVec>(src + h * stride_h + (int64_t)min(r0 + nw * i, L - 1) * stride_r, L, lane, y[i]);
-#pragma unroll
-            for (int i = 0; i < kRowsInFlight; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[i][k] += y[i][k];
-        }
 #pragma unroll
         for (int i = 0; i < kRowsInFlight; ++i) {
             const int r = r0 + nw * i;
-            if (heads > 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[i][k] = x[i][k] / (float)heads;
-            }
             if (is_logits) softmax_row4<kVec, kFast>(x[i], L, lane, use_clamp, clamp);
             if (r < L) {                                   // wave-uniform
                 if (kVec) {
@@ -849,6 +884,11 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
 #pragma unroll
     for (int k = 0; k < kCellsPerLane; ++k) rcnt[k] = 1.0f / (float)(cc.cnt[k] > 0 ? cc.cnt[k] : 1);
     unsigned long long dt_a = 0, dt_b = 0;                  // diagnostics (stamps on): wave 0's time in passes a / b
+    // KC = 64-column cells of an output row a lane holds: an image with at most 64 / 128 distinct words (the usual case:
+    // ~113 of 196 positions) needs one / two, not four - every per-cell instruction of the scan gathers, the means, the
+    // normalisation and the stores is issued KC times per row
+    auto edge_rows = [&](auto kc_c) {
+    constexpr int KC = decltype(kc_c)::value;
     for (int r = wid; r < a.n_pad; r += nw) {
         const int gi = (r < n_out && r < kMaxCols) ? s.rev[r] : -1;
         float c0[kCellsPerLane], c1[kCellsPerLane];
@@ -940,7 +980,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     if (4 * lane < L) *reinterpret_cast<f32x4 *>(stage + 16 * lane) = v4;
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int k = 0; k < kCellsPerLane; ++k) {
+                    for (int k = 0; k < KC; ++k) {
                         const int last = cc.cnt[k] > 0 ? cc.ja[k] + cc.cnt[k] - 1 : 0;
                         const float v = *reinterpret_cast<const float *>(stage + last * 4);
                         if (pass) sg[k] = v; else sa[k] = v;
@@ -955,7 +995,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     if (qok[k]) *reinterpret_cast<float *>(stage + qsidx4[k]) = pass ? csg[k] : csa[k];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int k = 0; k < kCellsPerLane; ++k) {
+                for (int k = 0; k < KC; ++k) {
                     float acc = 0.0f;
                     const char *run = stage + cc.ja[k] * 4;
                     const int last = cc.cnt[k] > 0 ? cc.cnt[k] - 1 : 0;
@@ -969,7 +1009,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             }
             if (stamps) { dt_a += ts1 - ts0; dt_b += __builtin_amdgcn_s_memtime() - ts1; }
 #pragma unroll
-            for (int k = 0; k < kCellsPerLane; ++k) {
+            for (int k = 0; k < KC; ++k) {
                 const bool has = cc.cnt[k] > 0;
                 c0[k] = has ? sg[k] : 0.0f;
                 c1[k] = has ? sa[k] : 0.0f;
@@ -977,7 +1017,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if (a.mean) {                                    // wave-uniform; 1 / (rows x columns) as two reciprocals (2 ulp)
                 const float rr = __builtin_amdgcn_rcpf((float)(ib - ia));
 #pragma unroll
-                for (int k = 0; k < kCellsPerLane; ++k) {
+                for (int k = 0; k < KC; ++k) {
                     const float inv = rr * rcnt[k];
                     c0[k] = c0[k] * inv;
                     c1[k] = c1[k] * inv;
@@ -993,7 +1033,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             continue;
         }
 #pragma unroll
-        for (int k = 0; k < kCellsPerLane; ++k) { t0 += c0[k]; t1 += c1[k]; }
+        for (int k = 0; k < KC; ++k) { t0 += c0[k]; t1 += c1[k]; }
         t0 = wave_sum_fast(t0);   // instance_edges.sum(1, keepdim)  :135
         t1 = wave_sum_fast(t1);
         const float i0 = __builtin_amdgcn_rcpf(t0), i1 = __builtin_amdgcn_rcpf(t1);     // one v_rcp_f32 per row (x * rcp(t) vs x / t: 2 ulp; a correctly rounded 1 / t is ten instructions)
@@ -1001,7 +1041,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
         const bool plain = t0 > 0.0f && t0 < INFINITY && t1 > 0.0f && t1 < INFINITY;      // wave-uniform
         const int64_t rowbase = ((int64_t)b * a.n_pad + r) * a.n_pad;
 #pragma unroll
-        for (int k = 0; k < kCellsPerLane; ++k) {
+        for (int k = 0; k < KC; ++k) {
             const int c = lane + SN_WAVE * k;
             if (c >= a.n_pad || (a.skip_edge_padding && c >= n_out)) continue;
             float e0 = 0.0f, e1 = 0.0f;
@@ -1017,10 +1057,17 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 a.out_e[rowbase + c] = p0 + p1;
             }
         }
-        for (int c = kMaxCols + lane; c < a.n_pad && !a.skip_edge_padding; c += SN_WAVE) {
+        for (int c = SN_WAVE * KC + lane; c < a.n_pad && !a.skip_edge_padding; c += SN_WAVE) {          // (columns past the cells this variant holds: padding)
             if (a.out_e2) { a.out_e2[2 * (rowbase + c)] = 0.0f; a.out_e2[2 * (rowbase + c) + 1] = 0.0f; }
             if (a.out_e) a.out_e[rowbase + c] = 0.0f;
         }
+    }
+    };
+    {
+        const int n_cols = a.n_pad < n_out ? a.n_pad : n_out;
+        if (n_cols <= SN_WAVE) edge_rows(std::integral_constant<int, 1>{});
+        else if (n_cols <= 2 * SN_WAVE) edge_rows(std::integral_constant<int, 2>{});
+        else edge_rows(std::integral_constant<int, kCellsPerLane>{});
     }
     __syncthreads();
     SN_GSTAMP(5);
