@@ -165,16 +165,16 @@ __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool u
 template <bool kVec, bool kFast>
 __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src, int64_t stride_r, int heads,
                                                       int64_t stride_h, int L, bool is_logits, bool use_clamp,
-                                                      float clamp, int wid, int nw, int lane)
+                                                      float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr)
 {
-    constexpr int kRowsInFlight = 4;        // HBM latency: 4 rows of loads in flight per wave
+    constexpr int kRowsInFlight = 7;        // HBM latency: 7 rows of loads in flight per wave (196 rows on 15 waves: two batches; four in flight = four batches of exposed latency: 25.6 k -> see DESIGN 3.2)
     if (heads > 1) {
         // Head mean fused (the backbone's [bs, H, L+1, L+1] tap): the loads of ALL heads of a pair of rows are issued before
         // the first add - up to 6 heads x 2 rows = 12 row loads in flight per wave (one head after the other was a chain
         // of H dependent HBM round trips per row batch: 6 heads, 931 KB per image).  Heads are added in order 0, 1, 2, ...
         // as before (same sums bit for bit).
         constexpr int kHB = 6, kRB = 2;
-        for (int r0 = wid; r0 < L; r0 += nw * kRB) {
+        for (int r0 = rb; r0 < re; r0 += rs * kRB) {
             float x[kRB][4];
             for (int h0 = 0; h0 < heads; h0 += kHB) {
                 float y[kHB][kRB][4];
@@ -183,7 +183,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
                     const int hc = min(h0 + hh, heads - 1);         // (past the last head: a repeated load nobody adds)
 #pragma unroll
                     for (int i = 0; i < kRB; ++i)
-                        load_row4<kVec>(src + hc * stride_h + (int64_t)min(r0 + nw * i, L - 1) * stride_r, L, lane, y[hh][i]);
+                        load_row4<kVec>(src + hc * stride_h + (int64_t)min(r0 + rs * i, L - 1) * stride_r, L, lane, y[hh][i]);
                 }
 #pragma unroll
                 for (int hh = 0; hh < kHB; ++hh) {
@@ -196,11 +196,11 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
             }
 #pragma unroll
             for (int i = 0; i < kRB; ++i) {
-                const int r = r0 + nw * i;
+                const int r = r0 + rs * i;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) x[i][k] = x[i][k] / (float)heads;
                 if (is_logits) softmax_row4<kVec, kFast>(x[i], L, lane, use_clamp, clamp);
-                if (r < L) {                                   // wave-uniform
+                if (r < re) {                                  // wave-uniform
                     if (kVec) {
                         if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
                     } else {
@@ -215,16 +215,59 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
         }
         return;
     }
-    for (int r0 = wid; r0 < L; r0 += nw * kRowsInFlight) {
+    if (rs == 0) {
+        // Dynamic batches (the sixteen-wave prediction kernel): a wave takes kDyn rows at a time from a counter in LDS and
+        // has the next batch's loads in flight while it soft-maxes this one.  The row phase ends with the slowest wave,
+        // and a static split loses both to the wave that shares its SIMD with the sorting wave and to whichever wave's
+        // loads come back late (first barrier at 35-37 k cycles with every wave's own work done by 27 k).
+        constexpr int kDyn = 4;
+        int r0 = rb;
+        float x[kDyn][4];
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(r0 + i, L - 1) * stride_r, L, lane, x[i]);
+        while (r0 < L) {
+            int rn = 0;
+            if (lane == 0) rn = atomicAdd(next_row, kDyn);
+            rn = __builtin_amdgcn_readfirstlane(rn);
+            float y[kDyn][4];
+            if (rn < L) {
+#pragma unroll
+                for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(rn + i, L - 1) * stride_r, L, lane, y[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) {
+                const int r = r0 + i;
+                if (is_logits) softmax_row4<kVec, kFast>(x[i], L, lane, use_clamp, clamp);
+                if (r < L) {                                   // wave-uniform
+                    if (kVec) {
+                        if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int c = lane + SN_WAVE * k;
+                            if (c < L) A[r * L + c] = x[i][k];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[i][k] = y[i][k];
+            r0 = rn;
+        }
+        return;
+    }
+    for (int r0 = rb; r0 < re; r0 += rs * kRowsInFlight) {
         float x[kRowsInFlight][4];
 #pragma unroll
         for (int i = 0; i < kRowsInFlight; ++i)
-            load_row4<kVec>(src + (int64_t)min(r0 + nw * i, L - 1) * stride_r, L, lane, x[i]);
+            load_row4<kVec>(src + (int64_t)min(r0 + rs * i, L - 1) * stride_r, L, lane, x[i]);
 #pragma unroll
         for (int i = 0; i < kRowsInFlight; ++i) {
-            const int r = r0 + nw * i;
+            const int r = r0 + rs * i;
             if (is_logits) softmax_row4<kVec, kFast>(x[i], L, lane, use_clamp, clamp);
-            if (r < L) {                                   // wave-uniform
+            if (r < re) {                                  // wave-uniform
                 if (kVec) {
                     if (lane * 4 < L) *reinterpret_cast<float4 *>(A + r * L + lane * 4) = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
                 } else {
@@ -242,13 +285,13 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
 template <bool kFast = false>
 __device__ inline void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
                                         int64_t stride_h, int L, bool is_logits, bool use_clamp,
-                                        float clamp, int wid, int nw, int lane)
+                                        float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr)
 {
     // (rows need not be 16-byte aligned in global memory: gfx950 serves a dword-aligned global_load_dwordx4 correctly,
     // tools/unaligned_probe.hip; the slices of the backbone's [.., 197, 197] tap never are.  The LDS rows are: L % 4 == 0.)
     const bool vec = (L % 4 == 0) && (kFast || ((stride_r % 4 == 0) && (stride_h % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)));
-    if (vec) attn_rows_to_lds_impl<true, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
-    else attn_rows_to_lds_impl<false, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, wid, nw, lane);
+    if (vec) attn_rows_to_lds_impl<true, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row);
+    else attn_rows_to_lds_impl<false, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,7 +460,15 @@ __device__ inline PosInfo group_positions(const Lds &s, int L, int tid, bool kep
 // ~36 000 of the ballot form above, and the other fifteen waves spend the time on the attention rows.
 // `w4[e]` / key slot e of lane l: position l + 64 e on entry.  Returns false (nothing written) when a word does not
 // fit the key; the caller then runs group_positions.
-__device__ inline bool group_positions_sorted(const Lds &s, int L, int lane, const int64_t (&w4)[4], bool want_sum)
+struct SortedGroups {                 // what a lane of the sorting wave knows about its four sorted slots (4 lane + e)
+    bool head[4];                     // first position of its word
+    int g[4], cnt[4];                 // group index, positions of the word
+    float sum[4];                     // heads: cls-attention sum of the word in position order
+    unsigned key[4];                  // word << 8 | position (0xFFFFFFFF: empty slot)
+    int n_groups;
+};
+
+__device__ __forceinline__ bool group_positions_sorted(const Lds &s, int L, int lane, const int64_t (&w4)[4], bool want_sum, SortedGroups &sg_out)
 {
     unsigned key[4];
     bool fits = true;
@@ -507,6 +558,11 @@ __device__ inline bool group_positions_sorted(const Lds &s, int L, int lane, con
         s.flag[pos] = (unsigned char)(1 | (head[e] ? 2 : 0) | 4);
         if (head[e]) { s.pgroup[pos] = (unsigned char)g[e]; s.psum[pos] = sum[e]; }
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sg_out.head[e] = head[e]; sg_out.g[e] = g[e]; sg_out.cnt[e] = cnt[e]; sg_out.sum[e] = sum[e]; sg_out.key[e] = key[e];
+    }
+    sg_out.n_groups = n_groups;
     return true;
 }
 
@@ -640,12 +696,23 @@ static unsigned long long *g_graph_stamps = nullptr;      // diagnostics only (s
 
 #define SN_GSTAMP(slot)                                                                          \
     do {                                                                                          \
-        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <bool kEdges>
+// kFast: the configuration of the prediction path, fixed at compile time - edges weighted by w_e only (no [.., 2]
+// attribute tensor), means, self loops kept, canonical rows (no dictionary), the built-in grid table in its signed form, the
+// zero padding of the edges left to the consumer, L a multiple of 4 and at most 256.  The edges phase is bound by the
+// VALU instructions it issues (4 SIMD-cycles each): every run-time option is a branch, a select or a scalar that lives
+// in a spilled SGPR (a v_readlane per use) in the row loop.
+template <bool kEdges, bool kFast = false>
 __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a, unsigned long long *stamps, int signed_table)
 {
+    const bool c_mean = kFast || a.mean != 0;
+    const bool c_rsl = !kFast && a.remove_self_loop != 0;
+    const bool c_skip = kFast || a.skip_edge_padding != 0;
+    float *const c_out_e2 = kFast ? nullptr : a.out_e2;
+    const float *const c_geo = kFast ? nullptr : a.geo;
+    const int64_t *const c_dict = kFast ? nullptr : a.dict_keys;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int L = a.L, b = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
@@ -656,17 +723,42 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // ---- stream this image's attention map into LDS (the only large HBM read)
     // The last wave groups the positions by word (one-wave sort, group_positions_sorted) while the others bring the rows in.
     const bool sorter = nw > 1 && wid == nw - 1;                // wave-uniform
+    const bool dyn_rows = kEdges && nw == 16 && a.attn_heads <= 1;          // block-uniform
+    if (dyn_rows) {
+        if (tid == 0) s.misc[4] = (nw - 1) * 4;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // (everybody is at the start of the kernel: a cheap barrier)
+    }
+    // (one wave against fifteen on an issue-bound CU: without priority its ~2 500 instructions - cls soft-max, sort, records,
+    // vertices - last longer than the row phase of the others, and everybody waits for it at the first barrier)
+    if (sorter) __builtin_amdgcn_s_setprio(3);
     if (kEdges) {
-        if (!sorter)
+        if (!sorter) {
+            // rows of this wave: strided over the row waves, or - sixteen waves, one head - in batches of four from a
+            // counter (s.misc[4]; the first batch of every wave is fixed, the counter starts behind them)
+            int rb = wid, re = L, rs = nw > 1 ? nw - 1 : 1;
+            if (dyn_rows) { rb = wid * 4; rs = 0; }
             attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
-                                   a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e,
-                                   wid, nw > 1 ? nw - 1 : 1, lane);
+                                   a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e, rb, re, rs, lane, &s.misc[4]);
+        }
         if (!a.geo) build_grid_table(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);
     }
     if (tid < L) s.words[tid] = a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)tid * a.ing_stride_l];
     for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;
     if (!sorter && wid == nw - 1 && lane == 0) s.misc[2] = 0;   // misc[2] = 1: the sorter wave has written the grouping records (only ever written by the last wave)
 
+    // The sorting wave's inputs - the words, the vertex attribute weights - are requested before its cls-attention row is
+    // soft-maxed: one global round trip instead of three dependent ones on the wave everybody waits for at the barrier.
+    int64_t w4[4] = {0, 0, 0, 0};
+    float wv0 = 0.0f, wv1 = 0.0f;
+    if (sorter && L <= 4 * SN_WAVE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = lane + SN_WAVE * e;
+            w4[e] = q < L ? a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)q * a.ing_stride_l] : 0;
+        }
+        if (do_v && a.out_v) { wv0 = a.w_v[0]; wv1 = a.w_v[1]; }
+    }
     // ---- attention to the cls token: clamp / softmax / nan_to_num(0)  (schema_net.py:295-297)
     if (do_v && wid == nw - 1) {
         const float *row = a.attn_cls + (int64_t)b * a.acls_stride_b;
@@ -691,7 +783,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                         (a.use_clamp_v && x[k] < a.clamp_v) ? -INFINITY : x[k];
                 }
             }
-            softmax_row4<false>(x, L, lane, a.use_clamp_v != 0, a.clamp_v);
+            softmax_row4<false>(x, L, lane, a.use_clamp_v != 0, a.clamp_v);      // (exact form in every configuration: the vertex weights do not depend on which kernel variant ran)
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = sn_nan_to_num(x[k]);
         }
@@ -703,20 +795,73 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     }
     if (sorter) {
         bool done = false;
+        if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
         if (L <= 4 * SN_WAVE) {
-        int64_t w4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int q = lane + SN_WAVE * e;
-            w4[e] = q < L ? a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)q * a.ing_stride_l] : 0;
-        }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wave's own s.acls stores)
-        done = group_positions_sorted(s, L, lane, w4, do_v);
+        SortedGroups sg;
+        done = group_positions_sorted(s, L, lane, w4, do_v, sg);
+        if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
+        if (done) {
+            // ---- vertices (large_scale_feat_to_v.cpp:100-125) by this wave, while the others still bring the attention
+            // rows in: it holds every word's count and cls-attention sum.  (The block-wide form below - two reductions over
+            // sixteen waves and the padding loops behind four barriers - took 8 k cycles of every image.)
+            const int n_groups = sg.n_groups;
+            if (a.out_n && lane == 0) a.out_n[b] = n_groups;
+            if (a.out_n_max && lane == 0) atomicMax(a.out_n_max, n_groups);
+            if (do_v) {
+                float a0[4], a1[4], m0 = -INFINITY, m1 = -INFINITY;
+                bool nan0 = false, nan1 = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a0[e] = (float)sg.cnt[e];
+                    a1[e] = a.mean ? sg.sum[e] / (float)sg.cnt[e] : sg.sum[e];
+                    if (sg.head[e]) {                             // max over the words, NaN propagating like at::max (:124)
+                        nan0 = nan0 || (a0[e] != a0[e]); nan1 = nan1 || (a1[e] != a1[e]);
+                        m0 = (a0[e] != a0[e]) ? m0 : fmaxf(m0, a0[e]);
+                        m1 = (a1[e] != a1[e]) ? m1 : fmaxf(m1, a1[e]);
+                    }
+                }
+                m0 = __any(nan0) ? NAN : sn_wave_max(m0);
+                m1 = __any(nan1) ? NAN : sn_wave_max(m1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!sg.head[e] || sg.g[e] >= a.n_pad) continue;
+                    const float v0 = sn_nan_to_num(a0[e] / m0), v1 = sn_nan_to_num(a1[e] / m1);
+                    const int64_t o = (int64_t)b * a.n_pad + sg.g[e];
+                    if (a.out_v2) { a.out_v2[2 * o] = v0; a.out_v2[2 * o + 1] = v1; }
+                    if (a.out_v) {
+                        const float t0 = v0 * wv0, t1 = v1 * wv1;
+                        a.out_v[o] = t0 + t1;
+                    }
+                }
+                for (int c = n_groups + lane; c < a.n_pad; c += SN_WAVE) {
+                    const int64_t o = (int64_t)b * a.n_pad + c;
+                    if (a.out_v2) { a.out_v2[2 * o] = 0.0f; a.out_v2[2 * o + 1] = 0.0f; }
+                    if (a.out_v) a.out_v[o] = 0.0f;
+                }
+            }
+            if (a.out_ids) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (sg.head[e] && sg.g[e] < a.n_pad) a.out_ids[(int64_t)b * a.n_pad + sg.g[e]] = (int64_t)(sg.key[e] >> 8);
+                for (int c = n_groups + lane; c < a.n_pad; c += SN_WAVE) a.out_ids[(int64_t)b * a.n_pad + c] = a.pad_id;
+            }
+        }
         }
         if (lane == 0) s.misc[2] = done ? 1 : 0;
+        __builtin_amdgcn_s_setprio(0);
+        if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime();      // diagnostics: the sorting wave is done
     }
-    __syncthreads();
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime();   // ... wave 0 has its rows in
+    if (stamps && threadIdx.x == 3 * 64) stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime(); // ... wave 3 (on the sorting wave's SIMD)
+    if (stamps && threadIdx.x == 5 * 64) stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime(); // ... wave 5
+    // (LDS contents only: __syncthreads() would also wait for the sorting wave's global stores and its atomic on the batch
+    // maximum - one address for every image of the launch - to complete, 7 k cycles with everybody standing at the barrier;
+    // nobody reads those in this kernel)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     SN_GSTAMP(1);
     // ---- group positions by word (the ballot form only when the sort does not apply: words >= 2^24)
@@ -733,10 +878,11 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     const int n_groups = s.misc[0];
     const bool owner = tid < L && me.first;
 
-    // ---- vertices  (large_scale_feat_to_v.cpp:100-125)
-    if (a.out_n && tid == 0) a.out_n[b] = n_groups;
-    if (a.out_n_max && tid == 0) atomicMax(a.out_n_max, n_groups);
-    if (do_v) {
+    // ---- vertices  (large_scale_feat_to_v.cpp:100-125); written by the sorting wave when it grouped the positions
+    const bool v_done = s.misc[2] != 0;                          // block-uniform
+    if (!v_done && a.out_n && tid == 0) a.out_n[b] = n_groups;
+    if (!v_done && a.out_n_max && tid == 0) atomicMax(a.out_n_max, n_groups);
+    if (do_v && !v_done) {
         const float a0 = (float)me.cnt;
         const float a1 = a.mean ? me.attn_sum / (float)me.cnt : me.attn_sum;
         const float m0 = block_max_nan(s, a0, owner, tid, wid, nw, lane);
@@ -756,7 +902,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if (a.out_v) a.out_v[o] = 0.0f;
         }
     }
-    if (a.out_ids) {
+    if (a.out_ids && !v_done) {
         if (owner && me.group < a.n_pad) a.out_ids[(int64_t)b * a.n_pad + me.group] = s.words[tid];
         for (int c = n_groups + tid; c < a.n_pad; c += blockDim.x) a.out_ids[(int64_t)b * a.n_pad + c] = a.pad_id;
     }
@@ -767,7 +913,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // (large_scale_feat_to_e.cpp:117-118; missing key -> 0; on collisions the last (gi, gj) in
     // iteration order wins, i.e. the largest group index)
     int n_out = n_groups;
-    if (a.dict_keys) {
+    if (c_dict) {
         n_out = (int)a.dict_len[b];
         if (owner) {
             const int64_t *keys = a.dict_keys + a.dict_off[b], *vals = a.dict_vals + a.dict_off[b];
@@ -791,7 +937,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // per cell and row visit (the column-sum loop below is instruction-bound).  Same floats, same sums.
     float *TS = nullptr;
     const int ts_S = 2 * a.feat_w - 1;
-    if (signed_table) {                                          // kernel argument: uniform
+    if (kFast || signed_table) {                                 // kernel argument: uniform
         __syncthreads();                                         // every thread has read its grouping results
         TS = reinterpret_cast<float *>(s.pless);
         const int sh = grid_shift(a.feat_w), fh = L / a.feat_w, n_ts = (2 * fh - 1) * ts_S;
@@ -838,7 +984,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
         qok[k] = q < L;
         const int qq = qok[k] ? q : L - 1;                  // (lanes past L accumulate a valid column nobody reads)
         qv4[k] = qq * 4;
-        const int rc = a.geo ? 0 : (int)s.prc[qq];
+        const int rc = c_geo ? 0 : (int)s.prc[qq];
         qrow[k] = rc >> 8;
         qcol4[k] = (rc & 255) * 4;
         qts[k] = TS ? ((L / a.feat_w - 1 - (rc >> 8)) * ts_S + (a.feat_w - 1 - (rc & 255))) * 4 : 0;
@@ -847,7 +993,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     const int tsh = grid_shift(a.feat_w) + 2;               // byte shift of a table row
     // segment heads of the sorted position order, for the lane's four sorted indices 4 lane + e (bit e):
     // a word's first position; indices past the kept positions are their own (empty) segments
-    const bool scan_ok = (L & 3) == 0 && L <= 4 * SN_WAVE;
+    const bool scan_ok = kFast || ((L & 3) == 0 && L <= 4 * SN_WAVE);
     unsigned hd = 0;
     if (scan_ok) {
 #pragma unroll
@@ -880,32 +1026,39 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if (lane >= 32) { take |= fl ? 0u : (1u << 5); fl |= fup; }
         }
     }
+    // the same flags as multipliers (see the scan below)
+    const float nh1 = (hd & 2) ? 0.0f : 1.0f, nh2 = (hd & 4) ? 0.0f : 1.0f, nh3 = (hd & 8) ? 0.0f : 1.0f;
+    const float cf0 = (hd & 1) ? 0.0f : 1.0f, cf1 = (hd & 3) ? 0.0f : 1.0f, cf2 = (hd & 7) ? 0.0f : 1.0f, cf3 = (hd & 15) ? 0.0f : 1.0f;
+    float tk[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tk[i] = ((take >> i) & 1u) ? 1.0f : 0.0f;
     float rcnt[kCellsPerLane];                             // 1 / (positions of the column's word)
 #pragma unroll
     for (int k = 0; k < kCellsPerLane; ++k) rcnt[k] = 1.0f / (float)(cc.cnt[k] > 0 ? cc.cnt[k] : 1);
-    unsigned long long dt_a = 0, dt_b = 0;                  // diagnostics (stamps on): wave 0's time in passes a / b
+    unsigned long long dt_a = 0, dt_b = 0, dt_c = 0, dt_pre = 0;      // diagnostics (stamps on): wave 0's time in passes a / b, in normalise + store, before the row loop
     // KC = 64-column cells of an output row a lane holds: an image with at most 64 / 128 distinct words (the usual case:
     // ~113 of 196 positions) needs one / two, not four - every per-cell instruction of the scan gathers, the means, the
     // normalisation and the stores is issued KC times per row
+    if (stamps && threadIdx.x == 0) dt_pre = __builtin_amdgcn_s_memtime() - stamps[(size_t)blockIdx.x * 16 + 4];
     auto edge_rows = [&](auto kc_c) {
     constexpr int KC = decltype(kc_c)::value;
     for (int r = wid; r < a.n_pad; r += nw) {
         const int gi = (r < n_out && r < kMaxCols) ? s.rev[r] : -1;
         float c0[kCellsPerLane], c1[kCellsPerLane];
         float t0 = 0.0f, t1 = 0.0f;
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
         if (gi >= 0) {
             const int ia = __builtin_amdgcn_readfirstlane((int)s.gstart[gi]);
             const int ib = __builtin_amdgcn_readfirstlane((int)s.gstart[gi + 1]);
             float csa[kCellsPerLane], csg[kCellsPerLane];
 #pragma unroll
             for (int k = 0; k < kCellsPerLane; ++k) { csa[k] = 0.0f; csg[k] = 0.0f; }
-            unsigned long long ts0 = 0, ts1 = 0;
             if (stamps) ts0 = __builtin_amdgcn_s_memtime();
             for (int x = ia; x < ib; ++x) {                 // a) column sums over the rows of group gi
                 const int p = __builtin_amdgcn_readfirstlane((int)s.pos_sorted[x]);
                 const char *arow = reinterpret_cast<const char *>(s.A + p * L);
-                if (a.geo) {
-                    const float *grow = a.geo + (int64_t)p * L;
+                if (c_geo) {
+                    const float *grow = c_geo + (int64_t)p * L;
 #pragma unroll
                     for (int k = 0; k < kCellsPerLane; ++k) {
                         const float av = *reinterpret_cast<const float *>(arow + qv4[k]);
@@ -913,7 +1066,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                         csa[k] += qok[k] ? av : 0.0f;
                         csg[k] += qok[k] ? gv : 0.0f;
                     }
-                } else if (TS) {
+                } else if (kFast || TS) {
                     const int prc = __builtin_amdgcn_readfirstlane((int)s.prc[p]);
                     const char *tp = reinterpret_cast<const char *>(TS) + ((prc >> 8) * ts_S + (prc & 255)) * 4;
 #pragma unroll
@@ -954,28 +1107,30 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     __builtin_amdgcn_wave_barrier();
                     f32x4 v4 = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (4 * lane < L) v4 = *reinterpret_cast<const f32x4 *>(stage + 16 * lane);
+                    // (run += incoming * tk: tk = 1.0 where the step adds, 0.0 where a head lies in between - one v_fmac with
+                    // a DPP source per step instead of a move, an add and a select.  x * 1.0 is exact; the values of one row's
+                    // scan are either all finite or all NaN (a fully clamped attention row), so 0 * NaN changes nothing.)
                     float s0 = v4.x;
-                    float s1 = (hd & 2) ? v4.y : s0 + v4.y;
-                    float s2 = (hd & 4) ? v4.z : s1 + v4.z;
-                    float s3 = (hd & 8) ? v4.w : s2 + v4.w;
+                    float s1 = fmaf(s0, nh1, v4.y);
+                    float s2 = fmaf(s1, nh2, v4.z);
+                    float s3 = fmaf(s2, nh3, v4.w);
                     float run = s3;                                 // sum since the last head of this lane (or of all four)
-                    // (which steps add is the same for every row: `take`; lanes a DPP step does not reach read 0)
-#define SN_SCAN_STEP(bit, ctrl, rows)                                                                                         \
-                    { const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(run), (ctrl), (rows), 0xF, true)); \
-                      run = ((take >> (bit)) & 1u) ? run + up : run; }
-                    SN_SCAN_STEP(0, 0x111, 0xF)                     // row_shr:1
-                    SN_SCAN_STEP(1, 0x112, 0xF)                     // row_shr:2
-                    SN_SCAN_STEP(2, 0x114, 0xF)                     // row_shr:4
-                    SN_SCAN_STEP(3, 0x118, 0xF)                     // row_shr:8
-                    SN_SCAN_STEP(4, 0x142, 0xA)                     // row_bcast:15 -> rows 1, 3
-                    SN_SCAN_STEP(5, 0x143, 0xC)                     // row_bcast:31 -> rows 2, 3
+#define SN_SCAN_STEP(i, ctrl, rows)                                                                                            \
+                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " ctrl " row_mask:" rows " bank_mask:0xf bound_ctrl:0" : "+v"(run) : "v"(tk[i]));
+                    SN_SCAN_STEP(0, "row_shr:1", "0xf")
+                    SN_SCAN_STEP(1, "row_shr:2", "0xf")
+                    SN_SCAN_STEP(2, "row_shr:4", "0xf")
+                    SN_SCAN_STEP(3, "row_shr:8", "0xf")
+                    SN_SCAN_STEP(4, "row_bcast:15", "0xa")            // -> rows 1, 3
+                    SN_SCAN_STEP(5, "row_bcast:31", "0xc")            // -> rows 2, 3
 #undef SN_SCAN_STEP
                     // running sum that reaches into this lane = the previous lane's total (wave_shr:1; lane 0: 0)
-                    const float carry = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(run), 0x138, 0xF, 0xF, true));
-                    v4.x = (hd & 1) ? s0 : s0 + carry;
-                    v4.y = (hd & 3) ? s1 : s1 + carry;
-                    v4.z = (hd & 7) ? s2 : s2 + carry;
-                    v4.w = (hd & 15) ? s3 : s3 + carry;
+                    float carry;
+                    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(carry) : "v"(run));
+                    v4.x = fmaf(carry, cf0, s0);
+                    v4.y = fmaf(carry, cf1, s1);
+                    v4.z = fmaf(carry, cf2, s2);
+                    v4.w = fmaf(carry, cf3, s3);
                     __builtin_amdgcn_wave_barrier();
                     if (4 * lane < L) *reinterpret_cast<f32x4 *>(stage + 16 * lane) = v4;
                     __builtin_amdgcn_wave_barrier();
@@ -1007,14 +1162,14 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 }
             }
             }
-            if (stamps) { dt_a += ts1 - ts0; dt_b += __builtin_amdgcn_s_memtime() - ts1; }
+            if (stamps) { ts2 = __builtin_amdgcn_s_memtime(); dt_a += ts1 - ts0; dt_b += ts2 - ts1; }
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 const bool has = cc.cnt[k] > 0;
                 c0[k] = has ? sg[k] : 0.0f;
                 c1[k] = has ? sa[k] : 0.0f;
             }
-            if (a.mean) {                                    // wave-uniform; 1 / (rows x columns) as two reciprocals (2 ulp)
+            if (c_mean) {                                    // wave-uniform; 1 / (rows x columns) as two reciprocals (2 ulp)
                 const float rr = __builtin_amdgcn_rcpf((float)(ib - ia));
 #pragma unroll
                 for (int k = 0; k < KC; ++k) {
@@ -1024,10 +1179,10 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 }
             }
         } else {                                             // padding row: zeros, nothing to normalise
-            if (a.skip_edge_padding) continue;               // (the consumer masks by the vertex count)
+            if (c_skip) continue;                            // (the consumer masks by the vertex count)
             const int64_t rowbase0 = ((int64_t)b * a.n_pad + r) * a.n_pad;
             for (int c = lane; c < a.n_pad; c += SN_WAVE) {
-                if (a.out_e2) { a.out_e2[2 * (rowbase0 + c)] = 0.0f; a.out_e2[2 * (rowbase0 + c) + 1] = 0.0f; }
+                if (c_out_e2) { c_out_e2[2 * (rowbase0 + c)] = 0.0f; c_out_e2[2 * (rowbase0 + c) + 1] = 0.0f; }
                 if (a.out_e) a.out_e[rowbase0 + c] = 0.0f;
             }
             continue;
@@ -1043,24 +1198,25 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int c = lane + SN_WAVE * k;
-            if (c >= a.n_pad || (a.skip_edge_padding && c >= n_out)) continue;
+            if (c >= a.n_pad || (c_skip && c >= n_out)) continue;
             float e0 = 0.0f, e1 = 0.0f;
             if (c < n_out) {
                 e0 = c0[k] * i0;
                 e1 = c1[k] * i1;
                 if (!plain) { e0 = sn_nan_to_num(e0); e1 = sn_nan_to_num(e1); }
-                if (a.remove_self_loop && c == r) { e0 = 0.0f; e1 = 0.0f; }
+                if (c_rsl && c == r) { e0 = 0.0f; e1 = 0.0f; }
             }
-            if (a.out_e2) { a.out_e2[2 * (rowbase + c)] = e0; a.out_e2[2 * (rowbase + c) + 1] = e1; }
+            if (c_out_e2) { c_out_e2[2 * (rowbase + c)] = e0; c_out_e2[2 * (rowbase + c) + 1] = e1; }
             if (a.out_e) {
                 const float p0 = e0 * w0, p1 = e1 * w1;
                 a.out_e[rowbase + c] = p0 + p1;
             }
         }
-        for (int c = SN_WAVE * KC + lane; c < a.n_pad && !a.skip_edge_padding; c += SN_WAVE) {          // (columns past the cells this variant holds: padding)
-            if (a.out_e2) { a.out_e2[2 * (rowbase + c)] = 0.0f; a.out_e2[2 * (rowbase + c) + 1] = 0.0f; }
+        for (int c = SN_WAVE * KC + lane; c < a.n_pad && !c_skip; c += SN_WAVE) {          // (columns past the cells this variant holds: padding)
+            if (c_out_e2) { c_out_e2[2 * (rowbase + c)] = 0.0f; c_out_e2[2 * (rowbase + c) + 1] = 0.0f; }
             if (a.out_e) a.out_e[rowbase + c] = 0.0f;
         }
+        if (stamps) dt_c += __builtin_amdgcn_s_memtime() - ts2;
     }
     };
     {
@@ -1071,7 +1227,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     }
     __syncthreads();
     SN_GSTAMP(5);
-    if (stamps && threadIdx.x == 0) { stamps[(size_t)blockIdx.x * 8 + 6] = dt_a; stamps[(size_t)blockIdx.x * 8 + 7] = dt_b; }
+    if (stamps && threadIdx.x == 0) { stamps[(size_t)blockIdx.x * 16 + 6] = dt_a; stamps[(size_t)blockIdx.x * 16 + 7] = dt_b; stamps[(size_t)blockIdx.x * 16 + 8] = dt_c; stamps[(size_t)blockIdx.x * 16 + 9] = dt_pre; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1134,7 +1290,7 @@ __global__ __launch_bounds__(1024) void limited_edges_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
     const Lds s = carve(smem, L, true);
-    attn_rows_to_lds(s.A, attn + (int64_t)b * L * L, L, 1, 0, L, is_logits != 0, use_clamp != 0, clamp, wid, nw, lane);
+    attn_rows_to_lds(s.A, attn + (int64_t)b * L * L, L, 1, 0, L, is_logits != 0, use_clamp != 0, clamp, wid, L, nw, lane);
     if (!geo) build_grid_table(s, L, feat_w, alpha, pw, tid);
     const int32_t *slot_tab = class_slot + (int64_t)label[b] * Mtab;
     int my_slot = -1;
@@ -1291,10 +1447,14 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
             const size_t extra = need > dead ? need - dead : 0;
             if (lds + extra <= 160 * 1024) { lds += extra; signed_table = 1; }
         }
-        int rc = ensure_lds((const void *)instance_graph_kernel<true>, lds, "sn_instance_graph");
+        const bool fast = signed_table && !a.geo && !a.out_e2 && a.out_e && a.mean && !a.remove_self_loop && !a.dict_keys &&
+                          a.skip_edge_padding && (a.L & 3) == 0 && a.L <= 4 * SN_WAVE;
+        int rc = fast ? ensure_lds((const void *)instance_graph_kernel<true, true>, lds, "sn_instance_graph")
+                      : ensure_lds((const void *)instance_graph_kernel<true>, lds, "sn_instance_graph");
         if (rc) return rc;
         sn_prof_start(2, st);
-        hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table);
+        if (fast) hipLaunchKernelGGL((instance_graph_kernel<true, true>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table);
+        else hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table);
         sn_prof_stop(2, st);
     } else {
         const size_t lds = lds_bytes(a.L, false);
