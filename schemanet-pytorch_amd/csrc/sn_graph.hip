@@ -283,7 +283,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
 }
 
 template <bool kFast = false>
-__device__ inline void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
+__device__ __forceinline__ void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
                                         int64_t stride_h, int L, bool is_logits, bool use_clamp,
                                         float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr)
 {
