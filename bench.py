@@ -208,12 +208,17 @@ def api_leg(device, disc, sn, m, n_calls, n_batches=4):
         mid = torch.randn(L + 1, B, D, generator=g(100 + 10 * i)).to(device)                 # sequence-first, cls row first
         ext = torch.randn(B * H, L + 1, L + 1, generator=g(103 + 10 * i)).to(device)         # randn(256*6,197,197)
         batches.append((mid, ext))
-    wrapper = IngredientModelWrapper(_ResidentBackbone(batches), discretization.DiscretizationModule(disc))
+    # the same taps with the heads already averaged (one "head": what the main bench line feeds), to separate what the API
+    # costs from what the per-head input costs (931 KB instead of 155 KB of attention per image)
+    batches_h1 = [(mid, ext.reshape(B, H, L + 1, L + 1).mean(dim=1).contiguous()) for mid, ext in batches]
+    backbone = _ResidentBackbone(batches)
+    wrapper = IngredientModelWrapper(backbone, discretization.DiscretizationModule(disc))
     pred = graph.SchemaNetPredictor(wrapper, sn, m).eval()
     x = torch.empty(B, 3, 1, 1, device=device)                                               # (the images: unused by the stand-in)
     out = {}
     with torch.no_grad():
-        for name, cache in (("value_api", False), ("value_api_eval_cache", True)):
+        for name, cache, bt in (("value_api", False, batches), ("value_api_eval_cache", True, batches), ("value_api_head_averaged", False, batches_h1)):
+            backbone.batches = bt
             pred.matcher.cache_atlas = cache
             pred.matcher.invalidate_atlas_cache()
             pred.invalidate_graphs()
@@ -233,7 +238,9 @@ def api_leg(device, disc, sn, m, n_calls, n_batches=4):
                        "raw taps in (tokens [197,256,384] sequence-first, per-head logits [256*6,197,197]: the head mean is fused into the "
                        "instance-graph kernel, 931 KB of attention per image instead of 155 KB), the reference's dict out (pred + class_vertices "
                        "+ class_edges + class_ingredients); value_api: class-graph branch recomputed in every call (Matcher.cache_atlas off, "
-                       "like value_depth1), value_api_eval_cache: the predictor's eval() default (class-graph features kept per parameter version)")
+                       "like value_depth1), value_api_eval_cache: the predictor's eval() default (class-graph features kept per parameter version), "
+                       "value_api_head_averaged: as value_api with the head mean taken beforehand ([256,197,197] logits in, the input of `value` / "
+                       "`value_depth1`): the API route itself against the hand-written step; the per-head input alone adds 199 MB of mandatory reads per call")
     return out
 
 
@@ -516,17 +523,17 @@ def main():
         variant = lib.sn_assign_variant()
         screen_name = {2: "assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)",
                        3: "assign_screen3_kernel<8> (S1 fp16-MFMA screen, K-outer token stream)"}.get(
-                           variant, "assign_screen_kernel<24,4,3> (S1 fp16-MFMA screen, token-stationary)")
+                           variant, "assign_screen_kernel<24,4,3,8,false> (S1 fp16-MFMA screen, token-stationary)")
         copy_gbps = stream_copy_GBps(device)
         ev_floor = event_pair_floor_ms()
         traffic, traffic_s3, traffic_src = None, None, None      # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
-        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     for row in json.load(fh)["kernels"]:
                         if "::" + screen_name.split(" ")[0].split("<")[0] + "<" in row["kernel"] or row["kernel"].startswith(screen_name.split("<")[0] + "<"):
                             traffic = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
-                        if "instance_graph_kernel<true>" in row["kernel"] or "instance_graph_kernel<1>" in row["kernel"]:
+                        if "instance_graph_kernel<true" in row["kernel"] or "instance_graph_kernel<1" in row["kernel"]:        # (<true, true>: the prediction configuration)
                             traffic_s3 = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
                 if traffic is not None:
                     traffic_src = f"profiles/{name} (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
@@ -571,7 +578,7 @@ def main():
                          "avg_launch_note": "avg_launch_ms = HIP event pair around the kernel on its launch stream (what achieved / frac use); an event pair with nothing between reads event_pair_floor_ms, so the kernel trace of rocprofv3 (profiles/) shows this kernel ~that much shorter; whole_assignment = screen + fp64 re-rank",
                          "peak_note": "peak = 8.0 TB/s HBM3E spec; copy_GBps = a 1 GiB device-to-device copy on this box (read + write)",
                          "copy_GBps": copy_gbps, "frac_of_copy": (ach / copy_gbps) if (ach and copy_gbps) else None},
-            "roofline_s3": {"bound": "hbm", "kernel": "instance_graph_kernel<true> (S2+S3: grouping, edge cells, normalise)",
+            "roofline_s3": {"bound": "hbm", "kernel": "instance_graph_kernel<true, true> (S2+S3: grouping, edge cells, normalise; compile-time prediction configuration)",
                             "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (g_ach / HBM_PEAK_GBS) if g_ach else None,
                             "traffic": traffic_s3, "algorithmic_bytes_per_launch": graph_bytes, "avg_launch_ms": avg["instance_graph"],
                             "mean_vertices_per_image": n_mean},

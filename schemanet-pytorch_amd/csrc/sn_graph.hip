@@ -136,6 +136,29 @@ __device__ __forceinline__ float wave_sum_fast(float v)
 template <bool kVec, bool kFast = false>
 __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool use_clamp, float clamp)
 {
+    if constexpr (kVec && kFast) {
+        // The row phase issues ~65 VALU instructions per row in the general form below and is bound by them.  Here a lane's
+        // four columns are valid together (4 lane < L, L a multiple of 4): masked and clamped elements become -inf once, and
+        // everything behind that needs no selects - exp2(-inf) is 0; (x - m) log2(e) is one packed fma per column pair
+        // (x log2(e) - m log2(e): 3e-7 relative on the probabilities); ~40 instructions.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const bool lane_ok = 4 * lane < L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = (!lane_ok || (use_clamp && x[k] < clamp)) ? -INFINITY : x[k];
+        const float m = wave_max_fast(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+        constexpr float kLog2e = 1.44269504088896340736f;
+        const float nm = -m * kLog2e;                 // all-clamped row: m = -inf, x log2(e) + nm = NaN, like torch ((-inf) - (-inf))
+        const f32x2 a01 = __builtin_elementwise_fma(f32x2{x[0], x[1]}, f32x2{kLog2e, kLog2e}, f32x2{nm, nm});
+        const f32x2 a23 = __builtin_elementwise_fma(f32x2{x[2], x[3]}, f32x2{kLog2e, kLog2e}, f32x2{nm, nm});
+        f32x2 e01 = {__builtin_amdgcn_exp2f(a01.x), __builtin_amdgcn_exp2f(a01.y)};
+        f32x2 e23 = {__builtin_amdgcn_exp2f(a23.x), __builtin_amdgcn_exp2f(a23.y)};
+        const f32x2 s2 = e01 + e23;
+        const float r = __builtin_amdgcn_rcpf(wave_sum_fast(s2.x + s2.y));
+        e01 = e01 * f32x2{r, r};
+        e23 = e23 * f32x2{r, r};
+        x[0] = e01.x; x[1] = e01.y; x[2] = e23.x; x[3] = e23.y;
+        return;
+    }
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -217,22 +240,25 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
     }
     if (rs == 0) {
         // Dynamic batches (the sixteen-wave prediction kernel): a wave takes kDyn rows at a time from a counter in LDS and
-        // has the next batch's loads in flight while it soft-maxes this one.  The row phase ends with the slowest wave,
+        // has the next two batches' loads in flight while it soft-maxes this one (small batches: the phase ends one batch
+        // after the last grab).  The row phase ends with the slowest wave,
         // and a static split loses both to the wave that shares its SIMD with the sorting wave and to whichever wave's
         // loads come back late (first barrier at 35-37 k cycles with every wave's own work done by 27 k).
-        constexpr int kDyn = 4;
-        int r0 = rb;
-        float x[kDyn][4];
+        constexpr int kDyn = 2;                 // rows per batch; two batches of loads in flight behind the one being soft-maxed
+        int r0 = rb, r1 = rb + kDyn;            // (the first two batches of a wave are fixed: rows 4 wid .. 4 wid + 3)
+        float x[kDyn][4], y[kDyn][4];
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(r0 + i, L - 1) * stride_r, L, lane, x[i]);
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(r1 + i, L - 1) * stride_r, L, lane, y[i]);
         while (r0 < L) {
             int rn = 0;
             if (lane == 0) rn = atomicAdd(next_row, kDyn);
             rn = __builtin_amdgcn_readfirstlane(rn);
-            float y[kDyn][4];
+            float z[kDyn][4];
             if (rn < L) {
 #pragma unroll
-                for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(rn + i, L - 1) * stride_r, L, lane, y[i]);
+                for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(rn + i, L - 1) * stride_r, L, lane, z[i]);
             }
 #pragma unroll
             for (int i = 0; i < kDyn; ++i) {
@@ -253,8 +279,9 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
 #pragma unroll
             for (int i = 0; i < kDyn; ++i)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) x[i][k] = y[i][k];
-            r0 = rn;
+                for (int k = 0; k < 4; ++k) { x[i][k] = y[i][k]; y[i][k] = z[i][k]; }
+            r0 = r1;
+            r1 = rn;
         }
         return;
     }
@@ -793,19 +820,26 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if (c < L) s.acls[c] = x[k];
         }
     }
+    SortedGroups sg;
+    bool done = false;                                          // (the sorting wave's: it grouped the positions)
+    sg.n_groups = 0;
     if (sorter) {
-        bool done = false;
         if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
         if (L <= 4 * SN_WAVE) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wave's own s.acls stores)
-        SortedGroups sg;
         done = group_positions_sorted(s, L, lane, w4, do_v, sg);
         if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
-        if (done) {
-            // ---- vertices (large_scale_feat_to_v.cpp:100-125) by this wave, while the others still bring the attention
-            // rows in: it holds every word's count and cls-attention sum.  (The block-wide form below - two reductions over
-            // sixteen waves and the padding loops behind four barriers - took 8 k cycles of every image.)
+        }
+        if (lane == 0) s.misc[2] = done ? 1 : 0;
+        __builtin_amdgcn_s_setprio(0);
+        if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime();      // diagnostics: the sorting wave is done
+    }
+    // ---- vertices (large_scale_feat_to_v.cpp:100-125) by the sorting wave, which holds every word's count and cls-attention
+    // sum in registers (the block-wide form further down - two reductions over sixteen waves and the padding loops behind
+    // four barriers - took 8 k cycles of every image).  In the edges kernel it runs BEHIND the first barrier: the edge rows
+    // are dealt dynamically, so the wave joins them a little later and nobody waits for it.
+    auto write_vertices = [&]() {
             const int n_groups = sg.n_groups;
             if (a.out_n && lane == 0) a.out_n[b] = n_groups;
             if (a.out_n_max && lane == 0) atomicMax(a.out_n_max, n_groups);
@@ -847,12 +881,8 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     if (sg.head[e] && sg.g[e] < a.n_pad) a.out_ids[(int64_t)b * a.n_pad + sg.g[e]] = (int64_t)(sg.key[e] >> 8);
                 for (int c = n_groups + lane; c < a.n_pad; c += SN_WAVE) a.out_ids[(int64_t)b * a.n_pad + c] = a.pad_id;
             }
-        }
-        }
-        if (lane == 0) s.misc[2] = done ? 1 : 0;
-        __builtin_amdgcn_s_setprio(0);
-        if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memtime();      // diagnostics: the sorting wave is done
-    }
+    };
+    if (sorter && done && !kEdges) write_vertices();
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime();   // ... wave 0 has its rows in
     if (stamps && threadIdx.x == 3 * 64) stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime(); // ... wave 3 (on the sorting wave's SIMD)
     if (stamps && threadIdx.x == 5 * 64) stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime(); // ... wave 5
@@ -949,6 +979,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // s.flag is free after the grouping: it now holds the inverse of pos_sorted (position -> sorted index)
     const int n_kept = s.misc[1];
     if (tid < n_kept) s.flag[s.pos_sorted[tid]] = (unsigned char)tid;
+    if (tid == 0) s.misc[5] = nw;                                // next edge row to deal (see the row loop)
     __syncthreads();
 
     SN_GSTAMP(4);
@@ -1040,10 +1071,28 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // ~113 of 196 positions) needs one / two, not four - every per-cell instruction of the scan gathers, the means, the
     // normalisation and the stores is issued KC times per row
     if (stamps && threadIdx.x == 0) dt_pre = __builtin_amdgcn_s_memtime() - stamps[(size_t)blockIdx.x * 16 + 4];
+    // Rows are dealt dynamically: a wave takes its first row by its index and every further one from a counter in LDS
+    // (s.misc[5], set to nw before the barrier above), asked for before the current row is worked on.  Rows cost what
+    // their word's position count costs and the sorting wave starts late (it writes the vertices first): a static deal
+    // ended with the slowest wave, 18 % behind the median.  Only rows that can hold a word are dealt (r < n_out); the
+    // zero rows of the padding come afterwards.
+    const int n_rows = n_out < a.n_pad ? n_out : a.n_pad;
+    if (kEdges && sorter && done) write_vertices();              // (behind the last barrier before the row loop: see write_vertices)
     auto edge_rows = [&](auto kc_c) {
     constexpr int KC = decltype(kc_c)::value;
-    for (int r = wid; r < a.n_pad; r += nw) {
-        const int gi = (r < n_out && r < kMaxCols) ? s.rev[r] : -1;
+    for (int r = wid < n_rows ? wid : n_rows + wid; r < a.n_pad;) {      // (padding rows: n_rows + wid, + nw, ... for every wave)
+        const int r_this = r;
+        {
+            int rn = 0;
+            if (r_this < n_rows) {                               // wave-uniform
+                if (lane == 0) rn = atomicAdd(&s.misc[5], 1);
+                rn = __builtin_amdgcn_readfirstlane(rn);
+                r = rn < n_rows ? rn : n_rows + wid;             // (out of real rows: on to this wave's share of the padding rows)
+            } else {
+                r = r_this + nw;
+            }
+        }
+        const int gi = (r_this < n_out && r_this < kMaxCols) ? s.rev[r_this] : -1;
         float c0[kCellsPerLane], c1[kCellsPerLane];
         float t0 = 0.0f, t1 = 0.0f;
         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
@@ -1180,7 +1229,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             }
         } else {                                             // padding row: zeros, nothing to normalise
             if (c_skip) continue;                            // (the consumer masks by the vertex count)
-            const int64_t rowbase0 = ((int64_t)b * a.n_pad + r) * a.n_pad;
+            const int64_t rowbase0 = ((int64_t)b * a.n_pad + r_this) * a.n_pad;
             for (int c = lane; c < a.n_pad; c += SN_WAVE) {
                 if (c_out_e2) { c_out_e2[2 * (rowbase0 + c)] = 0.0f; c_out_e2[2 * (rowbase0 + c) + 1] = 0.0f; }
                 if (a.out_e) a.out_e[rowbase0 + c] = 0.0f;
@@ -1194,7 +1243,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
         const float i0 = __builtin_amdgcn_rcpf(t0), i1 = __builtin_amdgcn_rcpf(t1);     // one v_rcp_f32 per row (x * rcp(t) vs x / t: 2 ulp; a correctly rounded 1 / t is ten instructions)
         // nan_to_num only matters when a row sum is 0 / inf / NaN (then some quotient is not finite)
         const bool plain = t0 > 0.0f && t0 < INFINITY && t1 > 0.0f && t1 < INFINITY;      // wave-uniform
-        const int64_t rowbase = ((int64_t)b * a.n_pad + r) * a.n_pad;
+        const int64_t rowbase = ((int64_t)b * a.n_pad + r_this) * a.n_pad;
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int c = lane + SN_WAVE * k;
@@ -1204,7 +1253,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 e0 = c0[k] * i0;
                 e1 = c1[k] * i1;
                 if (!plain) { e0 = sn_nan_to_num(e0); e1 = sn_nan_to_num(e1); }
-                if (c_rsl && c == r) { e0 = 0.0f; e1 = 0.0f; }
+                if (c_rsl && c == r_this) { e0 = 0.0f; e1 = 0.0f; }
             }
             if (c_out_e2) { c_out_e2[2 * (rowbase + c)] = e0; c_out_e2[2 * (rowbase + c) + 1] = e1; }
             if (a.out_e) {
