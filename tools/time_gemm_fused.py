@@ -50,4 +50,6 @@ for (G, n, nv_hi) in ((100, 512, 512), (256, 196, 125)):
             d = lambda a, b: (s8[:, a] - s8[:, b]).median().item()
             msg += (f"; LayerNorm {d(3, 1):.0f}, fragments + barriers {d(4, 3):.0f}, 16 k-steps {d(5, 4):.0f}, barrier {d(6, 5):.0f}, "
                     f"stores of half 0 + all of half 1 {d(2, 6):.0f}")
+        if name != "fused" and len(s8):
+            msg += f"; in the loop: wait + barrier median {s8[:, 3].median():.0f}, copy issue median {s8[:, 4].median():.0f} (cycles per wave)"
         print(f"G={G} n={n} {name:20s} {e0.elapsed_time(e1) * 1e3 / 20:7.1f} us per launch (launch-to-launch); {msg}", flush=True)
