@@ -138,7 +138,8 @@ class SchemaNetPredictor(nn.Module):
     def forward(self, x: torch.Tensor, requires_graph: bool = False) -> Dict[str, torch.Tensor]:
         wrapper = self.ingredient_wrapper
         if (self.graph_replay and not self.training and not requires_graph and not torch.is_grad_enabled()
-                and hasattr(wrapper, "taps_from") and self.schema_net.vertex_weights.tensor.is_cuda):
+                and hasattr(wrapper, "taps_from") and self.schema_net.vertex_weights.tensor.is_cuda
+                and not torch.cuda.is_current_stream_capturing()):       # (inside somebody else's capture: plain launches, theirs to replay)
             return self._forward_replayed(x)
         with torch.no_grad():
             if hasattr(wrapper, "taps"):
