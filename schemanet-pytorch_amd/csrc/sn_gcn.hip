@@ -42,6 +42,10 @@
 // 12 ds_read_b128 per wave per stage.
 #include "sn_common.h"
 
+#ifndef SN_GEMM_ISSUE_AT
+#define SN_GEMM_ISSUE_AT 1     // where in a stage the ring copies of stage t + 2 are issued: 0 in front of the MFMAs, 1 behind the first 8, 2 behind 16 (fewer loop cycles, the same launch time)
+#endif
+
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -489,7 +493,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // ... everybody's; the slot of stage t-1 is free
         if (p.stamps) tb = __builtin_amdgcn_s_memtime();
+#if SN_GEMM_ISSUE_AT == 0
         if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+#endif
         if (p.stamps) { t_wait += tb - ta; t_issue += __builtin_amdgcn_s_memtime() - tb; }
         const unsigned char *sa = smem + (t % kRing) * kStageBytes, *sb = sa + kChunksA * 1024;
         half8 ah[2], al[2], bh[4], bl[4];
@@ -523,10 +529,20 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#if SN_GEMM_ISSUE_AT == 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#if SN_GEMM_ISSUE_AT == 2
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
