@@ -26,6 +26,9 @@
 #ifndef SN_S1_EXACT_LOSS
 #define SN_S1_EXACT_LOSS 1  // window from the token's measured fp16 rounding loss |x - fp16(x)|_2 (0: from its bound u |x|_2: two VALU per pair less in the token phase, 1.4 x as many tokens to re-rank)
 #endif
+#ifndef SN_S1_TOKENS_NT
+#define SN_S1_TOKENS_NT 1   // token rows with the non-temporal hint: read once by the screen (the re-rank re-reads the 6.6 % it flags: +0.4 us there, -1.8 us here, +1.1 % on the replayed bench; round 1, with 13 % flagged, it lost)
+#endif
 #ifndef SN_S1_STAGE
 #define SN_S1_STAGE 1       // token rows through LDS in whole cache lines (0: fragment loads straight from global memory)
 #endif
@@ -694,7 +697,11 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
         const unsigned dst = stage_base + (u % kStageBufs) * 4096;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
+#if SN_S1_TOKENS_NT
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(rowq[q] + 128 * u), "s"(dst + q * 1024) : "memory");
+#else
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(rowq[q] + 128 * u), "s"(dst + q * 1024) : "memory");
+#endif
     };
     const unsigned char *frag_src = smem + wid * (kStageBufs * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
     const int sw = (r >> 1) & 7;
