@@ -128,7 +128,9 @@ class SchemaNetPredictor(nn.Module):
             self._graphs[key] = step
             while len(self._graphs) > self.max_graphs:
                 self._graphs.popitem(last=False)
-            step.taps = (mid_feat, extracted)                      # keep the captured input buffers alive
+            # (no reference to the tap tensors is kept: a backbone that allocates its outputs afresh gets the SAME blocks back
+            # from the caching allocator once the previous iteration's are released - that is what makes the next call a
+            # hit.  The capture is only ever replayed when both taps live at the captured addresses again.)
         else:
             self._graphs.move_to_end(key)
         ret = collections.OrderedDict(step.replay())

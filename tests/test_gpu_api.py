@@ -133,6 +133,36 @@ def test_predictor_with_moving_taps_falls_back_to_eager(mods):
         assert torch.equal(o, outs[0])
 
 
+def test_predictor_replay_with_a_backbone_that_allocates_its_outputs(mods):
+    """A real backbone returns NEW tensors on every call and the caller drops them after the forward pass: the caching
+    allocator then hands the next call the same blocks, and the predictor - which keeps no reference to the taps -
+    replays the capture it made for those addresses (a reference would pin the blocks and every call would miss)."""
+    bs, H, L, D, M, K = 4, 2, 196, 192, 128, 5
+    mids = [T(datagen.bellish((L + 1, bs, D), 430 + i, 1.0)) for i in range(3)]
+    exts = [T(datagen.bellish((bs * H, L + 1, L + 1), 440 + i, 2.0)) for i in range(3)]
+
+    class _Allocating(torch.nn.Module):
+        i = 0
+
+        def forward(self, x):
+            j = self.i % 3
+            self.i += 1
+            return {"mid_feat": mids[j] * 1.0, "extracted": exts[j] * 1.0}          # fresh outputs, nobody keeps them
+    pred, wrapper = _predictor(mods, [(mids[0], exts[0])], M, D, K, 32)
+    wrapper.backbone_jit = _Allocating()
+    x = torch.zeros(bs, 3, 4, 4, device=DEV)
+    with torch.no_grad():
+        pred.graph_replay = False
+        want = [pred(x)["pred"].clone() for _ in range(3)]
+        pred.graph_replay = True
+        wrapper.backbone_jit.i = 0
+        got = [pred(x)["pred"] for _ in range(12)]
+    torch.cuda.synchronize()
+    for i, g_ in enumerate(got):
+        assert torch.equal(g_, want[i % 3]), i
+    assert pred.graph_replay and 1 <= len(pred._graphs) <= 3 and pred._graph_misses <= 3, (len(pred._graphs), pred._graph_misses)
+
+
 # =============================================================================== the N > 1 branch of bench.py
 def test_bench_two_ranks_rehearsal():
     """What the driver launches for N = 2, with both ranks on this box's one GPU over gloo (SN_BENCH_REHEARSAL=1: RCCL
