@@ -35,7 +35,8 @@ the timed region over RCCL (the eval-meter merge of the reference, eval/evaluati
 `value_api` (N = 1): images/sec through the drop-in API itself - `SchemaNetPredictor.forward(x)` called once per batch on the
 RAW backbone taps (sequence-first tokens [197,256,384], per-head attention logits [256*6,197,197]: the fused head-mean
 input of SURVEY 8(d)), one call at a time, no hand-written step (the predictor captures and replays the launch sequence
-behind the backbone by itself); `c1_value` / `c4_value`: the same step at configs[0]'s and configs[3]'s shapes.
+behind the backbone by itself); `value_api_batches`: the same calls made by `SchemaNetPredictor.predict_batches` (the
+predictor's own evaluation loop, four batches in flight); `c1_value` / `c4_value`: the same step at configs[0]'s and configs[3]'s shapes.
 Outside the timed region every run also times one IR-Atlas initialisation over a synthetic image shard per rank
 (`init_atlas`): with N > 1 its two merges are the RCCL collectives of the per-class schema statistics
 (reference scripts/init_schema_net.py:19-65; 105 MB of edge sums at this configuration).
@@ -233,6 +234,25 @@ def api_leg(device, disc, sn, m, n_calls, n_batches=4):
             out[name] = B * n_calls / (time.perf_counter() - t1)
             out[name + "_replayed"] = bool(pred.graph_replay and len(pred._graphs) > 0)
         assert tuple(last.shape) == (B, K) and bool(torch.isfinite(last).all())
+        # the evaluation-loop form of the API: `predict_batches` keeps `depth` batches in flight by itself
+        for name, cache, bt in (("value_api_batches", False, batches), ("value_api_batches_eval_cache", True, batches),
+                                ("value_api_batches_head_averaged", False, batches_h1)):
+            backbone.batches = bt
+            pred.matcher.cache_atlas = cache
+            pred.matcher.invalidate_atlas_cache()
+            pred.invalidate_graphs()
+            wrapper.backbone_jit.i = 0
+            for o in pred.predict_batches((x for _ in range(2 * n_batches)), depth=n_batches):
+                last = o["pred"]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for o in pred.predict_batches((x for _ in range(n_calls)), depth=n_batches):
+                last = o["pred"]
+            t_host = time.perf_counter() - t1
+            torch.cuda.synchronize()
+            out[name] = B * n_calls / (time.perf_counter() - t1)
+            out[name + "_host_us_per_batch"] = 1e6 * t_host / n_calls       # time the submitting thread needs (no synchronisation in the loop)
+        assert tuple(last.shape) == (B, K) and bool(torch.isfinite(last).all())
         pred.invalidate_graphs()
     out["api_note"] = (f"SchemaNetPredictor.forward(x) once per batch, one call at a time ({n_calls} calls over {n_batches} resident batches): "
                        "raw taps in (tokens [197,256,384] sequence-first, per-head logits [256*6,197,197]: the head mean is fused into the "
@@ -240,7 +260,9 @@ def api_leg(device, disc, sn, m, n_calls, n_batches=4):
                        "+ class_edges + class_ingredients); value_api: class-graph branch recomputed in every call (Matcher.cache_atlas off, "
                        "like value_depth1), value_api_eval_cache: the predictor's eval() default (class-graph features kept per parameter version), "
                        "value_api_head_averaged: as value_api with the head mean taken beforehand ([256,197,197] logits in, the input of `value` / "
-                       "`value_depth1`): the API route itself against the hand-written step; the per-head input alone adds 199 MB of mandatory reads per call")
+                       "`value_depth1`): the API route itself against the hand-written step; the per-head input alone adds 199 MB of mandatory reads per call; "
+                       f"value_api_batches(_head_averaged): `SchemaNetPredictor.predict_batches(loader, depth={n_batches})` - the same calls made by the "
+                       "predictor's own evaluation loop, which keeps that many batches in flight on its own streams (what `value` does by hand)")
     return out
 
 

@@ -44,6 +44,7 @@ class SchemaNetPredictor(nn.Module):
         self.graph_replay = os.environ.get("SN_PREDICTOR_GRAPH", "1") != "0"
         self._graphs = collections.OrderedDict()
         self._graph_misses = 0
+        self._streams = None                                  # `predict_batches`: one HIP stream per batch in flight
 
     def train(self, mode: bool = True):
         """eval(): the class-graph features (a function of parameters only) are cached across forwards; train(): off"""
@@ -61,7 +62,7 @@ class SchemaNetPredictor(nn.Module):
         self._graph_misses = 0
 
     # ---- the path behind the backbone -----------------------------------------------------------------------
-    def _after_backbone(self, output, requires_graph: bool):
+    def _after_backbone(self, output, requires_graph: bool, side_stream=None):
         ret = collections.OrderedDict()
         # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
         # instance branch on the current one; joined inside forward_padded
@@ -69,7 +70,7 @@ class SchemaNetPredictor(nn.Module):
         if not torch.is_grad_enabled() and self.matcher.gnn.masks_adjacency(self.schema_net.edge_weights.tensor):
             # no autograd, MFMA GNN: the GCN operand and `class_edges` from ONE pass over the IR-Atlas
             get_atlas = lambda: self.schema_net.get_atlas(fused_adjacency="with_edges")       # noqa: E731
-        atlas = self.matcher.atlas_features_async(get_atlas, depends_on=self._atlas_depends_on())
+        atlas = self.matcher.atlas_features_async(get_atlas, depends_on=self._atlas_depends_on(), side_stream=side_stream)
         # (the zero padding of the instance edges is only written when the caller asks for the graphs)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
                                                       zero_padding=requires_graph, return_attn_cls=requires_graph)
@@ -92,39 +93,48 @@ class SchemaNetPredictor(nn.Module):
         return (sn.vertex_weights.tensor, sn.edge_weights.tensor, sn.class_ingredients.tensor,
                 ("prune", sn.prune_node_threshold, "self_loop", sn.remove_self_loop))
 
-    def _replay_key(self, mid_feat, extracted):
+    def _replay_key(self, mid_feat, extracted, side_stream=None):
         """A capture reads its inputs and every parameter BY ADDRESS and bakes in the operands derived from parameters
         (packed codebook, GNN.prepare, the cached class-graph features): it stays valid while the tap buffers are the
         same memory (the caching allocator hands a steady inference loop the same blocks every iteration) and no
-        parameter / buffer of this module has been written (version counters)."""
+        parameter / buffer of the modules behind the backbone has been written (version counters)."""
         key = [(t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype) for t in (mid_feat, extracted)]
-        key += [(t.data_ptr(), t._version) for t in self.parameters()]
-        key += [(t.data_ptr(), t._version) for t in self.buffers()]
+        # (the modules behind the backbone only: its own weights do not enter the captured part)
+        mods = [self.schema_net, self.matcher]
+        disc = getattr(self.ingredient_wrapper, "discretization_jit", None)
+        if disc is not None:
+            mods.append(disc)
+        for m_ in mods:
+            key += [(t.data_ptr(), t._version) for t in m_.parameters()]
+            key += [(t.data_ptr(), t._version) for t in m_.buffers()]
         sn = self.schema_net
         key.append((self.matcher.cache_atlas, sn.prune_node_threshold, sn.remove_self_loop, sn.clamp_vertex_attn, sn.clamp_edge_attn))
+        # a capture owns ONE set of buffers: it must never run on two streams at once (`predict_batches`)
+        key.append(side_stream)
+        key.append(torch.cuda.current_stream().cuda_stream)
         return tuple(key)
 
-    def _forward_replayed(self, x):
+    def _forward_replayed(self, x, own_pred: bool = True, side_stream=None):
         """eval + no_grad + `taps`: backbone eagerly, then the captured launch sequence of everything behind it."""
         from ..utils.graph_replay import GraphedStep
         wrapper = self.ingredient_wrapper
         out_backbone = wrapper.backbone_jit(x)
         mid_feat, extracted = out_backbone["mid_feat"], out_backbone["extracted"]
-        key = self._replay_key(mid_feat, extracted)
+        key = self._replay_key(mid_feat, extracted, side_stream)
         step = self._graphs.get(key)
         if step is None:
             if self._graph_misses >= 4 * self.max_graphs:       # tap buffers keep moving: replay cannot pay here
                 self.graph_replay = False
                 self._graphs.clear()
-                return self._after_backbone(wrapper.taps_from(out_backbone), False)
+                return self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream)
             self._graph_misses += 1
             try:
-                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone), False))
+                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream))
             except Exception as exc:                              # noqa: BLE001 - a configuration that cannot be captured
                 self.schema_net.logger.warning("hipGraph capture of the predictor failed (%r): eager launches from now on", exc)
                 self.graph_replay = False
                 self._graphs.clear()
-                return self._after_backbone(wrapper.taps_from(out_backbone), False)
+                return self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream)
             self._graphs[key] = step
             while len(self._graphs) > self.max_graphs:
                 self._graphs.popitem(last=False)
@@ -134,8 +144,62 @@ class SchemaNetPredictor(nn.Module):
         else:
             self._graphs.move_to_end(key)
         ret = collections.OrderedDict(step.replay())
-        ret["pred"] = ret["pred"].clone()                          # the capture's own buffer is rewritten by the next replay
+        if own_pred:
+            ret["pred"] = ret["pred"].clone()                      # the capture's own buffer is rewritten by the next replay
         return ret
+
+    def predict_batches(self, batches, depth: int = 4):
+        """`forward(x)` for every `x` of an iterable (an evaluation loop: reference eval/evaluation.py:63-80 calls the model
+        once per batch of the loader), yielded in order, with up to `depth` batches in flight on `depth` HIP streams.
+
+        One step of this path is a chain of ~30 short kernels, most of which fill every CU's LDS on their own: one batch
+        at a time leaves the chip idle at every kernel boundary.  Batch i runs - backbone eagerly, the rest replayed from
+        the capture of its stream - on stream i % depth; its results are handed to the caller's stream (an event wait,
+        no host synchronisation) when batch i + depth is submitted or the iterable ends.  `pred` is the batch's own
+        tensor; `class_*` are those of the capture (functions of the parameters only).  Same conditions as the replayed
+        `forward` (eval, no autograd, a wrapper with taps, a GPU); otherwise the batches are simply run one by one."""
+        wrapper = self.ingredient_wrapper
+        if not (self.graph_replay and not self.training and not torch.is_grad_enabled() and hasattr(wrapper, "taps_from")
+                and self.schema_net.vertex_weights.tensor.is_cuda and not torch.cuda.is_current_stream_capturing()):
+            for x in batches:
+                yield self.forward(x)
+            return
+        depth = max(1, min(int(depth), self.max_graphs))
+        if self._streams is None or len(self._streams) < depth:
+            self._streams = [torch.cuda.Stream() for _ in range(depth)]
+        home = torch.cuda.current_stream()
+        in_flight = collections.deque()
+        # one batch at a time: the class-graph branch overlaps the instance chain on a second stream; several in flight:
+        # every batch in line on its own stream (the other batches fill the gaps; forks on top of that only contend - DESIGN 5)
+        fork = None if depth == 1 else False
+
+        def hand_over(item):
+            # the capture's `pred` buffer is copied on the CALLER's stream: nothing allocated on a batch stream outlives
+            # the call that made it, so the allocator hands every visit of a stream the same tap blocks (= replay hits);
+            # the next replay of that capture is submitted after this copy (`st.wait_stream(home)` below)
+            out, done = item
+            home.wait_event(done)
+            out["pred"] = out["pred"].clone()
+            return out
+
+        for i, x in enumerate(batches):
+            if len(in_flight) == depth:
+                yield hand_over(in_flight.popleft())
+            st = self._streams[i % depth]
+            st.wait_stream(home)                       # `x` (and anything the parameters wait for) was produced there
+            with torch.cuda.stream(st):
+                if torch.is_tensor(x):
+                    x.record_stream(st)
+                if self.graph_replay:
+                    out = self._forward_replayed(x, own_pred=False, side_stream=fork)
+                else:                                  # (capture gave up on the way: eager launches, still `depth` streams)
+                    out = self._after_backbone(wrapper.taps(x), False, fork)
+                    out["pred"].record_stream(home)
+                done = torch.cuda.Event()
+                done.record(st)
+            in_flight.append((out, done))
+        while in_flight:
+            yield hand_over(in_flight.popleft())
 
     def forward(self, x: torch.Tensor, requires_graph: bool = False) -> Dict[str, torch.Tensor]:
         wrapper = self.ingredient_wrapper

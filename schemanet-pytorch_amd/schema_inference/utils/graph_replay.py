@@ -31,8 +31,16 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.outputs = fn()
+        # capture_begin / capture_end by hand: the `torch.cuda.graph` context also empties the caching allocator, which
+        # hands every LATER eager allocation of the process a new address - and a capture keyed on the addresses of its
+        # inputs (SchemaNetPredictor) would then see them move after every other capture
+        with torch.no_grad(), torch.cuda.stream(side):
+            self.graph.capture_begin()
+            try:
+                self.outputs = fn()
+            finally:
+                self.graph.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
 
     def replay(self):
         self.graph.replay()

@@ -163,6 +163,48 @@ def test_predictor_replay_with_a_backbone_that_allocates_its_outputs(mods):
     assert pred.graph_replay and 1 <= len(pred._graphs) <= 3 and pred._graph_misses <= 3, (len(pred._graphs), pred._graph_misses)
 
 
+def test_predict_batches_keeps_batches_in_flight_and_in_order(mods):
+    """`SchemaNetPredictor.predict_batches`: an evaluation loop over 11 batches from an allocating backbone with three
+    batches in flight on the predictor's own streams - every batch's `pred` equals the eager forward of the same batch,
+    in the order of the loader; one capture per stream (never one capture on two streams); a second loop over the same
+    predictor replays without a new capture; in train() / with autograd it degrades to one forward per batch."""
+    bs, H, L, D, M, K = 4, 2, 196, 192, 128, 5
+    n = 11
+    xs = [torch.full((bs, 3, 2, 2), float(i), device=DEV) for i in range(n)]
+    mids = [T(datagen.bellish((L + 1, bs, D), 450 + i, 1.0)) for i in range(n)]
+    exts = [T(datagen.bellish((bs * H, L + 1, L + 1), 470 + i, 2.0)) for i in range(n)]
+
+    class _Backbone(torch.nn.Module):                       # the batch is picked by the image tensor itself
+        def forward(self, x):
+            j = int(x[0, 0, 0, 0].item())
+            return {"mid_feat": mids[j] * 1.0, "extracted": exts[j] * 1.0}
+    pred, wrapper = _predictor(mods, [(mids[0], exts[0])], M, D, K, 32)
+    wrapper.backbone_jit = _Backbone()
+    with torch.no_grad():
+        pred.graph_replay = False
+        want = [pred(x)["pred"].clone() for x in xs]
+        pred.graph_replay = True
+        got = []
+        for o in pred.predict_batches(iter(xs), depth=3):
+            assert list(o.keys()) == ["pred", "class_vertices", "class_edges", "class_ingredients"]
+            got.append(o["pred"] + 0.0)                      # (read on the caller's stream right away)
+        torch.cuda.synchronize()
+        assert len(got) == n
+        for i in range(n):
+            assert torch.equal(got[i], want[i]), i
+        assert pred.graph_replay and 3 <= len(pred._graphs) <= pred.max_graphs
+        assert len({k[-1] for k in pred._graphs}) == 3       # three streams, each with captures of its own
+        misses = pred._graph_misses
+        again = [o["pred"] for o in pred.predict_batches(xs, depth=3)]
+        torch.cuda.synchronize()
+        assert pred._graph_misses == misses
+        for i in range(n):
+            assert torch.equal(again[i], want[i]), i
+    # not an inference loop: plain forwards, same results
+    outs = [o["pred"] for o in pred.predict_batches(xs[:2], depth=3)]
+    assert outs[0].requires_grad and torch.allclose(outs[0], want[0], rtol=1e-5, atol=1e-5 * float(want[0].abs().max()))
+
+
 # =============================================================================== the N > 1 branch of bench.py
 def test_bench_two_ranks_rehearsal():
     """What the driver launches for N = 2, with both ranks on this box's one GPU over gloo (SN_BENCH_REHEARSAL=1: RCCL
