@@ -270,6 +270,15 @@ int sn_mask_layernorm_act(float *x, int G, int n, int E, const int32_t *n_valid,
 int sn_weighted_pool(const float *feat, const float *nodes, int G, int n, int E,
                      const int32_t *divisor_dev, float *out, void *stream);
 
+/* The two above without the normalised rows in between (GNN widths other than 256, where LayerNorm is not a GEMM epilogue):
+ * mask + LayerNorm + activation of x [G, n, E] exactly as sn_mask_layernorm_act (x is NOT modified), then
+ *   sn_layernorm_weighted_pool: out [G, E] as sn_weighted_pool of the normalised rows (last layer, gnn.py:94-96);
+ *   sn_layernorm_split_planes (below, with the operand planes): the next product's operand.
+ * Both are bit-identical to the two-call sequences they replace.  E <= 1024. */
+int sn_layernorm_weighted_pool(const float *x, const float *nodes, int G, int n, int E, const int32_t *n_valid,
+                               const float *gamma, const float *beta, float eps, int relu,
+                               const int32_t *divisor_dev, float *out, void *stream);
+
 /* pred [B, K] from feat_inst [B, E], feat_kg [K, E]        match.py:21-31
  * similarity: 0 inner_product, 1 cosine ((cos+1)/2), 2 euclidean (1/(1+dist)). */
 int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, int E,
@@ -346,6 +355,13 @@ int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids,
  * blocked planes of a [rows, cols] operand per batch entry. */
 int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
                     const float *scale_dev, void *out_hi, void *out_lo, void *stream);
+
+/* sn_mask_layernorm_act(x [G, n, E]) followed by sn_split_planes of the result (times *scale_dev) as one pass that leaves x
+ * untouched and never stores the normalised rows: blocked planes of an [n, E] operand per graph (gnn.py:43-46 feeding the
+ * next layer's Linear).  E % 16 == 0, E <= 1024.  Bit-identical to the two calls. */
+int sn_layernorm_split_planes(const float *x, int G, int n, int E, const int32_t *n_valid, const float *gamma,
+                              const float *beta, float eps, int relu, const float *scale_dev, void *out_hi,
+                              void *out_lo, void *stream);
 
 /* C[b] = A[b] . Bt[b]^T for b < batches; A = planes of an [m, k] operand, Bt = planes of an [n, k]
  * operand, k % 16 == 0 (the padded k of the planes); batch strides in fp16 elements, 0 = shared

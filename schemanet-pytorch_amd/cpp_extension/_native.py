@@ -16,7 +16,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
-ABI_VERSION = 5
+ABI_VERSION = 6
 SN_MAX_TOKENS = 196
 _lib = None
 
@@ -102,6 +102,10 @@ _SIGNATURES = {
     "sn_gcn_adjacency": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sn_mask_layernorm_act": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "sn_weighted_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sn_layernorm_weighted_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                           c_void_p, c_void_p, c_void_p]),
+    "sn_layernorm_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
     "sn_match_scores": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sn_class_votes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sn_pool_fc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

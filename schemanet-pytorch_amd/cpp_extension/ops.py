@@ -761,6 +761,36 @@ def weighted_pool(feat, nodes, divisor_dev=None):
     return out
 
 
+def layernorm_weighted_pool(x, gamma, beta, eps, nodes, n_valid=None, relu=True, divisor_dev=None):
+    """weighted_pool(mask_layernorm_act_(x), nodes, divisor_dev) in one pass over x [G, n, E]; x is left as it is."""
+    lib = N.require_gpu()
+    dev = _check_dev(x, gamma, beta, nodes, n_valid, divisor_dev)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    G, n, E = x.shape
+    out = torch.empty((G, E), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_layernorm_weighted_pool(N.ptr(x), N.ptr(_f32c(nodes)), G, n, E, N.ptr(n_valid), N.ptr(_f32c(gamma.detach())),
+                                               N.ptr(_f32c(beta.detach())), float(eps), int(relu), N.ptr(divisor_dev), N.ptr(out),
+                                               N.stream_ptr(dev)), "sn_layernorm_weighted_pool")
+    return out
+
+
+def layernorm_split_planes(x, gamma, beta, eps, n_valid=None, relu=True, scale=None):
+    """split_planes(mask_layernorm_act_(x), scale) in one pass over x [G, n, E] (E % 16 == 0); x is left as it is.
+    `scale`: a device scalar (pow2_scale of a bound on the LayerNorm output) or None."""
+    lib = N.require_gpu()
+    dev = _check_dev(x, gamma, beta, n_valid)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    G, n, E = x.shape
+    out = _alloc_planes(lib, dev, G, n, E)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_layernorm_split_planes(N.ptr(x), G, n, E, N.ptr(n_valid), N.ptr(_f32c(gamma.detach())), N.ptr(_f32c(beta.detach())),
+                                              float(eps), int(relu), N.ptr(scale), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+                "sn_layernorm_split_planes")
+    out.scale = scale
+    return out
+
+
 SIMILARITY = {"inner_product": 0, "cosine": 1, "euclidean": 2}
 
 

@@ -69,6 +69,48 @@ __device__ __forceinline__ float sn_wave_sum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// LayerNorm + optional ReLU of one row held by a wave: v[k] = element lane + 64 k of the row (0 beyond E; all 0 for a
+// masked row, reference gnn.py:43-46) -> normalised values in place.  ONE definition for every kernel that normalises
+// rows (sn_mask_layernorm_act and the fused forms that never store the result): same sums in the same order, bit for bit.
+constexpr int SN_LN_MAX = 16;           // E <= 64 * 16
+// gm / bt: gamma and beta at the lane's columns (sn_layernorm_coeffs), loaded once per wave.
+__device__ __forceinline__ void sn_layernorm_coeffs(float (&gm)[SN_LN_MAX], float (&bt)[SN_LN_MAX], int lane, int E, const float *gamma,
+                                                    const float *beta)
+{
+#pragma unroll
+    for (int k = 0; k < SN_LN_MAX; ++k) {
+        const int c = lane + SN_WAVE * k;
+        gm[k] = c < E ? gamma[c] : 0.0f;
+        bt[k] = c < E ? beta[c] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void sn_layernorm_row(float (&v)[SN_LN_MAX], int lane, int E, const float (&gm)[SN_LN_MAX],
+                                                 const float (&bt)[SN_LN_MAX], float eps, int relu)
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SN_LN_MAX; ++k) s += v[k];
+    const float mean = sn_wave_sum(s) / (float)E;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SN_LN_MAX; ++k) {
+        const int c = lane + SN_WAVE * k;
+        const float d = (c < E) ? v[k] - mean : 0.0f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(sn_wave_sum(q) / (float)E + eps);
+#pragma unroll
+    for (int k = 0; k < SN_LN_MAX; ++k) {
+        const int c = lane + SN_WAVE * k;
+        if (c < E) {
+            float y = (v[k] - mean) * rstd * gm[k] + bt[k];
+            if (relu) y = fmaxf(y, 0.0f);
+            v[k] = y;
+        }
+    }
+}
+
 // fp64 xor butterfly (off = 32, 16, 8, 4, 2, 1): the summation order of the oracle's sno_dot64.
 // Same values as six __shfl_xor steps, but moved with v_permlane32/16_swap and DPP instead of
 // ds_bpermute (checked bit for bit on MI355X: the S1 parity tests compare every index with the oracle).  xor 8 / xor 4 use

@@ -306,6 +306,73 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float *x, int r
     store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(row, pk * 8, kb_count));
 }
 
+// mask + LayerNorm + activation of x [G][n][E] (exactly sn_mask_layernorm_act: sn_layernorm_row) and the hi/lo split of the
+// result into the blocked planes of an [n, E] operand per graph (exactly split_planes_kernel), without storing the fp32
+// rows in between: 8 bytes per element of HBM traffic instead of 24.  A tile = one block row (32 rows) of one graph: the
+// eight waves of a workgroup normalise four rows each into an LDS tile, then every thread converts 16-byte pieces -
+// consecutive threads, consecutive rows of one k block, i.e. 512 contiguous bytes per plane and half wave.  The workgroups
+// are persistent (two per CU, each walking tiles t, t + grid, ...): one workgroup per tile was bound by the rate at which
+// the chip starts waves (128 k waves of four rows each: 0.6 ms with loads and stores compiled out), and the next tile's
+// rows are requested before the current tile's pieces are stored, so a CU's one resident workgroup (the tile takes 132 KB
+// of LDS at E = 1024) keeps HBM busy in both phases.
+constexpr int kLnSplitThreads = 512, kLnSplitPad = 4;      // row stride E + 4 floats: 16 lanes' b128 reads cover all banks
+__global__ __launch_bounds__(kLnSplitThreads) void layernorm_split_planes_kernel(const float *x, int n, int E, const int32_t *n_valid,
+                                                                                 const float *gamma, const float *beta, float eps, int relu,
+                                                                                 int kb_count, int64_t batch_stride, _Float16 *out_h,
+                                                                                 _Float16 *out_l, const float *scale_dev, int row_blocks,
+                                                                                 int64_t tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float ln_tile[];      // [32][E + kLnSplitPad]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ldt = E + kLnSplitPad;
+    const float scale = scale_dev ? *scale_dev : 1.0f;
+    float gm[SN_LN_MAX], bt[SN_LN_MAX];
+    sn_layernorm_coeffs(gm, bt, lane, E, gamma, beta);
+    float v[4][SN_LN_MAX];
+    auto request = [&](int64_t t) {                                       // rows wid, wid + 8, ... of tile t -> v
+        const int g = (int)(t / row_blocks), rb = (int)(t % row_blocks);
+        const int nv = (n_valid && t < tiles) ? n_valid[g] : n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb * 32 + wid + 8 * i;
+            const bool live = t < tiles && r < n && r < nv;
+            const float *p = x + ((int64_t)g * n + r) * E;
+#pragma unroll
+            for (int k = 0; k < SN_LN_MAX; ++k) {
+                const int c = lane + SN_WAVE * k;
+                v[i][k] = (c < E && live) ? p[c] : 0.0f;
+            }
+        }
+    };
+    int64_t t = blockIdx.x;
+    if (t < tiles) request(t);
+    for (; t < tiles; t += gridDim.x) {
+        const int g = (int)(t / row_blocks), rb = (int)(t % row_blocks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = wid + 8 * i;
+            const bool row_exists = rb * 32 + rr < n;                      // rows that pad the operand to 32 stay zero
+            if (row_exists) sn_layernorm_row(v[i], lane, E, gm, bt, eps, relu);
+#pragma unroll
+            for (int k = 0; k < SN_LN_MAX; ++k) {
+                const int c = lane + SN_WAVE * k;
+                if (c < E) ln_tile[rr * ldt + c] = row_exists ? v[i][k] * scale : 0.0f;
+            }
+        }
+        __syncthreads();
+        request(t + gridDim.x);                                            // (in flight under the stores below)
+        const int pieces = 32 * kb_count * 2;
+        for (int q = tid; q < pieces; q += kLnSplitThreads) {
+            const int rr = q & 31, pk = q >> 5;
+            const float4 a = *reinterpret_cast<const float4 *>(ln_tile + rr * ldt + pk * 8);
+            const float4 b = *reinterpret_cast<const float4 *>(ln_tile + rr * ldt + pk * 8 + 4);
+            const float w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            store_piece(w, out_h, out_l, (int64_t)g * batch_stride + blocked_index(rb * 32 + rr, pk * 8, kb_count));
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ the GEMM
 struct GemmArgs {
     const _Float16 *a_hi, *a_lo;
@@ -974,6 +1041,26 @@ extern "C" int sn_split_planes(const float *x, int batches, int rows, int cols, 
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((pieces + 255) / 256), (unsigned)batches), dim3(256), 0, (hipStream_t)stream, x,
                        rows, cols, ld, batch_stride, kb, sn_gcn_plane_elems(rows, cols), (_Float16 *)out_hi, (_Float16 *)out_lo, scale_dev);
     SN_CHECK_LAUNCH("sn_split_planes");
+    return SN_OK;
+}
+
+extern "C" int sn_layernorm_split_planes(const float *x, int G, int n, int E, const int32_t *n_valid, const float *gamma,
+                                         const float *beta, float eps, int relu, const float *scale_dev, void *out_hi,
+                                         void *out_lo, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0 && E > 0, SN_ERR_BAD_ARG, "sn_layernorm_split_planes: bad G=%d n=%d E=%d", G, n, E);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(x && gamma && beta && out_hi && out_lo, SN_ERR_BAD_ARG, "sn_layernorm_split_planes: NULL pointer");
+    SN_REQUIRE(E % 16 == 0 && E <= SN_WAVE * SN_LN_MAX, SN_ERR_UNSUPPORTED, "sn_layernorm_split_planes: E=%d must be a multiple of 16, <= %d", E,
+               SN_WAVE * SN_LN_MAX);
+    const size_t lds = (size_t)32 * (E + kLnSplitPad) * sizeof(float);
+    if (int rc = sn_ensure_dynamic_lds((const void *)layernorm_split_planes_kernel, lds, "sn_layernorm_split_planes")) return rc;
+    const int row_blocks = (n + 31) / 32;
+    const int64_t tiles = (int64_t)G * row_blocks, slots = 2 * (int64_t)sn_device_cus();
+    hipLaunchKernelGGL(layernorm_split_planes_kernel, dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(kLnSplitThreads), lds,
+                       (hipStream_t)stream, x, n, E, n_valid, gamma, beta, eps, relu, E / 16, sn_gcn_plane_elems(n, E),
+                       (_Float16 *)out_hi, (_Float16 *)out_lo, scale_dev, row_blocks, tiles);
+    SN_CHECK_LAUNCH("sn_layernorm_split_planes");
     return SN_OK;
 }
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gcn_adjacency_kernel(const float *edges, 
 
 // ------------------------------------------------------------------ mask + LayerNorm + ReLU
 // one wave per row; E <= 64 * 16
-constexpr int kLnMax = 16;
+constexpr int kLnMax = SN_LN_MAX;
 
 __global__ __launch_bounds__(256) void mask_layernorm_act_kernel(float *x, int64_t rows, int n, int E,
                                                                  const int32_t *n_valid, const float *gamma,
@@ -51,30 +51,18 @@ __global__ __launch_bounds__(256) void mask_layernorm_act_kernel(float *x, int64
     const bool masked = n_valid && r >= n_valid[g];
     float *p = x + row * E;
     float v[kLnMax];
-    float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < kLnMax; ++k) {
         const int c = lane + SN_WAVE * k;
         v[k] = (c < E && !masked) ? p[c] : 0.0f;
-        s += v[k];
     }
-    const float mean = sn_wave_sum(s) / (float)E;
-    float q = 0.0f;
+    float gm[kLnMax], bt[kLnMax];
+    sn_layernorm_coeffs(gm, bt, lane, E, gamma, beta);
+    sn_layernorm_row(v, lane, E, gm, bt, eps, relu);
 #pragma unroll
     for (int k = 0; k < kLnMax; ++k) {
         const int c = lane + SN_WAVE * k;
-        const float d = (c < E) ? v[k] - mean : 0.0f;
-        q += d * d;
-    }
-    const float rstd = 1.0f / sqrtf(sn_wave_sum(q) / (float)E + eps);
-#pragma unroll
-    for (int k = 0; k < kLnMax; ++k) {
-        const int c = lane + SN_WAVE * k;
-        if (c < E) {
-            float y = (v[k] - mean) * rstd * gamma[c] + beta[c];
-            if (relu) y = fmaxf(y, 0.0f);
-            p[c] = y;
-        }
+        if (c < E) p[c] = v[k];
     }
 }
 
@@ -98,6 +86,57 @@ __global__ __launch_bounds__(256) void weighted_pool_kernel(const float *feat, c
     if (wid == 0 && c < E) {
         const float total = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
         const float div = divisor_dev ? (float)(*divisor_dev) : (float)n;
+        out[(int64_t)g * E + c] = total / div;
+    }
+}
+
+// mask + LayerNorm + activation of x [G, n, E] (as mask_layernorm_act_kernel) and the weighted pooling of the result (as
+// weighted_pool_kernel) in one pass: the normalised rows are never stored.  One workgroup per graph; wave w normalises
+// the rows r = w, w + 4, ... and adds them to its partial sums in that order, the four partial sums are combined as
+// (0 + 1) + (2 + 3): the sums of weighted_pool_kernel, bit for bit.  The next row's loads are issued before the current
+// row's reductions.
+__global__ __launch_bounds__(256) void layernorm_weighted_pool_kernel(const float *x, const float *nodes, int n, int E,
+                                                                      const int32_t *n_valid, const float *gamma, const float *beta,
+                                                                      float eps, int relu, const int32_t *divisor_dev, float *out)
+{
+    extern __shared__ float part[];                      // [4][E]
+    const int g = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nv = n_valid ? n_valid[g] : n;
+    const float *w = nodes + (int64_t)g * n;
+    const float *xg = x + (int64_t)g * n * E;
+    float acc[kLnMax], nxt[kLnMax], gm[kLnMax], bt[kLnMax];
+    sn_layernorm_coeffs(gm, bt, lane, E, gamma, beta);
+#pragma unroll
+    for (int k = 0; k < kLnMax; ++k) acc[k] = 0.0f;
+    auto load = [&](int r, float (&v)[kLnMax]) {
+        const bool live = r < n && r < nv;
+        const float *p = xg + (int64_t)r * E;
+#pragma unroll
+        for (int k = 0; k < kLnMax; ++k) {
+            const int c = lane + SN_WAVE * k;
+            v[k] = (c < E && live) ? p[c] : 0.0f;
+        }
+    };
+    load(wid, nxt);
+    for (int r = wid; r < n; r += 4) {
+        float v[kLnMax];
+#pragma unroll
+        for (int k = 0; k < kLnMax; ++k) v[k] = nxt[k];
+        load(r + 4, nxt);
+        sn_layernorm_row(v, lane, E, gm, bt, eps, relu);
+        const float wr = w[r];
+#pragma unroll
+        for (int k = 0; k < kLnMax; ++k) acc[k] = acc[k] + v[k] * wr;
+    }
+#pragma unroll
+    for (int k = 0; k < kLnMax; ++k) {
+        const int c = lane + SN_WAVE * k;
+        if (c < E) part[wid * E + c] = acc[k];
+    }
+    __syncthreads();
+    const float div = divisor_dev ? (float)(*divisor_dev) : (float)n;
+    for (int c = threadIdx.x; c < E; c += 256) {
+        const float total = (part[c] + part[E + c]) + (part[2 * E + c] + part[3 * E + c]);
         out[(int64_t)g * E + c] = total / div;
     }
 }
@@ -330,6 +369,20 @@ extern "C" int sn_weighted_pool(const float *feat, const float *nodes, int G, in
     hipLaunchKernelGGL(weighted_pool_kernel, dim3((unsigned)((E + SN_WAVE - 1) / SN_WAVE), (unsigned)G), dim3(256), 0,
                        (hipStream_t)stream, feat, nodes, n, E, divisor_dev, out);
     SN_CHECK_LAUNCH("sn_weighted_pool");
+    return SN_OK;
+}
+
+extern "C" int sn_layernorm_weighted_pool(const float *x, const float *nodes, int G, int n, int E, const int32_t *n_valid,
+                                          const float *gamma, const float *beta, float eps, int relu,
+                                          const int32_t *divisor_dev, float *out, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0 && E > 0, SN_ERR_BAD_ARG, "sn_layernorm_weighted_pool: bad G=%d n=%d E=%d", G, n, E);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(x && nodes && gamma && beta && out, SN_ERR_BAD_ARG, "sn_layernorm_weighted_pool: NULL pointer");
+    SN_REQUIRE(E <= SN_WAVE * kLnMax, SN_ERR_UNSUPPORTED, "sn_layernorm_weighted_pool: E=%d > %d", E, SN_WAVE * kLnMax);
+    hipLaunchKernelGGL(layernorm_weighted_pool_kernel, dim3((unsigned)G), dim3(256), (size_t)4 * E * sizeof(float), (hipStream_t)stream,
+                       x, nodes, n, E, n_valid, gamma, beta, eps, relu, divisor_dev, out);
+    SN_CHECK_LAUNCH("sn_layernorm_weighted_pool");
     return SN_OK;
 }
 

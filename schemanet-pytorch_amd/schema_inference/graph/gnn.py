@@ -202,8 +202,8 @@ class GNN(nn.Module):
 
     def _forward_mfma_wide(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None):
         """embed_dim != 256: a row of the result spans several 256-column tiles, so LayerNorm cannot be an epilogue of
-        the GEMM.  Same three products on the matrix cores (split fp16, fp32-GEMM accuracy), fp32 results, the
-        mask + LayerNorm + activation kernel in place, a hi/lo split for the next product, the pooling kernel."""
+        the GEMM.  Same three products on the matrix cores (split fp16, fp32-GEMM accuracy), fp32 results; mask + LayerNorm +
+        activation run inside the pass that splits H1 for the next product, and inside the pooling pass for H2."""
         G, n = ingredients.shape
         l1, l2 = self.layers
         ext = divisor if (divisor is not None and torch.is_tensor(divisor)) else None
@@ -214,13 +214,15 @@ class GNN(nn.Module):
         zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext, scale=prepared["table_scale"])   # Bt [G, E, n]
         c1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias, rows_valid=n_valid, want_c=True, zero_c=ext is not None,
                           m_extent=ext, k_extent=ext)["c"]                                           # [G, n, E]
-        ops.mask_layernorm_act_(c1, l1.norm.weight, l1.norm.bias, l1.norm.eps, n_valid=n_valid, relu=l1._is_relu)
-        zt2 = ops.gcn_gemm(prepared["w2"], ops.split_planes(c1, scale=prepared["h1_scale"]), G, want_planes=n,
-                           out_scale=prepared["zt2_scale"])["planes"]                                # [G, E, n]
+        # mask + LayerNorm + activation and the hi / lo split of H1 in one pass (H1 itself is never stored)
+        h1 = ops.layernorm_split_planes(c1, l1.norm.weight, l1.norm.bias, l1.norm.eps, n_valid=n_valid, relu=l1._is_relu,
+                                        scale=prepared["h1_scale"])
+        zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n, out_scale=prepared["zt2_scale"])["planes"]   # [G, E, n]
         c2 = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias, rows_valid=n_valid, want_c=True, zero_c=ext is not None,
                           m_extent=ext, k_extent=ext)["c"]
-        ops.mask_layernorm_act_(c2, l2.norm.weight, l2.norm.bias, l2.norm.eps, n_valid=n_valid, relu=l2._is_relu)
-        return ops.pool_fc(ops.weighted_pool(c2, nodes, divisor), 1.0, self.fc.weight, self.fc.bias, weight_t=prepared.get("fc_t"))    # (the final Linear without a library GEMM)
+        pooled = ops.layernorm_weighted_pool(c2, l2.norm.weight, l2.norm.bias, l2.norm.eps, nodes, n_valid=n_valid, relu=l2._is_relu,
+                                             divisor_dev=divisor)                                    # (nor H2)
+        return ops.pool_fc(pooled, 1.0, self.fc.weight, self.fc.bias, weight_t=prepared.get("fc_t"))    # (the final Linear without a library GEMM)
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
                 feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
