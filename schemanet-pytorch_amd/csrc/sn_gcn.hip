@@ -311,10 +311,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float *x, int r
 // rows in between: 8 bytes per element of HBM traffic instead of 24.  A tile = one block row (32 rows) of one graph: the
 // eight waves of a workgroup normalise four rows each into an LDS tile, then every thread converts 16-byte pieces -
 // consecutive threads, consecutive rows of one k block, i.e. 512 contiguous bytes per plane and half wave.  The workgroups
-// are persistent (two per CU, each walking tiles t, t + grid, ...): one workgroup per tile was bound by the rate at which
-// the chip starts waves (128 k waves of four rows each: 0.6 ms with loads and stores compiled out), and the next tile's
-// rows are requested before the current tile's pieces are stored, so a CU's one resident workgroup (the tile takes 132 KB
-// of LDS at E = 1024) keeps HBM busy in both phases.
+// are persistent (two per CU, each walking tiles t, t + grid, ...): the tile takes 132 KB of LDS at E = 1024, so with one
+// workgroup per tile a CU ran its workgroups one after the other, each paying launch, first-load latency and drain alone
+// (0.6 of 1.27 ms with loads and stores compiled out); the next tile's rows are requested before the current tile's pieces
+// are stored, so the one resident workgroup keeps HBM busy in both phases.
 constexpr int kLnSplitThreads = 512, kLnSplitPad = 4;      // row stride E + 4 floats: 16 lanes' b128 reads cover all banks
 __global__ __launch_bounds__(kLnSplitThreads) void layernorm_split_planes_kernel(const float *x, int n, int E, const int32_t *n_valid,
                                                                                  const float *gamma, const float *beta, float eps, int relu,
