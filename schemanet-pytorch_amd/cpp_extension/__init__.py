@@ -74,7 +74,7 @@ def cpp_feat_to_instance_v(
     num_v = g["n"].to(torch.int64).cpu()                       # the API returns it on the host
     mask = torch.arange(L, device=dev)[None, :] < g["n"][:, None]
     ids = g["ids"][mask]
-    weights = (g["v2"][mask] @ w_dev).squeeze(-1)              # autograd reaches w (survey 3.3)
+    weights = ops.weigh_attributes(g["v2"][mask], w_dev)              # autograd reaches w (survey 3.3)
     return [ids.to(w.device), weights.to(w.device), num_v]
 
 
@@ -182,5 +182,5 @@ def cpp_feat_to_instance_e(
     g = ops.instance_graph(ing, at, None, w_e=w_dev, n_pad=n_pad, pad_id=-1, attn_is_logits=False,
                            geo=geo, mean=mean, remove_self_loop=remove_self_loop, dicts=dicts,
                            want_attr2=True, want_weighted=False)
-    e = (g["e2"] @ w_dev).squeeze(-1)                          # [B, n_pad, n_pad], grad -> w
+    e = ops.weigh_attributes(g["e2"], w_dev)                            # [B, n_pad, n_pad], grad -> w
     return [e[b, :n, :n].to(w.device) for b, n in enumerate(ln)]

@@ -204,7 +204,7 @@ class SchemaNet(nn.Module):
             attr2, _ = ops.full_vertices(ing, attn_cls.to(dev), self.num_vertices, is_logits=True, clamp=None,
                                          want_attr2=True, want_weighted=False)
             graph_utils.normalize_max_(attr2, dim=1)
-            return (attr2 @ w).squeeze(-1)
+            return ops.weigh_attributes(attr2, w)
         _, v = ops.full_vertices(ing, attn_cls.to(dev), self.num_vertices, w_v=w, is_logits=True, clamp=None)
         return v
 
@@ -223,7 +223,7 @@ class SchemaNet(nn.Module):
             graph_utils.normalize_sum_(attr2, dim=2)
             if self.remove_self_loop:
                 attr2.diagonal(dim1=1, dim2=2).fill_(0)
-            return (attr2 @ w).squeeze(-1)
+            return ops.weigh_attributes(attr2, w)
         _, e = ops.limited_edges(ing, at, self.class_slot, lab, self.class_max_vertices, w_e=w, **kw)
         return e
 
@@ -270,8 +270,8 @@ class SchemaNet(nn.Module):
             want_attr2=need_grad, want_weighted=not need_grad, attn_cls_masked_out=masked_out,
             zero_padding=zero_padding or need_grad)
         if need_grad:   # keep `@ w` visible to autograd (the reference does it inside C++)
-            g["v"] = (g["v2"] @ w_v).squeeze(-1)
-            g["e"] = (g["e2"] @ w_e).squeeze(-1)
+            g["v"] = ops.weigh_attributes(g["v2"], w_v)
+            g["e"] = ops.weigh_attributes(g["e2"], w_e)
         ret = {"ids": g["ids"], "vertices": g["v"], "edges": g["e"], "n": g["n"], "n_max": g["n_max"],
                "edges_padded": bool(zero_padding or need_grad)}
         if return_attn_cls:
@@ -301,7 +301,7 @@ class SchemaNet(nn.Module):
         g = ops.instance_graph(ingredients.to(dev), None, attn_cls.to(dev), w_v=w_v, n_pad=self.default_n_pad(L),
                                pad_id=self.num_vertices, attn_cls_is_logits=True, clamp_v=self.clamp_vertex_attn,
                                want_attr2=need_grad, want_weighted=not need_grad, attn_cls_masked_out=masked_out)
-        v = (g["v2"] @ w_v).squeeze(-1) if need_grad else g["v"]
+        v = ops.weigh_attributes(g["v2"], w_v) if need_grad else g["v"]
         sizes = g["n"].tolist()
         return ([g["ids"][b, :n] for b, n in enumerate(sizes)], [v[b, :n] for b, n in enumerate(sizes)])
 
@@ -318,7 +318,7 @@ class SchemaNet(nn.Module):
                                feat_h=self.feat_h, feat_w=self.feat_w, dist_alpha=self.dist_alpha,
                                dist_pow=self.dist_pow, remove_self_loop=self.remove_self_loop,
                                want_attr2=need_grad, want_weighted=not need_grad)
-        e = (g["e2"] @ w_e).squeeze(-1) if need_grad else g["e"]
+        e = ops.weigh_attributes(g["e2"], w_e) if need_grad else g["e"]
         return [e[b, :n, :n] for b, n in enumerate(g["n"].tolist())]
 
     def forward(self, ingredients: torch.LongTensor, attn: torch.Tensor, attn_cls: torch.Tensor

@@ -229,6 +229,30 @@ def test_bench_two_ranks_rehearsal():
     assert "REHEARSAL" in out["launch"] and out["cpu_baseline"] is None
 
 
+def test_linear_with_per_graph_weight_gradient(mods):
+    """Training route of the GCN: the Linear of a layer takes its weight gradient as G per-graph products + one sum (the
+    library's single [out, in] product over G n rows runs on 256 tiny tiles): same y, same three gradients as nn.Linear
+    up to the order of the fp32 sums; taken on the GPU under autograd only."""
+    from schema_inference.graph import gnn as gnn_mod
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(96, 64).to(DEV)
+    x = torch.randn(7, 50, 96, device=DEV, requires_grad=True)
+    dy = torch.randn(7, 50, 64, device=DEV)
+    y = gnn_mod._linear(lin, x)
+    assert type(y.grad_fn).__name__.startswith("_LinearPerGraphWeightGrad")
+    y.backward(dy)
+    got = (y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None; lin.zero_grad()
+    y2 = lin(x)
+    y2.backward(dy)
+    want = (y2.detach(), x.grad, lin.weight.grad, lin.bias.grad)
+    for g_, w_ in zip(got, want):
+        assert (g_ - w_).abs().max().item() <= 2e-6 * w_.abs().max().item()
+    with torch.no_grad():
+        assert gnn_mod._linear(lin, x).grad_fn is None
+    assert not type(gnn_mod._linear(lin, x[0]).grad_fn).__name__.startswith("_LinearPerGraphWeightGrad")       # 2-D input: the library
+
+
 # =============================================================================== config [4] at its real size
 def test_c5_real_size_training_iterations(mods):
     """deit_small-l9-M_1024.yaml:22-47: B = 64, M = 1024, K = 101, n_max = 1024 (a 424 MB edge_weights with gradients),
