@@ -136,97 +136,118 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
         }
         if (pair_I < 0 || pair_J >= T) return;                 // (whole workgroup, before any barrier)
     }
-    for (int half = 0; half < 2; ++half) {
-        const int I = pair_tiles > 0 ? pair_I : (half == 0 ? (int)blockIdx.x : T - 1 - (int)blockIdx.x);
-        if (pair_tiles > 0 ? half == 1 : (I < 0 || I >= T || (half == 1 && I <= (int)blockIdx.x))) continue;      // (odd T: the middle tile once)
-        const int bi = I * 64;
-        for (int J = pair_tiles > 0 ? pair_J : I; J < (pair_tiles > 0 ? pair_J + 1 : T); ++J) {
-            const int bj = J * 64;
-            __syncthreads();                                   // previous tile pair fully consumed
-            if (rowsum && threadIdx.x < 64) {
-                rs_i[threadIdx.x] = bi + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bi + threadIdx.x] : 0.0f;
-                rs_j[threadIdx.x] = bj + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bj + threadIdx.x] : 0.0f;
-            }
-            // branch-free loads (clamped index + select): a conditional load per element would serialise them
-            float ve[16], vt[16];
+    // The tile pairs of this workgroup in walking order: (I0 = x; J = I0 .. T-1), then (I1 = T-1-x; J = I1 .. T-1) when
+    // I1 > x (odd T: the middle tile once); pair mode: the one pair.  The NEXT pair's tiles are requested as soon as the
+    // current pair's are in LDS, so its loads are in flight under the conversion and the plane stores (a walk used to be
+    // T + 1 rounds of load latency + store latency, one after the other, with 1.5 workgroups per CU to hide them).
+    const int x0 = (int)blockIdx.x;
+    int cI, cJ, chalf = 0;
+    bool have;
+    if (pair_tiles > 0) { cI = pair_I; cJ = pair_J; have = true; }
+    else {
+        cI = x0; cJ = x0; have = cI < T;
+        if (!have) { chalf = 1; cI = T - 1 - x0; cJ = cI; have = cI >= 0 && cI < T && cI > x0; }
+    }
+    auto advance = [&](int &I, int &J, int &half) -> bool {       // -> the pair after (I, J), false when the walk is over
+        if (pair_tiles > 0) return false;
+        if (J + 1 < T) { ++J; return true; }
+        if (half == 1) return false;
+        half = 1; I = T - 1 - x0; J = I;
+        return I >= 0 && I < T && I > x0;
+    };
+    float ve[16], vt[16], rsi = 0.0f, rsj = 0.0f;
+    // branch-free loads (clamped index + select): a conditional load per element would serialise them
+    auto fetch = [&](int I, int J) {
+        const int bi = I * 64, bj = J * 64;
+        if (rowsum && threadIdx.x < 64) {
+            rsi = bi + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bi + threadIdx.x] : 0.0f;
+            rsj = bj + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bj + threadIdx.x] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int rr = ty + 4 * it;
+            const int i = bi + rr, j = bj + tx;
+            const bool ok = i < nv && j < nv;
+            ve[it] = e[ok ? (int64_t)i * n + j : 0];                      // E[I][J] tile, [i - bi][j - bj]
+            const int i2 = bj + rr, j2 = bi + tx;
+            const bool ok2 = i2 < nv && j2 < nv;
+            vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                   // E[J][I] tile, [j - bj][i - bi]
+            ve[it] = ok ? ve[it] : 0.0f;
+            vt[it] = ok2 ? vt[it] : 0.0f;
+        }
+    };
+    if (have) fetch(cI, cJ);
+    while (have) {
+        const int I = cI, J = cJ, bi = I * 64, bj = J * 64;
+        __syncthreads();                                   // previous tile pair fully consumed
+        if (rowsum && threadIdx.x < 64) { rs_i[threadIdx.x] = rsi; rs_j[threadIdx.x] = rsj; }
+        __syncthreads();                                   // row scales visible
+        if (rowsum) {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int rr = ty + 4 * it;
-                const int i = bi + rr, j = bj + tx;
-                const bool ok = i < nv && j < nv;
-                ve[it] = e[ok ? (int64_t)i * n + j : 0];                      // E[I][J] tile, [i - bi][j - bj]
-                const int i2 = bj + rr, j2 = bi + tx;
-                const bool ok2 = i2 < nv && j2 < nv;
-                vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                   // E[J][I] tile, [j - bj][i - bi]
-                ve[it] = ok ? ve[it] : 0.0f;
-                vt[it] = ok2 ? vt[it] : 0.0f;
+                // == nan_to_num(max(x, 0) / row sum): the scale is finite (0 for empty / non-finite rows), NaN
+                // weights clamp to 0 in fmaxf, +inf to FLT_MAX
+                ve[it] = fminf(fmaxf(ve[it], 0.0f), 3.402823466e+38f) * rs_i[rr];   // row bi + rr
+                vt[it] = fminf(fmaxf(vt[it], 0.0f), 3.402823466e+38f) * rs_j[rr];   // row bj + rr
+                if (remove_self_loop && bi + rr == bj + tx) ve[it] = 0.0f;
+                if (remove_self_loop && bj + rr == bi + tx) vt[it] = 0.0f;
             }
-            __syncthreads();                                   // row scales visible
-            if (rowsum) {
+        }
 #pragma unroll
-                for (int it = 0; it < 16; ++it) {
-                    const int rr = ty + 4 * it;
-                    // == nan_to_num(max(x, 0) / row sum): the scale is finite (0 for empty / non-finite rows), NaN
-                    // weights clamp to 0 in fmaxf, +inf to FLT_MAX
-                    ve[it] = fminf(fmaxf(ve[it], 0.0f), 3.402823466e+38f) * rs_i[rr];   // row bi + rr
-                    vt[it] = fminf(fmaxf(vt[it], 0.0f), 3.402823466e+38f) * rs_j[rr];   // row bj + rr
-                    if (remove_self_loop && bi + rr == bj + tx) ve[it] = 0.0f;
-                    if (remove_self_loop && bj + rr == bi + tx) vt[it] = 0.0f;
-                }
-            }
+        for (int it = 0; it < 16; ++it) {
+            te[ty + 4 * it][tx] = ve[it];
+            tt[ty + 4 * it][tx] = vt[it];
+        }
+        if (edges_out) {
+            // by-product (atlas form only): the normalised class edges themselves, [n, n] fp32 per graph - what
+            // atlas_normalize_kernel writes (schema_net.py:152-175), for callers that return `class_edges` next to
+            // the scores (SchemaNetPredictor's dictionary) without a second pass over the atlas
+            float *eo = edges_out + (int64_t)g * n * n;
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
-                te[ty + 4 * it][tx] = ve[it];
-                tt[ty + 4 * it][tx] = vt[it];
+                const int rr = ty + 4 * it;
+                if (bi + rr < n && bj + tx < n) eo[(int64_t)(bi + rr) * n + bj + tx] = ve[it];
+                if (J != I && bj + rr < n && bi + tx < n) eo[(int64_t)(bj + rr) * n + bi + tx] = vt[it];
             }
-            if (edges_out) {
-                // by-product (atlas form only): the normalised class edges themselves, [n, n] fp32 per graph - what
-                // atlas_normalize_kernel writes (schema_net.py:152-175), for callers that return `class_edges` next to
-                // the scores (SchemaNetPredictor's dictionary) without a second pass over the atlas
-                float *eo = edges_out + (int64_t)g * n * n;
+        }
+        __syncthreads();
+        have = advance(cI, cJ, chalf);
+        if (have) fetch(cI, cJ);                           // (registers are free again; LDS holds the current pair)
+        // pieces: 64 rows x 8 (k / 8) per output tile; thread -> row tx, pieces ty, ty + 4
+        for (int pc = ty; pc < 8; pc += 4) {
+            {   // adj[I][J]: row i = bi + tx, k = bj + 8 pc ..
+                const int i = bi + tx, j0 = bj + pc * 8;
+                if (i < rows_lim && j0 < k_lim) {
+                    float v[8];
 #pragma unroll
-                for (int it = 0; it < 16; ++it) {
-                    const int rr = ty + 4 * it;
-                    if (bi + rr < n && bj + tx < n) eo[(int64_t)(bi + rr) * n + bj + tx] = ve[it];
-                    if (J != I && bj + rr < n && bi + tx < n) eo[(int64_t)(bj + rr) * n + bi + tx] = vt[it];
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = j0 + q;
+                        float x = 0.0f;
+                        if (i < n && j < n) {
+                            x = (te[tx][pc * 8 + q] + tt[pc * 8 + q][tx]) * 0.5f;       // == / 2 exactly
+                            if (i == j) x = x + 1.0f;
+                        }
+                        v[q] = x * scale;
+                    }
+                    store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(i, j0, kb_count));
                 }
             }
-            __syncthreads();
-            // pieces: 64 rows x 8 (k / 8) per output tile; thread -> row tx, pieces ty, ty + 4
-            for (int pc = ty; pc < 8; pc += 4) {
-                {   // adj[I][J]: row i = bi + tx, k = bj + 8 pc ..
-                    const int i = bi + tx, j0 = bj + pc * 8;
-                    if (i < rows_lim && j0 < k_lim) {
-                        float v[8];
+            if (J != I) {   // adj[J][I] = adj[I][J]^T: row j = bj + tx, k = bi + 8 pc ..
+                const int j = bj + tx, i0 = bi + pc * 8;
+                if (j < rows_lim && i0 < k_lim) {
+                    float v[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int j = j0 + q;
-                            float x = 0.0f;
-                            if (i < n && j < n) {
-                                x = (te[tx][pc * 8 + q] + tt[pc * 8 + q][tx]) * 0.5f;       // == / 2 exactly
-                                if (i == j) x = x + 1.0f;
-                            }
-                            v[q] = x * scale;
+                    for (int q = 0; q < 8; ++q) {
+                        const int i = i0 + q;
+                        float x = 0.0f;
+                        if (i < n && j < n) {
+                            x = (tt[tx][pc * 8 + q] + te[pc * 8 + q][tx]) * 0.5f;
+                            if (i == j) x = x + 1.0f;
                         }
-                        store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(i, j0, kb_count));
+                        v[q] = x * scale;
                     }
-                }
-                if (J != I) {   // adj[J][I] = adj[I][J]^T: row j = bj + tx, k = bi + 8 pc ..
-                    const int j = bj + tx, i0 = bi + pc * 8;
-                    if (j < rows_lim && i0 < k_lim) {
-                        float v[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int i = i0 + q;
-                            float x = 0.0f;
-                            if (i < n && j < n) {
-                                x = (tt[tx][pc * 8 + q] + te[pc * 8 + q][tx]) * 0.5f;
-                                if (i == j) x = x + 1.0f;
-                            }
-                            v[q] = x * scale;
-                        }
-                        store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(j, i0, kb_count));
-                    }
+                    store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(j, i0, kb_count));
                 }
             }
         }
