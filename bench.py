@@ -502,6 +502,7 @@ def main():
         # kernels (inside the library, on the launch stream) and around the stages
         lib.sn_profile_enable(args.steps)
         stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+        ings = {}
         for s in range(args.steps):
             tk, at = batches[s % n_batches]
             ev = stage_ev[s]
@@ -514,7 +515,18 @@ def main():
             ev[3].record()
             pred = m.forward_padded(g, atlas.class_dict, feat_kg=atlas)
             ev[4].record()
+            ings[s % n_batches] = ing
         torch.cuda.synchronize()
+        k_ms = {name: kernel_times(lib, kid) for kid, name in enumerate(("assign_screen", "assign_rerank", "instance_graph", "atlas_normalize", "gcn_gemm"))}
+        # S2+S3 alone on the GPU, like S1 above (in the pass it runs beside the class branch of the side stream, and how much
+        # of that branch it meets depends on how fast the host enqueued it: 36 us on one day, 56 us on another)
+        lib.sn_profile_enable(args.steps)
+        for s in range(args.steps):
+            tk, at = batches[s % n_batches]
+            sn.instance_graph_padded(ings[s % n_batches], at[:, 1:, 1:], at[:, 0, 1:], mutate_inputs=False, zero_padding=False)
+        torch.cuda.synchronize()
+        k_ms["instance_graph_beside_class_branch"] = k_ms["instance_graph"]
+        k_ms["instance_graph"] = kernel_times(lib, 2)
         atlas_leg = init_atlas_leg(device, rank, dist_world)
         extra = {}
         if world == 1 and not args.no_extra_legs:
@@ -532,7 +544,6 @@ def main():
         ms_step = 1e3 * dt / args.steps
         stage_ms = [sum(stage_ev[s][i].elapsed_time(stage_ev[s][i + 1]) for s in range(args.steps)) / args.steps
                     for i in range(4)]
-        k_ms = {name: kernel_times(lib, kid) for kid, name in enumerate(("assign_screen", "assign_rerank", "instance_graph", "atlas_normalize", "gcn_gemm"))}
         avg = {k_: (sum(v) / len(v) if v else None) for k_, v in k_ms.items()}
         # roofline of the assignment kernel (north_star): algorithmic bytes per launch =
         # B*196 tokens * (D*4 B read + 8 B index written)  (302,624 B / image)
@@ -609,6 +620,8 @@ def main():
             "roofline_s3": {"bound": "hbm", "kernel": "instance_graph_kernel<true, true> (S2+S3: grouping, edge cells, normalise; compile-time prediction configuration)",
                             "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (g_ach / HBM_PEAK_GBS) if g_ach else None,
                             "traffic": traffic_s3, "algorithmic_bytes_per_launch": graph_bytes, "avg_launch_ms": avg["instance_graph"],
+                            "avg_launch_note": "launched alone (HIP event pair inside the library); beside the class branch of the side stream, "
+                                               "as in the instrumented pass: kernels_ms.instance_graph_beside_class_branch",
                             "mean_vertices_per_image": n_mean},
             "roofline_step": {"algorithmic_bytes_per_step": step_bytes, "hbm_GBps": step_bytes / (ms_step * 1e-3) / 1e9,
                               "hbm_frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
