@@ -356,6 +356,11 @@ int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids,
 int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
                     const float *scale_dev, void *out_hi, void *out_lo, void *stream);
 
+/* The same for x^T: planes of the [cols, rows] operand per batch entry (k = rows), read from the untransposed x - the B
+ * operand of Y = adj . X for X [n, E] row-major (training: ops.sym_adj_matmul) without a transposed copy of X. */
+int sn_split_planes_transposed(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
+                               const float *scale_dev, void *out_hi, void *out_lo, void *stream);
+
 /* sn_mask_layernorm_act(x [G, n, E]) followed by sn_split_planes of the result (times *scale_dev) as one pass that leaves x
  * untouched and never stores the normalised rows: blocked planes of an [n, E] operand per graph (gnn.py:43-46 feeding the
  * next layer's Linear).  E % 16 == 0, E <= 1024.  Bit-identical to the two calls. */

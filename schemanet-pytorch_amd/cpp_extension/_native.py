@@ -16,7 +16,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
-ABI_VERSION = 6
+ABI_VERSION = 7
 SN_MAX_TOKENS = 196
 _lib = None
 
@@ -117,6 +117,7 @@ _SIGNATURES = {
     "sn_gcn_adjacency_planes_masked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sn_split_planes_transposed": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     # diagnostics (include/schemanet_hip.h, last section)
     "sn_debug_set_assign_options": (None, [c_int, c_int]),

@@ -494,11 +494,11 @@ def gcn_gather_planes(table, ids, extent=None, scale=None):
     return out
 
 
-def split_planes(x, scale="auto"):
+def split_planes(x, scale="auto", transpose=False):
     """fp32 [rows, k] or [batches, rows, k] -> blocked hi/lo planes with hi + lo ~= x * scale (22 significant bits down to
     2^-17 of the largest magnitude).  scale: "auto" = pow2_scale(x) (one reduction over x, no host synchronisation), a
     device scalar from pow2_scale(bound) when a bound on |x| is known without reading x, or None (= 1: only for operands
-    known to lie in 2^-3 .. 6e4)."""
+    known to lie in 2^-3 .. 6e4).  transpose: the planes of x^T ([k, rows] per batch entry), read from x as it is."""
     lib = N.require_gpu()
     dev = _check_dev(x)
     xc = _f32c(x.detach())
@@ -507,10 +507,11 @@ def split_planes(x, scale="auto"):
     B_, rows, k = xc.shape
     if isinstance(scale, str):
         scale = pow2_scale(xc) if xc.numel() else None
-    out = _alloc_planes(lib, dev, B_, rows, k)
+    out = _alloc_planes(lib, dev, B_, k, rows) if transpose else _alloc_planes(lib, dev, B_, rows, k)
     with torch.cuda.device(dev):
-        N.check(lib.sn_split_planes(N.ptr(xc), B_, rows, k, k, rows * k, N.ptr(scale), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
-                "sn_split_planes")
+        fn = lib.sn_split_planes_transposed if transpose else lib.sn_split_planes
+        N.check(fn(N.ptr(xc), B_, rows, k, k, rows * k, N.ptr(scale), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+                "sn_split_planes_transposed" if transpose else "sn_split_planes")
     out.scale = scale
     return out
 
@@ -634,7 +635,7 @@ class _SymAdjMatmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, adj, x, adj_planes):
         G, n, _ = adj.shape
-        xt = split_planes(x.detach().transpose(1, 2).contiguous())
+        xt = split_planes(x.detach(), transpose=True)
         y = gcn_gemm(adj_planes, xt, G, want_c=True)["c"]
         ctx.save_for_backward(x)
         ctx.adj_planes = adj_planes
@@ -655,7 +656,7 @@ class _SymAdjMatmul(torch.autograd.Function):
                     torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None)
         d_adj = d_x = None
         if ctx.needs_input_grad[1]:
-            d_x = gcn_gemm(ap, split_planes(dy.transpose(1, 2).contiguous()), G, want_c=True)["c"]
+            d_x = gcn_gemm(ap, split_planes(dy, transpose=True), G, want_c=True)["c"]
         if ctx.needs_input_grad[0]:
             d_adj = gcn_gemm(split_planes(dy), split_planes(x.detach()), G, want_c=True)["c"]
         return d_adj, d_x, None
@@ -670,7 +671,7 @@ class _EdgesAdjMatmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, edges, x, adj_planes):
         G = edges.shape[0]
-        y = gcn_gemm(adj_planes, split_planes(x.detach().transpose(1, 2).contiguous()), G, want_c=True)["c"]
+        y = gcn_gemm(adj_planes, split_planes(x.detach(), transpose=True), G, want_c=True)["c"]
         ctx.save_for_backward(x)
         ctx.adj_planes = adj_planes
         ctx.adj_like = torch.empty(edges.shape, dtype=edges.dtype, device="meta")
@@ -687,7 +688,7 @@ class _EdgesAdjMatmul(torch.autograd.Function):
                     torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None)
         d_e = d_x = None
         if ctx.needs_input_grad[1]:
-            d_x = gcn_gemm(ap, split_planes(dy.transpose(1, 2).contiguous()), G, want_c=True)["c"]
+            d_x = gcn_gemm(ap, split_planes(dy, transpose=True), G, want_c=True)["c"]
         if ctx.needs_input_grad[0]:
             s_ = gcn_gemm(split_planes(dy), split_planes(x.detach()), G, want_c=True)["c"]
             d_e = (s_ + s_.transpose(1, 2)) * 0.5
