@@ -158,6 +158,24 @@ class Matcher(nn.Module):
             feat_kg = self.atlas_features(class_dict)
         return self.similarity(feat_instance, feat_kg)
 
+    @staticmethod
+    def _padded_batch_of(instance_dict, ids, vs, es, sizes, n):
+        """The batch padded to its maximum, without a launch, when the lists are the untouched views `SchemaNet.forward` made
+        of its padded kernel output (schema_net.InstanceLists.padded: pad id / zeros in the padding); the callers' lists
+        are padded IN PLACE as the reference does - with views of that batch.  None: the general route."""
+        p = getattr(instance_dict, "padded", None)
+        if p is None or p["sizes"] != sizes or len(ids) != p["ids"].shape[0]:
+            return None
+        for lst, base in ((ids, p["ids"]), (vs, p["vertices"]), (es, p["edges"])):
+            for b, t in enumerate(lst):
+                if t._base is not base or t.storage_offset() != base.storage_offset() + b * base.stride(0) or t.stride() != base.stride()[1:]:
+                    return None
+        graph = {"ids": p["ids"][:, :n], "vertices": p["vertices"][:, :n], "edges": p["edges"][:, :n, :n], "n": p["n"],
+                 "n_max": torch.tensor([n], dtype=torch.int32, device=p["ids"].device)}
+        for b in range(len(sizes)):
+            ids[b], vs[b], es[b] = graph["ids"][b], graph["vertices"][b], graph["edges"][b]
+        return graph
+
     def forward(self, instance_dict: Dict[str, List[torch.Tensor]], class_dict: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Reference contract (match.py:33-76): ragged python lists in, [bs, K] out.  Like the
         reference it pads the caller's lists IN PLACE to the batch maximum."""
@@ -165,6 +183,9 @@ class Matcher(nn.Module):
                        instance_dict["instance_edges"])
         sizes = [len(x) for x in ids]
         n = max(sizes)
+        graph = self._padded_batch_of(instance_dict, ids, vs, es, sizes, n)
+        if graph is not None:
+            return self.forward_padded(graph, class_dict)
         for i, s in enumerate(sizes):
             ids[i] = F.pad(ids[i], (0, n - s), value=self.gnn.num_codes)
             vs[i] = F.pad(vs[i], (0, n - s))

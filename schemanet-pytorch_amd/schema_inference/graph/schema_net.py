@@ -19,6 +19,14 @@ from cpp_extension import ops
 from . import utils as graph_utils
 
 
+class InstanceLists(dict):
+    """The reference's dictionary of three per-image lists (schema_net.py:377-399) that also remembers the padded batch its
+    entries are views of (`padded`, or None).  `Matcher.forward` pads the lists to the batch maximum like the reference; when
+    every entry still is the view this class made, the padded batch IS that result and 3 x bs pads, their zero fills and -
+    in training - 3 x bs slice gradients (each a zero fill of the whole batch plus an add) are not launched."""
+    padded = None
+
+
 class SchemaNet(nn.Module):
     """
     Parameters (state-dict keys `<name>.tensor`):
@@ -283,11 +291,14 @@ class SchemaNet(nn.Module):
     @staticmethod
     def _as_lists(g: Dict[str, torch.Tensor]) -> Dict[str, List[torch.Tensor]]:
         sizes = g["n"].tolist()                                   # host sync, as in the reference (:302)
-        return {
+        out = InstanceLists({
             "instance_ingredients": [g["ids"][b, :n] for b, n in enumerate(sizes)],
             "instance_vertices": [g["vertices"][b, :n] for b, n in enumerate(sizes)],
             "instance_edges": [g["edges"][b, :n, :n] for b, n in enumerate(sizes)],
-        }
+        })
+        if g.get("edges_padded", False):                          # (the padding holds the pad id / zeros: Matcher may use the batch as it is)
+            out.padded = {"ids": g["ids"], "vertices": g["vertices"], "edges": g["edges"], "n": g["n"], "sizes": sizes}
+        return out
 
     def feat_to_instance_vertices(self, ingredients: torch.LongTensor, attn_cls: torch.Tensor
                                   ) -> Tuple[List[torch.LongTensor], List[torch.Tensor]]:

@@ -229,6 +229,46 @@ def test_bench_two_ranks_rehearsal():
     assert "REHEARSAL" in out["launch"] and out["cpu_baseline"] is None
 
 
+def test_matcher_uses_the_padded_batch_behind_untouched_lists(mods):
+    """`SchemaNet.forward` returns the reference's lists as views of its padded kernel output; `Matcher.forward` then takes
+    that batch instead of padding 3 x bs tensors (and, in training, back-propagating through 3 x bs slices).  Same scores,
+    same in-place padded lists and same gradients as the general route (lists the caller has touched), bit for bit."""
+    graph = mods["graph"]
+    B, L, M, K = 6, 196, 128, 5
+    ing, attn, acls = datagen.graph_case(B, L, M, seed=77)
+    torch.manual_seed(5)
+    sn = make_schema_net(mods, M, K)
+    sn.register_class_vertices(torch.arange(M, device=DEV).repeat(K, 1))
+    m = graph.Matcher("inner_product", M, dict(embed_dim=256, num_layers=2, identity_proj=False, activation="relu")).to(DEV)
+
+    def run(touch, train):
+        sn.train(train); m.train(train)
+        for p_ in list(sn.parameters()) + list(m.parameters()):
+            p_.grad = None
+        with torch.set_grad_enabled(train):
+            inst = sn(T(ing), T(attn), T(acls))
+            assert isinstance(inst, dict) and list(inst.keys()) == ["instance_ingredients", "instance_vertices", "instance_edges"]
+            assert inst.padded is not None
+            if touch:                                   # a caller that rebuilt a list entry: the general route
+                inst["instance_vertices"][1] = inst["instance_vertices"][1] * 1.0
+            pred = m(inst, sn.get_atlas())
+            if train:
+                pred.square().sum().backward()
+        grads = [sn.vertex_attribute_weights.tensor.grad, sn.edge_attribute_weights.tensor.grad] if train else []
+        return pred.detach(), inst, [g_.clone() for g_ in grads]
+
+    for train in (False, True):
+        fast, inst_f, g_f = run(False, train)
+        slow, inst_s, g_s = run(True, train)
+        assert torch.equal(fast, slow)
+        n = max(len(x) for x in inst_f["instance_ingredients"])
+        for k_ in ("instance_ingredients", "instance_vertices", "instance_edges"):
+            for a_, b_ in zip(inst_f[k_], inst_s[k_]):
+                assert a_.shape[0] == n and torch.equal(a_.detach(), b_.detach()), k_
+        for a_, b_ in zip(g_f, g_s):
+            assert (a_ - b_).abs().max().item() <= 1e-6 * b_.abs().max().item()
+
+
 def test_linear_with_per_graph_weight_gradient(mods):
     """Training route of the GCN: the Linear of a layer takes its weight gradient as G per-graph products + one sum (the
     library's single [out, in] product over G n rows runs on 256 tiny tiles): same y, same three gradients as nn.Linear
