@@ -99,7 +99,7 @@ def FUSED_ATLAS(sn):
     return lambda: sn.get_atlas(fused_adjacency=os.environ.get("SN_FUSED_ATLAS", "1") != "0")
 
 
-def step(disc, sn, m, tokens, attn, class_branch_first=True, side_stream=None):
+def step(disc, sn, m, tokens, attn, class_branch_first=True, side_stream=None, votes=None):
     """class_branch_first: the class branch (parameters only) is forked before S1, so the replayed
     graph can fill S1's tail and the gaps of the instance chain with it (483 vs 509 us per step);
     the instrumented pass forks it behind S1 so that the S1 kernels are timed alone on the GPU.
@@ -112,7 +112,7 @@ def step(disc, sn, m, tokens, attn, class_branch_first=True, side_stream=None):
         atlas = m.atlas_features_async(FUSED_ATLAS(sn), side_stream=side_stream)
     g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False,
                                  zero_padding=os.environ.get("SN_ZERO_PADDING", "0") == "1")   # S2 + S3 (as SchemaNetPredictor.forward)
-    return m.forward_padded(g, atlas.class_dict, feat_kg=atlas)                  # S4 (instance GNN, join, scores)
+    return m.forward_padded(g, atlas.class_dict, feat_kg=atlas, votes=votes)     # S4 (instance GNN, join, scores [+ the per-class votes])
 
 
 def stream_copy_GBps(device, n_bytes=1 << 30, reps=5):
@@ -426,9 +426,12 @@ def main():
         tk, at = batches[i]
 
         def one_step():
-            pred = step(disc, sn, m, tk, at, side_stream=side_stream)
-            ops.class_votes_(pred, votes)                # per-class vote aggregation (HIP, no host sync)
-            return pred
+            # (per-class vote aggregation in the launch that writes the scores: HIP, no host sync; SN_BENCH_VOTES_FUSED=0: its own launch)
+            if os.environ.get("SN_BENCH_VOTES_FUSED", "1") == "0":
+                pred = step(disc, sn, m, tk, at, side_stream=side_stream)
+                ops.class_votes_(pred, votes)
+                return pred
+            return step(disc, sn, m, tk, at, side_stream=side_stream, votes=votes)
         return one_step
 
     # Several steps in flight: each step runs in line on its own stream (the device maps streams onto four hardware

@@ -290,6 +290,12 @@ int sn_match_scores(const float *feat_inst, const float *feat_kg, int B, int K, 
  * schema_inference/eval/evaluation.py:95-97). */
 int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream);
 
+/* sn_match_scores followed by sn_class_votes as ONE launch (an evaluation loop that only counts votes per class,
+ * eval/evaluation.py:81-97): pred [B, K] is written as by sn_match_scores, votes [K + 1] accumulated as by sn_class_votes,
+ * both bit-identical to the two calls. */
+int sn_match_scores_votes(const float *feat_inst, const float *feat_kg, int B, int K, int E, int similarity,
+                          float *pred, float *votes, void *stream);
+
 /* out[g][o] = bias[o] + sum_e (pooled[g][e] / divisor) * weight[o][e] with pooled[g][e] = sum_t
  * pooled_parts[g][t][e], t < parts: the mean over the padded length followed by the GNN's final
  * Linear (gnn.py:96-98).  divisor = *divisor_dev (int32 on the device, e.g. the batch-maximum

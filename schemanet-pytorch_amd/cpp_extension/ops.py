@@ -805,16 +805,23 @@ def weigh_attributes(attr2, w):
 SIMILARITY = {"inner_product": 0, "cosine": 1, "euclidean": 2}
 
 
-def match_scores(feat_inst, feat_kg, similarity="inner_product"):
+def match_scores(feat_inst, feat_kg, similarity="inner_product", votes=None):
+    """pred [B, K]; votes (f32 [K + 1], optional): the per-class argmax counts of these scores are added to it in the same
+    launch (== class_votes_(pred, votes))."""
     lib = N.require_gpu()
-    dev = _check_dev(feat_inst, feat_kg)
+    dev = _check_dev(feat_inst, feat_kg, votes)
     a, b = _f32c(feat_inst), _f32c(feat_kg)
     B, E = a.shape
     K = b.shape[0]
     pred = torch.empty((B, K), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        N.check(lib.sn_match_scores(N.ptr(a), N.ptr(b), B, K, E, SIMILARITY[similarity], N.ptr(pred), N.stream_ptr(dev)),
-                "sn_match_scores")
+        if votes is not None:
+            assert votes.dtype == torch.float32 and votes.is_contiguous() and votes.numel() == K + 1
+            N.check(lib.sn_match_scores_votes(N.ptr(a), N.ptr(b), B, K, E, SIMILARITY[similarity], N.ptr(pred), N.ptr(votes),
+                                              N.stream_ptr(dev)), "sn_match_scores_votes")
+        else:
+            N.check(lib.sn_match_scores(N.ptr(a), N.ptr(b), B, K, E, SIMILARITY[similarity], N.ptr(pred), N.stream_ptr(dev)),
+                    "sn_match_scores")
     return pred
 
 

@@ -319,6 +319,71 @@ __global__ __launch_bounds__(256) void class_votes_kernel(const float *pred, int
     }
 }
 
+
+// Scores AND votes of an image in one launch (an evaluation loop: the scores' only reader besides the caller is the vote
+// counter, and a kernel boundary costs more than both kernels' work).  One workgroup of sixteen waves per image: a wave
+// owns four classes at a time exactly as in match_scores_kernel (same lane partials, same reductions: same scores bit for
+// bit), the row of K scores stays in LDS, wave 0 takes its argmax exactly as class_votes_kernel.
+constexpr int kVotesMaxK = 4096;
+__global__ __launch_bounds__(1024) void match_scores_votes_kernel(const float *fi, const float *fk, int K, int E, int similarity,
+                                                                  float *pred, float *votes)
+{
+    __shared__ float row[kVotesMaxK];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const float *a = fi + (int64_t)b * E;
+    for (int k0 = wid * 4; k0 < K; k0 += nw * 4) {
+        float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f}, nb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float na = 0.0f;
+        for (int c = lane; c < E; c += SN_WAVE) {
+            const float x = a[c];
+            na += x * x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j < K ? k0 + j : K - 1;
+                const float y = fk[(int64_t)k * E + c];
+                dot[j] += x * y;
+                nb[j] += y * y;
+                d2[j] += (x - y) * (x - y);
+            }
+        }
+        if (similarity == 1) na = sqrtf(sn_wave_sum(na));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r;
+            if (similarity == 0) {
+                r = sn_wave_sum(dot[j]);
+            } else if (similarity == 1) {
+                const float den = fmaxf(na, 1.0e-8f) * fmaxf(sqrtf(sn_wave_sum(nb[j])), 1.0e-8f);
+                r = (sn_wave_sum(dot[j]) / den + 1.0f) / 2.0f;
+            } else {
+                r = 1.0f / (1.0f + sqrtf(sn_wave_sum(d2[j])));
+            }
+            if (lane == 0 && k0 + j < K) { pred[(int64_t)b * K + k0 + j] = r; row[k0 + j] = r; }
+        }
+    }
+    __syncthreads();
+    if (wid != 0) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < K; k += SN_WAVE) {
+        const float v = row[k];
+        if (v > best || (v != v && best == best)) { best = v; bi = k; }     // NaN wins, like torch
+    }
+    if (bi == 0x7fffffff && lane < K) bi = lane;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, SN_WAVE);
+        const int oi = __shfl_xor(bi, off, SN_WAVE);
+        const bool take = (ov != ov && best == best) || (ov > best && best == best) || (ov == best && oi < bi) ||
+                          (ov != ov && best != best && oi < bi);
+        if (take) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        atomicAdd(&votes[bi < K ? bi : 0], 1.0f);
+        atomicAdd(&votes[K], 1.0f);
+    }
+}
+
 }  // namespace
 
 extern "C" int sn_class_votes(const float *pred, int B, int K, float *votes, void *stream)
@@ -397,6 +462,24 @@ extern "C" int sn_match_scores(const float *feat_inst, const float *feat_kg, int
     hipLaunchKernelGGL(match_scores_kernel, dim3((unsigned)B, (unsigned)((K + kScoreCols - 1) / kScoreCols)), dim3(256), 0,
                        (hipStream_t)stream, feat_inst, feat_kg, K, E, similarity, pred);
     SN_CHECK_LAUNCH("sn_match_scores");
+    return SN_OK;
+}
+
+extern "C" int sn_match_scores_votes(const float *feat_inst, const float *feat_kg, int B, int K, int E, int similarity,
+                                     float *pred, float *votes, void *stream)
+{
+    SN_REQUIRE(B >= 0 && K > 0 && E > 0, SN_ERR_BAD_ARG, "sn_match_scores_votes: bad B=%d K=%d E=%d", B, K, E);
+    if (B == 0) return SN_OK;
+    SN_REQUIRE(feat_inst && feat_kg && pred && votes, SN_ERR_BAD_ARG, "sn_match_scores_votes: NULL pointer");
+    SN_REQUIRE(similarity >= 0 && similarity <= 2, SN_ERR_BAD_ARG, "sn_match_scores_votes: similarity=%d", similarity);
+    if (K > kVotesMaxK) {                      // the row of scores does not fit the workgroup's LDS: the two kernels
+        if (int rc = sn_match_scores(feat_inst, feat_kg, B, K, E, similarity, pred, stream)) return rc;
+        return sn_class_votes(pred, B, K, votes, stream);
+    }
+    const int waves = K >= 64 ? 16 : (K + 3) / 4;
+    hipLaunchKernelGGL(match_scores_votes_kernel, dim3((unsigned)B), dim3(64u * (unsigned)waves), 0, (hipStream_t)stream, feat_inst, feat_kg,
+                       K, E, similarity, pred, votes);
+    SN_CHECK_LAUNCH("sn_match_scores_votes");
     return SN_OK;
 }
 

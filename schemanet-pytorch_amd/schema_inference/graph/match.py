@@ -50,16 +50,21 @@ class Matcher(nn.Module):
         self._atlas_cache = None
 
     # reference match.py:21-31
-    def similarity(self, feat_inst: torch.Tensor, feat_kg: torch.Tensor) -> torch.Tensor:
-        """feat_inst [bs, E], feat_kg [K, E] -> [bs, K]"""
+    def similarity(self, feat_inst: torch.Tensor, feat_kg: torch.Tensor, votes: torch.Tensor = None) -> torch.Tensor:
+        """feat_inst [bs, E], feat_kg [K, E] -> [bs, K].  votes (f32 [K + 1], optional): the evaluation loop's per-class vote
+        counter (reference eval/evaluation.py:81-97 via its meter), updated with the argmax of every image in the same launch."""
         if feat_inst.is_cuda and not (torch.is_grad_enabled() and (feat_inst.requires_grad or feat_kg.requires_grad)):
-            return ops.match_scores(feat_inst, feat_kg, self.similarity_name)
+            return ops.match_scores(feat_inst, feat_kg, self.similarity_name, votes=votes)
         a, b = feat_inst[:, None, :], feat_kg[None, :, :]
         if self.similarity_name == "inner_product":
-            return (a * b).sum(-1)
-        if self.similarity_name == "cosine":
-            return (torch.cosine_similarity(a, b, dim=-1) + 1) / 2
-        return 1 / (1 + torch.linalg.vector_norm(a - b, dim=-1))
+            pred = (a * b).sum(-1)
+        elif self.similarity_name == "cosine":
+            pred = (torch.cosine_similarity(a, b, dim=-1) + 1) / 2
+        else:
+            pred = 1 / (1 + torch.linalg.vector_norm(a - b, dim=-1))
+        if votes is not None:
+            ops.class_votes_(pred.detach(), votes)
+        return pred
 
     def atlas_features(self, class_dict: Dict[str, torch.Tensor], prepared=None) -> torch.Tensor:
         """GNN over the K class graphs -> [K, E]  (reference match.py:66-70)."""
@@ -139,7 +144,7 @@ class Matcher(nn.Module):
         return _AtlasHandle(class_dict, feat, done, prepared)
 
     def forward_padded(self, graph: Dict[str, torch.Tensor], class_dict: Dict[str, torch.Tensor],
-                       feat_kg=None) -> torch.Tensor:
+                       feat_kg=None, votes: torch.Tensor = None) -> torch.Tensor:
         """graph: ids [bs, n_pad], vertices [bs, n_pad], edges [bs, n_pad, n_pad], n [bs] i32,
         n_max [1] i32 (device).  The pooling divides by n_max, i.e. by the length the reference
         pads to (max_i n_i, match.py:46; gnn.py:96), so the result does not depend on n_pad.
@@ -156,7 +161,7 @@ class Matcher(nn.Module):
             feat_kg = feat_kg.join()
         elif feat_kg is None:
             feat_kg = self.atlas_features(class_dict)
-        return self.similarity(feat_instance, feat_kg)
+        return self.similarity(feat_instance, feat_kg, votes)
 
     @staticmethod
     def _padded_batch_of(instance_dict, ids, vs, es, sizes, n):
