@@ -38,8 +38,13 @@ class GraphedStep:
             self.graph.capture_begin()
             try:
                 self.outputs = fn()
-            finally:
-                self.graph.capture_end()
+            except BaseException:
+                try:                                      # leave capture mode, but report the step's own error
+                    self.graph.capture_end()
+                except Exception:                         # noqa: BLE001 - an invalidated capture fails again here
+                    pass
+                raise
+            self.graph.capture_end()
         torch.cuda.current_stream().wait_stream(side)
 
     def replay(self):
