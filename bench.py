@@ -36,7 +36,7 @@ the timed region over RCCL (the eval-meter merge of the reference, eval/evaluati
 RAW backbone taps (sequence-first tokens [197,256,384], per-head attention logits [256*6,197,197]: the fused head-mean
 input of SURVEY 8(d)), one call at a time, no hand-written step (the predictor captures and replays the launch sequence
 behind the backbone by itself); `value_api_batches`: the same calls made by `SchemaNetPredictor.predict_batches` (the
-predictor's own evaluation loop, four batches in flight); `c1_value` / `c4_value`: the same step at configs[0]'s and configs[3]'s shapes.
+predictor's own evaluation loop, four batches in flight); `c1_value` / `c4_value` / `c5_value`: the same step at the shapes of configs[0], [3] and [4] (inference).
 Outside the timed region every run also times one IR-Atlas initialisation over a synthetic image shard per rank
 (`init_atlas`): with N > 1 its two merges are the RCCL collectives of the per-class schema statistics
 (reference scripts/init_schema_net.py:19-65; 105 MB of edge sums at this configuration).
@@ -536,7 +536,8 @@ def main():
             extra.update(api_leg(device, disc, sn, m, n_calls=max(args.steps, 100)))
             c1 = shape_leg(device, "c1", 32, 192, 128, 10, 128, 256, torch.float32, max(args.steps, 100))
             c4 = shape_leg(device, "c4", 256, 768, 1024, 1000, 500, 1024, torch.bfloat16, 10)
-            extra.update({"c1_value": c1["value"], "c1": c1, "c4_value": c4["value"], "c4": c4})
+            c5 = shape_leg(device, "c5", 64, 384, 1024, 101, 1024, 256, torch.float32, 20)
+            extra.update({"c1_value": c1["value"], "c1": c1, "c4_value": c4["value"], "c4": c4, "c5_value": c5["value"], "c5": c5})
     t_max = torch.tensor(region_dt, device=device, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)         # per region: the slowest rank
