@@ -251,6 +251,12 @@ int sn_atlas_normalize(const float *vertex_weights, float *edge_weights, int K, 
                        int use_prune, float prune_threshold, int remove_self_loop,
                        float *class_vertices, float *class_edges, void *stream);
 
+/* Gradient of class_edges (above) with respect to edge_weights, for training: one pass instead of autograd's dozen through
+ * the reference's torch ops (schema_net.py:152-175: ew * mask, clamp_min(0), / detached row sum, nan_to_num, zero diagonal),
+ * with the same values including the NaN rows of vertices whose row sum is 0.  edge_weights in its pruned state. */
+int sn_atlas_normalize_backward(const float *vertex_weights, const float *edge_weights, const float *grad_class_edges, int K, int n,
+                                int use_prune, float prune_threshold, int remove_self_loop, float *grad_edge_weights, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * S4  graph matching
  * replaces pieces of Matcher.forward / GNN.forward  schema_inference/graph/match.py:33-76,

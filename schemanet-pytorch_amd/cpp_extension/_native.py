@@ -16,7 +16,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 SN_MAX_TOKENS = 196
 _lib = None
 
@@ -99,6 +99,7 @@ _SIGNATURES = {
                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_stats_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_atlas_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "sn_atlas_normalize_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "sn_gcn_adjacency": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sn_mask_layernorm_act": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "sn_weighted_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -361,6 +361,40 @@ def atlas_normalize(vertex_weights, edge_weights, prune_threshold=None, remove_s
     return cv, ce
 
 
+class _ClassEdges(torch.autograd.Function):
+    """class_edges = normalised, pruned edge_weights (reference schema_net.py:152-175) with autograd: the forward pass is
+    sn_atlas_normalize (one pass, pruning the parameter in place as the reference does), the backward pass
+    sn_atlas_normalize_backward (one pass) - instead of seven element-wise passes over [K, n, n] forward and as many back
+    (2.6 ms at the Caltech configuration's 404 MB, a sixth of a training iteration)."""
+
+    @staticmethod
+    def forward(ctx, edge_weights, vertex_weights, prune_threshold, remove_self_loop):
+        _, ce = atlas_normalize(vertex_weights, edge_weights.detach(), prune_threshold, remove_self_loop)
+        ctx.save_for_backward(edge_weights, vertex_weights)
+        ctx.opts = (prune_threshold, remove_self_loop)
+        return ce
+
+    @staticmethod
+    def backward(ctx, grad_ce):
+        ew, vw = ctx.saved_tensors
+        thr, rsl = ctx.opts
+        lib = N.require_gpu()
+        dev = _check_dev(ew, vw, grad_ce)
+        K, n = vw.shape
+        g = _f32c(grad_ce)
+        gx = torch.empty_like(ew)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_atlas_normalize_backward(N.ptr(vw), N.ptr(ew.detach()), N.ptr(g), K, n, int(thr is not None), float(thr or 0.0),
+                                                    int(rsl), N.ptr(gx), N.stream_ptr(dev)), "sn_atlas_normalize_backward")
+        return gx, None, None, None
+
+
+def class_edges_autograd(edge_weights, vertex_weights, prune_threshold=None, remove_self_loop=False):
+    """Differentiable class edges: edge_weights [K, n, n] (requires grad; pruned IN PLACE), vertex_weights [K, n] (detached)."""
+    assert edge_weights.is_contiguous() and vertex_weights.is_contiguous()
+    return _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop)
+
+
 def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, remove_self_loop=False, want_edges=False):
     """Fused atlas route: -> (class_vertices [K,n], Planes of (E + E^T)/2 + I with E the normalised
     class edges); edge_weights is pruned IN PLACE; the [K,n,n] class_edges tensor is never written - unless

@@ -117,6 +117,57 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
     }
 }
 
+
+// Gradient of the normalised class edges with respect to edge_weights, one pass: what autograd computes through the
+// reference's chain  ew * mask -> clamp_min(0) -> / sum(detached) -> nan_to_num [-> masked_fill(eye, 0)]
+// (schema_net.py:152-175, utils.py:25-52), multiplication by multiplication so that the non-finite cases come out the same:
+//   g_z = g_y where z = c / s is finite, else 0 (nan_to_num);  g_c = g_z / s  (a row whose sum is 0: 0 / 0 = NaN for every
+//   cell);  g_m = g_c * [m >= 0] (clamp_min passes the gradient AT 0);  g_x = g_m * mask.
+// edge_weights is read in its pruned state (the forward pass has zeroed the masked cells in place).  One wave per row,
+// two passes over the row (its sum, then the gradients; the second from L2).
+__global__ __launch_bounds__(256) void atlas_normalize_backward_kernel(const float *vw, const float *ew, const float *gy, int n, int use_prune,
+                                                                       float thr, int remove_self_loop, float *gx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *keep = smem;                       // [n]
+    float *red = (float *)(smem + ((n + 15) & ~15));  // [4]
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float *v = vw + (int64_t)k * n;
+    float part = 0.0f;
+    for (int i = tid; i < n; i += 256) part += fmaxf(v[i], 1.0e-5f);
+    part = sn_wave_sum(part);
+    if (lane == 0) red[wid] = part;
+    __syncthreads();
+    const float vsum = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int i = tid; i < n; i += 256) {
+        const float c = sn_nan_to_num(fmaxf(v[i], 1.0e-5f) / vsum);
+        keep[i] = (!use_prune || c > thr) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int rr = wid; rr < kRowsPerBlock; rr += 4) {
+        const int i = blockIdx.y * kRowsPerBlock + rr;
+        if (i >= n) break;
+        const float *row = ew + ((int64_t)k * n + i) * n;
+        const float *grow = gy + ((int64_t)k * n + i) * n;
+        float *orow = gx + ((int64_t)k * n + i) * n;
+        const float mi = keep[i] ? 1.0f : 0.0f;
+        float s = 0.0f;
+        for (int j = lane; j < n; j += SN_WAVE) s += fmaxf(row[j] * (mi * (keep[j] ? 1.0f : 0.0f)), 0.0f);
+        s = sn_wave_sum(s);
+        for (int j = lane; j < n; j += SN_WAVE) {
+            const float mask = mi * (keep[j] ? 1.0f : 0.0f);
+            const float m = row[j] * mask;
+            const float z = fmaxf(m, 0.0f) / s;
+            float g = grow[j];
+            if (remove_self_loop && j == i) g = 0.0f;                     // masked_fill(eye, 0) after the normalisation
+            const float gz = (z == z && fabsf(z) != INFINITY) ? g : 0.0f;   // nan_to_num: no gradient where z is not finite
+            const float gc = gz / s;
+            const float gm = gc * (m >= 0.0f ? 1.0f : 0.0f);
+            orow[j] = gm * mask;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sn_atlas_normalize(const float *vertex_weights, float *edge_weights, int K, int n,
@@ -156,5 +207,25 @@ extern "C" int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_we
                        prune_threshold, 0, class_vertices, (float *)nullptr, row_sum);
     sn_prof_stop(3, (hipStream_t)stream);
     SN_CHECK_LAUNCH("sn_atlas_prune_rowsum");
+    return SN_OK;
+}
+
+/* Backward of the normalised class edges (sn_atlas_normalize's class_edges as a function of edge_weights): grad_edge_weights
+ * [K, n, n] from grad_class_edges, with the values - NaN rows of empty classes' vertices included - autograd gives for the
+ * reference's chain of torch ops (schema_net.py:152-175). */
+extern "C" int sn_atlas_normalize_backward(const float *vertex_weights, const float *edge_weights, const float *grad_class_edges, int K, int n,
+                                           int use_prune, float prune_threshold, int remove_self_loop, float *grad_edge_weights,
+                                           void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_atlas_normalize_backward: bad K=%d n=%d", K, n);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(vertex_weights && edge_weights && grad_class_edges && grad_edge_weights, SN_ERR_BAD_ARG, "sn_atlas_normalize_backward: NULL pointer");
+    SN_REQUIRE(n <= 32768, SN_ERR_UNSUPPORTED, "sn_atlas_normalize_backward: n=%d > 32768", n);
+    const dim3 grid((unsigned)K, (unsigned)((n + kRowsPerBlock - 1) / kRowsPerBlock));
+    SN_REQUIRE(grid.y <= 65535, SN_ERR_UNSUPPORTED, "sn_atlas_normalize_backward: n too large");
+    const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
+    hipLaunchKernelGGL(atlas_normalize_backward_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights, edge_weights,
+                       grad_class_edges, n, use_prune, prune_threshold, remove_self_loop, grad_edge_weights);
+    SN_CHECK_LAUNCH("sn_atlas_normalize_backward");
     return SN_OK;
 }

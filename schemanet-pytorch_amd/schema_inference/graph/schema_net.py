@@ -11,6 +11,8 @@ without leaving HBM.
 import logging
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -156,6 +158,10 @@ class SchemaNet(nn.Module):
     def get_class_edges(self, detach: bool = False) -> torch.Tensor:
         """Differentiable form (reference :152-175) used when gradients are required."""
         ew = self.edge_weights.tensor.detach() if detach else self.edge_weights.tensor
+        if ew.is_cuda and ew.is_contiguous() and self._needs_grad(ew) and os.environ.get("SN_ATLAS_AUTOGRAD_FUSED", "1") != "0":
+            # one HIP pass forward (pruning the parameter in place, :164) and one back, the gradients - NaN rows included -
+            # those of the chain of torch ops below
+            return ops.class_edges_autograd(ew, self.vertex_weights.tensor.detach(), self.prune_node_threshold, self.remove_self_loop)
         if self.prune_node_threshold is not None:
             with torch.no_grad():
                 keep = self.get_class_vertices(detach=True) > self.prune_node_threshold

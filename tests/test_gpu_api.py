@@ -269,6 +269,43 @@ def test_matcher_uses_the_padded_batch_behind_untouched_lists(mods):
             assert (a_ - b_).abs().max().item() <= 1e-6 * b_.abs().max().item()
 
 
+@pytest.mark.parametrize("rsl", [False, True])
+def test_class_edges_with_fused_backward(mods, monkeypatch, rsl):
+    """Training: `SchemaNet.get_class_edges()` as one HIP pass forward and one back (`ops.class_edges_autograd`) against the
+    chain of torch ops of the reference (schema_net.py:152-175) differentiated by autograd: same class edges, same in-place
+    pruning of the parameter, same gradient - zeros at clamped negatives, the gradient AT zero, NaN for every cell of a
+    row whose sum is 0 (a pruned vertex), bit pattern of the NaNs aside."""
+    graph = mods["graph"]
+    K, n = 7, 96
+    torch.manual_seed(21)
+    vw = torch.rand(K, n)
+    vw[:, ::5] = 0.0                                   # pruned vertices: their rows sum to 0
+    ew = torch.randn(K, n, n)                          # negatives (clamped), and
+    ew[:, 3, :] = 0.0                                  # an all-zero row of a kept vertex
+    ew[1, 7, 9] = 0.0                                  # a single zero: clamp_min passes the gradient there
+    gy = torch.randn(K, n, n)
+
+    def run(fused):
+        monkeypatch.setenv("SN_ATLAS_AUTOGRAD_FUSED", "1" if fused else "0")
+        sn = graph.SchemaNet(num_vertices=n, num_classes=K, prune_node_threshold=0.001, remove_self_loop=rsl).to(DEV)
+        with torch.no_grad():
+            sn.vertex_weights.tensor.copy_(vw.to(DEV)); sn.edge_weights.tensor.copy_(ew.to(DEV))
+        sn.train()
+        ce = sn.get_class_edges()
+        assert ce.requires_grad
+        ce.backward(gy.to(DEV))
+        return ce.detach().cpu(), sn.edge_weights.tensor.grad.cpu(), sn.edge_weights.tensor.detach().cpu()
+
+    ce_f, g_f, p_f = run(True)
+    ce_t, g_t, p_t = run(False)
+    assert torch.equal(p_f, p_t)                        # the parameter, pruned in place
+    assert torch.allclose(ce_f, ce_t, rtol=2e-6, atol=1e-9)
+    assert torch.equal(torch.isnan(g_f), torch.isnan(g_t)) and torch.isnan(g_t).any() and not torch.isnan(g_t).all()
+    ok = ~torch.isnan(g_t)
+    assert torch.allclose(g_f[ok], g_t[ok], rtol=2e-6, atol=1e-9)
+    assert float(g_t[ok].abs().max()) > 0
+
+
 def test_linear_with_per_graph_weight_gradient(mods):
     """Training route of the GCN: the Linear of a layer takes its weight gradient as G per-graph products + one sum (the
     library's single [out, in] product over G n rows runs on 256 tiny tiles): same y, same three gradients as nn.Linear
