@@ -619,8 +619,8 @@ def main():
                          "matrix_TFLOPs": (s1_flops / (avg["assign_screen"] * 1e-3) / 1e12) if avg.get("assign_screen") else None,
                          "matrix_frac_of_2.5PF": (s1_flops / (avg["assign_screen"] * 1e-3) / 2.5e15) if avg.get("assign_screen") else None,
                          "matrix_note": "the screen multiplies every token with every word: 2 x tokens x words x D flops of f16 MFMA per launch take "
-                                        "15.8 us at the dense peak against 9.7 us for its bytes at 8 TB/s - on this workload (no bound prunes a word) the matrix "
-                                        "pipe, not HBM, is the roofline the kernel can reach first (frac <= 0.61 even at the dense peak; DESIGN 3.1d)"},
+                                        "7.9 us at the dense peak (~11 us at the clock the pipe holds under load) against 9.7 us for its bytes at 8 TB/s: on this "
+                                        "workload (no bound prunes a word) the matrix pipe is a second roofline at the height of the HBM one (DESIGN 3.1d)"},
             "roofline_s3": {"bound": "hbm", "kernel": "instance_graph_kernel<true, true> (S2+S3: grouping, edge cells, normalise; compile-time prediction configuration)",
                             "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (g_ach / HBM_PEAK_GBS) if g_ach else None,
                             "traffic": traffic_s3, "algorithmic_bytes_per_launch": graph_bytes, "avg_launch_ms": avg["instance_graph"],
