@@ -200,6 +200,16 @@ def test_predict_batches_keeps_batches_in_flight_and_in_order(mods):
         assert pred._graph_misses == misses
         for i in range(n):
             assert torch.equal(again[i], want[i]), i
+        # tap buffers that keep moving: the replay gives up on the way and the loop goes on with eager launches on its streams
+        pred.invalidate_graphs()
+        pred._graph_misses = 4 * pred.max_graphs
+        gave_up = [o["pred"] + 0.0 for o in pred.predict_batches(xs, depth=3)]
+        torch.cuda.synchronize()
+        assert pred.graph_replay is False
+        for i in range(n):
+            assert torch.equal(gave_up[i], want[i]), i
+        pred.graph_replay = True
+        pred._graph_misses = 0
     # not an inference loop: plain forwards, same results
     outs = [o["pred"] for o in pred.predict_batches(xs[:2], depth=3)]
     assert outs[0].requires_grad and torch.allclose(outs[0], want[0], rtol=1e-5, atol=1e-5 * float(want[0].abs().max()))
