@@ -46,6 +46,8 @@ class SchemaStatistics:
     """Accumulates per-class vertex / edge statistics for one rank and merges ranks."""
 
     large_bytes = 8 << 20      # flat buffers of at least this many bytes are merged by reduce_scatter + all_gather
+    #: run the merge through the backend even in a world of one (tests: the RCCL calls themselves on a one-GPU box)
+    merge_single_rank = False
 
     def __init__(self, num_classes: int, num_vertices: int, class_max_vertices: Optional[int] = None,
                  device: torch.device = None):
@@ -110,7 +112,7 @@ class SchemaStatistics:
     def _all_reduce_flat(self, store: torch.Tensor, n: int, large: bool):
         """SUM over ranks of store[:n].  `store` has >= _SLACK zero elements behind n."""
         rank, world = _world()
-        if world == 1:
+        if world == 1 and not (self.merge_single_rank and dist.is_available() and dist.is_initialized()):
             self.last_collective = None
             return
         if large and world <= _SLACK:
