@@ -14,6 +14,9 @@
 //   schema_inference/utils/ingredient_model_wrapper.py:58-68 (head mean + slicing)
 //   scripts/init_schema_net.py:33-35, 59-61 (per-class sums)
 #include "sn_common.h"
+#ifndef SN_S3_ROWS_NT
+#define SN_S3_ROWS_NT 1
+#endif
 
 #include <type_traits>
 
@@ -90,7 +93,12 @@ __device__ __forceinline__ void load_row4(const float *row, int L, int lane, flo
 {
     if (kVec) {                     // L % 4 == 0 and 16-byte aligned rows: one dwordx4 per lane
         const int c = min(lane * 4, L - 4);
-        const float4 v = *reinterpret_cast<const float4 *>(row + c);
+        typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+#if SN_S3_ROWS_NT
+        const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(row + c));     // read once: keep it out of the other kernels' L2
+#else
+        const f32x4_nt v = *reinterpret_cast<const f32x4_nt *>(row + c);
+#endif
         x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     } else {
 #pragma unroll
