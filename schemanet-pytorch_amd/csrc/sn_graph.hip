@@ -193,12 +193,18 @@ __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool u
     }
 }
 
-template <bool kVec, bool kFast>
+struct NoPreWork { __device__ __forceinline__ void operator()() const {} };
+
+// `pre_work()`: register-only work of the caller that has nothing to do with the rows; the dynamic form calls it once its first
+// two batches of loads are issued (the wave would otherwise sit out their HBM latency), the other forms up front.
+template <bool kVec, bool kFast, class Pre = NoPreWork>
 __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src, int64_t stride_r, int heads,
                                                       int64_t stride_h, int L, bool is_logits, bool use_clamp,
-                                                      float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr)
+                                                      float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr,
+                                                      Pre pre_work = Pre())
 {
     constexpr int kRowsInFlight = 7;        // HBM latency: 7 rows of loads in flight per wave (196 rows on 15 waves: two batches; four in flight = four batches of exposed latency: 25.6 k -> see DESIGN 3.2)
+    if (rs != 0 || heads > 1) pre_work();
     if (heads > 1) {
         // Head mean fused (the backbone's [bs, H, L+1, L+1] tap): the loads of ALL heads of a pair of rows are issued before
         // the first add - up to 6 heads x 2 rows = 12 row loads in flight per wave (one head after the other was a chain
@@ -259,6 +265,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
         for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(r0 + i, L - 1) * stride_r, L, lane, x[i]);
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(r1 + i, L - 1) * stride_r, L, lane, y[i]);
+        pre_work();
         while (r0 < L) {
             int rn = 0;
             if (lane == 0) rn = atomicAdd(next_row, kDyn);
@@ -317,16 +324,16 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
     }
 }
 
-template <bool kFast = false>
+template <bool kFast = false, class Pre = NoPreWork>
 __device__ __forceinline__ void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
                                         int64_t stride_h, int L, bool is_logits, bool use_clamp,
-                                        float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr)
+                                        float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr, Pre pre_work = Pre())
 {
     // (rows need not be 16-byte aligned in global memory: gfx950 serves a dword-aligned global_load_dwordx4 correctly,
     // tools/unaligned_probe.hip; the slices of the backbone's [.., 197, 197] tap never are.  The LDS rows are: L % 4 == 0.)
     const bool vec = (L % 4 == 0) && (kFast || ((stride_r % 4 == 0) && (stride_h % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)));
-    if (vec) attn_rows_to_lds_impl<true, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row);
-    else attn_rows_to_lds_impl<false, kFast>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row);
+    if (vec) attn_rows_to_lds_impl<true, kFast, Pre>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work);
+    else attn_rows_to_lds_impl<false, kFast, Pre>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -341,22 +348,36 @@ __device__ __forceinline__ int grid_shift(int feat_w)
     return sh;
 }
 
-__device__ inline void build_grid_table(const Lds &s, int L, int feat_w, float alpha, float pw, int tid)
+// entry (dr, dc) of the grid similarity table: the ONE expression every writer of s.T uses (same bits from every thread)
+__device__ __forceinline__ float grid_table_entry(int dr, int dc, int feat_h, int feat_w, float alpha, float pw)
+{
+    float v = 0.0f;
+    if (dr < feat_h && dc < feat_w) {
+        float d;
+        if (pw == 2.0f) d = sqrtf((float)(dr * dr + dc * dc));
+        else d = powf(powf((float)dr, pw) + powf((float)dc, pw), 1.0f / pw);
+        d = d / alpha;
+        v = 1.0f / (1.0f + d);
+    }
+    return v;
+}
+
+__device__ inline void build_grid_T(const Lds &s, int L, int feat_w, float alpha, float pw, int tid)
 {
     const int sh = grid_shift(feat_w), feat_h = L / feat_w;
-    for (int i = tid; i < kTFloats; i += blockDim.x) {
-        const int dr = i >> sh, dc = i & ((1 << sh) - 1);
-        float v = 0.0f;
-        if (dr < feat_h && dc < feat_w) {
-            float d;
-            if (pw == 2.0f) d = sqrtf((float)(dr * dr + dc * dc));
-            else d = powf(powf((float)dr, pw) + powf((float)dc, pw), 1.0f / pw);
-            d = d / alpha;
-            v = 1.0f / (1.0f + d);
-        }
-        s.T[i] = v;
-    }
+    for (int i = tid; i < kTFloats; i += blockDim.x)
+        s.T[i] = grid_table_entry(i >> sh, i & ((1 << sh) - 1), feat_h, feat_w, alpha, pw);
+}
+
+__device__ inline void build_grid_prc(const Lds &s, int L, int feat_w, int tid)
+{
     if (tid < L) s.prc[tid] = (unsigned short)(((tid / feat_w) << 8) | (tid % feat_w));
+}
+
+__device__ inline void build_grid_table(const Lds &s, int L, int feat_w, float alpha, float pw, int tid)
+{
+    build_grid_T(s, L, feat_w, alpha, pw, tid);
+    build_grid_prc(s, L, feat_w, tid);
 }
 
 __device__ inline float geo_at(const Lds &s, const float *geo, int L, int feat_w, int p, int q)
@@ -503,8 +524,15 @@ struct SortedGroups {                 // what a lane of the sorting wave knows a
     int n_groups;
 };
 
-__device__ __forceinline__ bool group_positions_sorted(const Lds &s, int L, int lane, const int64_t (&w4)[4], bool want_sum, SortedGroups &sg_out)
+// kLean (the prediction kernel's hand-over, see the kernel): nobody reads the per-position records - the vertices are written
+// from `sg_out`, the row map is the identity - so they are not written (their storage holds the signed grid table by then),
+// the cls attention in sorted order is staged in `tmp` instead of s.psum, and s.flag receives what the edges phase wants
+// there: position -> sorted index.
+template <bool kLean = false>
+__device__ __forceinline__ bool group_positions_sorted(const Lds &s, int L, int lane, const int64_t (&w4)[4], bool want_sum, SortedGroups &sg_out,
+                                                       float *tmp = nullptr)
 {
+    float *const stage = kLean ? tmp : s.psum;
     unsigned key[4];
     bool fits = true;
 #pragma unroll
@@ -566,7 +594,7 @@ __device__ __forceinline__ bool group_positions_sorted(const Lds &s, int L, int 
         const int i = 4 * lane + e, pos = (int)(key[e] & 255u);
         s.pos_sorted[i] = (unsigned char)pos;
         if (head[e]) s.gstart[g[e]] = (unsigned short)i;
-        if (want_sum) s.psum[i] = s.acls[pos];                    // (temporarily: cls attention in sorted order)
+        if (want_sum) stage[i] = s.acls[pos];                     // (temporarily: cls attention in sorted order)
     }
     if (lane == 0) { s.gstart[n_groups] = (unsigned short)n_kept; s.misc[0] = n_groups; s.misc[1] = n_kept; }
     __builtin_amdgcn_wave_barrier();
@@ -580,7 +608,7 @@ __device__ __forceinline__ bool group_positions_sorted(const Lds &s, int L, int 
         gs[e] = s.gstart[g[e]];
         cnt[e] = (int)s.gstart[g[e] + 1] - gs[e];
         if (want_sum && head[e])
-            for (int t = 0; t < cnt[e]; ++t) sum[e] = sum[e] + s.psum[gs[e] + t];      // position order (utils.cpp:9)
+            for (int t = 0; t < cnt[e]; ++t) sum[e] = sum[e] + stage[gs[e] + t];       // position order (utils.cpp:9)
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // every sum is in registers: psum can take its final contents
@@ -588,6 +616,7 @@ __device__ __forceinline__ bool group_positions_sorted(const Lds &s, int L, int 
     for (int e = 0; e < 4; ++e) {
         if (!valid[e]) continue;
         const int pos = (int)(key[e] & 255u);
+        if (kLean) { s.flag[pos] = (unsigned char)(4 * lane + e); continue; }
         s.pless[pos] = (unsigned short)gs[e];
         s.pcnt[pos] = (unsigned short)cnt[e];
         s.flag[pos] = (unsigned char)(1 | (head[e] ? 2 : 0) | 4);
@@ -759,8 +788,15 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // The last wave groups the positions by word (one-wave sort, group_positions_sorted) while the others bring the rows in.
     const bool sorter = nw > 1 && wid == nw - 1;                // wave-uniform
     const bool dyn_rows = kEdges && nw == 16 && a.attn_heads <= 1;          // block-uniform
+    // lean hand-over (prediction kernel, sixteen waves, one head): the sorting wave also prepares what the edges phase needs -
+    // the identity row map, the inverse of pos_sorted, the signed grid table, the edge-row counter - while the others are
+    // still bringing rows in; behind the first barrier nobody rebuilds them (two barriers, a table build with two integer
+    // divisions per thread and the record reads of 1 024 threads used to sit between the phases: 2.7 k cycles per image)
+    const int ts_S = 2 * a.feat_w - 1;
+    const bool lean_ok = kFast && dyn_rows && ts_S <= SN_WAVE;
     if (dyn_rows) {
         if (tid == 0) s.misc[4] = (nw - 1) * 4;
+        for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;       // (in front of the barrier: ordered before the sorting wave's row map)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                            // (everybody is at the start of the kernel: a cheap barrier)
     }
@@ -773,13 +809,33 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             // counter (s.misc[4]; the first batch of every wave is fixed, the counter starts behind them)
             int rb = wid, re = L, rs = nw > 1 ? nw - 1 : 1;
             if (dyn_rows) { rb = wid * 4; rs = 0; }
+            // lean form: this wave's rows of the signed grid table (straight from the expression of the unsigned one,
+            // grid_table_entry: the same floats; over the grouping scratch nobody uses in the lean form; table rows w, w + 15, ..,
+            // lane = column), computed while its first loads are on their way
+            auto table_rows = [&]() {
+                if (!(lean_ok && !a.geo)) return;
+                build_grid_prc(s, L, a.feat_w, tid);             // (positions -> grid coordinates: an integer division per thread)
+                if (lane >= ts_S) return;
+                float *ts = reinterpret_cast<float *>(s.pless);
+                const int fh = L / a.feat_w;
+                const int dc = lane - (a.feat_w - 1), adc = dc < 0 ? -dc : dc;
+                for (int r = wid; r < 2 * fh - 1; r += nw - 1) {
+                    const int dr = r - (fh - 1);
+                    ts[r * ts_S + lane] = grid_table_entry(dr < 0 ? -dr : dr, adc, fh, a.feat_w, a.dist_alpha, a.dist_pow);
+                }
+            };
             attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
-                                   a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e, rb, re, rs, lane, &s.misc[4]);
+                                   a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e, rb, re, rs, lane, &s.misc[4],
+                                   table_rows);
         }
-        if (!a.geo) build_grid_table(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);
+        if (!a.geo) {
+            // (lean form: grid coordinates and signed table are written under the row waves' first loads, the unsigned table only
+            // when the hand-over fails: behind the barrier)
+            if (!lean_ok) build_grid_table(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);
+        }
     }
     if (tid < L) s.words[tid] = a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)tid * a.ing_stride_l];
-    for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;
+    if (!dyn_rows) for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;
     if (!sorter && wid == nw - 1 && lane == 0) s.misc[2] = 0;   // misc[2] = 1: the sorter wave has written the grouping records (only ever written by the last wave)
 
     // The sorting wave's inputs - the words, the vertex attribute weights - are requested before its cls-attention row is
@@ -836,8 +892,17 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
         if (L <= 4 * SN_WAVE) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (this wave's own s.acls stores)
-        done = group_positions_sorted(s, L, lane, w4, do_v, sg);
+        if (lean_ok) done = group_positions_sorted<true>(s, L, lane, w4, do_v, sg, s.T);      // (s.T: unused before the barrier in the lean form)
+        else done = group_positions_sorted(s, L, lane, w4, do_v, sg);
         if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
+        }
+        if (lean_ok && done) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                         // canonical rows: output row / column g = group g
+                const int c = lane + SN_WAVE * k;
+                if (c < sg.n_groups && c < kMaxCols) s.rev[c] = c;
+            }
+            if (lane == 0) s.misc[5] = nw;                        // next edge row to deal (see the row loop)
         }
         if (lane == 0) s.misc[2] = done ? 1 : 0;
         __builtin_amdgcn_s_setprio(0);
@@ -902,9 +967,13 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     asm volatile("" ::: "memory");
 
     SN_GSTAMP(1);
+    const bool lean = lean_ok && s.misc[2] != 0;                 // block-uniform: the sorting wave has prepared the edges phase
     // ---- group positions by word (the ballot form only when the sort does not apply: words >= 2^24)
     PosInfo me = {0, 0, 0, 0.0f};
-    if (s.misc[2] == 0) {
+    if (lean_ok && !lean && !a.geo) build_grid_T(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);    // (complete at the barrier in front of the signed table's build)
+    if (lean) {
+        // (nothing to read: the vertices are the sorting wave's, the row map is the identity)
+    } else if (s.misc[2] == 0) {
         me = group_positions(s, L, tid, tid < L, do_v);
     } else if (tid < L) {
         me.first = (s.flag[tid] & 2) != 0;
@@ -951,7 +1020,9 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // (large_scale_feat_to_e.cpp:117-118; missing key -> 0; on collisions the last (gi, gj) in
     // iteration order wins, i.e. the largest group index)
     int n_out = n_groups;
-    if (c_dict) {
+    if (lean) {
+        // (row map, signed table, inverse of pos_sorted, row counter: written in front of the barrier)
+    } else if (c_dict) {
         n_out = (int)a.dict_len[b];
         if (owner) {
             const int64_t *keys = a.dict_keys + a.dict_off[b], *vals = a.dict_vals + a.dict_off[b];
@@ -974,8 +1045,9 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // P(p) + Q(q) - one scalar and one per-lane constant - instead of two absolute differences, a shift and an add
     // per cell and row visit (the column-sum loop below is instruction-bound).  Same floats, same sums.
     float *TS = nullptr;
-    const int ts_S = 2 * a.feat_w - 1;
-    if (kFast || signed_table) {                                 // kernel argument: uniform
+    if (lean) {
+        TS = reinterpret_cast<float *>(s.pless);
+    } else if (kFast || signed_table) {                          // kernel argument: uniform
         __syncthreads();                                         // every thread has read its grouping results
         TS = reinterpret_cast<float *>(s.pless);
         const int sh = grid_shift(a.feat_w), fh = L / a.feat_w, n_ts = (2 * fh - 1) * ts_S;
@@ -986,9 +1058,11 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     }
     // s.flag is free after the grouping: it now holds the inverse of pos_sorted (position -> sorted index)
     const int n_kept = s.misc[1];
-    if (tid < n_kept) s.flag[s.pos_sorted[tid]] = (unsigned char)tid;
-    if (tid == 0) s.misc[5] = nw;                                // next edge row to deal (see the row loop)
-    __syncthreads();
+    if (!lean) {
+        if (tid < n_kept) s.flag[s.pos_sorted[tid]] = (unsigned char)tid;
+        if (tid == 0) s.misc[5] = nw;                            // next edge row to deal (see the row loop)
+        __syncthreads();
+    }
 
     SN_GSTAMP(4);
     // ---- edges: one wave per output row, lanes over output columns
