@@ -810,7 +810,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             int rb = wid, re = L, rs = nw > 1 ? nw - 1 : 1;
             if (dyn_rows) { rb = wid * 4; rs = 0; }
             // lean form: this wave's rows of the signed grid table (straight from the expression of the unsigned one,
-            // grid_table_entry: the same floats; over the grouping scratch nobody uses in the lean form; table rows w, w + 15, ..,
+            // grid_table_entry: the same floats; over the grouping scratch nobody uses in the lean form; rows fh - 1 +- w of the table,
             // lane = column), computed while its first loads are on their way
             auto table_rows = [&]() {
                 if (!(lean_ok && !a.geo)) return;
@@ -819,9 +819,10 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 float *ts = reinterpret_cast<float *>(s.pless);
                 const int fh = L / a.feat_w;
                 const int dc = lane - (a.feat_w - 1), adc = dc < 0 ? -dc : dc;
-                for (int r = wid; r < 2 * fh - 1; r += nw - 1) {
-                    const int dr = r - (fh - 1);
-                    ts[r * ts_S + lane] = grid_table_entry(dr < 0 ? -dr : dr, adc, fh, a.feat_w, a.dist_alpha, a.dist_pow);
+                for (int dr = wid; dr < fh; dr += nw - 1) {       // table rows fh - 1 +- dr hold the same values
+                    const float v = grid_table_entry(dr, adc, fh, a.feat_w, a.dist_alpha, a.dist_pow);
+                    ts[(fh - 1 + dr) * ts_S + lane] = v;
+                    ts[(fh - 1 - dr) * ts_S + lane] = v;
                 }
             };
             attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
