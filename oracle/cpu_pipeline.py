@@ -115,9 +115,11 @@ def matcher(P, inst_ids, inst_v, inst_e, cv, ce, class_ingredients, num_codes):
 
 
 @torch.no_grad()
-def forward(tokens_bf, attn_full, codebook, vertex_weights, edge_weights, class_ingredients, P, w_v, w_e):
+def forward(tokens_bf, attn_full, codebook, vertex_weights, edge_weights, class_ingredients, P, w_v, w_e, also_fp64=False):
     """tokens_bf [B, L+1, D] batch-first, attn_full [B, L+1, L+1] head-averaged logits.
-    Returns (pred [B, K], per-stage seconds)."""
+    Returns (pred [B, K], word ids, per-stage seconds).  also_fp64: the matcher (GNN on instances and on the atlas,
+    similarity) is run a second time in float64 on the same fp32 graphs - the value the reference's fp32 arithmetic and
+    the HIP path both approximate; stages["pred_fp64"] holds it (parity tests: |hip - fp64| <= |fp32 - fp64| + slack)."""
     t = [time.perf_counter()]
     mid = tokens_bf.transpose(0, 1).contiguous()                       # backbone layout [L+1, bs, D]
     ing = discretize(mid, codebook).transpose(0, 1).contiguous()
@@ -128,7 +130,15 @@ def forward(tokens_bf, attn_full, codebook, vertex_weights, edge_weights, class_
     t.append(time.perf_counter())
     cv, ce = get_atlas(vertex_weights, edge_weights.clone())
     t.append(time.perf_counter())
+    pred64 = None
+    if also_fp64:                                                      # (before the fp32 call: `matcher` pads its lists in place)
+        P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+        pred64 = matcher(P64, [x.clone() for x in inst_ids], [x.double() for x in inst_v], [x.double() for x in inst_e],
+                         cv.double(), ce.double(), class_ingredients, codebook.shape[0])
+        t[-1] = time.perf_counter()
     pred = matcher(P, inst_ids, inst_v, inst_e, cv, ce, class_ingredients, codebook.shape[0])
     t.append(time.perf_counter())
     stages = dict(zip(("discretize", "instance_graph", "atlas", "match"), np.diff(t).tolist()))
+    if also_fp64:
+        stages["pred_fp64"] = pred64
     return pred, ing, stages

@@ -433,7 +433,7 @@ def _dp(t):
     return None if t is None else t.data_ptr()
 
 
-ADJ_SCALE = 1024.0     # static scale of adjacency planes: (E + E^T)/2 + I of normalised graphs is <= 2 + |w_e|_1; room up to 63
+ADJ_SCALE = 1024.0     # static scale of adjacency planes: (E + E^T)/2 + I of normalised graphs is <= 2 + |w_e|_1; room up to 63 (caller-supplied edges beyond that saturate at the fp16 maximum in the producer instead of becoming inf: csrc/sn_gcn.hip, saturate_f16_range)
 _PLANE_TOP = 8192.0    # a scaled operand's largest magnitude lands in [2^13, 2^14)
 _const_scales = {}
 

@@ -18,7 +18,7 @@
 // down to 2^-17 of that maximum and 2^-39 of it absolutely below - whatever the magnitudes of the weights - and
 // nothing below 65504 / 4 can overflow.  The scales are device scalars next to the planes (`*_scale`; NULL = 1): static
 // for the adjacency (entries <= 2 + |w_e|_1: s = 2^10), from the actual maximum for weight-only operands (table, W2),
-// from the LayerNorm bound 16 max|gamma| + max|beta| for operands written by an epilogue.  The accumulators are
+// from the LayerNorm bound ceil(sqrt(E - 1)) max|gamma| + max|beta| for operands written by an epilogue.  The accumulators are
 // multiplied by 1 / (s_a s_b) (exact) before the bias.  With da, db the representation errors above, a product row
 // errs by at most  sum_k (|da_k| |b_k| + |a_k| |db_k| + |lo_a,k lo_b,k|) <= 3.1 x 2^-22 sum_k |a_k b_k| + 2^-38 n max|a| max|b|
 // plus the fp32 accumulation of its 3 n MFMA terms - against n 2^-24 sum_k |a_k b_k| for the reference's fp32 GEMM.
@@ -104,6 +104,16 @@ __device__ __forceinline__ void store_piece(const float (&v)[8], _Float16 *out_h
 // adj[J][I] (each atlas byte is read once, not twice).  Workgroup x of a graph owns row tiles x and T-1-x
 // and walks J >= I for each (T + 1 tile pairs per workgroup, whatever x): few fat workgroups - one per
 // 64 x 64 tile would be bound by the dispatch rate (~10 ns per workgroup chip-wide), not by HBM.
+// Caller-supplied edges (no `rowsum`: the public GNN.forward / gcn_adjacency_planes route) carry the STATIC scale 2^10, chosen
+// for adjacencies of normalised graphs (entries <= 3): an entry of magnitude >= 64 would leave the fp16 range and its inf
+// would turn every score of the graph into NaN.  Such entries saturate at the largest fp16 instead (the product is then
+// off by the clipped amount - the split cannot represent it - but finite); NaN entries stay NaN, as in the reference.
+__device__ __forceinline__ float saturate_f16_range(float x)
+{
+    const float c = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+    return x != x ? x : c;
+}
+
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
                                                                const int32_t *extent, const int32_t *n_valid, int pair_tiles, float scale,
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
                             x = (te[tx][pc * 8 + q] + tt[pc * 8 + q][tx]) * 0.5f;       // == / 2 exactly
                             if (i == j) x = x + 1.0f;
                         }
-                        v[q] = x * scale;
+                        v[q] = rowsum ? x * scale : saturate_f16_range(x * scale);
                     }
                     store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(i, j0, kb_count));
                 }
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
                             x = (tt[tx][pc * 8 + q] + te[pc * 8 + q][tx]) * 0.5f;
                             if (i == j) x = x + 1.0f;
                         }
-                        v[q] = x * scale;
+                        v[q] = rowsum ? x * scale : saturate_f16_range(x * scale);
                     }
                     store_piece(v, out_h, out_l, (int64_t)g * batch_stride + blocked_index(j, i0, kb_count));
                 }

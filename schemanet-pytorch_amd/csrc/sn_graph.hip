@@ -1596,7 +1596,7 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
     return SN_OK;
 }
 
-/* diagnostics: device buffer of 8 x u64 per image for instance_graph_kernel<true> (NULL = off) */
+/* diagnostics: device buffer of 16 x u64 per image (slots 0 .. 15) for instance_graph_kernel<true> (NULL = off) */
 extern "C" void sn_debug_set_graph_stamps(void *device_buffer) { g_graph_stamps = (unsigned long long *)device_buffer; }
 
 extern "C" int sn_full_vertices(const int64_t *ingredients, int64_t ing_stride_b, int64_t ing_stride_l,

@@ -42,8 +42,11 @@ class SchemaNetPredictor(nn.Module):
         # short launches, host-bound when launched from Python) is captured into a hipGraph per tap-buffer set and
         # replayed ("the API path").  SN_PREDICTOR_GRAPH=0 or `graph_replay = False`: eager launches.
         self.graph_replay = os.environ.get("SN_PREDICTOR_GRAPH", "1") != "0"
+        # `forward` hands out `pred` from a two-deep ring (two captures per tap-buffer set, see `_forward_replayed`)
+        self.output_ring = os.environ.get("SN_PREDICTOR_RING", "1") != "0"
         self._graphs = collections.OrderedDict()
-        self._graph_misses = 0
+        self._graph_misses = 0                                # CONSECUTIVE calls that found nothing to replay
+        self._key_dicts_cache = None
         self._streams = None                                  # `predict_batches`: one HIP stream per batch in flight
 
     def train(self, mode: bool = True):
@@ -53,6 +56,7 @@ class SchemaNetPredictor(nn.Module):
         if mode:
             self.matcher.invalidate_atlas_cache()
             self._graphs.clear()
+        self._graph_misses = 0                                # (a fine-tune loop alternates train / eval: every eval phase starts afresh)
         return self
 
     def invalidate_graphs(self):
@@ -60,6 +64,7 @@ class SchemaNetPredictor(nn.Module):
         e.g. `p.data.copy_`, or after changing a scalar option of `schema_net` / `matcher`)."""
         self._graphs.clear()
         self._graph_misses = 0
+        self._key_dicts_cache = None
 
     # ---- the path behind the backbone -----------------------------------------------------------------------
     def _after_backbone(self, output, requires_graph: bool, side_stream=None):
@@ -93,58 +98,101 @@ class SchemaNetPredictor(nn.Module):
         return (sn.vertex_weights.tensor, sn.edge_weights.tensor, sn.class_ingredients.tensor,
                 ("prune", sn.prune_node_threshold, "self_loop", sn.remove_self_loop))
 
+    def _key_dicts(self):
+        """The `_parameters` / `_buffers` dicts of every module behind the backbone, collected once: `_replay_key` reads
+        their CURRENT values on every call (a replaced Parameter is seen), without the recursion, name building and
+        de-duplication of `Module.parameters()` - that walk was 40-50 us of host time per call.  Adding or removing
+        SUB-MODULES after the first call is not seen: `invalidate_graphs()`."""
+        if self._key_dicts_cache is None:
+            mods = [self.schema_net, self.matcher]
+            disc = getattr(self.ingredient_wrapper, "discretization_jit", None)     # (the backbone's own weights do not enter the captured part)
+            if disc is not None:
+                mods.append(disc)
+            dicts = []
+            for m_ in mods:
+                for sub in m_.modules():
+                    if sub._parameters:
+                        dicts.append(sub._parameters)
+                    if sub._buffers:
+                        dicts.append(sub._buffers)
+            self._key_dicts_cache = dicts
+        return self._key_dicts_cache
+
     def _replay_key(self, mid_feat, extracted, side_stream=None):
         """A capture reads its inputs and every parameter BY ADDRESS and bakes in the operands derived from parameters
         (packed codebook, GNN.prepare, the cached class-graph features): it stays valid while the tap buffers are the
         same memory (the caching allocator hands a steady inference loop the same blocks every iteration) and no
-        parameter / buffer of the modules behind the backbone has been written (version counters)."""
-        key = [(t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype) for t in (mid_feat, extracted)]
-        # (the modules behind the backbone only: its own weights do not enter the captured part)
-        mods = [self.schema_net, self.matcher]
-        disc = getattr(self.ingredient_wrapper, "discretization_jit", None)
-        if disc is not None:
-            mods.append(disc)
-        for m_ in mods:
-            key += [(t.data_ptr(), t._version) for t in m_.parameters()]
-            key += [(t.data_ptr(), t._version) for t in m_.buffers()]
+        parameter / buffer of the modules behind the backbone has been written or moved.  Version counters only ever
+        grow, so their SUM over a fixed set of tensors changes with every write; the addresses are summed with distinct
+        odd weights (a swap of two buffers changes the sum)."""
+        ver = 0
+        ptr = 0
+        i = 1
+        for d in self._key_dicts():
+            for t in d.values():
+                if t is not None:
+                    ver += t._version
+                    ptr += i * t.data_ptr()
+                    i += 2
         sn = self.schema_net
-        key.append((self.matcher.cache_atlas, sn.prune_node_threshold, sn.remove_self_loop, sn.clamp_vertex_attn, sn.clamp_edge_attn))
         # a capture owns ONE set of buffers: it must never run on two streams at once (`predict_batches`)
-        key.append(side_stream)
-        key.append(torch.cuda.current_stream().cuda_stream)
-        return tuple(key)
+        return (mid_feat.data_ptr(), extracted.data_ptr(), mid_feat.shape, extracted.shape, mid_feat.stride(), extracted.stride(),
+                mid_feat.dtype, extracted.dtype, ver, ptr, i, self.matcher.cache_atlas, sn.prune_node_threshold, sn.remove_self_loop,
+                sn.clamp_vertex_attn, sn.clamp_edge_attn, side_stream, torch.cuda.current_stream().cuda_stream)
+
+    def _give_up_replay(self, why: str):
+        self.schema_net.logger.warning("SchemaNetPredictor: hipGraph replay switched off (%s): eager launches from now on; "
+                                       "`graph_replay = True` switches it back on", why)
+        self.graph_replay = False
+        self._graphs.clear()
+        self._graph_misses = 0
 
     def _forward_replayed(self, x, own_pred: bool = True, side_stream=None):
-        """eval + no_grad + `taps`: backbone eagerly, then the captured launch sequence of everything behind it."""
+        """eval + no_grad + `taps`: backbone eagerly, then the captured launch sequence of everything behind it.
+
+        own_pred: `pred` must survive the next call.  The capture's output buffer is rewritten by its next replay, so a
+        key gets a SECOND capture of the same step (same memory pool: the two never run at the same time, every
+        intermediate buffer is shared; only the outputs exist twice) and the calls alternate between the two: the tensor a
+        call returns is valid until the next call BUT ONE with the same taps - a two-deep output ring instead of a copy
+        kernel between two graph launches (`SN_PREDICTOR_RING=0`: one capture and `pred.clone()`, valid for ever)."""
         from ..utils.graph_replay import GraphedStep
         wrapper = self.ingredient_wrapper
         out_backbone = wrapper.backbone_jit(x)
         mid_feat, extracted = out_backbone["mid_feat"], out_backbone["extracted"]
         key = self._replay_key(mid_feat, extracted, side_stream)
-        step = self._graphs.get(key)
-        if step is None:
-            if self._graph_misses >= 4 * self.max_graphs:       # tap buffers keep moving: replay cannot pay here
-                self.graph_replay = False
-                self._graphs.clear()
-                return self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream)
-            self._graph_misses += 1
+        entry = self._graphs.get(key)
+        ring = own_pred and self.output_ring
+        if entry is None or (ring and len(entry) < 3 and entry[0] == 1):
+            # consecutive misses: tap buffers that keep moving (or weights written before every call) - replay cannot pay
+            if entry is None:
+                if self._graph_misses >= 4 * self.max_graphs:
+                    self._give_up_replay(f"{self._graph_misses} consecutive calls found no capture to replay: the backbone's tap "
+                                         "buffers or the parameters change on every call")
+                    return self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream)
+                self._graph_misses += 1
             try:
-                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream))
+                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream),
+                                   pool=None if entry is None else entry[1].pool)
             except Exception as exc:                              # noqa: BLE001 - a configuration that cannot be captured
-                self.schema_net.logger.warning("hipGraph capture of the predictor failed (%r): eager launches from now on", exc)
-                self.graph_replay = False
-                self._graphs.clear()
+                self._give_up_replay(f"capture failed: {exc!r}")
                 return self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream)
-            self._graphs[key] = step
-            while len(self._graphs) > self.max_graphs:
-                self._graphs.popitem(last=False)
+            if entry is None:
+                entry = [0, step]                                 # [calls so far, capture A (, capture B)]
+                self._graphs[key] = entry
+                while len(self._graphs) > self.max_graphs:
+                    self._graphs.popitem(last=False)
+            else:
+                entry.append(step)
             # (no reference to the tap tensors is kept: a backbone that allocates its outputs afresh gets the SAME blocks back
             # from the caching allocator once the previous iteration's are released - that is what makes the next call a
             # hit.  The capture is only ever replayed when both taps live at the captured addresses again.)
         else:
+            self._graph_misses = 0
             self._graphs.move_to_end(key)
+        step = entry[1 + (entry[0] & 1)] if (ring and len(entry) > 2) else entry[1]
+        entry[0] += 1
         ret = collections.OrderedDict(step.replay())
-        if own_pred:
+        if own_pred and not self.output_ring:
             ret["pred"] = ret["pred"].clone()                      # the capture's own buffer is rewritten by the next replay
         return ret
 

@@ -10,6 +10,7 @@ Training (any input or parameter requires grad): the same maths as differentiabl
 adjacency products adj @ X - forward and both gradients, the 27 GFLOP per step of the class graphs - on the
 same MFMA GEMM through `ops.sym_adj_matmul` (an autograd.Function); the Linear layers stay library GEMMs.
 """
+import math
 import os
 from typing import Callable, Optional
 
@@ -54,10 +55,22 @@ class _LinearPerGraphWeightGrad(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = dy.matmul(weight)
         if ctx.needs_input_grad[1]:
-            dw = torch.bmm(dy.transpose(1, 2), x).sum(dim=0)
+            G, out_f, in_f = dy.shape[0], dy.shape[2], x.shape[2]
+            # the [G, out, in] temporary of the per-graph products is 4 G out in bytes (config [3]: 1000 class graphs of width
+            # 1024 = 4.2 GB): above _DW_TEMP_BYTES the graphs are taken in groups, each group's sum added into one [out, in] buffer
+            group = max(1, min(G, _DW_TEMP_BYTES // max(1, 4 * out_f * in_f)))
+            if group >= G:
+                dw = torch.bmm(dy.transpose(1, 2), x).sum(dim=0)
+            else:
+                dw = torch.zeros(out_f, in_f, dtype=x.dtype, device=x.device)
+                for g0 in range(0, G, group):
+                    dw += torch.bmm(dy[g0:g0 + group].transpose(1, 2), x[g0:g0 + group]).sum(dim=0)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=(0, 1))
         return dx, dw, db
+
+
+_DW_TEMP_BYTES = 256 << 20     # largest [group, out, in] fp32 temporary of _LinearPerGraphWeightGrad.backward
 
 
 def _linear(lin, x):
@@ -170,10 +183,12 @@ class GNN(nn.Module):
         # Power-of-two scales of the split-fp16 operands (csrc/sn_gcn.hip, "What hi + lo holds"): device scalars, computed
         # here once per weight version without a host synchronisation.  Weight-only operands: from their largest
         # magnitude.  Operands written by a GEMM epilogue: from a BOUND on what the epilogue can produce - a LayerNorm
-        # output is at most sqrt(255) < 16 standard deviations from its mean, so |H| <= 16 max|gamma| + max|beta|, and
-        # |W2 . H^T| <= max_o |W2[o, :]|_1 x that.
+        # output of width E is at most sqrt(E - 1) standard deviations from its mean (16 at E = 256, 32 at E = 1024: the wide
+        # route uses the same scales), so |H| <= ceil(sqrt(E - 1)) max|gamma| + max|beta|, and |W2 . H^T| <= max_o |W2[o, :]|_1 x that.
+        ln_sigmas = float(math.ceil(math.sqrt(max(1, self.embed_dim - 1))))
+
         def ln_bound(norm):
-            return 16.0 * norm.weight.detach().abs().amax() + norm.bias.detach().abs().amax()
+            return ln_sigmas * norm.weight.detach().abs().amax() + norm.bias.detach().abs().amax()
         w2 = l2.g_conv.linear.weight.detach()
         h1_bound = ln_bound(l1.norm)
         out = {"table": table, "table_scale": ops.pow2_scale(table), "w2": ops.split_planes(w2),

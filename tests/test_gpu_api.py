@@ -81,7 +81,8 @@ def test_predictor_replays_its_own_launch_sequence(mods, E):
             first = [pred(x)["pred"] for _ in range(3)]                  # three captures (one per tap-buffer set)
             assert len(pred._graphs) == 3
             again = [pred(x) for _ in range(6)]                         # replays, twice around
-        assert len(pred._graphs) == 3 and pred._graph_misses == 3
+        assert len(pred._graphs) == 3 and pred._graph_misses == 0        # (consecutive misses: a hit clears the count)
+        assert all(len(e) == 3 for e in pred._graphs.values())          # two captures per tap-buffer set: the output ring
         torch.cuda.synchronize()
         for i in range(3):
             assert torch.equal(first[i], eager_pred[i]), f"capture pass differs from eager (cache {cache}, batch {i})"
@@ -109,6 +110,43 @@ def test_predictor_replays_its_own_launch_sequence(mods, E):
     scores_close(full["pred"], want, "requires_graph route vs replayed route")
     pred.train()
     assert len(pred._graphs) == 0
+
+
+def test_predictor_output_ring_and_miss_counting(mods):
+    """`forward` hands out `pred` from a two-deep ring (no copy kernel between two graph launches): the tensor of call n is
+    still intact after call n + 1 on the same taps and is rewritten by call n + 2; SN_PREDICTOR_RING=0 semantics
+    (`output_ring = False`) give every call a tensor of its own.  A fine-tune loop that alternates weight updates and
+    evaluation phases misses once per phase for ever: the miss count is of CONSECUTIVE misses, so replay stays on
+    (a lifetime count switched it off silently after 32)."""
+    bs, H, L, D, M, K = 4, 2, 196, 192, 128, 5
+    mid, ext = T(datagen.bellish((L + 1, bs, D), 425, 1.0)), T(datagen.bellish((bs * H, L + 1, L + 1), 426, 2.0))
+    mid2 = T(datagen.bellish((L + 1, bs, D), 427, 1.0))
+    pred, wrapper = _predictor(mods, [(mid, ext)], M, D, K, 32)
+    x = torch.zeros(bs, 3, 4, 4, device=DEV)
+    with torch.no_grad():
+        a = pred(x)["pred"]
+        a0 = a.clone()
+        mid.copy_(mid2)                                   # same buffers, new tokens: the next calls compute something else
+        b = pred(x)["pred"]
+        torch.cuda.synchronize()
+        assert a.data_ptr() != b.data_ptr() and torch.equal(a, a0) and not torch.equal(a, b)
+        c = pred(x)["pred"]                               # the ring comes round: call n + 2 rewrites call n's tensor
+        torch.cuda.synchronize()
+        assert c.data_ptr() == a.data_ptr() and torch.equal(c, b)
+        pred.output_ring = False
+        d, e = pred(x)["pred"], pred(x)["pred"]
+        assert len({a.data_ptr(), b.data_ptr(), d.data_ptr(), e.data_ptr()}) == 4 and torch.equal(d, b) and torch.equal(e, b)
+        pred.output_ring = True
+        for phase in range(5 * pred.max_graphs):          # 40 phases: a weight update, then two evaluation calls
+            pred.train()
+            pred.matcher.gnn.layers[0].g_conv.linear.bias.add_(1.0e-3)
+            pred.eval()
+            pred(x), pred(x), pred(x)
+        assert pred.graph_replay and pred._graph_misses == 0 and len(pred._graphs) == 1
+        pred.graph_replay = False
+        want = pred(x)["pred"]
+        pred.graph_replay = True
+        assert torch.equal(pred(x)["pred"], want)
 
 
 def test_predictor_with_moving_taps_falls_back_to_eager(mods):
@@ -216,26 +254,32 @@ def test_predict_batches_keeps_batches_in_flight_and_in_order(mods):
 
 
 # =============================================================================== the N > 1 branch of bench.py
-def test_bench_two_ranks_rehearsal():
-    """What the driver launches for N = 2, with both ranks on this box's one GPU over gloo (SN_BENCH_REHEARSAL=1: RCCL
-    cannot form a 2-rank group on one device; the numbers mean nothing, the code path is the one of the scaling run):
-    stdout is ONE JSON line, world_size 2, every image of every region voted, the edge statistics merged by
-    reduce_scatter + all_gather."""
-    steps, port = 3, str(29600 + os.getpid() % 300)
-    env = dict(os.environ, SN_BENCH_REHEARSAL="1", SN_BENCH_BATCHES="4", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "2",
-           "--regions", "2", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("world", [2, 6])
+def test_bench_ranks_rehearsal(world):
+    """What the driver launches for N > 1, with every rank on this box's one GPU over gloo (SN_BENCH_REHEARSAL=1: RCCL
+    cannot form a multi-rank group on one device; the numbers mean nothing, the code path is the one of the scaling run):
+    stdout is ONE JSON line, world_size as asked, every image of every region voted, the edge statistics (C2's
+    26 214 500 floats: a multiple of 2, not of 6 or 8 - the zero-padded length) merged by reduce_scatter + all_gather.
+    Six ranks is what a GPU box admits (at most six processes on its card); world size 8 runs on the CPU over gloo:
+    tests/test_host_cpu.py::test_statistics_eight_ranks_gloo_at_c2_length."""
+    steps, port = (3 if world == 2 else 2), str(29600 + (os.getpid() + 17 * world) % 300)
+    regions = 2 if world == 2 else 1
+    env = dict(os.environ, SN_BENCH_REHEARSAL="1", SN_BENCH_BATCHES="4" if world == 2 else "2", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if world > 2:
+        env["SN_BENCH_DEPTH"] = "2"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "2",
+           "--regions", str(regions), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["steps"] == steps and out["regions"] == 2
-    assert out["votes_merged"] == 256 * steps * 2
-    assert out["config"]["global_batch"] == 512 and out["scaling"] == "weak"
-    assert out["init_atlas"]["world_size"] == 2 and out["init_atlas"]["edge_stats_collective"] == "reduce_scatter+all_gather"
-    assert out["value"] > 0 and abs(out["ms_per_step"] * steps * 1e-3 * out["value"] - 512 * steps) < 1e-3 * 512 * steps
+    assert out["n_gpus"] == world and out["world_size"] == world and out["steps"] == steps and out["regions"] == regions
+    assert out["votes_merged"] == 256 * steps * world
+    assert out["config"]["global_batch"] == 256 * world and out["scaling"] == "weak"
+    assert out["init_atlas"]["world_size"] == world and out["init_atlas"]["edge_stats_collective"] == "reduce_scatter+all_gather"
+    assert out["value"] > 0 and abs(out["ms_per_step"] * steps * 1e-3 * out["value"] - 256 * world * steps) < 1e-3 * 256 * world * steps
     assert "REHEARSAL" in out["launch"] and out["cpu_baseline"] is None
 
 
@@ -440,6 +484,58 @@ def test_c5_real_size_training_iterations(mods):
         "edge_weight_gradients_nan_rows_of_pruned_vertices": n_nan / n_all,
         "losses_mfma": l_mfma, "losses_library": l_lib, "iter_seconds_mfma": t_mfma, "iter_seconds_library": t_lib,
         "peak_GiB_mfma": mem_mfma, "peak_GiB_library": mem_lib})
+
+
+def test_c5_real_size_forward_matches_cpu_pipeline(mods):
+    """Config [4] at its real size (B = 64, M = 1024, K = 101, class graphs of 1024 vertices: the 404 MB IR-Atlas) through
+    the drop-in modules in eval() - `SchemaNet.forward` -> `get_atlas` -> `Matcher.forward` - against the reference's forward
+    restated op for op on the host (oracle/cpu_pipeline.py: the reference's C++ graph stage, bmm / Linear / LayerNorm), run in
+    fp32 AND in fp64: instance graphs equal, scores element-wise within 1e-5 and no further from fp64 than the reference's own
+    fp32 (the training test at this size compares two routes of this package with each other)."""
+    from oracle import cpu_pipeline
+    from test_gpu_parity import as_good_as_fp32_reference
+    graph = mods["graph"]
+    B, L, M, K, E = 64, 196, 1024, 101, 256
+    g = lambda s: torch.Generator().manual_seed(s)  # noqa: E731
+    ing = torch.randint(0, M, (B, L), generator=g(1))
+    ing[:, ::3] = ing[:, :1]
+    attn = torch.randn(B, L, L, generator=g(2))
+    acls = torch.randn(B, L, generator=g(3))
+    torch.manual_seed(11)
+    sn = graph.SchemaNet(num_vertices=M, num_classes=K, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0, prune_node_threshold=0.001)
+    sn.register_class_vertices(torch.stack([torch.randperm(M, generator=g(20 + k)) for k in range(K)]))
+    with torch.no_grad():
+        sn.vertex_weights.tensor[:, ::7] = 0.0                                   # pruned vertices
+        sn.vertex_attribute_weights.tensor.copy_(torch.tensor([[0.3], [0.7]]))
+        sn.edge_attribute_weights.tensor.copy_(torch.tensor([[0.6], [0.4]]))
+    torch.manual_seed(12)
+    m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu"))
+    with torch.no_grad():
+        for layer in m.gnn.layers:
+            layer.norm.weight.uniform_(0.5, 1.5); layer.norm.bias.uniform_(-0.5, 0.5)
+    P = {"gnn." + k: v.detach().clone() for k, v in m.gnn.state_dict().items()}
+    with torch.no_grad():
+        w_v, w_e = sn.vertex_attribute_weights.tensor.detach().clone(), sn.edge_attribute_weights.tensor.detach().clone()
+        ids_c, v_c, e_c = cpu_pipeline.instance_graph(ing, attn.clone(), acls.clone(), w_v, w_e)
+        cv, ce = cpu_pipeline.get_atlas(sn.vertex_weights.tensor.detach().clone(), sn.edge_weights.tensor.detach().clone())
+        ci = sn.class_ingredients.tensor.clone()
+        P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+        ref64 = cpu_pipeline.matcher(P64, [x.clone() for x in ids_c], [x.double() for x in v_c], [x.double() for x in e_c],
+                                     cv.double(), ce.double(), ci, M)
+        n_c = [len(x) for x in ids_c]
+        ids_keep = [x.clone() for x in ids_c]
+        ref32 = cpu_pipeline.matcher(P, ids_c, v_c, e_c, cv, ce, ci, M)
+        sn, m = sn.to(DEV).eval(), m.to(DEV).eval()
+        inst = sn(ing.to(DEV), attn.to(DEV), acls.to(DEV))
+        atlas = sn.get_atlas()
+        for b in (0, 17, B - 1):
+            assert torch.equal(inst["instance_ingredients"][b].cpu(), ids_keep[b]) and len(inst["instance_ingredients"][b]) == n_c[b]
+        assert torch.allclose(atlas["class_edges"].cpu(), ce, rtol=2e-6, atol=1e-9)
+        got = m(inst, atlas).cpu()
+    assert tuple(got.shape) == (B, K)
+    rel = scores_close(got, ref32, "C5 real size forward")
+    vs64 = as_good_as_fp32_reference(got, ref32, ref64, "C5 real size forward")
+    _report("c5_real_size_forward.json", {"shape": {"B": B, "M": M, "K": K, "n_max": M, "E": E}, "max_rel_err_above_floor": rel, "vs_fp64": vs64})
 
 
 # =============================================================================== split-fp16 GCN outside its comfort zone

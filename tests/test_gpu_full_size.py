@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from oracle import cabi
-from test_gpu_parity import DEV, RTOL, mods, scores_close  # noqa: F401  (mods: fixture)
+from test_gpu_parity import DEV, RTOL, as_good_as_fp32_reference, mods, scores_close  # noqa: F401  (mods: fixture)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,9 +65,10 @@ def test_c4_real_size_one_gpu(mods):
         disc.vocabulary.weight.copy_(codebook)
     sample = torch.tensor([0, 1, 37, 100, 101, 202, 254, 255])
     P = {"gnn." + k: v.detach().clone() for k, v in m.gnn.state_dict().items()}
-    want, ing_cpu, _ = cpu_pipeline.forward(tokens[sample].float(), attn[sample], codebook, sn.vertex_weights.tensor.detach().clone(),
-                                            sn.edge_weights.tensor.detach().clone(), sn.class_ingredients.tensor.clone(), P,
-                                            sn.vertex_attribute_weights.tensor.detach().clone(), sn.edge_attribute_weights.tensor.detach().clone())
+    want, ing_cpu, stages = cpu_pipeline.forward(tokens[sample].float(), attn[sample], codebook, sn.vertex_weights.tensor.detach().clone(),
+                                                 sn.edge_weights.tensor.detach().clone(), sn.class_ingredients.tensor.clone(), P,
+                                                 sn.vertex_attribute_weights.tensor.detach().clone(), sn.edge_attribute_weights.tensor.detach().clone(),
+                                                 also_fp64=True)
     disc, sn, m = disc.to(DEV), sn.to(DEV), m.to(DEV)
     tok_d, attn_d = tokens.to(DEV), attn.to(DEV)
 
@@ -93,6 +94,7 @@ def test_c4_real_size_one_gpu(mods):
     # ---- scores of the 8 sampled images x 1000 classes against the reference forward on the host
     assert tuple(pred_full.shape) == (B, K) and tuple(pred_sub.shape) == (len(sample), K)
     rel = scores_close(pred_sub, want, "C4 real size, 8 images x 1000 classes")
+    vs64 = as_good_as_fp32_reference(pred_sub, want, stages["pred_fp64"], "C4 real size, 8 images x 1000 classes")
     scale = want.abs().max().item()
     top2 = want.topk(2, dim=1).values
     decided = (top2[:, 0] - top2[:, 1]) > 4 * RTOL * scale
@@ -107,7 +109,7 @@ def test_c4_real_size_one_gpu(mods):
     err = (rescaled - pred_sub.cpu().double()).abs().max().item()
     assert err <= RTOL * scale, (err, scale)
     assert torch.equal(pred_full[sample.to(DEV)].argmax(1)[decided.to(DEV)], pred_sub.argmax(1)[decided.to(DEV)])
-    _report("c4_real_size.json", {"images": B, "classes": K, "vertices_per_class": n_max, "gnn_width": E, "score_scale": scale,
+    _report("c4_real_size.json", {"images": B, "classes": K, "vertices_per_class": n_max, "gnn_width": E, "score_scale": scale, "vs_fp64": vs64,
                                   "max_elementwise_rel_err_above_floor": rel, "n_max_full": n_full, "n_max_sample": n_sub})
 
 

@@ -325,6 +325,57 @@ def test_statistics_all_reduce_two_ranks_gloo(tmp_path):
     assert codes == [0, 0], codes
 
 
+# ------------------------------------------------------------------ N = 8 (the world size the target names): gloo, eight ranks
+_WORKER8 = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "schemanet-pytorch_amd"))
+import schema_inference.graph as graph
+W = 8
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=W)
+rank = dist.get_rank()
+torch.set_num_threads(1)
+K, M, n_max, B, steps = 100, 512, 512, 256, 2          # configs[1] / [2]: the 105 MB edge statistics of the C2 IR-Atlas
+stats = graph.SchemaStatistics(K, M, n_max)
+flat = stats._edges()
+n = flat.numel()
+ok = n == K * n_max * n_max + K and n % W != 0          # 26 214 500 floats: NOT a multiple of 8
+pattern = (torch.arange(n, dtype=torch.int64) % 97).float()
+flat.copy_(pattern * float(rank + 1))                   # small integers: the fp32 sums are exact in any order
+stats.all_reduce_edges()
+ok &= stats.last_collective == "reduce_scatter+all_gather"
+ok &= bool(torch.equal(stats._edges(), pattern * 36.0))
+ok &= bool((stats._e_store[n:] == 0).all()) and stats._e_store.numel() >= graph.SchemaStatistics.collective_length(n, W)
+# vertex statistics (205 KB): one fused all-reduce
+stats._v_flat.fill_(float(rank))
+stats.all_reduce_vertices()
+ok &= stats.last_collective == "all_reduce" and bool((stats._v_flat == 28.0).all())
+# image sharding r::W of a global batch (DistributedSampler split) and the vote merge of bench.py's timed region
+idx = graph.shard_indices(W * B, rank, W)
+ok &= idx.numel() == B and int(idx[0]) == rank and int(idx[1] - idx[0]) == W
+votes = torch.zeros(K + 1)
+votes[:K] = torch.bincount(idx % K, minlength=K).float() * steps
+votes[K] = B * steps
+dist.all_reduce(votes)
+ok &= int(votes[K]) == 256 * steps * W and int(votes[:K].sum()) == 256 * steps * W
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_statistics_eight_ranks_gloo_at_c2_length(tmp_path):
+    """World size 8 - the size BASELINE's target names - has only ever been run here, on the CPU, over gloo (a GPU box
+    admits six processes on its card and has one GPU; tests/test_gpu_api.py rehearses `bench.py` with six ranks): the
+    105 MB edge statistics of config [2] (26 214 500 floats, not a multiple of 8) merged by reduce_scatter + all_gather
+    on the zero-padded buffer, the vertex statistics by one all-reduce, images sharded r::8, votes of 256 x 2 x 8 images."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)]) for r in range(8)]
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0] * 8, codes
+
+
 # ------------------------------------------------------------------ k-means driver: sharded == single process (gloo, world_size 2)
 _KM_WORKER = r'''
 import os, sys
