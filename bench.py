@@ -104,14 +104,16 @@ def step(disc, sn, m, tokens, attn, class_branch_first=True, side_stream=None, v
     graph can fill S1's tail and the gaps of the instance chain with it (483 vs 509 us per step);
     the instrumented pass forks it behind S1 so that the S1 kernels are timed alone on the GPU.
     side_stream: see Matcher.atlas_features_async (False = the class branch in line on the step's own stream)."""
+    # S1 = the fp16-MFMA screen; the tokens it cannot decide are finished in fp64 inside the instance-graph kernel's row phase
+    # (`defer`, as SchemaNetPredictor.forward does; SN_S1_DEFER=0: by the stand-alone re-rank launch of rounds 1-3)
     if class_branch_first and os.environ.get("SN_CLASS_BRANCH_FIRST", "1") != "0":
         atlas = m.atlas_features_async(FUSED_ATLAS(sn), side_stream=side_stream)  # atlas normalise + class-graph GNN
-        ing = disc.assign(tokens[:, 1:, :])                                      # S1
+        ing, rerank = disc.assign(tokens[:, 1:, :], defer=True)                  # S1
     else:
-        ing = disc.assign(tokens[:, 1:, :])
+        ing, rerank = disc.assign(tokens[:, 1:, :], defer=True)
         atlas = m.atlas_features_async(FUSED_ATLAS(sn), side_stream=side_stream)
     g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False,
-                                 zero_padding=os.environ.get("SN_ZERO_PADDING", "0") == "1")   # S2 + S3 (as SchemaNetPredictor.forward)
+                                 zero_padding=os.environ.get("SN_ZERO_PADDING", "0") == "1", rerank=rerank)   # S2 + S3 (as SchemaNetPredictor.forward)
     return m.forward_padded(g, atlas.class_dict, feat_kg=atlas, votes=votes)     # S4 (instance GNN, join, scores [+ the per-class votes])
 
 

@@ -93,7 +93,10 @@ size_t sn_assign_workspace_bytes(int64_t n_tokens);
  *   batch-first tokens ([B, 197, D], cls row skipped by passing x + D): n_outer=B, n_inner=196,
  *                      x strides (197*D, D), out strides (196, 1) -> ingredients [B, 196]
  * mode: 0 = fp16-MFMA screening + fp64 re-rank (fast path), 1 = fp64 full scan (slow, exact by
- * construction; used as fallback and cross-check).  Both give identical indices. */
+ * construction; used as fallback and cross-check).  Both give identical indices.
+ * mode 2 = the screen of mode 0 with the re-rank left to sn_instance_graph (sn_rerank_args below; needs the workspace);
+ * mode 3 = only the re-rank of an earlier mode-2 call with the same arguments (the stand-alone kernels: for a consumer
+ * that cannot take the deferred finish after all). */
 int sn_assign_words(const float *x, int64_t n_outer, int64_t n_inner, int64_t x_stride_outer,
                     int64_t x_stride_inner, const float *codebook, const void *packed, int M, int D,
                     int64_t *out, int64_t out_stride_outer, int64_t out_stride_inner,
@@ -155,6 +158,33 @@ int sn_head_mean_attention(const float *extracted, int B, int H, int L, float *a
  * One workgroup per image.  Outputs are PADDED to n_pad vertices per image (pad id = pad_id,
  * pad weights / edges = 0): the layout Matcher.forward builds with F.pad (match.py:48-54).
  * ------------------------------------------------------------------------------------------ */
+/* Deferred finish of S1 (round 4).  sn_assign_words(mode = 2) runs the fp16 screen only: `out` holds its words - final
+ * wherever the screen could prove them - and the workspace keeps a flag word and the candidate codes of every token it could
+ * not decide (~7 % on isotropic tokens, none on k-means-like ones).  sn_instance_graph with `rerank` set finishes them
+ * inside its row phase - fp64, the oracle's summation order, the same ids bit for bit as mode 0 - and writes them back
+ * to `out`: no stand-alone re-rank launch between S1 and the graph (reference op: discretization/discretization.py:65,
+ * consumer schema_net.py:278-305).  Applies to the edges kernel (attn != NULL) in its prediction configuration and to
+ * D in {192, 384}, M <= 2048, L <= 210 (sn_assign_defers); sn_instance_graph returns SN_ERR_UNSUPPORTED otherwise. */
+typedef struct sn_rerank_args {
+    const void *x;                /* the tokens sn_assign_words screened: token (b, l) is the row at element offset
+                                     b*x_stride_b + l*x_stride_l (fp32, or bf16 when x_bf16)                      */
+    int64_t x_stride_b, x_stride_l;
+    int x_bf16;
+    int64_t tok_stride_b, tok_stride_l; /* its flat index in the screen's [n_outer, n_inner] grid: b*tok_stride_b + l*tok_stride_l
+                                     (batch-first: (n_inner, 1); sequence-first: (1, n_inner))                     */
+    int64_t n_tokens;             /* n_outer * n_inner of that call                                              */
+    const float *codebook;        /* [M, D]                                                                      */
+    const void *packed;           /* sn_codebook_prepare image                                                   */
+    int M, D;
+    const void *workspace;        /* of the mode-2 call                                                          */
+    int64_t *ids;                 /* its `out`: word of (b, l) at [b*ids_stride_b + l*ids_stride_l] (rewritten)   */
+    int64_t ids_stride_b, ids_stride_l;
+} sn_rerank_args;
+
+/* 1 when sn_assign_words(mode = 2) on this shape leaves flagged tokens to a consumer (0: it finishes them itself and
+ * clears the flag words: nothing to pass on) - what the host needs to know before it hands `rerank` to the graph kernel */
+int sn_assign_defers(int M, int D);
+
 typedef struct sn_graph_args {
     /* inputs */
     const int64_t *ingredients;   /* word of token (b, l) at [b*ing_stride_b + l*ing_stride_l] */
@@ -203,6 +233,8 @@ typedef struct sn_graph_args {
                                      out_e2 are left UNWRITTEN (two thirds of the padded batch
                                      are such zeros); the consumer must mask by out_n, as
                                      sn_gcn_adjacency_planes_masked does                         */
+    const sn_rerank_args *rerank; /* NULL, or the deferred finish of the S1 call that produced `ingredients`
+                                     (host pointer, read during the call)                        */
 } sn_graph_args;
 
 int sn_instance_graph(const sn_graph_args *args, void *stream);

@@ -21,6 +21,16 @@ SN_MAX_TOKENS = 196
 _lib = None
 
 
+class RerankArgs(Structure):
+    """struct sn_rerank_args (include/schemanet_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("x_stride_b", c_int64), ("x_stride_l", c_int64), ("x_bf16", c_int),
+        ("tok_stride_b", c_int64), ("tok_stride_l", c_int64), ("n_tokens", c_int64),
+        ("codebook", c_void_p), ("packed", c_void_p), ("M", c_int), ("D", c_int),
+        ("workspace", c_void_p), ("ids", c_void_p), ("ids_stride_b", c_int64), ("ids_stride_l", c_int64),
+    ]
+
+
 class GraphArgs(Structure):
     """struct sn_graph_args (include/schemanet_hip.h)."""
     _fields_ = [
@@ -43,6 +53,7 @@ class GraphArgs(Structure):
         ("out_e2", c_void_p), ("out_e", c_void_p),
         ("out_n", c_void_p), ("out_n_max", c_void_p), ("attn_cls_masked", c_void_p),
         ("skip_edge_padding", c_int),
+        ("rerank", POINTER(RerankArgs)),
     ]
 
 
@@ -78,6 +89,7 @@ _SIGNATURES = {
     "sn_assign_variant": (c_int, []),
     "sn_assign_set_variant": (c_int, [c_int]),
     "sn_assign_workspace_bytes": (c_size_t, [c_int64]),
+    "sn_assign_defers": (c_int, [c_int, c_int]),
     "sn_assign_words": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_int, c_void_p]),
     "sn_assign_words_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int,

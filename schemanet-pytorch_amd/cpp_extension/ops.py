@@ -2,8 +2,8 @@
 stream, raise RuntimeError on a non-zero status.  All tensors are CUDA tensors here; the
 reference-compatible shims (CPU tensors in, lists out) live in cpp_extension/__init__.py.
 """
-from ctypes import byref, c_void_p
-
+import os
+from ctypes import byref, c_void_p, pointer
 
 import torch
 
@@ -58,9 +58,60 @@ class PackedCodebook:
         return self.codebook, self.buf
 
 
-def assign_words(tokens, codebook, packed, out=None, mode=0):
+class DeferredRerank:
+    """What `assign_words(..., defer=True)` hands to the consumer of the word ids: the screen has run, `out` holds its
+    words (final wherever it could prove them), the flag words and candidate records of the undecided tokens are in
+    `ws`.  `instance_graph(..., rerank=handle)` finishes them inside its row phase (no re-rank launch between S1 and
+    the graph); `finish()` runs the stand-alone re-rank instead (a consumer that cannot fuse it).  Either way the ids are
+    those of mode 0, bit for bit."""
+
+    def __init__(self, tokens, bf16, codebook, packed, out, ws, ws_bytes):
+        self.tokens, self.bf16, self.codebook, self.packed, self.out, self.ws, self.ws_bytes = tokens, bf16, codebook, packed, out, ws, ws_bytes
+        self.done = False
+
+    def args_for(self, ingredients):
+        """sn_rerank_args for a [B, L] view of `out` (the ids as the graph kernel sees them), or None when `ingredients`
+        is not such a view"""
+        if self.done or ingredients.data_ptr() != self.out.data_ptr():
+            return None
+        n_outer, n_inner, D = self.tokens.shape
+        if tuple(ingredients.shape) == (n_outer, n_inner) and ingredients.stride() == self.out.stride():
+            axis = 0                                              # batch-first tokens
+        elif tuple(ingredients.shape) == (n_inner, n_outer) and ingredients.stride() == (self.out.stride(1), self.out.stride(0)):
+            axis = 1                                              # sequence-first tokens: the batch is the inner axis
+        else:
+            return None
+        r = N.RerankArgs()
+        r.x = self.tokens.data_ptr()
+        r.x_stride_b, r.x_stride_l = self.tokens.stride(axis), self.tokens.stride(1 - axis)
+        r.x_bf16 = int(self.bf16)
+        r.tok_stride_b, r.tok_stride_l = (n_inner, 1) if axis == 0 else (1, n_inner)
+        r.n_tokens = n_outer * n_inner
+        r.codebook, r.packed = self.codebook.data_ptr(), self.packed.data_ptr()
+        r.M, r.D = self.codebook.shape[0], D
+        r.workspace = self.ws.data_ptr()
+        r.ids = self.out.data_ptr()
+        r.ids_stride_b, r.ids_stride_l = self.out.stride(axis), self.out.stride(1 - axis)
+        return r
+
+    def finish(self):
+        if self.done:
+            return
+        lib = N.require_gpu()
+        t, o, dev = self.tokens, self.out, self.out.device
+        with torch.cuda.device(dev):
+            fn = lib.sn_assign_words_bf16 if self.bf16 else lib.sn_assign_words
+            N.check(fn(N.ptr(t), t.shape[0], t.shape[1], t.stride(0), t.stride(1), N.ptr(self.codebook), N.ptr(self.packed),
+                       self.codebook.shape[0], t.shape[2], N.ptr(o), o.stride(0), o.stride(1), N.ptr(self.ws), self.ws_bytes, 3,
+                       N.stream_ptr(dev)), "sn_assign_words (mode 3)")
+        self.done = True
+
+
+def assign_words(tokens, codebook, packed, out=None, mode=0, defer=False):
     """tokens: [n_outer, n_inner, D] view (last dim contiguous, any outer strides);
-    returns int64 [n_outer, n_inner] word ids (or fills `out`, any strides)."""
+    returns int64 [n_outer, n_inner] word ids (or fills `out`, any strides).
+    defer=True (mode 0 only): returns (ids, handle) - handle a `DeferredRerank` whose consumer finishes the tokens the
+    fp16 screen could not decide, or None where the shape has no deferred form (the ids are final then)."""
     lib = N.require_gpu()
     dev = _check_dev(tokens, codebook, packed, out)
     bf16 = tokens.dtype == torch.bfloat16 and tokens.stride(-1) == 1      # consumed in place (half the token bytes)
@@ -76,11 +127,14 @@ def assign_words(tokens, codebook, packed, out=None, mode=0):
     n_tok = n_outer * n_inner
     ws_bytes = lib.sn_assign_workspace_bytes(n_tok)
     ws = torch.empty(max(ws_bytes, 32), dtype=torch.uint8, device=dev)
+    deferred = bool(defer) and int(mode) == 0 and n_tok > 0 and lib.sn_assign_defers(M, D) == 1 and os.environ.get("SN_S1_DEFER", "1") != "0"
     with torch.cuda.device(dev):
         fn = lib.sn_assign_words_bf16 if bf16 else lib.sn_assign_words
         N.check(fn(
             N.ptr(tokens), n_outer, n_inner, tokens.stride(0), tokens.stride(1), N.ptr(codebook), N.ptr(packed), M, D,
-            N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws_bytes, int(mode), N.stream_ptr(dev)), "sn_assign_words")
+            N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws_bytes, 2 if deferred else int(mode), N.stream_ptr(dev)), "sn_assign_words")
+    if defer:
+        return out, (DeferredRerank(tokens, bf16, codebook, packed, out, ws, ws_bytes) if deferred else None)
     return out
 
 
@@ -211,12 +265,14 @@ def instance_graph(ingredients, attn=None, attn_cls=None, *, w_v=None, w_e=None,
                    attn_is_logits=True, attn_cls_is_logits=True, clamp_v=None, clamp_e=None,
                    geo=None, feat_h=14, feat_w=14, dist_alpha=1.0, dist_pow=2.0, mean=True,
                    remove_self_loop=False, dicts=None, want_attr2=False, want_weighted=True,
-                   attn_cls_masked_out=None, zero_padding=True):
+                   attn_cls_masked_out=None, zero_padding=True, rerank=None):
     """One launch of sn_instance_graph.  Returns a dict of padded tensors:
     ids [B,n_pad] i64, n [B] i32, n_max [1] i32, and (when the inputs are given)
     v / v2 ([B,n_pad] / [B,n_pad,2]) and e / e2 ([B,n_pad,n_pad] / [...,2]).
     zero_padding=False leaves the rows / columns of e / e2 beyond an image's vertex count unwritten (two thirds of the
-    padded batch): only for consumers that mask by n (gcn_adjacency_planes(..., n_valid=n))."""
+    padded batch): only for consumers that mask by n (gcn_adjacency_planes(..., n_valid=n)).
+    rerank: the `DeferredRerank` of the S1 call that produced `ingredients` - its flagged tokens are finished inside the
+    kernel's row phase (prediction configuration) or, where that does not apply, by the stand-alone re-rank first."""
     lib = N.require_gpu()
     dev = _check_dev(ingredients, attn, attn_cls, w_v, w_e, geo)
     assert ingredients.dtype == torch.int64 and ingredients.dim() == 2
@@ -282,8 +338,20 @@ def instance_graph(ingredients, attn=None, attn_cls=None, *, w_v=None, w_e=None,
     out["n"] = torch.empty((B,), dtype=torch.int32, device=dev)
     out["n_max"] = torch.zeros((1,), dtype=torch.int32, device=dev)
     a.out_ids, a.out_n, a.out_n_max = out["ids"].data_ptr(), out["n"].data_ptr(), out["n_max"].data_ptr()
+    rr = rerank.args_for(ingredients) if rerank is not None else None
     with torch.cuda.device(dev):
-        N.check(lib.sn_instance_graph(byref(a), N.stream_ptr(dev)), "sn_instance_graph")
+        if rr is not None:
+            a.rerank = pointer(rr)
+            rc = lib.sn_instance_graph(byref(a), N.stream_ptr(dev))
+            if rc == 0:
+                rerank.done = True
+            else:                                                 # (not the prediction configuration: nothing was launched)
+                a.rerank = None
+                rr = None
+        if rr is None:
+            if rerank is not None:
+                rerank.finish()
+            N.check(lib.sn_instance_graph(byref(a), N.stream_ptr(dev)), "sn_instance_graph")
     del keep
     return out
 

@@ -18,6 +18,7 @@
 // HBM traffic (algorithmic): tokens read once (D*4 B each) + 8 B index out; the packed
 // codebook (M*D*2 B) stays L2 resident.
 #include "sn_common.h"
+#include "sn_assign_shared.h"
 
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -40,8 +41,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTokPerWave = 32;
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxCand = 24;            // 2 half-lanes x 4 accumulator groups x top-3
-constexpr int kCodeBytes = 24;          // per-token candidate record: one key code per candidate slot
+using sn_s1::kMaxCand;                  // 24 = 2 half-lanes x 4 accumulator groups x top-3
+using sn_s1::kCodeBytes;                // per-token candidate record: one key code per candidate slot (sn_assign_shared.h)
+using sn_s1::PackLayout;
+using sn_s1::pack_layout;
+using sn_s1::dot64;
 // workspace per token: token-stationary records = flag word + 24 code bytes + overflow-list slot (32 B)
 constexpr int kWsPerToken2 = 4 + 48 + 4;          // the largest record format: flag word + 24 16-bit codes + overflow-list slot
 constexpr int kMaxTilesScreen = 256;    // tile code in the keys: 6 bits (M <= 2048, byte codes) or 8 bits (M <= 8192, 16-bit codes)
@@ -65,47 +69,7 @@ constexpr float kAccUlpPerMfma = 8.0f * 5.9604645e-8f;
 //                                           holds word row r at k = 32 (js / 2) + {4g..4g+3, 16+4g..16+4g+3},
 //                                           g = 2 (js & 1) + h (the order the token converter produces)
 //   hn2     [4][nt2][2 halves][16] f32      |c|^2 / 2 in accumulator-register order (padding words: 1e30)
-struct PackLayout {
-    size_t tiles_off, cn64_off, scal_off, frag2_off, hn2_off, total;
-    int n_tiles, n_steps, tile_bytes, m_pad;
-    int nt2, ks2;                       // nt2 == 0: no register-stationary image for this shape
-};
-
 constexpr float kPadHalfNorm = 1.0e30f;     // |c|^2/2 of the padding words of the frag2 image (finite: keys stay ordered floats)
-
-__host__ __device__ inline PackLayout pack_layout(int M, int D)
-{
-    PackLayout p;
-    p.n_tiles = 2 * ((M + 63) / 64);      // even: the screen kernel walks tiles in pairs; padding words carry |c|^2 = inf
-    p.n_steps = D / 16;
-    p.m_pad = p.n_tiles * 32;
-    p.tile_bytes = (p.n_steps + 1) * 1024;
-    p.tiles_off = 0;
-    p.cn64_off = (size_t)p.n_tiles * p.tile_bytes;
-    p.scal_off = p.cn64_off + (((size_t)p.m_pad * 8 + 255) & ~size_t(255));
-    p.frag2_off = p.scal_off + 256;
-    // the whole fp16 codebook must fit the register file of one CU: 4 waves x nt2 x ks2 fragments of
-    // 4 registers, at most 96 fragments per wave
-    p.ks2 = D / 16;
-    p.nt2 = M <= 256 ? 2 : (M <= 512 ? 4 : 0);
-    if (D % 32 != 0 || (p.ks2 != 12 && p.ks2 != 24) || p.nt2 * p.ks2 > 96) p.nt2 = 0;
-    p.hn2_off = p.frag2_off + (size_t)4 * p.nt2 * p.ks2 * 1024;
-    p.total = p.hn2_off + (((size_t)4 * p.nt2 * 128 + 255) & ~size_t(255));
-    return p;
-}
-
-// fp64 dot in the oracle's order: lane l accumulates k = l, l+64, ... then xor-butterfly.
-template <int NT>
-__device__ __forceinline__ double dot64(const double (&x)[NT], const float *c, int D, int lane)
-{
-    double p = 0.0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int k = lane + SN_WAVE * t;
-        if (k < D) p = fma(x[t], (double)c[k], p);
-    }
-    return sn_wave_sum_f64(p);
-}
 
 // ------------------------------------------------------------------------------------------
 // codebook_prepare
@@ -293,41 +257,32 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 }
 
 // ------------------------------------------------------------------------------------------
-// mode 0, pass 2: fp64 re-rank
-//   phase A  one wave per work-list entry: the <= 6 candidates the screen could not separate
-//   phase B  one BLOCK per overflow token: fp32 scan of every word through the transposed
-//            codebook (coalesced, thread = word), survivors inside a rigorous fp32 window are
-//            re-ranked in fp64.  All fp64 scores use the oracle's summation order.
+// mode 0, pass 2: fp64 re-rank, two kernels (one launch each; sn_assign_words(mode = 2) launches neither: the
+// instance-graph kernel finishes the flagged tokens of its image itself, csrc/sn_graph.hip)
+//   assign_rerank_kernel    one wave per flagged token: the <= 24 candidates the screen could not separate
+//   assign_overflow_kernel  one BLOCK per overflow token: fp16 scan of every word through the packed tile image,
+//                           survivors inside a rigorous window are re-ranked in fp64
+// All fp64 scores use the oracle's summation order.
 // ------------------------------------------------------------------------------------------
 constexpr int kMaxSurvivors = 64;
-constexpr int kOverflowBlocks = 64;     // blocks reserved for phase B
+constexpr int kOverflowBlocks = 64;     // grid of assign_overflow_kernel
 
 // FMT 0: records of assign_screen_kernel (24 code bytes per token); FMT 1: records of
 // assign_screen2_kernel (8 code dwords, slot c = 2 wave + accumulator half, key j: bit 3c + j);
 // FMT 2: 16-bit codes (M > 2048); FMT 3: records of assign_screen3_kernel (24 code bytes, its own slot order).
-// (six waves per SIMD: phase B, compiled alone, takes 139 registers and would leave phase A - 51 registers, one block per
-// chunk, latency-bound - three waves per SIMD, i.e. less than half of its blocks resident)
+// (Round 4: its own kernel.  Fused with the overflow scan - 139 registers - under amdgpu_waves_per_eu(6, 8) it was capped at
+// 80 registers and every instantiation spilled, 46 VGPRs / 188 bytes of scratch in <6, 0>: a latency-chain kernel that
+// needed a scratch segment at dispatch to serve two overflow tokens.  Alone it takes ~50 registers, no scratch.)
 template <int NT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void assign_rerank_kernel(const AssignArgs p)
 {
-    __shared__ float xs[NT * SN_WAVE];
-    __shared__ __attribute__((aligned(16))) _Float16 xh[NT * SN_WAVE];
-    __shared__ float red[12];
-    __shared__ int surv[kMaxSurvivors];
-    __shared__ int n_surv;
-    __shared__ double best_s[4];
-    __shared__ int best_i[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const PackLayout lay = pack_layout(p.M, p.D);
     const double *cn64 = (const double *)(p.packed + lay.cn64_off);
-    const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
-
-    // ---- phase A (blocks kOverflowBlocks .. gridDim.x - 1): a block owns 32 consecutive tokens per
-    // round, reads their flag words, and its four waves share the flagged ones round-robin.
-    // Candidate slot c = 12 h + 3 g + j holds code (tile << 2 | e): word = 32 tile + 8 g + 4 h + e.
+    // a block owns 32 consecutive tokens per round, reads their flag words, and its four waves share the flagged ones
+    // round-robin.  Candidate slot c = 12 h + 3 g + j holds code (tile << 2 | e): word = 32 tile + 8 g + 4 h + e.
     const int64_t n_chunks = (p.n_tokens + 31) / 32;
-    for (int64_t chunk = (int64_t)blockIdx.x - kOverflowBlocks; chunk < n_chunks && (int)blockIdx.x >= kOverflowBlocks;
-         chunk += (int64_t)gridDim.x - kOverflowBlocks) {
+    for (int64_t chunk = (int64_t)blockIdx.x; chunk < n_chunks; chunk += (int64_t)gridDim.x) {
         const int64_t t = chunk * 32 + (lane & 31);
         unsigned long long flag = 0ull;
         if (lane < 32 && t < p.n_tokens) {
@@ -393,12 +348,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
     }
 
-    // ---- phase B: every word of the overflow tokens, from the fp16 tile image (L2-hot: the screen
-    // kernel has just streamed it) with v_dot2_f32_f16; candidates = everything inside the fp16
-    // error window of the best, then fp64.
+}
+
+// every word of the overflow tokens, from the fp16 tile image (L2-hot: the screen kernel has just streamed it) with
+// v_dot2_f32_f16; candidates = everything inside the fp16 error window of the best, then fp64.
+template <int NT>
+__global__ __launch_bounds__(256) void assign_overflow_kernel(const AssignArgs p)
+{
+    __shared__ float xs[NT * SN_WAVE];
+    __shared__ __attribute__((aligned(16))) _Float16 xh[NT * SN_WAVE];
+    __shared__ float red[12];
+    __shared__ int surv[kMaxSurvivors];
+    __shared__ int n_surv;
+    __shared__ double best_s[4];
+    __shared__ int best_i[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const PackLayout lay = pack_layout(p.M, p.D);
+    const double *cn64 = (const double *)(p.packed + lay.cn64_off);
+    const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
     typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     const unsigned char *tiles = p.packed + lay.tiles_off;
-    const int n_over = ((int)blockIdx.x < kOverflowBlocks) ? p.work[1] : 0;     // blocks 0 .. kOverflowBlocks - 1 only
+    const int n_over = p.work[1];
     for (int e = blockIdx.x; e < n_over; e += kOverflowBlocks) {
         const int64_t n = p.overflow[e];
         const float *row = token_row(p, n);
@@ -1001,8 +971,12 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     // MFMA loop when every wave has a flagged token.  Each token gets a flag word (dense, coalesced)
     // and, if flagged, its 24 candidate codes at a fixed slot; the re-rank kernel walks the flags.
     const bool flagged = !overflow && nc > 1;
-    if (writer) p.flags[n] = overflow ? 0x80000000u : (flagged ? (hmask | (omask << 12)) : 0u);
-    if (valid && flagged) {                                // both half-lanes of the token write their 12 codes
+    // (overflow with a bounded window: the candidate mask and the codes are written as well - a consumer may then restrict
+    // itself to the candidates and the 64 words of every group whose triple is inside the window whole, sn_assign_shared.h;
+    // the stand-alone overflow kernel scans every word)
+    const bool fullscan = bad || !any_finite;
+    if (writer) p.flags[n] = fullscan ? sn_s1::kFlagFullScan : ((overflow ? sn_s1::kFlagOverflow : 0u) | ((flagged || overflow) ? (hmask | (omask << 12)) : 0u));
+    if (valid && (flagged || (overflow && !fullscan))) {   // both half-lanes of the token write their 12 codes
         const unsigned c0 = m1[0] & kCodeMask, c1 = m2[0] & kCodeMask, c2 = m3[0] & kCodeMask, c3 = m1[1] & kCodeMask;
         const unsigned c4 = m2[1] & kCodeMask, c5 = m3[1] & kCodeMask, c6 = m1[2] & kCodeMask, c7 = m2[2] & kCodeMask;
         const unsigned c8 = m3[2] & kCodeMask, c9 = m1[3] & kCodeMask, c10 = m2[3] & kCodeMask, c11 = m3[3] & kCodeMask;
@@ -1790,8 +1764,19 @@ bool assign_option(int i, const char *env)
     return g_assign_opt[i] != 0;
 }
 
+// the two kernels that finish a screen's flagged / overflow tokens (one event pair: kernel id 1 = the whole re-rank)
+template <int NT, int FMT>
+void launch_rerank(const AssignArgs &a, hipStream_t st)
+{
+    const int64_t chunks = (a.n_tokens + 31) / 32;
+    sn_prof_start(1, st);
+    hipLaunchKernelGGL((assign_rerank_kernel<NT, FMT>), dim3((unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((assign_overflow_kernel<NT>), dim3(kOverflowBlocks), dim3(256), 0, st, a);
+    sn_prof_stop(1, st);
+}
+
 template <int NSTEPS, int NW, int R, int CB = 8, bool DUAL = false>
-int launch_screen(const AssignArgs &a, hipStream_t st)
+int launch_screen(const AssignArgs &a, hipStream_t st, bool defer = false)
 {
     size_t lds = (size_t)R * (NSTEPS + 1) * 1024;
     if (const char *pad = getenv("SN_ASSIGN_LDS_PAD")) lds += (size_t)atoi(pad);     // diagnostics: force 1 workgroup per CU
@@ -1821,10 +1806,7 @@ int launch_screen(const AssignArgs &a, hipStream_t st)
     hipLaunchKernelGGL((assign_screen_kernel<NSTEPS, NW, R, CB, DUAL>), dim3(grid), dim3(64 * NW), lds, st, ag);
     sn_prof_stop(0, st);
     constexpr int NT = NSTEPS / 4;
-    sn_prof_start(1, st);
-    const int64_t chunks = (a.n_tokens + 31) / 32;
-    hipLaunchKernelGGL((assign_rerank_kernel<NT, (CB == 8 ? 0 : 2)>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, ag);
-    sn_prof_stop(1, st);
+    if (!defer) launch_rerank<NT, (CB == 8 ? 0 : 2)>(ag, st);      // (deferred: the consumer of the ids finishes them, sn_assign_words mode 2)
     return 0;
 }
 
@@ -1839,10 +1821,7 @@ int launch_screen2(const AssignArgs &a, hipStream_t st)
     hipLaunchKernelGGL((assign_screen2_kernel<NT, KS>), dim3(grid), dim3(256), lds, st, a);
     sn_prof_stop(0, st);
     constexpr int NTR = KS / 4;                                             // fp64 re-rank: 64 k per lane-step
-    sn_prof_start(1, st);
-    const int64_t chunks = (a.n_tokens + 31) / 32;
-    hipLaunchKernelGGL((assign_rerank_kernel<NTR, 1>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
-    sn_prof_stop(1, st);
+    launch_rerank<NTR, 1>(a, st);
     return 0;
 }
 
@@ -1866,10 +1845,7 @@ int launch_screen3(const AssignArgs &a, hipStream_t st)
     sn_prof_start(0, st);
     hipLaunchKernelGGL((assign_screen3_kernel<NTW, NCH>), dim3(grid), dim3(1024), lds, st, ag);
     sn_prof_stop(0, st);
-    sn_prof_start(1, st);
-    const int64_t chunks = (a.n_tokens + 31) / 32;
-    hipLaunchKernelGGL((assign_rerank_kernel<NTR, 3>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, ag);
-    sn_prof_stop(1, st);
+    launch_rerank<NTR, 3>(ag, st);
     return 0;
 }
 
@@ -1922,6 +1898,14 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
 
 extern "C" int sn_assign_variant(void) { return screen_variant(); }
 
+// mode 2 leaves its flagged tokens to the consumer only on the default (token-stationary) screen with byte codes
+extern "C" int sn_assign_defers(int M, int D)
+{
+    const int v = screen_variant();
+    const bool dflt = v == 0 || (v == 2 && pack_layout(M, D).nt2 == 0) || (v == 3 && !(pack_layout(M, D).n_tiles == 8 || pack_layout(M, D).n_tiles == 16));
+    return (dflt && M > 0 && M <= 2048 && (D == 192 || D == 384)) ? 1 : 0;      // (D = 768: the finish's state - three 12-register rows - does not fit the graph kernel's 128 registers)
+}
+
 extern "C" int sn_assign_set_variant(int variant)
 {
     SN_REQUIRE(variant >= 0 && variant <= 3, SN_ERR_BAD_ARG, "sn_assign_set_variant: variant=%d", variant);
@@ -1965,7 +1949,21 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
     SN_REQUIRE(M > 0 && M <= 65536, SN_ERR_BAD_ARG, "sn_assign_words: M=%d out of range", M);
     SN_REQUIRE(D > 0 && D % 32 == 0 && D <= 1024, SN_ERR_UNSUPPORTED, "sn_assign_words: D=%d must be a multiple of 32, <= 1024", D);
     SN_REQUIRE(n_tokens < 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_assign_words: too many tokens");
-    SN_REQUIRE(mode == 0 || mode == 1, SN_ERR_BAD_ARG, "sn_assign_words: mode=%d", mode);
+    SN_REQUIRE(mode >= 0 && mode <= 3, SN_ERR_BAD_ARG, "sn_assign_words: mode=%d", mode);
+    // mode 3 = only the re-rank of an earlier mode-2 call with the same arguments (a consumer that could not take the
+    // deferred finish after all): the stand-alone kernels on the records of the workspace.
+    const bool finish_only = mode == 3;
+    // mode 2 = mode 0 with the re-rank left to the consumer of the ids (sn_instance_graph with `rerank` set): the screen
+    // runs, `out` holds its words (final wherever the flag word is 0), the flag words and candidate records stay in the
+    // workspace.  Where the deferred form does not apply (screen forms other than the default, codebooks of more than
+    // 2048 words, shapes the screen is not built for) the call does everything itself and clears the flag words.
+    const bool want_defer = mode == 2;
+    if (want_defer || finish_only) {
+        mode = 0;
+        SN_REQUIRE(workspace && workspace_bytes >= sn_assign_workspace_bytes(n_tokens), SN_ERR_WORKSPACE,
+                   "sn_assign_words: mode 2 needs the workspace (%zu < %zu bytes)", workspace_bytes, sn_assign_workspace_bytes(n_tokens));
+    }
+    bool deferred = false;
     AssignArgs a;
     a.x = x; a.n_tokens = n_tokens; a.n_inner = n_inner; a.xso = x_stride_outer; a.xsi = x_stride_inner;
     a.cb = codebook; a.packed = (const unsigned char *)packed; a.M = M; a.D = D;
@@ -1985,6 +1983,14 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
     const int per16 = x_bf16 ? 8 : 4;                            // elements per 16 bytes
     const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && x_stride_outer % per16 == 0 && x_stride_inner % per16 == 0;
     const bool screen_ok = mode == 0 && aligned && (SN_S1_STAGE || !x_bf16) && M <= 32 * kMaxTilesScreen && (D == 192 || D == 384 || D == 768);
+    if (finish_only) {
+        // (where mode 2 did not defer it has cleared the flag words and the overflow count: the kernels find nothing)
+        if (D == 192) launch_rerank<3, 0>(a, st);
+        else if (D == 384) launch_rerank<6, 0>(a, st);
+        else SN_REQUIRE(false, SN_ERR_UNSUPPORTED, "sn_assign_words: mode 3 for D=%d", D);
+        SN_CHECK_LAUNCH("sn_assign_words");
+        return SN_OK;
+    }
     if (screen_ok) {
         SN_REQUIRE(workspace && workspace_bytes >= sn_assign_workspace_bytes(n_tokens), SN_ERR_WORKSPACE,
                    "sn_assign_words: workspace %zu < %zu bytes", workspace_bytes, sn_assign_workspace_bytes(n_tokens));
@@ -2006,8 +2012,8 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
             if (D == 192) rc = launch_screen<12, 4, 3, 10>(a, st);
             else if (D == 384) rc = launch_screen<24, 4, 3, 10>(a, st);
             else rc = launch_screen<48, 4, 3, 10>(a, st);
-        } else if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st);
-        else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : (assign_dual() ? launch_screen<24, 4, 3, 8, true>(a, st) : launch_screen<24, 4, 3>(a, st));
+        } else if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st, deferred = want_defer);
+        else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : (assign_dual() ? launch_screen<24, 4, 3, 8, true>(a, st) : launch_screen<24, 4, 3>(a, st, deferred = want_defer));
         else rc = launch_screen<48, 4, 3>(a, st);
         if (rc) return rc;
     } else {
@@ -2016,6 +2022,9 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
         else if (nt <= 6) launch_exact<6>(a, st);
         else if (nt <= 12) launch_exact<12>(a, st);
         else launch_exact<16>(a, st);
+    }
+    if (want_defer && !deferred) {                      // everything is final: a consumer must find no flag
+        if (int rc0 = sn_zero_async(a.flags, (size_t)n_tokens * 4, st)) return rc0;
     }
     SN_CHECK_LAUNCH("sn_assign_words");
     return SN_OK;

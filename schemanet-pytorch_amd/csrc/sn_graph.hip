@@ -14,6 +14,7 @@
 //   schema_inference/utils/ingredient_model_wrapper.py:58-68 (head mean + slicing)
 //   scripts/init_schema_net.py:33-35, 59-61 (per-class sums)
 #include "sn_common.h"
+#include "sn_assign_shared.h"
 #ifndef SN_S3_ROWS_NT
 #define SN_S3_ROWS_NT 1
 #endif
@@ -195,15 +196,280 @@ __device__ __forceinline__ void softmax_row4(float x[4], int L, int lane, bool u
 
 struct NoPreWork { __device__ __forceinline__ void operator()() const {} };
 
+// ------------------------------------------------------------------------------------------
+// Deferred finish of S1 inside the row phase (sn_assign_words mode 2, sn_graph_args.rerank).
+// The screen has left a flag word per token and, for the tokens it could not decide, the codes of the candidate words
+// (csrc/sn_assign_shared.h).  The stand-alone re-rank is a launch of its own on the critical path of a prediction - 15 us
+// of dependent fetches for ~13 tokens of an image - while the fifteen row waves of this kernel sit out the HBM burst of the
+// attention maps.  Here row wave w OWNS the positions l = w, w + 15, ...: it requests their flag words and candidate
+// records at the start of the kernel (one round trip, ahead of its first rows), and `tick()` - called once per iteration
+// of the row loop, behind that iteration's row loads - moves one token forward by one stage: token row + a pair of
+// candidate rows requested / their fp64 scores compared, the next pair requested / the final word written (to the
+// ingredients tensor and to s.words).  Every stage's loads are in flight while a batch of rows is soft-maxed.  The
+// arithmetic is the stand-alone kernel's (assign_rerank_kernel): fp64, the oracle's summation order, lowest index on
+// ties - the same ids bit for bit.  Overflow tokens (rare: a handful per 50 000) are finished by their owner in a blocking
+// loop over the candidates and the 64 words of every group whose triple lay inside the window whole (every word when the
+// screen could not bound the token).  The sorting wave waits for the fifteen `done` signals (a counter in LDS) before it
+// sorts.  NT = ceil(D / 64).
+// ------------------------------------------------------------------------------------------
+struct NoTick {
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ void operator()() {}
+    __device__ __forceinline__ void finish() {}
+};
+
+// An overflow token of the deferred S1 finish (a handful per 50 000).  The SORTING wave finishes these itself, in front of its
+// wait for the row waves (one site in the kernel: inlined into the row waves' state machine the scan was replicated per
+// loop form and spilled 1 400 registers; called out of line it forced spills around every call).  Candidates = the slots of the token's mask, plus - for every group
+// whose three slots are all inside the window - whatever a scan of the group's words 32 t + 8 g + 4 h + e through the
+// fp16 tile image (v_dot2_f32_f16, one word per lane, the token's fp16 pairs broadcast from registers) leaves inside
+// the rigorous fp16 window of the group's best (the window of assign_overflow_kernel; the group's best is no better
+// than the token's, so nothing that could win is cut); every word when the screen could not bound the token.
+// Returns the word (0 for an all-NaN row, like the oracle), or -1: keep the screen's.  my_word: word of candidate slot `lane`.
+template <int NT>
+__device__ __forceinline__ int rerank_overflow_token(const sn_s1::RerankView &rv, int b, int l, int lane, unsigned fj, int my_word)
+{
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    float xf[NT];
+    const void *row = sn_s1::token_row_ptr(rv.x, rv.x_bf16, (int64_t)b * rv.xsb + (int64_t)l * rv.xsl);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xf[t] = sn_s1::token_elem(row, rv.x_bf16, lane + SN_WAVE * t);       // (D == 64 NT)
+    double best = (double)INFINITY;
+    int bi = 0x7fffffff;
+    auto eval2 = [&](int ma, int m1, bool two) {                   // two words per round: their loads overlap
+        const int mb = two ? m1 : ma;
+        const float *ra = rv.cb + (int64_t)ma * rv.D, *rb = rv.cb + (int64_t)mb * rv.D;
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = lane + SN_WAVE * t;
+            pa = fma((double)xf[t], (double)ra[k], pa); pb = fma((double)xf[t], (double)rb[k], pb);
+        }
+        const double sa = rv.cn64[ma] - 2.0 * sn_wave_sum_f64(pa);
+        const double sb = rv.cn64[mb] - 2.0 * sn_wave_sum_f64(pb);
+        if (sa < best || (sa == best && ma < bi)) { best = sa; bi = ma; }
+        if (two && (sb < best || (sb == best && mb < bi))) { best = sb; bi = mb; }
+    };
+    if ((fj & sn_s1::kFlagFullScan) == sn_s1::kFlagFullScan) {
+        for (int m = 0; m < rv.M; m += 2) eval2(m, m + 1, m + 1 < rv.M);
+        return bi != 0x7fffffff ? bi : 0;                          // all-NaN row -> 0 (oracle)
+    }
+    const unsigned mask = fj & 0xFFFFFFu;
+    // the token's statistics and the fp16 window (assign_overflow_kernel's e16)
+    float sq = 0.0f, sabs = 0.0f, mabs = 0.0f;
+    unsigned xh2[NT];                                               // even lanes: fp16 pair (x[k], x[k + 1]), k = lane + 64 t
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float v = xf[t];
+        sq = fmaf(v, v, sq); sabs += fabsf(v); mabs = fmaxf(mabs, fabsf(v));
+        const float nx = __shfl_down(v, 1, SN_WAVE);
+        half2_t hp; hp.x = (_Float16)v; hp.y = (_Float16)nx;
+        xh2[t] = __builtin_bit_cast(unsigned, hp);
+    }
+    const float X2 = sqrtf(sn_wave_sum(sq)) * 1.001f, X1 = sn_wave_sum(sabs) * 1.001f, XM = sn_wave_max(mabs);
+    const float C2 = __uint_as_float(rv.scal[0]), C1 = __uint_as_float(rv.scal[1]);
+    const float CN = __uint_as_float(rv.scal[2]), CMAX = __uint_as_float(rv.scal[3]);
+    const float vmax = 0.5f * CN + X2 * C2;
+    const float e16 = 1.01f * (2.01f * 4.8828125e-4f * X2 * C2 + 5.96e-8f * (X1 + C1) +
+                               2.0f * (float)(rv.D + 2) * 5.9604645e-8f * vmax + 1.2e-7f * vmax);
+    const bool finite = (XM <= 3.0e4f) && (CMAX <= 3.0e4f) && (e16 < 1.0e30f);
+    constexpr int kSteps = 4 * NT;                                   // D / 16
+    const int tile_bytes = (kSteps + 1) * 1024;
+    for (int G = 0; G < 8; ++G) {                                   // G = 4 h + g
+        const unsigned bits = (mask >> (3 * G)) & 7u;
+        if (bits != 7u) {
+            for (int j = 0; j < 3; ++j)
+                if ((bits >> j) & 1u) eval2(__builtin_amdgcn_readlane(my_word, 3 * G + j), 0, false);
+            continue;
+        }
+        const int g = G & 3, hh = G >> 2;
+        for (int t0 = 0; t0 < rv.n_tiles; t0 += 16) {              // 16 tiles x 4 rows = one word per lane
+            const int tile = t0 + (lane >> 2), i = 8 * g + 4 * hh + (lane & 3), m = 32 * tile + i;
+            const bool in = tile < rv.n_tiles && m < rv.M;
+            const unsigned char *ta = rv.tiles + (size_t)(in ? tile : 0) * tile_bytes;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int s0 = 0; s0 < kSteps; s0 += 2) {                // two k-steps = 32 consecutive k (half of xh2[s0 / 4]) per round of loads
+                // (opaque copy: the v_readlane of a round are otherwise hoisted out of the group / tile loops and live in
+                // scalar registers for the whole kernel; the scheduling barrier keeps the rounds one after the other: all
+                // 8 NT 16-byte loads in flight at once do not fit the register file)
+                unsigned xt = xh2[s0 / 4];
+                asm volatile("" : "+v"(xt));
+                __builtin_amdgcn_sched_barrier(0);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (an array of float4 STRUCTS lives in scratch memory)
+                u32x4 fr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)                          // (step s0 + (q >> 1), lane half q & 1)
+                    fr[q] = *reinterpret_cast<const u32x4 *>(ta + (size_t)(s0 + (q >> 1)) * 1024 + (i + 32 * (q & 1)) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sstep = s0 + (q >> 1);
+                    const int k0 = 32 * (sstep >> 1) + 16 * (q & 1) + 8 * (sstep & 1);     // pack_frag_kernel: s = 2 u + e, k = 32 u + 16 h + 8 e + j
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const int k = k0 + 2 * jp;                  // (k >> 6 == s0 / 4)
+                        const unsigned xs = (unsigned)__builtin_amdgcn_readlane((int)xt, k & 63);
+                        const half2_t xv = __builtin_bit_cast(half2_t, xs), cv = __builtin_bit_cast(half2_t, (unsigned)fr[q][jp]);
+                        if (jp & 1) a1 = __builtin_amdgcn_fdot2(xv, cv, a1, false);
+                        else a0 = __builtin_amdgcn_fdot2(xv, cv, a0, false);
+                    }
+                }
+                asm volatile("" : "+v"(a0), "+v"(a1));              // (the sums are formed HERE, in every lane: left alone the products sink into the branch of the select below, their 32 NT broadcast operands spilled on the way)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float hn = *reinterpret_cast<const float *>(ta + (size_t)kSteps * 1024 + ((g * 2 + hh) * 4 + (lane & 3)) * 4);
+            const float sc = (in && finite) ? hn + (a0 + a1) : INFINITY;       // dist^2/2 - |x|^2/2 (tiles hold -c)
+            const float smin = sn_wave_min(sc);
+            // (nothing finite: every word of the group goes to fp64)
+            unsigned long long sv = __ballot(in && (!(smin < INFINITY) || sc <= smin + 2.0f * e16));
+            while (sv) {
+                const int la = __ffsll((long long)sv) - 1;
+                sv &= sv - 1;
+                const bool has1 = sv != 0ull;
+                const int lb = has1 ? __ffsll((long long)sv) - 1 : la;
+                if (has1) sv &= sv - 1;
+                eval2(__builtin_amdgcn_readlane(m, la), __builtin_amdgcn_readlane(m, lb), has1);
+            }
+        }
+    }
+    return bi != 0x7fffffff ? bi : -1;
+}
+
+constexpr int kRowWaves = 15;           // the sixteen-wave kernel: waves 0 .. 14 bring rows in, wave 15 sorts
+constexpr int kOwnMax = 14;             // positions a row wave owns: ceil(196 / 15) (L <= 210)
+
+template <int NT>
+struct RerankWave {
+    sn_s1::RerankView rv;
+    int b, L, lane, wid;
+    int64_t *words;             // s.words (LDS): final word of every flagged position, -1 when none could be ranked
+    int *done_counter;          // s.misc[6]
+    int st;                     // 0 flags in flight, 1 between tokens, 2 a candidate pair in flight, 3 done
+    unsigned f, cp0, cp1;       // lane j: flag word of position wid + 15 j;  lane t: dwords 2 (t % 3), + 1 of the record of position t / 3's slot
+    unsigned long long todo;
+    int l, my_word, ma, mb, bi;
+    bool two;                   // (RerankView carries `scal` and `tiles` of the packed image for the overflow scan)
+    unsigned cm;
+    float xf[NT], ra[NT], rb[NT];
+    double best;
+
+    __device__ __forceinline__ int64_t token_index(int pos) const { return (int64_t)b * rv.tsb + (int64_t)pos * rv.tsl; }
+
+    __device__ __forceinline__ void begin()
+    {
+        st = 0; f = 0; cp0 = 0; cp1 = 0;
+        const int pj = wid + kRowWaves * lane;
+        if (lane < kOwnMax && pj < L) f = rv.flags[token_index(pj)];
+        const int pt = wid + kRowWaves * (lane / 3);
+        if (lane < 3 * kOwnMax && pt < L) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(rv.codes + token_index(pt) * sn_s1::kCodeBytes + 8 * (lane % 3));
+            cp0 = v.x; cp1 = v.y;
+        }
+    }
+
+    __device__ __forceinline__ void load_row(float (&dst)[NT], const void *row, int x_bf16) const
+    {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            dst[t] = sn_s1::token_elem(row, x_bf16, lane + SN_WAVE * t);      // (D == 64 NT: the host launches no other shape)
+        }
+    }
+
+    __device__ __forceinline__ void issue_pair()
+    {
+        const int ca = __ffs((int)cm) - 1;
+        cm &= cm - 1;
+        two = cm != 0u;
+        const int cb2 = two ? __ffs((int)cm) - 1 : ca;
+        if (two) cm &= cm - 1;
+        ma = __builtin_amdgcn_readlane(my_word, ca);
+        mb = __builtin_amdgcn_readlane(my_word, cb2);
+        load_row(ra, rv.cb + (int64_t)ma * rv.D, 0);
+        load_row(rb, rv.cb + (int64_t)mb * rv.D, 0);
+    }
+
+    __device__ __forceinline__ void score_pair()
+    {
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { pa = fma((double)xf[t], (double)ra[t], pa); pb = fma((double)xf[t], (double)rb[t], pb); }
+        const double sa = rv.cn64[ma] - 2.0 * sn_wave_sum_f64(pa);
+        const double sb = rv.cn64[mb] - 2.0 * sn_wave_sum_f64(pb);
+        if (sa < best || (sa == best && ma < bi)) { best = sa; bi = ma; }
+        if (two && (sb < best || (sb == best && mb < bi))) { best = sb; bi = mb; }
+    }
+
+    __device__ __forceinline__ void write_word(int word, int fallback)
+    {
+        if (lane == 0) {
+            const int w = word != 0x7fffffff ? word : fallback;
+            if (w >= 0) rv.ids[(int64_t)b * rv.isb + (int64_t)l * rv.isl] = w;
+            words[l] = w;                                           // (-1: keep the screen's word)
+        }
+    }
+
+    // word of candidate slot `lane` (< 24) of owned position jj, from the record dwords held by lanes 3 jj .. 3 jj + 2
+    __device__ __forceinline__ int slot_words(int jj) const
+    {
+        const int src = 3 * jj + ((lane & 31) >> 3);
+        const unsigned d0 = (unsigned)__shfl((int)cp0, src, SN_WAVE), d1 = (unsigned)__shfl((int)cp1, src, SN_WAVE);
+        const unsigned code = (((lane >> 2) & 1) ? d1 : d0) >> (8 * (lane & 3)) & 0xFFu;
+        return lane < sn_s1::kMaxCand ? sn_s1::slot_word(lane, code) : 0;
+    }
+
+    __device__ __forceinline__ void operator()()
+    {
+        if (st == 3) return;
+        if (st == 0) {
+            todo = __ballot(f != 0u);
+            st = 1;
+        }
+        if (st == 2) {
+            score_pair();
+            if (cm) { issue_pair(); return; }
+            write_word(bi, -1);
+            st = 1;
+        }
+        // st == 1: the next flagged position of this wave
+        while (todo) {
+            const int jj = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned fj = (unsigned)__builtin_amdgcn_readlane((int)f, jj);
+            l = wid + kRowWaves * jj;
+            if (fj >> 31) continue;                                  // an overflow token: the sorting wave's (rerank_overflow_token)
+            cm = fj & 0xFFFFFFu;
+            my_word = slot_words(jj);
+            const void *row = sn_s1::token_row_ptr(rv.x, rv.x_bf16, (int64_t)b * rv.xsb + (int64_t)l * rv.xsl);
+            load_row(xf, row, rv.x_bf16);
+            best = (double)INFINITY; bi = 0x7fffffff;
+            issue_pair();
+            st = 2;
+            return;
+        }
+        // nothing left: tell the sorting wave (LDS operations of a wave are performed in order: the words are written)
+        if (lane == 0) atomicAdd(done_counter, 1);
+        st = 3;
+    }
+
+    __device__ __forceinline__ void finish()
+    {
+        while (st != 3) (*this)();
+    }
+};
+
+
 // `pre_work()`: register-only work of the caller that has nothing to do with the rows; the dynamic form calls it once its first
 // two batches of loads are issued (the wave would otherwise sit out their HBM latency), the other forms up front.
-template <bool kVec, bool kFast, class Pre = NoPreWork>
+// `tick`: the deferred S1 finish of this wave (RerankWave; NoTick: none): begin() in front of the first row loads, one
+// call per iteration of the row loop behind that iteration's loads, finish() when the rows are in.
+template <bool kVec, bool kFast, class Pre, class Tick>
 __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src, int64_t stride_r, int heads,
                                                       int64_t stride_h, int L, bool is_logits, bool use_clamp,
-                                                      float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr,
-                                                      Pre pre_work = Pre())
+                                                      float clamp, int rb, int re, int rs, int lane, int *next_row,
+                                                      Pre pre_work, Tick &tick)
 {
-    constexpr int kRowsInFlight = 7;        // HBM latency: 7 rows of loads in flight per wave (196 rows on 15 waves: two batches; four in flight = four batches of exposed latency: 25.6 k -> see DESIGN 3.2)
+    constexpr int kRowsInFlight = 7;
+    tick.begin();        // HBM latency: 7 rows of loads in flight per wave (196 rows on 15 waves: two batches; four in flight = four batches of exposed latency: 25.6 k -> see DESIGN 3.2)
     if (rs != 0 || heads > 1) pre_work();
     if (heads > 1) {
         // Head mean fused (the backbone's [bs, H, L+1, L+1] tap): the loads of ALL heads of a pair of rows are issued before
@@ -222,6 +488,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
                     for (int i = 0; i < kRB; ++i)
                         load_row4<kVec>(src + hc * stride_h + (int64_t)min(r0 + rs * i, L - 1) * stride_r, L, lane, y[hh][i]);
                 }
+                if (h0 == 0) tick();
 #pragma unroll
                 for (int hh = 0; hh < kHB; ++hh) {
                     if (h0 + hh >= heads) break;                     // wave-uniform
@@ -250,6 +517,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
                 }
             }
         }
+        tick.finish();
         return;
     }
     if (rs == 0) {
@@ -275,6 +543,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
 #pragma unroll
                 for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(rn + i, L - 1) * stride_r, L, lane, z[i]);
             }
+            tick();
 #pragma unroll
             for (int i = 0; i < kDyn; ++i) {
                 const int r = r0 + i;
@@ -298,6 +567,7 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
             r0 = r1;
             r1 = rn;
         }
+        tick.finish();
         return;
     }
     for (int r0 = rb; r0 < re; r0 += rs * kRowsInFlight) {
@@ -322,18 +592,32 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
             }
         }
     }
+    tick.finish();
 }
 
-template <bool kFast = false, class Pre = NoPreWork>
+template <bool kFast = false, class Pre = NoPreWork, class Tick = NoTick>
 __device__ __forceinline__ void attn_rows_to_lds(float *A, const float *src, int64_t stride_r, int heads,
                                         int64_t stride_h, int L, bool is_logits, bool use_clamp,
-                                        float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr, Pre pre_work = Pre())
+                                        float clamp, int rb, int re, int rs, int lane, int *next_row = nullptr, Pre pre_work = Pre(),
+                                        Tick *tick = nullptr)
 {
     // (rows need not be 16-byte aligned in global memory: gfx950 serves a dword-aligned global_load_dwordx4 correctly,
     // tools/unaligned_probe.hip; the slices of the backbone's [.., 197, 197] tap never are.  The LDS rows are: L % 4 == 0.)
     const bool vec = (L % 4 == 0) && (kFast || ((stride_r % 4 == 0) && (stride_h % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)));
-    if (vec) attn_rows_to_lds_impl<true, kFast, Pre>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work);
-    else attn_rows_to_lds_impl<false, kFast, Pre>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work);
+    NoTick none;
+    if constexpr (std::is_same<Tick, NoTick>::value) {
+        if (vec) attn_rows_to_lds_impl<true, kFast, Pre, NoTick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, none);
+        else attn_rows_to_lds_impl<false, kFast, Pre, NoTick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, none);
+    } else {
+        // (a deferred finish rides on the vector path only: its kernel is launched for L % 4 == 0; anywhere else the
+        // finish runs after the rows)
+        if (vec) attn_rows_to_lds_impl<true, kFast, Pre, Tick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, *tick);
+        else {
+            attn_rows_to_lds_impl<false, kFast, Pre, NoTick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, none);
+            tick->begin();
+            tick->finish();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -768,8 +1052,10 @@ static unsigned long long *g_graph_stamps = nullptr;      // diagnostics only (s
 // zero padding of the edges left to the consumer, L a multiple of 4 and at most 256.  The edges phase is bound by the
 // VALU instructions it issues (4 SIMD-cycles each): every run-time option is a branch, a select or a scalar that lives
 // in a spilled SGPR (a v_readlane per use) in the row loop.
-template <bool kEdges, bool kFast = false>
-__global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a, unsigned long long *stamps, int signed_table)
+// RR > 0: the deferred finish of S1 rides in the row phase (RerankWave<RR>, RR = ceil(D / 64); sixteen waves only).
+template <bool kEdges, bool kFast = false, int RR = 0>
+__global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_args a, unsigned long long *stamps, int signed_table,
+                                                              const sn_s1::RerankView rv)
 {
     const bool c_mean = kFast || a.mean != 0;
     const bool c_rsl = !kFast && a.remove_self_loop != 0;
@@ -794,8 +1080,8 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     // divisions per thread and the record reads of 1 024 threads used to sit between the phases: 2.7 k cycles per image)
     const int ts_S = 2 * a.feat_w - 1;
     const bool lean_ok = kFast && dyn_rows && ts_S <= SN_WAVE;
-    if (dyn_rows) {
-        if (tid == 0) s.misc[4] = (nw - 1) * 4;
+    if (dyn_rows || RR > 0) {
+        if (tid == 0) { s.misc[4] = (nw - 1) * 4; s.misc[6] = 0; }           // ([6]: row waves whose share of the deferred S1 finish is done)
         for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;       // (in front of the barrier: ordered before the sorting wave's row map)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                            // (everybody is at the start of the kernel: a cheap barrier)
@@ -825,9 +1111,17 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     ts[(fh - 1 - dr) * ts_S + lane] = v;
                 }
             };
-            attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
-                                   a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e, rb, re, rs, lane, &s.misc[4],
-                                   table_rows);
+            if constexpr (RR > 0) {
+                RerankWave<RR> tick;
+                tick.rv = rv; tick.b = b; tick.L = L; tick.lane = lane; tick.wid = wid; tick.words = s.words; tick.done_counter = &s.misc[6];
+                attn_rows_to_lds<true, decltype(table_rows), RerankWave<RR>>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
+                                       a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e, rb, re, rs, lane, &s.misc[4],
+                                       table_rows, &tick);
+            } else {
+                attn_rows_to_lds<true>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
+                                       a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e, rb, re, rs, lane, &s.misc[4],
+                                       table_rows);
+            }
         }
         if (!a.geo) {
             // (lean form: grid coordinates and signed table are written under the row waves' first loads, the unsigned table only
@@ -835,19 +1129,22 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if (!lean_ok) build_grid_table(s, L, a.feat_w, a.dist_alpha, a.dist_pow, tid);
         }
     }
-    if (tid < L) s.words[tid] = a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)tid * a.ing_stride_l];
+    // (RR: s.words is the sorting wave's - it holds every word, final ones included, once the row waves have finished theirs)
+    if (RR == 0 && tid < L) s.words[tid] = a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)tid * a.ing_stride_l];
     if (!dyn_rows) for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;
     if (!sorter && wid == nw - 1 && lane == 0) s.misc[2] = 0;   // misc[2] = 1: the sorter wave has written the grouping records (only ever written by the last wave)
 
     // The sorting wave's inputs - the words, the vertex attribute weights - are requested before its cls-attention row is
     // soft-maxed: one global round trip instead of three dependent ones on the wave everybody waits for at the barrier.
     int64_t w4[4] = {0, 0, 0, 0};
+    unsigned f4[4] = {0u, 0u, 0u, 0u};                          // (RR: flag words of the screen - non-zero: the word is still to come)
     float wv0 = 0.0f, wv1 = 0.0f;
     if (sorter && L <= 4 * SN_WAVE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int q = lane + SN_WAVE * e;
             w4[e] = q < L ? a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)q * a.ing_stride_l] : 0;
+            if (RR > 0 && q < L) f4[e] = rv.flags[(int64_t)b * rv.tsb + (int64_t)q * rv.tsl];
         }
         if (do_v && a.out_v) { wv0 = a.w_v[0]; wv1 = a.w_v[1]; }
     }
@@ -889,6 +1186,44 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     bool done = false;                                          // (the sorting wave's: it grouped the positions)
     sg.n_groups = 0;
     if (sorter) {
+        if constexpr (RR > 0) {
+            // overflow tokens of this image (rare): finished here, while the row waves finish the flagged ones.  (ONE call
+            // site: the four position slots of a lane are walked through uniform selects, not an unrolled loop)
+            unsigned long long om0 = __ballot(lane < L && (f4[0] >> 31) != 0u), om1 = __ballot(lane + SN_WAVE < L && (f4[1] >> 31) != 0u);
+            unsigned long long om2 = __ballot(lane + 2 * SN_WAVE < L && (f4[2] >> 31) != 0u), om3 = __ballot(lane + 3 * SN_WAVE < L && (f4[3] >> 31) != 0u);
+            while (om0 | om1 | om2 | om3) {
+                const int e = om0 ? 0 : (om1 ? 1 : (om2 ? 2 : 3));
+                const unsigned long long me = e == 0 ? om0 : (e == 1 ? om1 : (e == 2 ? om2 : om3));
+                const int src = __ffsll((long long)me) - 1;
+                const unsigned long long rest = me & (me - 1);
+                om0 = e == 0 ? rest : om0; om1 = e == 1 ? rest : om1; om2 = e == 2 ? rest : om2; om3 = e == 3 ? rest : om3;
+                const unsigned fsel = e == 0 ? f4[0] : (e == 1 ? f4[1] : (e == 2 ? f4[2] : f4[3]));
+                const unsigned fj = (unsigned)__builtin_amdgcn_readlane((int)fsel, src);
+                const int q = src + SN_WAVE * e;
+                const int64_t n = (int64_t)b * rv.tsb + (int64_t)q * rv.tsl;
+                const unsigned code = lane < sn_s1::kMaxCand ? (unsigned)rv.codes[n * sn_s1::kCodeBytes + lane] : 0u;
+                const int wfin = rerank_overflow_token<RR>(rv, b, q, lane, fj, lane < sn_s1::kMaxCand ? sn_s1::slot_word(lane, code) : 0);
+                if (wfin >= 0) {
+                    if (lane == src) {
+                        w4[0] = e == 0 ? (int64_t)wfin : w4[0]; w4[1] = e == 1 ? (int64_t)wfin : w4[1];
+                        w4[2] = e == 2 ? (int64_t)wfin : w4[2]; w4[3] = e == 3 ? (int64_t)wfin : w4[3];
+                    }
+                    if (lane == 0) rv.ids[(int64_t)b * rv.isb + (int64_t)q * rv.isl] = wfin;
+                }
+            }
+            // the flagged tokens' final words: every row wave has finished its share (15 signals), the words lie in s.words
+            // (-1: none of the candidates could be ranked - keep the screen's)
+            while (__hip_atomic_load(&s.misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nw - 1) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = lane + SN_WAVE * e;
+                if (q < L) {
+                    if (f4[e] != 0u && (f4[e] >> 31) == 0u) { const int64_t w = s.words[q]; if (w >= 0) w4[e] = w; }
+                    s.words[q] = w4[e];
+                }
+            }
+        }
         if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
         if (L <= 4 * SN_WAVE) {
         __builtin_amdgcn_wave_barrier();
@@ -1581,16 +1916,43 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
         }
         const bool fast = signed_table && !a.geo && !a.out_e2 && a.out_e && a.mean && !a.remove_self_loop && !a.dict_keys &&
                           a.skip_edge_padding && (a.L & 3) == 0 && a.L <= 4 * SN_WAVE;
-        int rc = fast ? ensure_lds((const void *)instance_graph_kernel<true, true>, lds, "sn_instance_graph")
-                      : ensure_lds((const void *)instance_graph_kernel<true>, lds, "sn_instance_graph");
+        sn_s1::RerankView rv = {};
+        int rr = 0;
+        if (a.rerank) {
+            const sn_rerank_args &r = *a.rerank;
+            SN_REQUIRE(fast, SN_ERR_UNSUPPORTED, "sn_instance_graph: the deferred S1 finish needs the prediction configuration of the edges kernel");
+            SN_REQUIRE(r.x && r.codebook && r.packed && r.workspace && r.ids && r.n_tokens > 0, SN_ERR_BAD_ARG, "sn_instance_graph: incomplete rerank arguments");
+            SN_REQUIRE(sn_assign_defers(r.M, r.D) == 1, SN_ERR_UNSUPPORTED, "sn_instance_graph: no deferred S1 finish for M=%d D=%d", r.M, r.D);
+            SN_REQUIRE(a.L <= kRowWaves * kOwnMax, SN_ERR_UNSUPPORTED, "sn_instance_graph: deferred S1 finish for L=%d > %d", a.L, kRowWaves * kOwnMax);
+            const sn_s1::PackLayout lay = sn_s1::pack_layout(r.M, r.D);
+            const unsigned char *ws = (const unsigned char *)r.workspace, *pk = (const unsigned char *)r.packed;
+            rv.flags = (const unsigned *)(ws + 32);
+            rv.codes = ws + 32 + (size_t)r.n_tokens * 4;
+            rv.x = r.x; rv.xsb = r.x_stride_b; rv.xsl = r.x_stride_l; rv.x_bf16 = r.x_bf16;
+            rv.tsb = r.tok_stride_b; rv.tsl = r.tok_stride_l;
+            rv.cb = r.codebook;
+            rv.cn64 = (const double *)(pk + lay.cn64_off);
+            rv.tiles = pk + lay.tiles_off;
+            rv.scal = (const unsigned *)(pk + lay.scal_off);
+            rv.ids = r.ids; rv.isb = r.ids_stride_b; rv.isl = r.ids_stride_l;
+            rv.M = r.M; rv.D = r.D; rv.n_tiles = lay.n_tiles;
+            rr = r.D / 64;                                        // (sn_assign_defers: D in {192, 384})
+        }
+        const void *fn = rr == 3 ? (const void *)instance_graph_kernel<true, true, 3>
+                       : rr == 6 ? (const void *)instance_graph_kernel<true, true, 6>
+                       : fast ? (const void *)instance_graph_kernel<true, true> : (const void *)instance_graph_kernel<true>;
+        int rc = ensure_lds(fn, lds, "sn_instance_graph");
         if (rc) return rc;
         sn_prof_start(2, st);
-        if (fast) hipLaunchKernelGGL((instance_graph_kernel<true, true>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table);
-        else hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table);
+        if (rr == 3) hipLaunchKernelGGL((instance_graph_kernel<true, true, 3>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
+        else if (rr == 6) hipLaunchKernelGGL((instance_graph_kernel<true, true, 6>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
+        else if (fast) hipLaunchKernelGGL((instance_graph_kernel<true, true>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
+        else hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
         sn_prof_stop(2, st);
     } else {
         const size_t lds = lds_bytes(a.L, false);
-        hipLaunchKernelGGL(instance_graph_kernel<false>, dim3(a.B), dim3(256), lds, st, a, (unsigned long long *)nullptr, 0);
+        SN_REQUIRE(!a.rerank, SN_ERR_UNSUPPORTED, "sn_instance_graph: the deferred S1 finish needs the edges kernel (attn != NULL)");
+        hipLaunchKernelGGL(instance_graph_kernel<false>, dim3(a.B), dim3(256), lds, st, a, (unsigned long long *)nullptr, 0, sn_s1::RerankView{});
     }
     SN_CHECK_LAUNCH("sn_instance_graph");
     return SN_OK;

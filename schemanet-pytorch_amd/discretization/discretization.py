@@ -69,10 +69,13 @@ class Discretization(nn.Module):
     def activate(self):
         self._activate = True
 
-    def assign(self, seq: torch.Tensor, out: torch.Tensor = None) -> torch.LongTensor:
-        """seq [n_outer, n_inner, dim] (any outer strides) -> word ids int64 [n_outer, n_inner]."""
+    def assign(self, seq: torch.Tensor, out: torch.Tensor = None, defer: bool = False):
+        """seq [n_outer, n_inner, dim] (any outer strides) -> word ids int64 [n_outer, n_inner].
+        defer=True: -> (ids, handle): the tokens the fp16 screen could not decide are left to the consumer of the ids
+        (`SchemaNet.instance_graph_padded(..., rerank=handle)` finishes them inside its kernel, `handle.finish()` by the
+        stand-alone re-rank); handle is None where everything is final already."""
         codebook, packed = self._packed.get(self.vocabulary.weight)
-        return ops.assign_words(seq, codebook, packed, out=out, mode=1 if self.exact else 0)
+        return ops.assign_words(seq, codebook, packed, out=out, mode=1 if self.exact else 0, defer=defer)
 
     def encode(self, seq: torch.Tensor) -> Tuple[torch.Tensor, torch.LongTensor]:
         if self.detach_input_seq:

@@ -78,7 +78,8 @@ class SchemaNetPredictor(nn.Module):
         atlas = self.matcher.atlas_features_async(get_atlas, depends_on=self._atlas_depends_on(), side_stream=side_stream)
         # (the zero padding of the instance edges is only written when the caller asks for the graphs)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
-                                                      zero_padding=requires_graph, return_attn_cls=requires_graph)
+                                                      zero_padding=requires_graph, return_attn_cls=requires_graph,
+                                                      rerank=output.get("rerank"))
         ret["pred"] = self.matcher.forward_padded(graph, atlas.class_dict, feat_kg=atlas)
         for k in ("class_vertices", "class_edges", "class_ingredients"):                  # (the reference's keys, in its order)
             ret[k] = atlas.class_dict[k]
@@ -151,8 +152,8 @@ class SchemaNetPredictor(nn.Module):
         """eval + no_grad + `taps`: backbone eagerly, then the captured launch sequence of everything behind it.
 
         own_pred: `pred` must survive the next call.  The capture's output buffer is rewritten by its next replay, so a
-        key gets a SECOND capture of the same step (same memory pool: the two never run at the same time, every
-        intermediate buffer is shared; only the outputs exist twice) and the calls alternate between the two: the tensor a
+        key gets a SECOND capture of the same step (with buffers of its own: a shared memory pool would let one capture's
+        intermediates land on the other's outputs) and the calls alternate between the two: the tensor a
         call returns is valid until the next call BUT ONE with the same taps - a two-deep output ring instead of a copy
         kernel between two graph launches (`SN_PREDICTOR_RING=0`: one capture and `pred.clone()`, valid for ever)."""
         from ..utils.graph_replay import GraphedStep
@@ -168,14 +169,13 @@ class SchemaNetPredictor(nn.Module):
                 if self._graph_misses >= 4 * self.max_graphs:
                     self._give_up_replay(f"{self._graph_misses} consecutive calls found no capture to replay: the backbone's tap "
                                          "buffers or the parameters change on every call")
-                    return self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream)
+                    return self._after_backbone(wrapper.taps_from(out_backbone, defer=True), False, side_stream)
                 self._graph_misses += 1
             try:
-                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream),
-                                   pool=None if entry is None else entry[1].pool)
+                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone, defer=True), False, side_stream))
             except Exception as exc:                              # noqa: BLE001 - a configuration that cannot be captured
                 self._give_up_replay(f"capture failed: {exc!r}")
-                return self._after_backbone(wrapper.taps_from(out_backbone), False, side_stream)
+                return self._after_backbone(wrapper.taps_from(out_backbone, defer=True), False, side_stream)
             if entry is None:
                 entry = [0, step]                                 # [calls so far, capture A (, capture B)]
                 self._graphs[key] = entry
@@ -241,7 +241,7 @@ class SchemaNetPredictor(nn.Module):
                 if self.graph_replay:
                     out = self._forward_replayed(x, own_pred=False, side_stream=fork)
                 else:                                  # (capture gave up on the way: eager launches, still `depth` streams)
-                    out = self._after_backbone(wrapper.taps(x), False, fork)
+                    out = self._after_backbone(wrapper.taps(x, defer=True), False, fork)
                     out["pred"].record_stream(home)
                 done = torch.cuda.Event()
                 done.record(st)
@@ -257,7 +257,7 @@ class SchemaNetPredictor(nn.Module):
             return self._forward_replayed(x)
         with torch.no_grad():
             if hasattr(wrapper, "taps"):
-                output = wrapper.taps(x)
+                output = wrapper.taps(x, defer=True)
             else:
                 output = wrapper(x)
         return self._after_backbone(output, requires_graph)

@@ -247,7 +247,7 @@ class SchemaNet(nn.Module):
 
     def instance_graph_padded(self, ingredients: torch.LongTensor, attn: torch.Tensor, attn_cls: torch.Tensor,
                               n_pad: int = None, mutate_inputs: bool = True, zero_padding: bool = True,
-                              return_attn_cls: bool = False) -> Dict[str, torch.Tensor]:
+                              return_attn_cls: bool = False, rerank=None) -> Dict[str, torch.Tensor]:
         """One fused launch: logits -> padded instance graphs.
 
         ingredients [bs, L] i64; attn [bs, L, L] or [bs, H, L, L] logits (head mean fused);
@@ -261,6 +261,8 @@ class SchemaNet(nn.Module):
         zero_padding=False: the rows / columns of `edges` beyond an image's own vertex count are left unwritten
         (about two thirds of the padded batch are such zeros) and the dict says `edges_padded: False`;
         `Matcher.forward_padded` masks by `n` instead.  For callers that only want the scores.
+        rerank: the handle of `Discretization.assign(..., defer=True)` that produced `ingredients`: the word ids the fp16
+        screen left undecided are finished inside this launch (and written back to `ingredients`).
         return_attn_cls: also return `attn_cls` [bs, L] = the head-averaged cls-attention logits after the clamp
         (< clamp_vertex_attn -> -inf), i.e. what the reference's `attn_cls` holds after schema_net.py:296, when the
         input is a per-head view that cannot be masked in place.
@@ -282,7 +284,7 @@ class SchemaNet(nn.Module):
             clamp_v=self.clamp_vertex_attn, clamp_e=self.clamp_edge_attn, feat_h=self.feat_h, feat_w=self.feat_w,
             dist_alpha=self.dist_alpha, dist_pow=self.dist_pow, mean=True, remove_self_loop=self.remove_self_loop,
             want_attr2=need_grad, want_weighted=not need_grad, attn_cls_masked_out=masked_out,
-            zero_padding=zero_padding or need_grad)
+            zero_padding=zero_padding or need_grad, rerank=rerank)
         if need_grad:   # keep `@ w` visible to autograd (the reference does it inside C++)
             g["v"] = ops.weigh_attributes(g["v2"], w_v)
             g["e"] = ops.weigh_attributes(g["e2"], w_e)

@@ -20,9 +20,7 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, fn, warmup: int = 2, pool=None):
-        """pool: the memory pool of another capture (`other.pool`) whose replays NEVER overlap this one's in time (same
-        stream, one after the other): the two then share every buffer that is not alive at the end of the other's capture."""
+    def __init__(self, fn, warmup: int = 2):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs a GPU (the HIP path has no CPU fallback)")
         side = torch.cuda.Stream()
@@ -37,10 +35,7 @@ class GraphedStep:
         # hands every LATER eager allocation of the process a new address - and a capture keyed on the addresses of its
         # inputs (SchemaNetPredictor) would then see them move after every other capture
         with torch.no_grad(), torch.cuda.stream(side):
-            if pool is None:
-                self.graph.capture_begin()
-            else:
-                self.graph.capture_begin(pool=pool)
+            self.graph.capture_begin()
             try:
                 self.outputs = fn()
             except BaseException:
@@ -50,7 +45,6 @@ class GraphedStep:
                     pass
                 raise
             self.graph.capture_end()
-        self.pool = self.graph.pool()
         torch.cuda.current_stream().wait_stream(side)
 
     def replay(self):

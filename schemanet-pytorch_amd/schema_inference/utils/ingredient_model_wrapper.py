@@ -62,18 +62,28 @@ class IngredientModelWrapper(nn.Module):
         return ret
 
     @torch.no_grad()
-    def taps(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
-        return self.taps_from(self.backbone_jit(x))
+    def taps(self, x: torch.Tensor, defer: bool = False) -> Dict[str, torch.Tensor]:
+        return self.taps_from(self.backbone_jit(x), defer=defer)
 
     @torch.no_grad()
-    def taps_from(self, out_backbone: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """The part of `taps` behind the backbone (no host synchronisation: SchemaNetPredictor captures it)."""
+    def taps_from(self, out_backbone: Dict[str, torch.Tensor], defer: bool = False) -> Dict[str, torch.Tensor]:
+        """The part of `taps` behind the backbone (no host synchronisation: SchemaNetPredictor captures it).
+        defer=True (SchemaNetPredictor): `ingredients` holds the words of the fp16 screen and the dict carries `rerank`,
+        the handle with which `SchemaNet.instance_graph_padded` finishes the undecided ones inside its kernel; the caller
+        MUST pass it on (or call `rerank.finish()`).  Default: the ids are final on return."""
         mid_feat = out_backbone["mid_feat"]                     # [L+1, bs, D] sequence-first
         extracted = out_backbone["extracted"]                   # [bs*H, L+1, L+1]
         Lp1, bs, _ = mid_feat.shape
         L = Lp1 - 1
         ingredients = torch.empty((bs, L), dtype=torch.int64, device=mid_feat.device)
         # tokens [L, bs, D] view; word ids land transposed ([bs, L]) through the output strides
-        self.discretization_jit.discretization.assign(mid_feat[1:], out=ingredients.t())
+        rerank = None
+        if defer:
+            _, rerank = self.discretization_jit.discretization.assign(mid_feat[1:], out=ingredients.t(), defer=True)
+        else:
+            self.discretization_jit.discretization.assign(mid_feat[1:], out=ingredients.t())
         heads = extracted.reshape(bs, -1, Lp1, Lp1)
-        return {"ingredients": ingredients, "attn": heads[:, :, 1:, 1:], "attn_cls": heads[:, :, 0, 1:]}
+        ret = {"ingredients": ingredients, "attn": heads[:, :, 1:, 1:], "attn_cls": heads[:, :, 0, 1:]}
+        if rerank is not None:
+            ret["rerank"] = rerank
+        return ret

@@ -40,20 +40,28 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.sn_assign_variant() in (0, 1, 2)
 
 
-def test_graph_args_struct_matches_header(lib):
-    """field order of the ctypes mirror == field order of struct sn_graph_args"""
-    import cpp_extension._native as N
-    header = open(os.path.join(ROOT, "include", "schemanet_hip.h")).read()
-    body = header[header.index("typedef struct sn_graph_args {"):header.index("} sn_graph_args;")]
+def _struct_field_names(header, name):
+    body = header[header.index("typedef struct %s {" % name):header.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for stmt in body.split(";"):
         stmt = stmt.strip().split("{")[-1]
         if not stmt:
             continue
-        decl = re.sub(r"^(const\s+)?(int64_t|int32_t|float|int)\s*", "", stmt.strip())
+        decl = re.sub(r"^(const\s+)?(int64_t|int32_t|float|int|void|sn_rerank_args)\s*", "", stmt.strip())
         names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
-    assert names == [f[0] for f in N.GraphArgs._fields_]
+    return names
+
+
+def test_graph_args_struct_matches_header(lib):
+    """field order of the ctypes mirrors == field order of struct sn_graph_args / sn_rerank_args"""
+    import cpp_extension._native as N
+    header = open(os.path.join(ROOT, "include", "schemanet_hip.h")).read()
+    assert _struct_field_names(header, "sn_graph_args") == [f[0] for f in N.GraphArgs._fields_]
+    assert _struct_field_names(header, "sn_rerank_args") == [f[0] for f in N.RerankArgs._fields_]
+    # the deferred S1 finish exists for the shipped DeiT-Tiny / DeiT-Small widths with byte word codes (host-side rule)
+    assert lib.sn_assign_defers(512, 384) == 1 and lib.sn_assign_defers(128, 192) == 1
+    assert lib.sn_assign_defers(1024, 768) == 0 and lib.sn_assign_defers(4096, 384) == 0
 
 
 def test_bad_arguments_are_rejected_without_a_gpu(lib):
