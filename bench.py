@@ -99,18 +99,26 @@ def FUSED_ATLAS(sn):
     return lambda: sn.get_atlas(fused_adjacency=os.environ.get("SN_FUSED_ATLAS", "1") != "0")
 
 
-def step(disc, sn, m, tokens, attn, class_branch_first=True, side_stream=None, votes=None):
+def step(disc, sn, m, tokens, attn, class_branch_first=True, side_stream=None, votes=None, defer=None):
     """class_branch_first: the class branch (parameters only) is forked before S1, so the replayed
     graph can fill S1's tail and the gaps of the instance chain with it (483 vs 509 us per step);
     the instrumented pass forks it behind S1 so that the S1 kernels are timed alone on the GPU.
     side_stream: see Matcher.atlas_features_async (False = the class branch in line on the step's own stream)."""
-    # S1 = the fp16-MFMA screen; the tokens it cannot decide are finished in fp64 inside the instance-graph kernel's row phase
-    # (`defer`, as SchemaNetPredictor.forward does; SN_S1_DEFER=0: by the stand-alone re-rank launch of rounds 1-3)
+    # S1 = the fp16-MFMA screen + the fp64 finish of the tokens it cannot decide.  One step at a time (`defer`, as
+    # SchemaNetPredictor.forward does): the finish rides in the instance-graph kernel's row phase - no re-rank launch on the
+    # step's critical path (+2 % one at a time).  Several steps in flight: the stand-alone re-rank - a light kernel the
+    # other steps' kernels run beside, where the fused form lengthens a kernel that holds every CU's LDS (-3.5 %).
+    # SN_S1_DEFER=0 / 1 forces either.
+    if defer is None:
+        defer = side_stream is not False
+    env = os.environ.get("SN_S1_DEFER", "")
+    if env in ("0", "1"):
+        defer = env == "1"
     if class_branch_first and os.environ.get("SN_CLASS_BRANCH_FIRST", "1") != "0":
         atlas = m.atlas_features_async(FUSED_ATLAS(sn), side_stream=side_stream)  # atlas normalise + class-graph GNN
-        ing, rerank = disc.assign(tokens[:, 1:, :], defer=True)                  # S1
+        ing, rerank = disc.assign(tokens[:, 1:, :], defer=True) if defer else (disc.assign(tokens[:, 1:, :]), None)      # S1
     else:
-        ing, rerank = disc.assign(tokens[:, 1:, :], defer=True)
+        ing, rerank = disc.assign(tokens[:, 1:, :], defer=True) if defer else (disc.assign(tokens[:, 1:, :]), None)
         atlas = m.atlas_features_async(FUSED_ATLAS(sn), side_stream=side_stream)
     g = sn.instance_graph_padded(ing, attn[:, 1:, 1:], attn[:, 0, 1:], mutate_inputs=False,
                                  zero_padding=os.environ.get("SN_ZERO_PADDING", "0") == "1", rerank=rerank)   # S2 + S3 (as SchemaNetPredictor.forward)
@@ -220,8 +228,10 @@ def api_leg(device, disc, sn, m, n_calls, n_batches=4):
     x = torch.empty(B, 3, 1, 1, device=device)                                               # (the images: unused by the stand-in)
     out = {}
     with torch.no_grad():
-        for name, cache, bt in (("value_api", False, batches), ("value_api_eval_cache", True, batches), ("value_api_head_averaged", False, batches_h1)):
+        for name, cache, bt, ring in (("value_api", False, batches, False), ("value_api_eval_cache", True, batches, False),
+                                      ("value_api_head_averaged", False, batches_h1, False), ("value_api_head_averaged_ring", False, batches_h1, True)):
             backbone.batches = bt
+            pred.output_ring = ring          # (opt-in: `pred` from a two-deep ring of captures instead of a copy - valid until the next call but one)
             pred.matcher.cache_atlas = cache
             pred.matcher.invalidate_atlas_cache()
             pred.invalidate_graphs()
@@ -235,6 +245,7 @@ def api_leg(device, disc, sn, m, n_calls, n_batches=4):
             torch.cuda.synchronize()
             out[name] = B * n_calls / (time.perf_counter() - t1)
             out[name + "_replayed"] = bool(pred.graph_replay and len(pred._graphs) > 0)
+        pred.output_ring = False
         assert tuple(last.shape) == (B, K) and bool(torch.isfinite(last).all())
         # the evaluation-loop form of the API: `predict_batches` keeps `depth` batches in flight by itself
         for name, cache, bt in (("value_api_batches", False, batches), ("value_api_batches_eval_cache", True, batches),

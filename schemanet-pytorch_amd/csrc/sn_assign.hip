@@ -257,22 +257,24 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 }
 
 // ------------------------------------------------------------------------------------------
-// mode 0, pass 2: fp64 re-rank, two kernels (one launch each; sn_assign_words(mode = 2) launches neither: the
-// instance-graph kernel finishes the flagged tokens of its image itself, csrc/sn_graph.hip)
-//   assign_rerank_kernel    one wave per flagged token: the <= 24 candidates the screen could not separate
-//   assign_overflow_kernel  one BLOCK per overflow token: fp16 scan of every word through the packed tile image,
-//                           survivors inside a rigorous window are re-ranked in fp64
+// mode 0, pass 2: fp64 re-rank (sn_assign_words(mode = 2) does not launch it: the instance-graph kernel finishes the
+// flagged tokens of its image itself, csrc/sn_graph.hip)
+//   blocks kOverflowBlocks ..    one wave per flagged token: the <= 24 candidates the screen could not separate
+//   blocks 0 .. kOverflowBlocks  one WAVE per overflow token (sn_s1::rerank_overflow_token): its candidates plus, for every
+//                                group whose triple lies inside the window whole, a v_dot2_f32_f16 scan of the group's 64
+//                                words through the fp16 tile image, survivors inside a rigorous window re-ranked in fp64
 // All fp64 scores use the oracle's summation order.
+// (Round 4.  Rounds 1-3 scanned EVERY word of an overflow token with a whole block - 139 registers under the 80 of
+// amdgpu_waves_per_eu(6, 8): every instantiation spilled, 46 VGPRs / 188 bytes of scratch in <6, 0>, a latency-chain kernel
+// that needed a scratch segment at dispatch.  As two kernels - flagged / overflow, no scratch in either - the pair took
+// 19.3 us instead of 13.0: the two latency chains of ~10 us ran one after the other.  The screen now writes the candidate
+// mask of an overflow token too, the scan is limited to the groups that can hide a word - one wave, one kernel.)
 // ------------------------------------------------------------------------------------------
-constexpr int kMaxSurvivors = 64;
-constexpr int kOverflowBlocks = 64;     // grid of assign_overflow_kernel
+constexpr int kOverflowBlocks = 64;     // blocks reserved for the overflow list (4 tokens each per round)
 
 // FMT 0: records of assign_screen_kernel (24 code bytes per token); FMT 1: records of
 // assign_screen2_kernel (8 code dwords, slot c = 2 wave + accumulator half, key j: bit 3c + j);
 // FMT 2: 16-bit codes (M > 2048); FMT 3: records of assign_screen3_kernel (24 code bytes, its own slot order).
-// (Round 4: its own kernel.  Fused with the overflow scan - 139 registers - under amdgpu_waves_per_eu(6, 8) it was capped at
-// 80 registers and every instantiation spilled, 46 VGPRs / 188 bytes of scratch in <6, 0>: a latency-chain kernel that
-// needed a scratch segment at dispatch to serve two overflow tokens.  Alone it takes ~50 registers, no scratch.)
 template <int NT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void assign_rerank_kernel(const AssignArgs p)
 {
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // a block owns 32 consecutive tokens per round, reads their flag words, and its four waves share the flagged ones
     // round-robin.  Candidate slot c = 12 h + 3 g + j holds code (tile << 2 | e): word = 32 tile + 8 g + 4 h + e.
     const int64_t n_chunks = (p.n_tokens + 31) / 32;
-    for (int64_t chunk = (int64_t)blockIdx.x; chunk < n_chunks; chunk += (int64_t)gridDim.x) {
+    for (int64_t chunk = (int64_t)blockIdx.x - kOverflowBlocks; chunk < n_chunks && (int)blockIdx.x >= kOverflowBlocks;
+         chunk += (int64_t)gridDim.x - kOverflowBlocks) {
         const int64_t t = chunk * 32 + (lane & 31);
         unsigned long long flag = 0ull;
         if (lane < 32 && t < p.n_tokens) {
@@ -348,155 +351,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
     }
 
-}
-
-// every word of the overflow tokens, from the fp16 tile image (L2-hot: the screen kernel has just streamed it) with
-// v_dot2_f32_f16; candidates = everything inside the fp16 error window of the best, then fp64.
-template <int NT>
-__global__ __launch_bounds__(256) void assign_overflow_kernel(const AssignArgs p)
-{
-    __shared__ float xs[NT * SN_WAVE];
-    __shared__ __attribute__((aligned(16))) _Float16 xh[NT * SN_WAVE];
-    __shared__ float red[12];
-    __shared__ int surv[kMaxSurvivors];
-    __shared__ int n_surv;
-    __shared__ double best_s[4];
-    __shared__ int best_i[4];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const PackLayout lay = pack_layout(p.M, p.D);
-    const double *cn64 = (const double *)(p.packed + lay.cn64_off);
-    const unsigned *scal = (const unsigned *)(p.packed + lay.scal_off);
-    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-    const unsigned char *tiles = p.packed + lay.tiles_off;
+    // ---- the overflow list: blocks 0 .. kOverflowBlocks - 1, one wave per token
+    if ((int)blockIdx.x >= kOverflowBlocks) return;
     const int n_over = p.work[1];
-    for (int e = blockIdx.x; e < n_over; e += kOverflowBlocks) {
+    for (int e = blockIdx.x * 4 + wid; e < n_over; e += kOverflowBlocks * 4) {
         const int64_t n = p.overflow[e];
-        const float *row = token_row(p, n);
-        __syncthreads();
-        float sq = 0.0f, sabs = 0.0f, mabs = 0.0f;
-        for (int k = tid; k < NT * SN_WAVE; k += 256) {
-            const float v = k < p.D ? token_elem(p, row, k) : 0.0f;
-            xs[k] = v;
-            xh[k] = (_Float16)v;
-            sq = fmaf(v, v, sq);
-            sabs += fabsf(v);
-            mabs = fmaxf(mabs, fabsf(v));
-        }
-        if (tid == 0) n_surv = 0;
-        sq = sn_wave_sum(sq); sabs = sn_wave_sum(sabs); mabs = sn_wave_max(mabs);
-        if (lane == 0) { red[wid] = sq; red[4 + wid] = sabs; red[8 + wid] = mabs; }
-        __syncthreads();
-        const float X2 = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * 1.001f;
-        const float X1 = ((red[4] + red[5]) + (red[6] + red[7])) * 1.001f;
-        const float XM = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
-        const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
-        const float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
-        const float vmax = 0.5f * CN + X2 * C2;
-        // |score_fp16 - score_exact| <= e16: fp16 rounding of both operands, subnormal flush,
-        // fp32 accumulation of the dot2 chain, rounding of |c|^2/2
-        const float e16 = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1) +
-                                   2.0f * (float)(p.D + 2) * 5.9604645e-8f * vmax + 1.2e-7f * vmax);
-        const bool finite = (XM <= kHugeIn) && (CMAX <= kHugeIn) && (e16 < 1.0e30f);   // false for NaN / inf / huge
-        // fp16 score of the words ma and ma + 256 (same row i inside their 32-word tiles) from the packed tile image
-        auto score2 = [&](int ma, float &sa, float &sb) {
-            const int mb = ma + 256;
-            sa = INFINITY; sb = INFINITY;
-            if (ma >= p.M || !finite) return;
-            const bool has_b = mb < p.M;
-            const int i = ma & 31;                                       // (mb & 31) == i as well
-            const unsigned char *ta = tiles + (size_t)(ma >> 5) * lay.tile_bytes;
-            const unsigned char *tb = tiles + (size_t)((has_b ? mb : ma) >> 5) * lay.tile_bytes;
-            float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
-            for (int s2 = 0; s2 < lay.n_steps; s2 += 2) {                // two k-steps = 32 consecutive k
-                float4 fa[4], fb[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {                            // (step s2 + (q & 1), half q >> 1)
-                    const size_t off = (size_t)(s2 + (q & 1)) * 1024 + (i + 32 * (q >> 1)) * 16;
-                    fa[q] = *reinterpret_cast<const float4 *>(ta + off);
-                    fb[q] = *reinterpret_cast<const float4 *>(tb + off);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k0 = 16 * s2 + 16 * (q >> 1) + 8 * (q & 1);
-                    const half2_t *x2 = reinterpret_cast<const half2_t *>(xh + k0);
-                    const half2_t *ca = reinterpret_cast<const half2_t *>(&fa[q]);
-                    const half2_t *cb2 = reinterpret_cast<const half2_t *>(&fb[q]);
-                    a0 = __builtin_amdgcn_fdot2(x2[0], ca[0], a0, false);  b0 = __builtin_amdgcn_fdot2(x2[0], cb2[0], b0, false);
-                    a1 = __builtin_amdgcn_fdot2(x2[1], ca[1], a1, false);  b1 = __builtin_amdgcn_fdot2(x2[1], cb2[1], b1, false);
-                    a0 = __builtin_amdgcn_fdot2(x2[2], ca[2], a0, false);  b0 = __builtin_amdgcn_fdot2(x2[2], cb2[2], b0, false);
-                    a1 = __builtin_amdgcn_fdot2(x2[3], ca[3], a1, false);  b1 = __builtin_amdgcn_fdot2(x2[3], cb2[3], b1, false);
-                }
-            }
-            const int g = i >> 3, hh = (i >> 2) & 1, ee = i & 3;
-            const size_t hoff = (size_t)lay.n_steps * 1024 + ((g * 2 + hh) * 4 + ee) * 4;
-            sa = *reinterpret_cast<const float *>(ta + hoff) + (a0 + a1);          // dist^2/2 - |x|^2/2 (tiles hold -c)
-            if (has_b) sb = *reinterpret_cast<const float *>(tb + hoff) + (b0 + b1);
-        };
-        const bool big = p.M > 2048;              // more words than a thread keeps scores for: two passes, nothing kept
-        float smin = INFINITY;
-        float sc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {                                 // two words per thread in flight
-            sc[j] = INFINITY; sc[j + 1] = INFINITY;
-            if (big) continue;
-            score2(tid + 256 * j, sc[j], sc[j + 1]);
-            smin = fminf(smin, fminf(sc[j], sc[j + 1]));
-        }
-        if (big) {
-            for (int m0 = tid; m0 < p.M; m0 += 512) {
-                float sa, sb;
-                score2(m0, sa, sb);
-                smin = fminf(smin, fminf(sa, sb));
-            }
-        }
-        smin = sn_wave_min(smin);
-        __syncthreads();
-        if (lane == 0) red[wid] = smin;
-        __syncthreads();
-        smin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-        bool too_many = false;
-        const float cut16 = smin + 2.0f * e16;
-        auto keep = [&](int m, float v) {
-            if (m < p.M && finite && v <= cut16) {
-                const int slot = atomicAdd(&n_surv, 1);
-                if (slot < kMaxSurvivors) surv[slot] = m;
-            }
-        };
-        if (!big) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) keep(tid + 256 * j, sc[j]);
+        sn_s1::RerankView rv;
+        rv.x = token_row(p, n); rv.xsb = 0; rv.xsl = 0; rv.x_bf16 = p.x_bf16;
+        rv.cb = p.cb; rv.cn64 = cn64; rv.tiles = p.packed + lay.tiles_off; rv.scal = (const unsigned *)(p.packed + lay.scal_off);
+        rv.M = p.M; rv.D = p.D; rv.n_tiles = lay.n_tiles;
+        unsigned fj = p.flags[n];
+        int my_word = 0;
+        if constexpr (FMT == 0) {
+            if (lane < kMaxCand) my_word = sn_s1::slot_word(lane, (unsigned)p.codes[n * kCodeBytes + lane]);
+        } else if constexpr (FMT == 2) {            // 16-bit codes (tile < 256): the same word formula
+            if (lane < kMaxCand) my_word = sn_s1::slot_word(lane, (unsigned)reinterpret_cast<const unsigned short *>(p.codes)[n * kMaxCand + lane]);
         } else {
-            for (int m0 = tid; m0 < p.M; m0 += 512) {                    // same arithmetic as the first pass: same scores
-                float sa, sb;
-                score2(m0, sa, sb);
-                keep(m0, sa);
-                keep(m0 + 256, sb);
-            }
+            fj = sn_s1::kFlagFullScan;              // (the other record formats carry no candidate mask for overflow tokens: every word)
         }
-        __syncthreads();
-        const int ns = n_surv;
-        too_many = too_many || !finite || ns > kMaxSurvivors || ns == 0;
-        // fp64 re-rank: wave w takes survivors w, w+4, ... (or every word when the window failed)
-        double x[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) x[t] = (double)xs[lane + SN_WAVE * t];
-        double best = (double)INFINITY;
-        int bi = 0x7fffffff;
-        const int total = too_many ? p.M : ns;
-        for (int q = wid; q < total; q += 4) {
-            const int m = too_many ? q : surv[q];
-            const double s = cn64[m] - 2.0 * dot64<NT>(x, p.cb + (int64_t)m * p.D, p.D, lane);
-            if (s < best || (s == best && m < bi)) { best = s; bi = m; }
-        }
-        if (lane == 0) { best_s[wid] = best; best_i[wid] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            double b = best_s[0];
-            int i0 = best_i[0];
-            for (int w = 1; w < 4; ++w)
-                if (best_s[w] < b || (best_s[w] == b && best_i[w] < i0)) { b = best_s[w]; i0 = best_i[w]; }
-            p.out[out_index(p, n)] = i0 == 0x7fffffff ? 0 : i0;   // all-NaN row -> 0 (oracle)
-        }
+        const int w = sn_s1::rerank_overflow_token<NT>(rv, 0, 0, lane, fj, my_word);
+        if (lane == 0 && w >= 0) p.out[out_index(p, n)] = w;
     }
 }
 
@@ -1764,14 +1638,13 @@ bool assign_option(int i, const char *env)
     return g_assign_opt[i] != 0;
 }
 
-// the two kernels that finish a screen's flagged / overflow tokens (one event pair: kernel id 1 = the whole re-rank)
+// the kernel that finishes a screen's flagged / overflow tokens
 template <int NT, int FMT>
 void launch_rerank(const AssignArgs &a, hipStream_t st)
 {
     const int64_t chunks = (a.n_tokens + 31) / 32;
     sn_prof_start(1, st);
-    hipLaunchKernelGGL((assign_rerank_kernel<NT, FMT>), dim3((unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((assign_overflow_kernel<NT>), dim3(kOverflowBlocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((assign_rerank_kernel<NT, FMT>), dim3(kOverflowBlocks + (unsigned)(chunks < 4096 ? chunks : 4096)), dim3(256), 0, st, a);
     sn_prof_stop(1, st);
 }
 

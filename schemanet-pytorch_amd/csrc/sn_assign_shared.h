@@ -97,4 +97,122 @@ __device__ __forceinline__ int slot_word(int c, unsigned code)
     return (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
 }
 
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// An overflow token (a handful per 50 000), by ONE wave.  Callers: the re-rank kernel (csrc/sn_assign.hip: its first blocks
+// take the overflow list, one wave per token) and, in the deferred finish, the sorting wave of the instance-graph kernel
+// (csrc/sn_graph.hip), in front of its wait for the row waves.  Candidates = the slots of the token's mask, plus - for every group
+// whose three slots are all inside the window - whatever a scan of the group's words 32 t + 8 g + 4 h + e through the
+// fp16 tile image (v_dot2_f32_f16, one word per lane, the token's fp16 pairs broadcast from registers) leaves inside
+// the rigorous fp16 window of the group's best (the window of the round-1..3 overflow scan; the group's best is no better
+// than the token's, so nothing that could win is cut); every word when the screen could not bound the token.
+// Returns the word (0 for an all-NaN row, like the oracle), or -1: keep the screen's.  my_word: word of candidate slot `lane`.
+template <int NT>
+__device__ __forceinline__ int rerank_overflow_token(const RerankView &rv, int b, int l, int lane, unsigned fj, int my_word)
+{
+    float xf[NT];
+    const void *row = token_row_ptr(rv.x, rv.x_bf16, (int64_t)b * rv.xsb + (int64_t)l * rv.xsl);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xf[t] = token_elem(row, rv.x_bf16, lane + SN_WAVE * t);       // (D == 64 NT)
+    double best = (double)INFINITY;
+    int bi = 0x7fffffff;
+    auto eval2 = [&](int ma, int m1, bool two) {                   // two words per round: their loads overlap
+        const int mb = two ? m1 : ma;
+        const float *ra = rv.cb + (int64_t)ma * rv.D, *rb = rv.cb + (int64_t)mb * rv.D;
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = lane + SN_WAVE * t;
+            pa = fma((double)xf[t], (double)ra[k], pa); pb = fma((double)xf[t], (double)rb[k], pb);
+        }
+        const double sa = rv.cn64[ma] - 2.0 * sn_wave_sum_f64(pa);
+        const double sb = rv.cn64[mb] - 2.0 * sn_wave_sum_f64(pb);
+        if (sa < best || (sa == best && ma < bi)) { best = sa; bi = ma; }
+        if (two && (sb < best || (sb == best && mb < bi))) { best = sb; bi = mb; }
+    };
+    if ((fj & kFlagFullScan) == kFlagFullScan) {
+        for (int m = 0; m < rv.M; m += 2) eval2(m, m + 1, m + 1 < rv.M);
+        return bi != 0x7fffffff ? bi : 0;                          // all-NaN row -> 0 (oracle)
+    }
+    const unsigned mask = fj & 0xFFFFFFu;
+    // the token's statistics and the fp16 window (fp16 rounding of both operands, subnormal flush, fp32 accumulation of the dot2 chain, rounding of |c|^2/2)
+    float sq = 0.0f, sabs = 0.0f, mabs = 0.0f;
+    unsigned xh2[NT];                                               // even lanes: fp16 pair (x[k], x[k + 1]), k = lane + 64 t
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float v = xf[t];
+        sq = fmaf(v, v, sq); sabs += fabsf(v); mabs = fmaxf(mabs, fabsf(v));
+        const float nx = __shfl_down(v, 1, SN_WAVE);
+        half2_t hp; hp.x = (_Float16)v; hp.y = (_Float16)nx;
+        xh2[t] = __builtin_bit_cast(unsigned, hp);
+    }
+    const float X2 = sqrtf(sn_wave_sum(sq)) * 1.001f, X1 = sn_wave_sum(sabs) * 1.001f, XM = sn_wave_max(mabs);
+    const float C2 = __uint_as_float(rv.scal[0]), C1 = __uint_as_float(rv.scal[1]);
+    const float CN = __uint_as_float(rv.scal[2]), CMAX = __uint_as_float(rv.scal[3]);
+    const float vmax = 0.5f * CN + X2 * C2;
+    const float e16 = 1.01f * (2.01f * 4.8828125e-4f * X2 * C2 + 5.96e-8f * (X1 + C1) +
+                               2.0f * (float)(rv.D + 2) * 5.9604645e-8f * vmax + 1.2e-7f * vmax);
+    const bool finite = (XM <= 3.0e4f) && (CMAX <= 3.0e4f) && (e16 < 1.0e30f);
+    constexpr int kSteps = 4 * NT;                                   // D / 16
+    const int tile_bytes = (kSteps + 1) * 1024;
+    for (int G = 0; G < 8; ++G) {                                   // G = 4 h + g
+        const unsigned bits = (mask >> (3 * G)) & 7u;
+        if (bits != 7u) {
+            for (int j = 0; j < 3; ++j)
+                if ((bits >> j) & 1u) eval2(__builtin_amdgcn_readlane(my_word, 3 * G + j), 0, false);
+            continue;
+        }
+        const int g = G & 3, hh = G >> 2;
+        for (int t0 = 0; t0 < rv.n_tiles; t0 += 16) {              // 16 tiles x 4 rows = one word per lane
+            const int tile = t0 + (lane >> 2), i = 8 * g + 4 * hh + (lane & 3), m = 32 * tile + i;
+            const bool in = tile < rv.n_tiles && m < rv.M;
+            const unsigned char *ta = rv.tiles + (size_t)(in ? tile : 0) * tile_bytes;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int s0 = 0; s0 < kSteps; s0 += 2) {                // two k-steps = 32 consecutive k (half of xh2[s0 / 4]) per round of loads
+                // (opaque copy: the v_readlane of a round are otherwise hoisted out of the group / tile loops and live in
+                // scalar registers for the whole kernel; the scheduling barrier keeps the rounds one after the other: all
+                // 8 NT 16-byte loads in flight at once do not fit the register file)
+                unsigned xt = xh2[s0 / 4];
+                asm volatile("" : "+v"(xt));
+                __builtin_amdgcn_sched_barrier(0);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (an array of float4 STRUCTS lives in scratch memory)
+                u32x4 fr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)                          // (step s0 + (q >> 1), lane half q & 1)
+                    fr[q] = *reinterpret_cast<const u32x4 *>(ta + (size_t)(s0 + (q >> 1)) * 1024 + (i + 32 * (q & 1)) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sstep = s0 + (q >> 1);
+                    const int k0 = 32 * (sstep >> 1) + 16 * (q & 1) + 8 * (sstep & 1);     // pack_frag_kernel: s = 2 u + e, k = 32 u + 16 h + 8 e + j
+#pragma unroll
+                    for (int jp = 0; jp < 4; ++jp) {
+                        const int k = k0 + 2 * jp;                  // (k >> 6 == s0 / 4)
+                        const unsigned xs = (unsigned)__builtin_amdgcn_readlane((int)xt, k & 63);
+                        const half2_t xv = __builtin_bit_cast(half2_t, xs), cv = __builtin_bit_cast(half2_t, (unsigned)fr[q][jp]);
+                        if (jp & 1) a1 = __builtin_amdgcn_fdot2(xv, cv, a1, false);
+                        else a0 = __builtin_amdgcn_fdot2(xv, cv, a0, false);
+                    }
+                }
+                asm volatile("" : "+v"(a0), "+v"(a1));              // (the sums are formed HERE, in every lane: left alone the products sink into the branch of the select below, their 32 NT broadcast operands spilled on the way)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float hn = *reinterpret_cast<const float *>(ta + (size_t)kSteps * 1024 + ((g * 2 + hh) * 4 + (lane & 3)) * 4);
+            const float sc = (in && finite) ? hn + (a0 + a1) : INFINITY;       // dist^2/2 - |x|^2/2 (tiles hold -c)
+            const float smin = sn_wave_min(sc);
+            // (nothing finite: every word of the group goes to fp64)
+            unsigned long long sv = __ballot(in && (!(smin < INFINITY) || sc <= smin + 2.0f * e16));
+            while (sv) {
+                const int la = __ffsll((long long)sv) - 1;
+                sv &= sv - 1;
+                const bool has1 = sv != 0ull;
+                const int lb = has1 ? __ffsll((long long)sv) - 1 : la;
+                if (has1) sv &= sv - 1;
+                eval2(__builtin_amdgcn_readlane(m, la), __builtin_amdgcn_readlane(m, lb), has1);
+            }
+        }
+    }
+    return bi != 0x7fffffff ? bi : -1;
+}
+
 }  // namespace sn_s1

@@ -199,144 +199,31 @@ struct NoPreWork { __device__ __forceinline__ void operator()() const {} };
 // ------------------------------------------------------------------------------------------
 // Deferred finish of S1 inside the row phase (sn_assign_words mode 2, sn_graph_args.rerank).
 // The screen has left a flag word per token and, for the tokens it could not decide, the codes of the candidate words
-// (csrc/sn_assign_shared.h).  The stand-alone re-rank is a launch of its own on the critical path of a prediction - 15 us
-// of dependent fetches for ~13 tokens of an image - while the fifteen row waves of this kernel sit out the HBM burst of the
-// attention maps.  Here row wave w OWNS the positions l = w, w + 15, ...: it requests their flag words and candidate
-// records at the start of the kernel (one round trip, ahead of its first rows), and `tick()` - called once per iteration
-// of the row loop, behind that iteration's row loads - moves one token forward by one stage: token row + a pair of
-// candidate rows requested / their fp64 scores compared, the next pair requested / the final word written (to the
-// ingredients tensor and to s.words).  Every stage's loads are in flight while a batch of rows is soft-maxed.  The
-// arithmetic is the stand-alone kernel's (assign_rerank_kernel): fp64, the oracle's summation order, lowest index on
-// ties - the same ids bit for bit.  Overflow tokens (rare: a handful per 50 000) are finished by their owner in a blocking
-// loop over the candidates and the 64 words of every group whose triple lay inside the window whole (every word when the
-// screen could not bound the token).  The sorting wave waits for the fifteen `done` signals (a counter in LDS) before it
-// sorts.  NT = ceil(D / 64).
+// (csrc/sn_assign_shared.h).  The stand-alone re-rank is a launch of its own on the critical path of a prediction - 13-19 us
+// of dependent fetches for ~13 tokens of an image - while this kernel's row waves sit out the HBM burst of the attention
+// maps.  Here row wave w OWNS the positions l = w, w + 15, ...: it requests their flag words and candidate records in
+// front of its first rows (one round trip, together with them), then - its first two batches of rows landed - the token row
+// and the first candidate pair of up to three flagged tokens together (a second round trip, with its next rows in flight
+// and its first batch soft-maxed meanwhile), scores them in fp64, further pairs / tokens one by one (rare), and writes the
+// final words (to the ingredients tensor and to s.words).  The arithmetic is the stand-alone kernel's
+// (assign_rerank_kernel): fp64, the oracle's summation order, lowest index on ties - the same ids bit for bit.  The sorting
+// wave waits for the fifteen `done` signals (a counter in LDS) before it sorts, and finishes the overflow tokens (a handful
+// per 50 000) itself meanwhile: rerank_overflow_token.  NT = D / 64.
+// (Measured and dropped, tools/time_defer.py: (i) one token moved one stage per iteration of the row loop - hipcc waits for a
+// loop-carried load with vmcnt(0), i.e. for the rows just requested: one batch in flight per wave instead of three, rows in
+// at 28-33 k cycles instead of 21 k, the finish at 31 k, the launch 43-45 us against 31.7; (ii) five waves finishing the
+// whole image before they join the row dealing: three tokens in flight, two rounds - every round trip is ~6 k cycles under
+// the burst - the sorting wave starts at 24 k instead of 11 k: 39.7 us.)
 // ------------------------------------------------------------------------------------------
 struct NoTick {
     __device__ __forceinline__ void begin() {}
-    __device__ __forceinline__ void operator()() {}
-    __device__ __forceinline__ void finish() {}
+    __device__ __forceinline__ void request(bool) {}
+    __device__ __forceinline__ void complete() {}
 };
 
-// An overflow token of the deferred S1 finish (a handful per 50 000).  The SORTING wave finishes these itself, in front of its
-// wait for the row waves (one site in the kernel: inlined into the row waves' state machine the scan was replicated per
-// loop form and spilled 1 400 registers; called out of line it forced spills around every call).  Candidates = the slots of the token's mask, plus - for every group
-// whose three slots are all inside the window - whatever a scan of the group's words 32 t + 8 g + 4 h + e through the
-// fp16 tile image (v_dot2_f32_f16, one word per lane, the token's fp16 pairs broadcast from registers) leaves inside
-// the rigorous fp16 window of the group's best (the window of assign_overflow_kernel; the group's best is no better
-// than the token's, so nothing that could win is cut); every word when the screen could not bound the token.
-// Returns the word (0 for an all-NaN row, like the oracle), or -1: keep the screen's.  my_word: word of candidate slot `lane`.
-template <int NT>
-__device__ __forceinline__ int rerank_overflow_token(const sn_s1::RerankView &rv, int b, int l, int lane, unsigned fj, int my_word)
-{
-    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-    float xf[NT];
-    const void *row = sn_s1::token_row_ptr(rv.x, rv.x_bf16, (int64_t)b * rv.xsb + (int64_t)l * rv.xsl);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) xf[t] = sn_s1::token_elem(row, rv.x_bf16, lane + SN_WAVE * t);       // (D == 64 NT)
-    double best = (double)INFINITY;
-    int bi = 0x7fffffff;
-    auto eval2 = [&](int ma, int m1, bool two) {                   // two words per round: their loads overlap
-        const int mb = two ? m1 : ma;
-        const float *ra = rv.cb + (int64_t)ma * rv.D, *rb = rv.cb + (int64_t)mb * rv.D;
-        double pa = 0.0, pb = 0.0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int k = lane + SN_WAVE * t;
-            pa = fma((double)xf[t], (double)ra[k], pa); pb = fma((double)xf[t], (double)rb[k], pb);
-        }
-        const double sa = rv.cn64[ma] - 2.0 * sn_wave_sum_f64(pa);
-        const double sb = rv.cn64[mb] - 2.0 * sn_wave_sum_f64(pb);
-        if (sa < best || (sa == best && ma < bi)) { best = sa; bi = ma; }
-        if (two && (sb < best || (sb == best && mb < bi))) { best = sb; bi = mb; }
-    };
-    if ((fj & sn_s1::kFlagFullScan) == sn_s1::kFlagFullScan) {
-        for (int m = 0; m < rv.M; m += 2) eval2(m, m + 1, m + 1 < rv.M);
-        return bi != 0x7fffffff ? bi : 0;                          // all-NaN row -> 0 (oracle)
-    }
-    const unsigned mask = fj & 0xFFFFFFu;
-    // the token's statistics and the fp16 window (assign_overflow_kernel's e16)
-    float sq = 0.0f, sabs = 0.0f, mabs = 0.0f;
-    unsigned xh2[NT];                                               // even lanes: fp16 pair (x[k], x[k + 1]), k = lane + 64 t
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float v = xf[t];
-        sq = fmaf(v, v, sq); sabs += fabsf(v); mabs = fmaxf(mabs, fabsf(v));
-        const float nx = __shfl_down(v, 1, SN_WAVE);
-        half2_t hp; hp.x = (_Float16)v; hp.y = (_Float16)nx;
-        xh2[t] = __builtin_bit_cast(unsigned, hp);
-    }
-    const float X2 = sqrtf(sn_wave_sum(sq)) * 1.001f, X1 = sn_wave_sum(sabs) * 1.001f, XM = sn_wave_max(mabs);
-    const float C2 = __uint_as_float(rv.scal[0]), C1 = __uint_as_float(rv.scal[1]);
-    const float CN = __uint_as_float(rv.scal[2]), CMAX = __uint_as_float(rv.scal[3]);
-    const float vmax = 0.5f * CN + X2 * C2;
-    const float e16 = 1.01f * (2.01f * 4.8828125e-4f * X2 * C2 + 5.96e-8f * (X1 + C1) +
-                               2.0f * (float)(rv.D + 2) * 5.9604645e-8f * vmax + 1.2e-7f * vmax);
-    const bool finite = (XM <= 3.0e4f) && (CMAX <= 3.0e4f) && (e16 < 1.0e30f);
-    constexpr int kSteps = 4 * NT;                                   // D / 16
-    const int tile_bytes = (kSteps + 1) * 1024;
-    for (int G = 0; G < 8; ++G) {                                   // G = 4 h + g
-        const unsigned bits = (mask >> (3 * G)) & 7u;
-        if (bits != 7u) {
-            for (int j = 0; j < 3; ++j)
-                if ((bits >> j) & 1u) eval2(__builtin_amdgcn_readlane(my_word, 3 * G + j), 0, false);
-            continue;
-        }
-        const int g = G & 3, hh = G >> 2;
-        for (int t0 = 0; t0 < rv.n_tiles; t0 += 16) {              // 16 tiles x 4 rows = one word per lane
-            const int tile = t0 + (lane >> 2), i = 8 * g + 4 * hh + (lane & 3), m = 32 * tile + i;
-            const bool in = tile < rv.n_tiles && m < rv.M;
-            const unsigned char *ta = rv.tiles + (size_t)(in ? tile : 0) * tile_bytes;
-            float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-            for (int s0 = 0; s0 < kSteps; s0 += 2) {                // two k-steps = 32 consecutive k (half of xh2[s0 / 4]) per round of loads
-                // (opaque copy: the v_readlane of a round are otherwise hoisted out of the group / tile loops and live in
-                // scalar registers for the whole kernel; the scheduling barrier keeps the rounds one after the other: all
-                // 8 NT 16-byte loads in flight at once do not fit the register file)
-                unsigned xt = xh2[s0 / 4];
-                asm volatile("" : "+v"(xt));
-                __builtin_amdgcn_sched_barrier(0);
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (an array of float4 STRUCTS lives in scratch memory)
-                u32x4 fr[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)                          // (step s0 + (q >> 1), lane half q & 1)
-                    fr[q] = *reinterpret_cast<const u32x4 *>(ta + (size_t)(s0 + (q >> 1)) * 1024 + (i + 32 * (q & 1)) * 16);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sstep = s0 + (q >> 1);
-                    const int k0 = 32 * (sstep >> 1) + 16 * (q & 1) + 8 * (sstep & 1);     // pack_frag_kernel: s = 2 u + e, k = 32 u + 16 h + 8 e + j
-#pragma unroll
-                    for (int jp = 0; jp < 4; ++jp) {
-                        const int k = k0 + 2 * jp;                  // (k >> 6 == s0 / 4)
-                        const unsigned xs = (unsigned)__builtin_amdgcn_readlane((int)xt, k & 63);
-                        const half2_t xv = __builtin_bit_cast(half2_t, xs), cv = __builtin_bit_cast(half2_t, (unsigned)fr[q][jp]);
-                        if (jp & 1) a1 = __builtin_amdgcn_fdot2(xv, cv, a1, false);
-                        else a0 = __builtin_amdgcn_fdot2(xv, cv, a0, false);
-                    }
-                }
-                asm volatile("" : "+v"(a0), "+v"(a1));              // (the sums are formed HERE, in every lane: left alone the products sink into the branch of the select below, their 32 NT broadcast operands spilled on the way)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const float hn = *reinterpret_cast<const float *>(ta + (size_t)kSteps * 1024 + ((g * 2 + hh) * 4 + (lane & 3)) * 4);
-            const float sc = (in && finite) ? hn + (a0 + a1) : INFINITY;       // dist^2/2 - |x|^2/2 (tiles hold -c)
-            const float smin = sn_wave_min(sc);
-            // (nothing finite: every word of the group goes to fp64)
-            unsigned long long sv = __ballot(in && (!(smin < INFINITY) || sc <= smin + 2.0f * e16));
-            while (sv) {
-                const int la = __ffsll((long long)sv) - 1;
-                sv &= sv - 1;
-                const bool has1 = sv != 0ull;
-                const int lb = has1 ? __ffsll((long long)sv) - 1 : la;
-                if (has1) sv &= sv - 1;
-                eval2(__builtin_amdgcn_readlane(m, la), __builtin_amdgcn_readlane(m, lb), has1);
-            }
-        }
-    }
-    return bi != 0x7fffffff ? bi : -1;
-}
-
 constexpr int kRowWaves = 15;           // the sixteen-wave kernel: waves 0 .. 14 bring rows in, wave 15 sorts
-constexpr int kOwnMax = 14;             // positions a row wave owns: ceil(196 / 15) (L <= 210)
+constexpr int kOwnMax = 14;             // positions a row wave owns in the deferred S1 finish: ceil(L / 15) (L <= 210)
+constexpr int kFinishItems = 4;         // candidate pairs it has in flight at once (0.9 flagged tokens, ~1.1 pairs expected per wave)
 
 template <int NT>
 struct RerankWave {
@@ -344,20 +231,47 @@ struct RerankWave {
     int b, L, lane, wid;
     int64_t *words;             // s.words (LDS): final word of every flagged position, -1 when none could be ranked
     int *done_counter;          // s.misc[6]
-    int st;                     // 0 flags in flight, 1 between tokens, 2 a candidate pair in flight, 3 done
-    unsigned f, cp0, cp1;       // lane j: flag word of position wid + 15 j;  lane t: dwords 2 (t % 3), + 1 of the record of position t / 3's slot
-    unsigned long long todo;
-    int l, my_word, ma, mb, bi;
-    bool two;                   // (RerankView carries `scal` and `tiles` of the packed image for the overflow scan)
-    unsigned cm;
-    float xf[NT], ra[NT], rb[NT];
-    double best;
+    unsigned long long *stamp;  // diagnostics (sn_debug_set_graph_stamps): slots 14 / 15 of the image = wave 3's requests out / finish complete
+
+    // One work item = one candidate pair of one owned token: the token's row and the two words' rows (a token with more than
+    // two candidates is several items).  A token's running best lives in LANE jj (its index among the owned positions) of
+    // three registers, its remaining candidates in lane jj of `cmv`: items are scored in any grouping, v_readlane and a
+    // select on the token's lane pick its state.
+    struct Item {
+        int jj, ma, mb;
+        bool two;
+        float xf[NT], ra[NT], rb[NT];
+    };
+    unsigned f, cp0, cp1;       // lane j: flag word of position wid + 15 j;  lane t: dwords 2 (t % 3), + 1 of the record of owned position t / 3
+    unsigned cmv;               // lane j: candidate slots of token j not yet requested
+    unsigned best_lo, best_hi;  // lane j: best fp64 score of token j so far (+inf)
+    int best_i;                 // lane j: its word (0x7fffffff: none)
+    Item it[kFinishItems];
+    int cnt;
 
     __device__ __forceinline__ int64_t token_index(int pos) const { return (int64_t)b * rv.tsb + (int64_t)pos * rv.tsl; }
 
+    __device__ __forceinline__ void load_row(float (&dst)[NT], const void *row, int x_bf16) const
+    {
+        // (D == 64 NT: the host launches no other shape.  One branch per row: a select per element makes hipcc branch and wait per element.)
+        if (x_bf16) {
+            const unsigned short *r = reinterpret_cast<const unsigned short *>(row);
+            unsigned short u[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) u[t] = r[lane + SN_WAVE * t];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dst[t] = __uint_as_float((unsigned)u[t] << 16);
+        } else {
+            const float *r = reinterpret_cast<const float *>(row);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dst[t] = r[lane + SN_WAVE * t];
+        }
+    }
+
+    // stage 1, in front of everything: flag words and candidate records of the owned positions (one round trip)
     __device__ __forceinline__ void begin()
     {
-        st = 0; f = 0; cp0 = 0; cp1 = 0;
+        f = 0u; cp0 = 0u; cp1 = 0u; cnt = 0;
         const int pj = wid + kRowWaves * lane;
         if (lane < kOwnMax && pj < L) f = rv.flags[token_index(pj)];
         const int pt = wid + kRowWaves * (lane / 3);
@@ -367,110 +281,104 @@ struct RerankWave {
         }
     }
 
-    __device__ __forceinline__ void load_row(float (&dst)[NT], const void *row, int x_bf16) const
+    // the next pair of the lowest pending token -> item `q` (false: nothing pending)
+    __device__ __forceinline__ bool issue_item(Item &q)
     {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            dst[t] = sn_s1::token_elem(row, x_bf16, lane + SN_WAVE * t);      // (D == 64 NT: the host launches no other shape)
-        }
-    }
-
-    __device__ __forceinline__ void issue_pair()
-    {
+        const unsigned long long pend = __ballot(cmv != 0u);
+        if (!pend) return false;                                     // wave-uniform
+        const int jj = __ffsll((long long)pend) - 1;
+        unsigned cm = (unsigned)__builtin_amdgcn_readlane((int)cmv, jj);
         const int ca = __ffs((int)cm) - 1;
         cm &= cm - 1;
-        two = cm != 0u;
-        const int cb2 = two ? __ffs((int)cm) - 1 : ca;
-        if (two) cm &= cm - 1;
-        ma = __builtin_amdgcn_readlane(my_word, ca);
-        mb = __builtin_amdgcn_readlane(my_word, cb2);
-        load_row(ra, rv.cb + (int64_t)ma * rv.D, 0);
-        load_row(rb, rv.cb + (int64_t)mb * rv.D, 0);
-    }
-
-    __device__ __forceinline__ void score_pair()
-    {
-        double pa = 0.0, pb = 0.0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { pa = fma((double)xf[t], (double)ra[t], pa); pb = fma((double)xf[t], (double)rb[t], pb); }
-        const double sa = rv.cn64[ma] - 2.0 * sn_wave_sum_f64(pa);
-        const double sb = rv.cn64[mb] - 2.0 * sn_wave_sum_f64(pb);
-        if (sa < best || (sa == best && ma < bi)) { best = sa; bi = ma; }
-        if (two && (sb < best || (sb == best && mb < bi))) { best = sb; bi = mb; }
-    }
-
-    __device__ __forceinline__ void write_word(int word, int fallback)
-    {
-        if (lane == 0) {
-            const int w = word != 0x7fffffff ? word : fallback;
-            if (w >= 0) rv.ids[(int64_t)b * rv.isb + (int64_t)l * rv.isl] = w;
-            words[l] = w;                                           // (-1: keep the screen's word)
-        }
-    }
-
-    // word of candidate slot `lane` (< 24) of owned position jj, from the record dwords held by lanes 3 jj .. 3 jj + 2
-    __device__ __forceinline__ int slot_words(int jj) const
-    {
+        q.two = cm != 0u;
+        const int cb2 = q.two ? __ffs((int)cm) - 1 : ca;
+        if (q.two) cm &= cm - 1;
+        cmv = lane == jj ? cm : cmv;
+        // word of candidate slot `lane` (< 24): byte `lane` of the record, held as dword pairs by lanes 3 jj .. 3 jj + 2
         const int src = 3 * jj + ((lane & 31) >> 3);
         const unsigned d0 = (unsigned)__shfl((int)cp0, src, SN_WAVE), d1 = (unsigned)__shfl((int)cp1, src, SN_WAVE);
         const unsigned code = (((lane >> 2) & 1) ? d1 : d0) >> (8 * (lane & 3)) & 0xFFu;
-        return lane < sn_s1::kMaxCand ? sn_s1::slot_word(lane, code) : 0;
+        const int my_word = lane < sn_s1::kMaxCand ? sn_s1::slot_word(lane, code) : 0;
+        q.jj = jj;
+        q.ma = __builtin_amdgcn_readlane(my_word, ca);
+        q.mb = __builtin_amdgcn_readlane(my_word, cb2);
+        const int l = wid + kRowWaves * jj;
+        load_row(q.xf, sn_s1::token_row_ptr(rv.x, rv.x_bf16, (int64_t)b * rv.xsb + (int64_t)l * rv.xsl), rv.x_bf16);
+        load_row(q.ra, rv.cb + (int64_t)q.ma * rv.D, 0);
+        load_row(q.rb, rv.cb + (int64_t)q.mb * rv.D, 0);
+        return true;
     }
 
-    __device__ __forceinline__ void operator()()
+    __device__ __forceinline__ void score_item(const Item &q)
     {
-        if (st == 3) return;
-        if (st == 0) {
-            todo = __ballot(f != 0u);
-            st = 1;
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) { pa = fma((double)q.xf[k], (double)q.ra[k], pa); pb = fma((double)q.xf[k], (double)q.rb[k], pb); }
+        const double sa = rv.cn64[q.ma] - 2.0 * sn_wave_sum_f64(pa);
+        const double sb = rv.cn64[q.mb] - 2.0 * sn_wave_sum_f64(pb);
+        double best = __hiloint2double(__builtin_amdgcn_readlane((int)best_hi, q.jj), __builtin_amdgcn_readlane((int)best_lo, q.jj));
+        int bi = __builtin_amdgcn_readlane(best_i, q.jj);
+        if (sa < best || (sa == best && q.ma < bi)) { best = sa; bi = q.ma; }
+        if (q.two && (sb < best || (sb == best && q.mb < bi))) { best = sb; bi = q.mb; }
+        if (lane == q.jj) { best_lo = (unsigned)__double2loint(best); best_hi = (unsigned)__double2hiint(best); best_i = bi; }
+    }
+
+    // stage 2: token and candidate rows of up to kFinishItems pairs requested
+    __device__ __forceinline__ void request(bool)
+    {
+        cmv = (f >> 31) ? 0u : (f & 0xFFFFFFu);                      // (overflow tokens: the sorting wave's)
+        best_lo = 0u; best_hi = 0x7FF00000u; best_i = 0x7fffffff;    // +inf
+        cnt = 0;
+#pragma unroll
+        for (int i = 0; i < kFinishItems; ++i) {
+            if (!issue_item(it[i])) break;
+            cnt = i + 1;
         }
-        if (st == 2) {
-            score_pair();
-            if (cm) { issue_pair(); return; }
-            write_word(bi, -1);
-            st = 1;
+        if (stamp && wid == 3 && lane == 0) stamp[14] = __builtin_amdgcn_s_memtime();
+    }
+
+    // stage 3: the requested pairs scored (straight-line); whatever is left (more than kFinishItems pairs: rare) one pair at a
+    // time, blocking; every owned token's word written by its lane; then the `done` signal
+    __device__ __forceinline__ void complete()
+    {
+#pragma unroll
+        for (int i = 0; i < kFinishItems; ++i) {
+            if (i >= cnt) break;                                     // wave-uniform
+            score_item(it[i]);
         }
-        // st == 1: the next flagged position of this wave
-        while (todo) {
-            const int jj = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const unsigned fj = (unsigned)__builtin_amdgcn_readlane((int)f, jj);
-            l = wid + kRowWaves * jj;
-            if (fj >> 31) continue;                                  // an overflow token: the sorting wave's (rerank_overflow_token)
-            cm = fj & 0xFFFFFFu;
-            my_word = slot_words(jj);
-            const void *row = sn_s1::token_row_ptr(rv.x, rv.x_bf16, (int64_t)b * rv.xsb + (int64_t)l * rv.xsl);
-            load_row(xf, row, rv.x_bf16);
-            best = (double)INFINITY; bi = 0x7fffffff;
-            issue_pair();
-            st = 2;
-            return;
+        {
+            Item q;
+            while (issue_item(q)) score_item(q);
         }
-        // nothing left: tell the sorting wave (LDS operations of a wave are performed in order: the words are written)
+        const int pj = wid + kRowWaves * lane;
+        if (lane < kOwnMax && pj < L && f != 0u && (f >> 31) == 0u) {
+            const int w = best_i != 0x7fffffff ? best_i : -1;        // (-1: keep the screen's word)
+            if (w >= 0) rv.ids[(int64_t)b * rv.isb + (int64_t)pj * rv.isl] = w;
+            words[pj] = w;
+        }
+        // tell the sorting wave (LDS operations of a wave are performed in order: the words are written)
         if (lane == 0) atomicAdd(done_counter, 1);
-        st = 3;
-    }
-
-    __device__ __forceinline__ void finish()
-    {
-        while (st != 3) (*this)();
+        if (stamp && wid == 3 && lane == 0) stamp[15] = __builtin_amdgcn_s_memtime();
     }
 };
 
-
 // `pre_work()`: register-only work of the caller that has nothing to do with the rows; the dynamic form calls it once its first
 // two batches of loads are issued (the wave would otherwise sit out their HBM latency), the other forms up front.
-// `tick`: the deferred S1 finish of this wave (RerankWave; NoTick: none): begin() in front of the first row loads, one
-// call per iteration of the row loop behind that iteration's loads, finish() when the rows are in.
+// `tick`: the deferred S1 finish (RerankWave; NoTick: none): begin() in front of the first row loads, request() behind them
+// (and the caller's register-only work), complete() behind the first batch's soft-max.
 template <bool kVec, bool kFast, class Pre, class Tick>
 __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src, int64_t stride_r, int heads,
                                                       int64_t stride_h, int L, bool is_logits, bool use_clamp,
                                                       float clamp, int rb, int re, int rs, int lane, int *next_row,
                                                       Pre pre_work, Tick &tick)
 {
-    constexpr int kRowsInFlight = 7;
-    tick.begin();        // HBM latency: 7 rows of loads in flight per wave (196 rows on 15 waves: two batches; four in flight = four batches of exposed latency: 25.6 k -> see DESIGN 3.2)
-    if (rs != 0 || heads > 1) pre_work();
+    constexpr int kRowsInFlight = 7;        // HBM latency: 7 rows of loads in flight per wave (196 rows on 15 waves: two batches; four in flight = four batches of exposed latency: 25.6 k -> see DESIGN 3.2)
+    tick.begin();
+    if (rs != 0 || heads > 1) {
+        pre_work();
+        tick.request(true);         // (the static forms: the finish runs ahead of the rows; six heads of rows follow)
+        tick.complete();
+    }
     if (heads > 1) {
         // Head mean fused (the backbone's [bs, H, L+1, L+1] tap): the loads of ALL heads of a pair of rows are issued before
         // the first add - up to 6 heads x 2 rows = 12 row loads in flight per wave (one head after the other was a chain
@@ -488,7 +396,6 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
                     for (int i = 0; i < kRB; ++i)
                         load_row4<kVec>(src + hc * stride_h + (int64_t)min(r0 + rs * i, L - 1) * stride_r, L, lane, y[hh][i]);
                 }
-                if (h0 == 0) tick();
 #pragma unroll
                 for (int hh = 0; hh < kHB; ++hh) {
                     if (h0 + hh >= heads) break;                     // wave-uniform
@@ -517,7 +424,6 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
                 }
             }
         }
-        tick.finish();
         return;
     }
     if (rs == 0) {
@@ -529,12 +435,21 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
         constexpr int kDyn = 2;                 // rows per batch; two batches of loads in flight behind the one being soft-maxed
         int r0 = rb, r1 = rb + kDyn;            // (the first two batches of a wave are fixed: rows 4 wid .. 4 wid + 3)
         float x[kDyn][4], y[kDyn][4];
+        if constexpr (!std::is_same<Tick, NoTick>::value) {
+            // The deferred S1 finish goes out AHEAD of the rows: a request issued behind the burst of 256 images' maps
+            // queues for 6-10 k cycles (two dependent round trips behind it: the sorting wave started at 25 k cycles instead
+            // of 11 k, tools/time_defer.py); in front of it the memory system is idle - the flag words come back, the token
+            // and candidate rows are requested, and the rows right behind them; the caller's register-only work (4 k cycles
+            // of table building) runs under all of it.
+            tick.request(true);
+        }
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(r0 + i, L - 1) * stride_r, L, lane, x[i]);
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(r1 + i, L - 1) * stride_r, L, lane, y[i]);
         pre_work();
-        while (r0 < L) {
+        // one iteration: the next batch requested, the oldest soft-maxed and stored, [the deferred S1 finish completed], rotate
+        auto iteration = [&](auto with_finish) {
             int rn = 0;
             if (lane == 0) rn = atomicAdd(next_row, kDyn);
             rn = __builtin_amdgcn_readfirstlane(rn);
@@ -543,7 +458,6 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
 #pragma unroll
                 for (int i = 0; i < kDyn; ++i) load_row4<kVec>(src + (int64_t)min(rn + i, L - 1) * stride_r, L, lane, z[i]);
             }
-            tick();
 #pragma unroll
             for (int i = 0; i < kDyn; ++i) {
                 const int r = r0 + i;
@@ -560,14 +474,18 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
                     }
                 }
             }
+            // (behind the first soft-max: the finish's loads are older than this iteration's rows - a counted wait, straight-line code)
+            if constexpr (decltype(with_finish)::value) tick.complete();
 #pragma unroll
             for (int i = 0; i < kDyn; ++i)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { x[i][k] = y[i][k]; y[i][k] = z[i][k]; }
             r0 = r1;
             r1 = rn;
-        }
-        tick.finish();
+        };
+        // (the first iteration apart: inside the loop the finish's registers would be live around the whole row phase)
+        if constexpr (!std::is_same<Tick, NoTick>::value) iteration(std::true_type{});       // (r0 < L: every wave has fixed first rows)
+        while (r0 < L) iteration(std::false_type{});
         return;
     }
     for (int r0 = rb; r0 < re; r0 += rs * kRowsInFlight) {
@@ -592,7 +510,6 @@ __device__ __forceinline__ void attn_rows_to_lds_impl(float *A, const float *src
             }
         }
     }
-    tick.finish();
 }
 
 template <bool kFast = false, class Pre = NoPreWork, class Tick = NoTick>
@@ -609,14 +526,8 @@ __device__ __forceinline__ void attn_rows_to_lds(float *A, const float *src, int
         if (vec) attn_rows_to_lds_impl<true, kFast, Pre, NoTick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, none);
         else attn_rows_to_lds_impl<false, kFast, Pre, NoTick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, none);
     } else {
-        // (a deferred finish rides on the vector path only: its kernel is launched for L % 4 == 0; anywhere else the
-        // finish runs after the rows)
         if (vec) attn_rows_to_lds_impl<true, kFast, Pre, Tick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, *tick);
-        else {
-            attn_rows_to_lds_impl<false, kFast, Pre, NoTick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, none);
-            tick->begin();
-            tick->finish();
-        }
+        else attn_rows_to_lds_impl<false, kFast, Pre, Tick>(A, src, stride_r, heads, stride_h, L, is_logits, use_clamp, clamp, rb, re, rs, lane, next_row, pre_work, *tick);
     }
 }
 
@@ -1081,7 +992,8 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     const int ts_S = 2 * a.feat_w - 1;
     const bool lean_ok = kFast && dyn_rows && ts_S <= SN_WAVE;
     if (dyn_rows || RR > 0) {
-        if (tid == 0) { s.misc[4] = (nw - 1) * 4; s.misc[6] = 0; }           // ([6]: row waves whose share of the deferred S1 finish is done)
+        // ([4]: next attention row to deal - behind the fixed first rows; [6]: row waves whose share of the deferred S1 finish is done)
+        if (tid == 0) { s.misc[4] = (nw - 1) * 4; s.misc[6] = 0; }
         for (int c = tid; c < kMaxCols; c += blockDim.x) s.rev[c] = -1;       // (in front of the barrier: ordered before the sorting wave's row map)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                            // (everybody is at the start of the kernel: a cheap barrier)
@@ -1114,6 +1026,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             if constexpr (RR > 0) {
                 RerankWave<RR> tick;
                 tick.rv = rv; tick.b = b; tick.L = L; tick.lane = lane; tick.wid = wid; tick.words = s.words; tick.done_counter = &s.misc[6];
+                tick.stamp = stamps ? stamps + (size_t)blockIdx.x * 16 : nullptr;
                 attn_rows_to_lds<true, decltype(table_rows), RerankWave<RR>>(s.A, a.attn + (int64_t)b * a.attn_stride_b, a.attn_stride_r, a.attn_heads,
                                        a.attn_stride_h, L, a.attn_is_logits != 0, a.use_clamp_e != 0, a.clamp_e, rb, re, rs, lane, &s.misc[4],
                                        table_rows, &tick);
@@ -1202,7 +1115,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                 const int q = src + SN_WAVE * e;
                 const int64_t n = (int64_t)b * rv.tsb + (int64_t)q * rv.tsl;
                 const unsigned code = lane < sn_s1::kMaxCand ? (unsigned)rv.codes[n * sn_s1::kCodeBytes + lane] : 0u;
-                const int wfin = rerank_overflow_token<RR>(rv, b, q, lane, fj, lane < sn_s1::kMaxCand ? sn_s1::slot_word(lane, code) : 0);
+                const int wfin = sn_s1::rerank_overflow_token<RR>(rv, b, q, lane, fj, lane < sn_s1::kMaxCand ? sn_s1::slot_word(lane, code) : 0);
                 if (wfin >= 0) {
                     if (lane == src) {
                         w4[0] = e == 0 ? (int64_t)wfin : w4[0]; w4[1] = e == 1 ? (int64_t)wfin : w4[1];
@@ -1211,7 +1124,7 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
                     if (lane == 0) rv.ids[(int64_t)b * rv.isb + (int64_t)q * rv.isl] = wfin;
                 }
             }
-            // the flagged tokens' final words: every row wave has finished its share (15 signals), the words lie in s.words
+            // the flagged tokens' final words: every row wave has done its share (fifteen signals), the words lie in s.words
             // (-1: none of the candidates could be ranked - keep the screen's)
             while (__hip_atomic_load(&s.misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nw - 1) __builtin_amdgcn_s_sleep(2);
             asm volatile("" ::: "memory");
@@ -1293,8 +1206,8 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     };
     if (sorter && done && !kEdges) write_vertices();
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_memtime();   // ... wave 0 has its rows in
-    if (stamps && threadIdx.x == 3 * 64) stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime(); // ... wave 3 (on the sorting wave's SIMD)
-    if (stamps && threadIdx.x == 5 * 64) stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime(); // ... wave 5
+    if (RR == 0 && stamps && threadIdx.x == 3 * 64) stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime(); // ... wave 3 (on the sorting wave's SIMD)
+    if (RR == 0 && stamps && threadIdx.x == 5 * 64) stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime(); // ... wave 5
     // (LDS contents only: __syncthreads() would also wait for the sorting wave's global stores and its atomic on the batch
     // maximum - one address for every image of the launch - to complete, 7 k cycles with everybody standing at the barrier;
     // nobody reads those in this kernel)

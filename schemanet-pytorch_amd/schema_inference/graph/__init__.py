@@ -42,8 +42,11 @@ class SchemaNetPredictor(nn.Module):
         # short launches, host-bound when launched from Python) is captured into a hipGraph per tap-buffer set and
         # replayed ("the API path").  SN_PREDICTOR_GRAPH=0 or `graph_replay = False`: eager launches.
         self.graph_replay = os.environ.get("SN_PREDICTOR_GRAPH", "1") != "0"
-        # `forward` hands out `pred` from a two-deep ring (two captures per tap-buffer set, see `_forward_replayed`)
-        self.output_ring = os.environ.get("SN_PREDICTOR_RING", "1") != "0"
+        # `output_ring = True` (SN_PREDICTOR_RING=1): `forward` hands out `pred` from a two-deep ring - two captures per
+        # tap-buffer set, no copy kernel between two graph launches - valid until the next call BUT ONE (see
+        # `_forward_replayed`).  Off by default: the reference's forward returns a tensor the caller owns for ever, and an
+        # evaluation loop that collects `output["pred"]` over the batches would read rewritten buffers.
+        self.output_ring = os.environ.get("SN_PREDICTOR_RING", "0") == "1"
         self._graphs = collections.OrderedDict()
         self._graph_misses = 0                                # CONSECUTIVE calls that found nothing to replay
         self._key_dicts_cache = None
@@ -75,6 +78,9 @@ class SchemaNetPredictor(nn.Module):
         if not torch.is_grad_enabled() and self.matcher.gnn.masks_adjacency(self.schema_net.edge_weights.tensor):
             # no autograd, MFMA GNN: the GCN operand and `class_edges` from ONE pass over the IR-Atlas
             get_atlas = lambda: self.schema_net.get_atlas(fused_adjacency="with_edges")       # noqa: E731
+        # (S1: one call at a time the fp64 finish of the undecided tokens rides in the instance-graph kernel - `rerank` in
+        # `output` -, with several batches in flight (`predict_batches`, side_stream False) it stays a launch of its own: the
+        # light kernel runs beside the other batches' kernels, the fused form lengthens one that holds every CU - DESIGN 3.1e)
         atlas = self.matcher.atlas_features_async(get_atlas, depends_on=self._atlas_depends_on(), side_stream=side_stream)
         # (the zero padding of the instance edges is only written when the caller asks for the graphs)
         graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
@@ -151,11 +157,12 @@ class SchemaNetPredictor(nn.Module):
     def _forward_replayed(self, x, own_pred: bool = True, side_stream=None):
         """eval + no_grad + `taps`: backbone eagerly, then the captured launch sequence of everything behind it.
 
-        own_pred: `pred` must survive the next call.  The capture's output buffer is rewritten by its next replay, so a
+        own_pred: `pred` must survive the next call.  The capture's output buffer is rewritten by its next replay: by default
+        the caller gets a copy (`clone()`: its own tensor, as from the reference).  With `output_ring` a
         key gets a SECOND capture of the same step (with buffers of its own: a shared memory pool would let one capture's
         intermediates land on the other's outputs) and the calls alternate between the two: the tensor a
         call returns is valid until the next call BUT ONE with the same taps - a two-deep output ring instead of a copy
-        kernel between two graph launches (`SN_PREDICTOR_RING=0`: one capture and `pred.clone()`, valid for ever)."""
+        kernel between two graph launches."""
         from ..utils.graph_replay import GraphedStep
         wrapper = self.ingredient_wrapper
         out_backbone = wrapper.backbone_jit(x)
@@ -169,13 +176,13 @@ class SchemaNetPredictor(nn.Module):
                 if self._graph_misses >= 4 * self.max_graphs:
                     self._give_up_replay(f"{self._graph_misses} consecutive calls found no capture to replay: the backbone's tap "
                                          "buffers or the parameters change on every call")
-                    return self._after_backbone(wrapper.taps_from(out_backbone, defer=True), False, side_stream)
+                    return self._after_backbone(wrapper.taps_from(out_backbone, defer=side_stream is not False), False, side_stream)
                 self._graph_misses += 1
             try:
-                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone, defer=True), False, side_stream))
+                step = GraphedStep(lambda: self._after_backbone(wrapper.taps_from(out_backbone, defer=side_stream is not False), False, side_stream))
             except Exception as exc:                              # noqa: BLE001 - a configuration that cannot be captured
                 self._give_up_replay(f"capture failed: {exc!r}")
-                return self._after_backbone(wrapper.taps_from(out_backbone, defer=True), False, side_stream)
+                return self._after_backbone(wrapper.taps_from(out_backbone, defer=side_stream is not False), False, side_stream)
             if entry is None:
                 entry = [0, step]                                 # [calls so far, capture A (, capture B)]
                 self._graphs[key] = entry
@@ -241,7 +248,7 @@ class SchemaNetPredictor(nn.Module):
                 if self.graph_replay:
                     out = self._forward_replayed(x, own_pred=False, side_stream=fork)
                 else:                                  # (capture gave up on the way: eager launches, still `depth` streams)
-                    out = self._after_backbone(wrapper.taps(x, defer=True), False, fork)
+                    out = self._after_backbone(wrapper.taps(x, defer=fork is not False), False, fork)
                     out["pred"].record_stream(home)
                 done = torch.cuda.Event()
                 done.record(st)

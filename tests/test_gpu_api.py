@@ -82,7 +82,7 @@ def test_predictor_replays_its_own_launch_sequence(mods, E):
             assert len(pred._graphs) == 3
             again = [pred(x) for _ in range(6)]                         # replays, twice around
         assert len(pred._graphs) == 3 and pred._graph_misses == 0        # (consecutive misses: a hit clears the count)
-        assert all(len(e) == 3 for e in pred._graphs.values())          # two captures per tap-buffer set: the output ring
+        assert all(len(e) == 2 for e in pred._graphs.values())          # one capture per tap-buffer set (the output ring is opt-in)
         torch.cuda.synchronize()
         for i in range(3):
             assert torch.equal(first[i], eager_pred[i]), f"capture pass differs from eager (cache {cache}, batch {i})"
@@ -113,9 +113,9 @@ def test_predictor_replays_its_own_launch_sequence(mods, E):
 
 
 def test_predictor_output_ring_and_miss_counting(mods):
-    """`forward` hands out `pred` from a two-deep ring (no copy kernel between two graph launches): the tensor of call n is
-    still intact after call n + 1 on the same taps and is rewritten by call n + 2; SN_PREDICTOR_RING=0 semantics
-    (`output_ring = False`) give every call a tensor of its own.  A fine-tune loop that alternates weight updates and
+    """With `output_ring` (opt-in) `forward` hands out `pred` from a two-deep ring (no copy kernel between two graph
+    launches): the tensor of call n is still intact after call n + 1 on the same taps and is rewritten by call n + 2; the
+    default (`output_ring = False`) gives every call a tensor of its own.  A fine-tune loop that alternates weight updates and
     evaluation phases misses once per phase for ever: the miss count is of CONSECUTIVE misses, so replay stays on
     (a lifetime count switched it off silently after 32)."""
     bs, H, L, D, M, K = 4, 2, 196, 192, 128, 5
@@ -123,6 +123,8 @@ def test_predictor_output_ring_and_miss_counting(mods):
     mid2 = T(datagen.bellish((L + 1, bs, D), 427, 1.0))
     pred, wrapper = _predictor(mods, [(mid, ext)], M, D, K, 32)
     x = torch.zeros(bs, 3, 4, 4, device=DEV)
+    assert pred.output_ring is False                      # default: the caller owns what `forward` returns (a copy), like the reference
+    pred.output_ring = True
     with torch.no_grad():
         a = pred(x)["pred"]
         a0 = a.clone()
@@ -254,13 +256,14 @@ def test_predict_batches_keeps_batches_in_flight_and_in_order(mods):
 
 
 # =============================================================================== the N > 1 branch of bench.py
-@pytest.mark.parametrize("world", [2, 6])
+@pytest.mark.parametrize("world", [2, 3])
 def test_bench_ranks_rehearsal(world):
     """What the driver launches for N > 1, with every rank on this box's one GPU over gloo (SN_BENCH_REHEARSAL=1: RCCL
     cannot form a multi-rank group on one device; the numbers mean nothing, the code path is the one of the scaling run):
     stdout is ONE JSON line, world_size as asked, every image of every region voted, the edge statistics (C2's
-    26 214 500 floats: a multiple of 2, not of 6 or 8 - the zero-padded length) merged by reduce_scatter + all_gather.
-    Six ranks is what a GPU box admits (at most six processes on its card); world size 8 runs on the CPU over gloo:
+    26 214 500 floats: a multiple of 2, not of 3 or 8 - the zero-padded length) merged by reduce_scatter + all_gather.
+    A GPU box admits six processes on its card - three ranks, the test runner and the launcher stay inside that (six ranks
+    were killed by its process guard); world size 8 runs on the CPU over gloo:
     tests/test_host_cpu.py::test_statistics_eight_ranks_gloo_at_c2_length."""
     steps, port = (3 if world == 2 else 2), str(29600 + (os.getpid() + 17 * world) % 300)
     regions = 2 if world == 2 else 1

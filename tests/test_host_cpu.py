@@ -373,7 +373,7 @@ sys.exit(0 if ok else 3)
 
 def test_statistics_eight_ranks_gloo_at_c2_length(tmp_path):
     """World size 8 - the size BASELINE's target names - has only ever been run here, on the CPU, over gloo (a GPU box
-    admits six processes on its card and has one GPU; tests/test_gpu_api.py rehearses `bench.py` with six ranks): the
+    admits six processes on its card and has one GPU; tests/test_gpu_api.py rehearses `bench.py` with two and three ranks): the
     105 MB edge statistics of config [2] (26 214 500 floats, not a multiple of 8) merged by reduce_scatter + all_gather
     on the zero-padded buffer, the vertex statistics by one all-reduce, images sharded r::8, votes of 256 x 2 x 8 images."""
     script = tmp_path / "worker8.py"
