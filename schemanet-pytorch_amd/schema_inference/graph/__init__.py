@@ -16,6 +16,64 @@ from .statistics import SchemaStatistics, shard_indices
 __all__ = ["SchemaNet", "Matcher", "GNN", "SchemaNetPredictor", "SchemaStatistics", "shard_indices"]
 
 
+class LazyOutputs(collections.OrderedDict):
+    """The reference's output dictionary with entries that are only computed when somebody reads them.  `class_edges`
+    [K, n, n] is 105 MB at config [1] (419 MB at 1024 words): the reference returns it from every forward, its evaluation
+    loop (eval/evaluation.py:63-80) never looks at it - it is what the sparsity terms of the TRAINING loss read.  In eval()
+    under no_grad the predictor therefore hands out the key with the value deferred: reading it (`out["class_edges"]`, `.get`,
+    `.items()`, `.values()`) runs the atlas normalisation then, from the parameters as they are at that moment (the same
+    values unless they were written in between).  Keys, their order, `in`, `len` and iteration over keys never compute."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._lazy = {}
+
+    def set_lazy(self, key, fn):
+        super().__setitem__(key, None)
+        self._lazy[key] = fn
+
+    def _force(self, key=None):
+        for k in ([key] if key is not None else list(self._lazy)):
+            fn = self._lazy.pop(k, None)
+            if fn is not None:
+                super().__setitem__(k, fn())
+
+    def __getitem__(self, key):
+        self._force(key)
+        return super().__getitem__(key)
+
+    def __setitem__(self, key, value):
+        if getattr(self, "_lazy", None):
+            self._lazy.pop(key, None)
+        super().__setitem__(key, value)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        if key in self:
+            self._force(key)
+        return super().pop(key, *default)
+
+    def items(self):
+        self._force()
+        return super().items()
+
+    def values(self):
+        self._force()
+        return super().values()
+
+    def lazy_copy(self):
+        """a copy that keeps the deferred entries deferred (`OrderedDict(self)` would compute them)"""
+        out = LazyOutputs()
+        for k in self.keys():
+            if k in self._lazy:
+                out.set_lazy(k, self._lazy[k])
+            else:
+                collections.OrderedDict.__setitem__(out, k, collections.OrderedDict.__getitem__(self, k))
+        return out
+
+
 class SchemaNetPredictor(nn.Module):
     """images -> ingredients -> instance IR-graph -> match against the IR-Atlas.
 
@@ -47,6 +105,9 @@ class SchemaNetPredictor(nn.Module):
         # `_forward_replayed`).  Off by default: the reference's forward returns a tensor the caller owns for ever, and an
         # evaluation loop that collects `output["pred"]` over the batches would read rewritten buffers.
         self.output_ring = os.environ.get("SN_PREDICTOR_RING", "0") == "1"
+        # eval() under no_grad: `class_edges` of the returned dictionary is computed when it is read (LazyOutputs);
+        # SN_PREDICTOR_LAZY_EDGES=0 / `lazy_class_edges = False`: written by every forward, like the reference
+        self.lazy_class_edges = os.environ.get("SN_PREDICTOR_LAZY_EDGES", "1") != "0"
         self._graphs = collections.OrderedDict()
         self._graph_misses = 0                                # CONSECUTIVE calls that found nothing to replay
         self._key_dicts_cache = None
@@ -71,13 +132,18 @@ class SchemaNetPredictor(nn.Module):
 
     # ---- the path behind the backbone -----------------------------------------------------------------------
     def _after_backbone(self, output, requires_graph: bool, side_stream=None):
-        ret = collections.OrderedDict()
+        ret = LazyOutputs()
         # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
         # instance branch on the current one; joined inside forward_padded
         get_atlas = self.schema_net.get_atlas
+        lazy_edges = False
         if not torch.is_grad_enabled() and self.matcher.gnn.masks_adjacency(self.schema_net.edge_weights.tensor):
-            # no autograd, MFMA GNN: the GCN operand and `class_edges` from ONE pass over the IR-Atlas
-            get_atlas = lambda: self.schema_net.get_atlas(fused_adjacency="with_edges")       # noqa: E731
+            # no autograd, MFMA GNN: the GCN operand straight from the pruned parameters.  `class_edges` - nobody's input on
+            # this path - from the same pass when the caller is going to look at it (requires_graph, `lazy_class_edges`
+            # off), otherwise deferred until read (LazyOutputs: 105 MB less written per call at config [1])
+            lazy_edges = self.lazy_class_edges and not requires_graph
+            mode = True if lazy_edges else "with_edges"
+            get_atlas = lambda: self.schema_net.get_atlas(fused_adjacency=mode)       # noqa: E731
         # (S1: one call at a time the fp64 finish of the undecided tokens rides in the instance-graph kernel - `rerank` in
         # `output` -, with several batches in flight (`predict_batches`, side_stream False) it stays a launch of its own: the
         # light kernel runs beside the other batches' kernels, the fused form lengthens one that holds every CU - DESIGN 3.1e)
@@ -88,7 +154,10 @@ class SchemaNetPredictor(nn.Module):
                                                       rerank=output.get("rerank"))
         ret["pred"] = self.matcher.forward_padded(graph, atlas.class_dict, feat_kg=atlas)
         for k in ("class_vertices", "class_edges", "class_ingredients"):                  # (the reference's keys, in its order)
-            ret[k] = atlas.class_dict[k]
+            if k == "class_edges" and lazy_edges:
+                ret.set_lazy(k, self._class_edges_now)
+            else:
+                ret[k] = atlas.class_dict[k]
         if requires_graph:
             n = int(graph["n_max"].item())
             bs = graph["ids"].shape[0]
@@ -98,6 +167,15 @@ class SchemaNetPredictor(nn.Module):
             ret["ingredients"] = output["ingredients"]
             ret["attn_cls"] = graph["attn_cls"]          # [bs, L] head mean, clamp-masked (reference schema_net.py:296)
         return ret
+
+    def _class_edges_now(self):
+        """`class_edges` of the reference's dictionary from the parameters as they are now: one fused HIP pass
+        (reference schema_net.py:152-175: prune, clamp, row-normalise; w / row sum, the reference's own form)"""
+        from cpp_extension import ops
+        sn = self.schema_net
+        with torch.no_grad():
+            return ops.atlas_normalize(sn.vertex_weights.tensor.detach(), sn.edge_weights.tensor.detach(), sn.prune_node_threshold,
+                                       sn.remove_self_loop)[1]
 
     def _atlas_depends_on(self):
         """what the cached class-graph features are a function of besides the GNN weights (Matcher.cache_atlas)"""
@@ -198,7 +276,7 @@ class SchemaNetPredictor(nn.Module):
             self._graphs.move_to_end(key)
         step = entry[1 + (entry[0] & 1)] if (ring and len(entry) > 2) else entry[1]
         entry[0] += 1
-        ret = collections.OrderedDict(step.replay())
+        ret = step.replay().lazy_copy()
         if own_pred and not self.output_ring:
             ret["pred"] = ret["pred"].clone()                      # the capture's own buffer is rewritten by the next replay
         return ret
