@@ -619,7 +619,7 @@ def split_planes(x, scale="auto", transpose=False):
 
 
 def table_planes(table, scale=None):
-    """fp32 [rows, 256] -> (hi, lo) row-major fp16 planes [rows + 1, 256] with hi + lo ~= table * scale (the same split as
+    """fp32 [rows, E] (E a multiple of 256) -> (hi, lo) row-major fp16 planes [rows + 1, E] with hi + lo ~= table * scale (the same split as
     split_planes) and a zero last row: the gathered-B operand of gcn_gemm (pass the same device scalar as `b_scale`)."""
     t = _f32c(table.detach())
     if scale is not None:
@@ -649,7 +649,7 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     per-row-tile partial sums of sum_m pool_w[m] C[m, :] (add them up, or hand them to pool_fc).
     zero_c: the fp32 result starts as zeros (row tiles beyond m_extent are never written).
     b_table = (hi, lo, ids): B is gathered inside the kernel, Bt[g, f, j] = table[ids[g, j], f] (hi, lo = table_planes(table),
-    ids int64 [batches, n_ids]); `b` is then None.  Needs the LayerNorm epilogue and 256 features.
+    ids int64 [batches, n_ids]); `b` is then None.  256 features with the LayerNorm epilogue, any multiple of 256 without.
     next_w = next_layer_weight_planes(W): the epilogue result H [m, 256] is not stored; "planes" is Zt = W . H^T as a
     [256, want_planes >= m] operand (the next GraphConv's Linear, fused: no H round trip, one launch less).
     Scales: the operands' `.scale` (b_table: an optional 4th entry) are divided out of the accumulators; out_scale
@@ -665,8 +665,8 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
         t_hi, t_lo, ids = b_table[:3]
         dev = _check_dev(a.hi, a.lo, t_hi, t_lo, ids)
         assert b is None and a.batches in (1, batches) and ids.dtype == torch.int64 and ids.is_contiguous() and ids.shape[0] == batches
-        assert t_hi.dtype == torch.float16 and t_hi.is_contiguous() and t_lo.is_contiguous() and t_hi.shape == t_lo.shape and t_hi.shape[1] == 256
-        m, n = a.rows, 256
+        assert t_hi.dtype == torch.float16 and t_hi.is_contiguous() and t_lo.is_contiguous() and t_hi.shape == t_lo.shape and t_hi.shape[1] % 256 == 0
+        m, n = a.rows, t_hi.shape[1]
         args.b_table_hi, args.b_table_lo, args.b_ids = _dp(t_hi), _dp(t_lo), _dp(ids)
         args.b_ids_stride, args.b_ids_n, args.b_table_rows = ids.shape[1], ids.shape[1], t_hi.shape[0] - 1
     else:

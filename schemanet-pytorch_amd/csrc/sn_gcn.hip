@@ -484,7 +484,7 @@ struct GemmArgs {
     const _Float16 *tab_hi, *tab_lo;
     const int64_t *ids;
     int64_t ids_stride;
-    int ids_n, tab_rows;
+    int ids_n, tab_rows, tab_ld;            // tab_ld: features per table row (= n: 256, or a multiple of it - the workgroup gathers its own 256-column slice)
     // fused second product (FL kernels): planes of W2 [256, 256] with its columns in the order the epilogue holds them
     const _Float16 *w2_hi, *w2_lo;
     int fl_twin;                     // idle row tiles take the second half of the fused epilogue (SN_GEMM_FL_TWIN=0: off)
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
             if (GB && wid * kDmaPerWave + j >= kChunksA) {            // (wave-uniform) piece = plane, node pair; lane = (node, 16-byte chunk)
                 const int pb = wid * kDmaPerWave + j - kChunksA, row = 2 * (pb & 7) + h;
                 const int id = next_id[j];
-                const _Float16 *gsrc = ((pb >> 3) ? p.tab_lo : p.tab_hi) + (int64_t)id * kTileN + ((r ^ ((row & 3) << 2)) << 3);
+                const _Float16 *gsrc = ((pb >> 3) ? p.tab_lo : p.tab_hi) + (int64_t)id * p.tab_ld + tile_n + ((r ^ ((row & 3) << 2)) << 3);
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %1, off\n\t"
                              "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst + j * 1024) : "memory");
@@ -1184,8 +1184,8 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     SN_REQUIRE(u->a_hi && u->a_lo && (gathered || (u->b_hi && u->b_lo)), SN_ERR_BAD_ARG, "sn_gcn_gemm: NULL operand plane");
     if (gathered) {
         SN_REQUIRE(u->b_table_lo && u->b_ids && u->b_table_rows > 0 && u->b_ids_n >= 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: incomplete gathered-B arguments");
-        SN_REQUIRE(u->layernorm && u->n == kTileN && u->k <= kMaxGatherK, SN_ERR_UNSUPPORTED,
-                   "sn_gcn_gemm: gathered B needs n == 256, the LayerNorm epilogue and k <= %d (got n=%d k=%d)", kMaxGatherK, u->n, u->k);
+        SN_REQUIRE(u->n % kTileN == 0 && (u->layernorm ? u->n == kTileN : !u->next_w_hi) && u->k <= kMaxGatherK, SN_ERR_UNSUPPORTED,
+                   "sn_gcn_gemm: gathered B needs n a multiple of 256 (== 256 with the LayerNorm epilogue) and k <= %d (got n=%d k=%d)", kMaxGatherK, u->n, u->k);
         SN_REQUIRE(((uintptr_t)u->b_table_hi | (uintptr_t)u->b_table_lo) % 16 == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: table planes must be 16-byte aligned");
     }
     SN_REQUIRE(u->k % kStageK == 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: k=%d must be a multiple of 16 (the planes' padded k)", u->k);
@@ -1216,7 +1216,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.stamps = g_gemm_stamps;
     a.m_extent = u->m_extent; a.k_extent = u->k_extent;
     a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
-    a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows;
+    a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows; a.tab_ld = u->n;
     a.w2_hi = (const _Float16 *)u->next_w_hi; a.w2_lo = (const _Float16 *)u->next_w_lo;
     a.a_scale = u->a_scale; a.b_scale = u->b_scale; a.out_scale = u->out_scale; a.w2_scale = u->next_w_scale; a.h_scale = u->next_h_scale;
     {
@@ -1239,14 +1239,16 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     const size_t lds = (size_t)kRing * kStageBytes;
     {
         const void *fn = fused2 ? (gathered ? (const void *)gcn_gemm_kernel<true, true, true> : (const void *)gcn_gemm_kernel<true, false, true>)
-                                : gathered ? (const void *)gcn_gemm_kernel<true, true> : (u->layernorm ? (const void *)gcn_gemm_kernel<true> : (const void *)gcn_gemm_kernel<false>);
+                                : gathered ? (u->layernorm ? (const void *)gcn_gemm_kernel<true, true> : (const void *)gcn_gemm_kernel<false, true>)
+                                           : (u->layernorm ? (const void *)gcn_gemm_kernel<true> : (const void *)gcn_gemm_kernel<false>);
         if (int rc = sn_ensure_dynamic_lds(fn, lds, "sn_gcn_gemm")) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
     sn_prof_start(4, st);
     if (fused2 && gathered) hipLaunchKernelGGL((gcn_gemm_kernel<true, true, true>), grid, dim3(kGemmThreads), lds, st, a);
     else if (fused2) hipLaunchKernelGGL((gcn_gemm_kernel<true, false, true>), grid, dim3(kGemmThreads), lds, st, a);
-    else if (gathered) hipLaunchKernelGGL((gcn_gemm_kernel<true, true>), grid, dim3(kGemmThreads), lds, st, a);
+    else if (gathered && u->layernorm) hipLaunchKernelGGL((gcn_gemm_kernel<true, true>), grid, dim3(kGemmThreads), lds, st, a);
+    else if (gathered) hipLaunchKernelGGL((gcn_gemm_kernel<false, true>), grid, dim3(kGemmThreads), lds, st, a);      // (wide GNNs: E = 512, 1024 - each column tile gathers its slice of the table rows)
     else if (u->layernorm) hipLaunchKernelGGL(gcn_gemm_kernel<true>, grid, dim3(kGemmThreads), lds, st, a);
     else hipLaunchKernelGGL(gcn_gemm_kernel<false>, grid, dim3(kGemmThreads), lds, st, a);
     sn_prof_stop(4, st);

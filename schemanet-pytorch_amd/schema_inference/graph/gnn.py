@@ -174,7 +174,7 @@ class GNN(nn.Module):
         # of S1; `p.data.copy_` writes need `invalidate_prepared()`), so a forward pass launches no library GEMM
         srcs = (self.embedding.weight, l1.g_conv.linear.weight, l2.g_conv.linear.weight, self.fc.weight,
                 l1.norm.weight, l1.norm.bias, l2.norm.weight, l2.norm.bias)       # (the LayerNorm parameters: the operand scales)
-        fused_gather = self.embed_dim == 256 and os.environ.get("SN_GCN_GATHER_FUSED", "1") == "1"
+        fused_gather = self.embed_dim % 256 == 0 and os.environ.get("SN_GCN_GATHER_FUSED", "1") == "1"
         fused_linear = self.embed_dim == 256 and os.environ.get("SN_GCN_FUSE_LINEAR", "1") == "1"
         key = tuple((t.data_ptr(), t._version, t.device) for t in srcs) + (fused_gather, fused_linear)
         if getattr(self, "_prepared", None) is not None and self._prepared[0] == key:
@@ -261,9 +261,15 @@ class GNN(nn.Module):
             adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)
         if prepared is None:
             prepared = self.prepare()
-        zt1 = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext, scale=prepared["table_scale"])   # Bt [G, E, n]
+        if "table_planes" in prepared and adj.kpad <= 1024:
+            # Bt[g, f, j] = table[ids[g, j], f] gathered inside the product, each 256-column tile its own slice of the table rows
+            # (round 4: the [G, E, n] planes - 2.1 GB at config [3] - are neither written nor read back)
+            t_hi, t_lo = prepared["table_planes"]
+            zt1, b_table = None, (t_hi, t_lo, ingredients.contiguous(), prepared["table_scale"])
+        else:
+            zt1, b_table = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext, scale=prepared["table_scale"]), None   # Bt [G, E, n]
         c1 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias, rows_valid=n_valid, want_c=True, zero_c=ext is not None,
-                          m_extent=ext, k_extent=ext)["c"]                                           # [G, n, E]
+                          m_extent=ext, k_extent=ext, b_table=b_table)["c"]                          # [G, n, E]
         # mask + LayerNorm + activation and the hi / lo split of H1 in one pass (H1 itself is never stored)
         h1 = ops.layernorm_split_planes(c1, l1.norm.weight, l1.norm.bias, l1.norm.eps, n_valid=n_valid, relu=l1._is_relu,
                                         scale=prepared["h1_scale"])
