@@ -368,9 +368,28 @@ int sn_pool_fc_t(const float *pooled_parts, int G, int parts, int E, const int32
  *    i.e. within one rounding of sn_atlas_normalize's w / row sum. */
 int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,
                           float prune_threshold, float *class_vertices, float *row_sum, void *stream);
+/* One-shot hint for the NEXT sn_atlas_prune_rowsum call: the rows of pruned vertices are already zero (an earlier call on
+ * the same versions of vertex_weights and edge_weights zeroed them in place) and need not be read - 70 % of a trained atlas. */
+void sn_atlas_skip_pruned_rows(int on);
 int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n,
                                   int remove_self_loop, float scale, void *adj_hi, void *adj_lo, float *class_edges_out,
                                   void *stream);
+/* A PRUNED atlas, compacted (round 4).  The sparsity terms of the training loss push most vertex weights of a class under
+ * prune_node_threshold (schema_net.py:152-166): their rows and columns of the class graph are zero, the vertex is an
+ * isolated node.  perm [K, n] int32: vertex a of class k's operand is vertex perm[k][a] of the stored graph - the kept
+ * vertices first, in their own order; n_kept [K] int32.  Only the n_kept[k] x n_kept[k] corner (+ identity) of the operand
+ * is produced (rounded up to the 32 x 16 blocks, zero inside them), from the kept rows of the atlas only; sn_gcn_gemm
+ * consumes it with per-graph extents (sn_gemm_args.extent_stride = 1, m_extent = k_extent = rows_valid = n_kept).  The
+ * isolated vertices' share of the class feature does not need a product (host: GNN.prepare()["iso"]).  n <= 1024. */
+int sn_atlas_keep_perm(const float *class_vertices, int K, int n, float prune_threshold, int32_t *perm, int32_t *n_kept,
+                       void *stream);
+/* ids_c / w_c [K, n]: class_ingredients and node weights in the compacted operand's vertex order (w_c zero beyond
+ * n_kept[k]); pooled_iso [K, E] = sum over class k's pruned vertices of weight * iso[word] (iso [rows_iso, E] fp32). */
+int sn_class_compact(const int32_t *perm, const int32_t *n_kept, const float *nodes, const int64_t *ids, const float *iso,
+                     int K, int n, int E, int rows_iso, int64_t *ids_c, float *w_c, float *pooled_iso, void *stream);
+int sn_gcn_atlas_adjacency_planes_compact(const float *pruned_edge_weights, const float *row_sum, int K, int n,
+                                          int remove_self_loop, float scale, const int32_t *perm, const int32_t *n_kept,
+                                          void *adj_hi, void *adj_lo, void *stream);
 
 /* fp16 elements of one plane of a [rows, k] operand (per batch entry). */
 int64_t sn_gcn_plane_elems(int rows, int k);
@@ -431,7 +450,8 @@ typedef struct sn_gemm_args {
     const int32_t *rows_valid;
     const float *pool_w; int64_t pool_w_stride; float *pooled;
     const int32_t *m_extent, *k_extent;   /* device scalars or NULL: row tiles >= *m_extent are skipped (their
-                                             pooled partial is zero), the k loop stops at *k_extent */
+                                             pooled partial is zero), the k loop stops at *k_extent (per graph with
+                                             extent_stride = 1) */
     /* gathered B (optional; then b_hi / b_lo are ignored): Bt[g][f][j] = table[b_ids[g * b_ids_stride + j]][f] for
      * j < b_ids_n, zero for other j and for ids outside [0, b_table_rows).  b_table_hi / _lo: row-major fp16 planes
      * [b_table_rows + 1][256] of the table split as hi + lo, the last row zero.  Needs n == 256, the LayerNorm
@@ -453,6 +473,7 @@ typedef struct sn_gemm_args {
      * Zt * (*out_scale).  Every scale must be a power of two (then all of this is exact) chosen so that the largest
      * magnitude the operand can hold lands at 2^13 .. 2^14: see "precision" above. */
     const float *a_scale, *b_scale, *out_scale, *next_w_scale, *next_h_scale;
+    int extent_stride;            /* 0: m_extent / k_extent are one value for the batch; 1: one per graph ([batches]) */
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 

@@ -485,6 +485,51 @@ def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, r
     return (cv, out, ce) if want_edges else (cv, out)
 
 
+def atlas_adjacency_planes_compact(vertex_weights, edge_weights, prune_threshold, remove_self_loop=False, pruned_rows_are_zero=False):
+    """The fused atlas route for a PRUNED atlas: -> (class_vertices [K, n], Planes of the compacted operand, perm int32 [K, n],
+    n_kept int32 [K]).  perm[k] lists class k's kept vertices (class_vertices > threshold) first, in their own order, then the
+    pruned ones; the operand is (E + E^T)/2 + I of the kept vertices only - an n_kept[k] x n_kept[k] corner, nothing
+    produced beyond its blocks - for `gcn_gemm(..., m_extent = k_extent = rows_valid = n_kept)`.  A pruned vertex has no edge
+    (schema_net.py:152-166 zeroes its row and column): it is an isolated node whose share of the class feature needs no
+    product (GNN.prepare()["iso"]).  edge_weights is pruned IN PLACE like everywhere else.  No host synchronisation.
+    pruned_rows_are_zero: the caller knows that an earlier call on the same versions of both parameters has run."""
+    lib = N.require_gpu()
+    dev = _check_dev(vertex_weights, edge_weights)
+    K, n = vertex_weights.shape
+    assert vertex_weights.is_contiguous() and edge_weights.is_contiguous() and prune_threshold is not None
+    cv = torch.empty((K, n), dtype=torch.float32, device=dev)
+    rs = torch.empty((K, n), dtype=torch.float32, device=dev)
+    out = _alloc_planes(lib, dev, K, n, n)
+    with torch.cuda.device(dev):
+        if pruned_rows_are_zero:                     # (an earlier call on these versions of the parameters has zeroed them: not read again)
+            lib.sn_atlas_skip_pruned_rows(1)
+        N.check(lib.sn_atlas_prune_rowsum(N.ptr(vertex_weights), N.ptr(edge_weights), K, n, 1, float(prune_threshold), N.ptr(cv), N.ptr(rs),
+                                          N.stream_ptr(dev)), "sn_atlas_prune_rowsum")
+        perm = torch.empty((K, n), dtype=torch.int32, device=dev)
+        n_kept = torch.empty((K,), dtype=torch.int32, device=dev)
+        N.check(lib.sn_atlas_keep_perm(N.ptr(cv), K, n, float(prune_threshold), N.ptr(perm), N.ptr(n_kept), N.stream_ptr(dev)), "sn_atlas_keep_perm")
+        N.check(lib.sn_gcn_atlas_adjacency_planes_compact(N.ptr(edge_weights), N.ptr(rs), K, n, int(remove_self_loop), ADJ_SCALE, N.ptr(perm),
+                                                          N.ptr(n_kept), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+                "sn_gcn_atlas_adjacency_planes_compact")
+    out.scale = const_scale(ADJ_SCALE, dev)
+    return cv, out, perm, n_kept
+
+
+def class_compact(perm, n_kept, nodes, ids, iso):
+    """-> (ids_c int64 [K, n], w_c [K, n], pooled_iso [K, E]): see sn_class_compact"""
+    lib = N.require_gpu()
+    dev = _check_dev(perm, n_kept, nodes, ids, iso)
+    K, n = ids.shape
+    nodes, iso, ids = _f32c(nodes), _f32c(iso), ids.contiguous()
+    ids_c = torch.empty((K, n), dtype=torch.int64, device=dev)
+    w_c = torch.empty((K, n), dtype=torch.float32, device=dev)
+    pooled_iso = torch.empty((K, iso.shape[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_class_compact(N.ptr(perm), N.ptr(n_kept), N.ptr(nodes), N.ptr(ids), N.ptr(iso), K, n, iso.shape[1], iso.shape[0],
+                                     N.ptr(ids_c), N.ptr(w_c), N.ptr(pooled_iso), N.stream_ptr(dev)), "sn_class_compact")
+    return ids_c, w_c, pooled_iso
+
+
 # ------------------------------------------------------------------------------- S4
 def gcn_adjacency(edges):
     lib = N.require_gpu()
@@ -718,8 +763,11 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
         out["pooled"] = pooled
     for name, t in (("m_extent", m_extent), ("k_extent", k_extent)):
         if t is not None:
-            assert t.dtype == torch.int32 and t.device == dev
+            assert t.dtype == torch.int32 and t.device == dev and t.numel() in (1, batches)
             setattr(args, name, _dp(t))
+            if t.numel() == batches and batches > 1:         # one extent per graph (compacted class graphs)
+                args.extent_stride = 1
+    assert not args.extent_stride or all(t is None or t.numel() == batches for t in (m_extent, k_extent))
     with torch.cuda.device(dev):
         N.check(lib.sn_gcn_gemm(byref(args), N.stream_ptr(dev)), "sn_gcn_gemm")
     return out

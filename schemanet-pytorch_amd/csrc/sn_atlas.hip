@@ -20,9 +20,12 @@ constexpr int kRowsPerBlock = 16;
 // up to one rounding (one correctly rounded reciprocal per row instead of a division per element)
 __device__ __forceinline__ float row_scale(float s) { return (s > 0.0f && s < INFINITY) ? 1.0f / s : 0.0f; }
 
+// skip_pruned_rows (fused route only): the rows of pruned vertices are KNOWN to be zero - this kernel zeroed them in an
+// earlier launch on the same parameter versions (the host keeps that fact, SchemaNet._pruned_in_place) - and are not read:
+// their row sum is 0.  70 % of a trained atlas.
 __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, float *ew, int n,
                                                               int use_prune, float thr,
-                                                              int remove_self_loop, float *cv, float *ce, float *rowsum)
+                                                              int remove_self_loop, float *cv, float *ce, float *rowsum, int skip_pruned_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *keep = smem;                       // [n] vertex survives pruning
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
         unsigned rowk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) rowk[q] = (!use_prune || (i0 + q < n && keep[i0 + q])) ? 0xFFFFFFFFu : 0u;
+        if (skip_pruned_rows && (rowk[0] | rowk[1] | rowk[2] | rowk[3]) == 0u) {       // wave-uniform: four pruned rows, already zero
+            if (rowsum && lane < 4 && i0 + lane < n) rowsum[(int64_t)k * n + i0 + lane] = 0.0f;
+            return;
+        }
         float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int j0 = 0; j0 < n; j0 += 256) {
             const int j = j0 + lane * 4;
@@ -168,6 +175,105 @@ __global__ __launch_bounds__(256) void atlas_normalize_backward_kernel(const flo
     }
 }
 
+
+// ------------------------------------------------------------------ a pruned atlas, compacted (round 4)
+// perm[k] = the vertices of class k whose normalised weight is above the threshold (the rule of atlas_normalize_kernel:
+// c > thr) first, in their own order, then the pruned ones in theirs (a stable partition); n_kept[k] = how many are kept.
+// One workgroup per class, four consecutive vertices per thread (n <= 1024), a block-wide exclusive scan of the keep flags.
+__global__ __launch_bounds__(256) void atlas_keep_perm_kernel(const float *cv, int n, float thr, int32_t *perm, int32_t *n_kept)
+{
+    __shared__ int wave_tot[4];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float *c = cv + (int64_t)k * n;
+    int keep[4], cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = 4 * tid + e;
+        keep[e] = (i < n && c[i] > thr) ? 1 : 0;
+        cnt += keep[e];
+    }
+    int incl = cnt;                                     // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < SN_WAVE; off <<= 1) {
+        const int up = __shfl_up(incl, off, SN_WAVE);
+        if (lane >= off) incl += up;
+    }
+    if (lane == SN_WAVE - 1) wave_tot[wid] = incl;
+    __syncthreads();
+    int before = incl - cnt;
+    for (int w = 0; w < wid; ++w) before += wave_tot[w];
+    const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    if (tid == 0) n_kept[k] = total;
+    int32_t *p = perm + (int64_t)k * n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = 4 * tid + e;
+        if (i >= n) break;
+        if (keep[e]) p[before] = i;
+        else p[total + (i - before)] = i;               // (i - before) = pruned vertices in front of i
+        before += keep[e];
+    }
+}
+
+// What the GNN needs of a compacted class graph: the words and node weights in the operand's vertex order (weights zero
+// beyond the class's extent - those vertices are not in the products) and the isolated vertices' share of the pooled
+// feature, pooled_iso[k][f] = sum over the pruned vertices a of class k, in perm order, of w_a * iso[word_a][f] (iso: what an
+// isolated vertex of a word contributes per unit of weight, GNN.prepare()).  One workgroup per class; thread = feature.
+__global__ __launch_bounds__(256) void class_compact_kernel(const int32_t *perm, const int32_t *n_kept, const float *nodes, const int64_t *ids,
+                                                            const float *iso, int n, int E, int rows_iso, int64_t *ids_c, float *w_c,
+                                                            float *pooled_iso)
+{
+    __shared__ int id_s[1024];
+    __shared__ float w_s[1024];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int nk = min(max(n_kept[k], 0), n);
+    for (int a = tid; a < n; a += 256) {
+        const int p = perm[(int64_t)k * n + a];
+        const int64_t id = ids[(int64_t)k * n + p];
+        const float w = nodes[(int64_t)k * n + p];
+        ids_c[(int64_t)k * n + a] = id;
+        w_c[(int64_t)k * n + a] = a < nk ? w : 0.0f;
+        id_s[a] = (id >= 0 && id < rows_iso) ? (int)id : -1;
+        w_s[a] = w;
+    }
+    __syncthreads();
+    // wave w takes the pruned vertices nk + w, nk + w + 4, ... (a fixed order: the same sums in every launch), lane l the
+    // features 4 l .. 4 l + 3 of a 256-feature slab - one 16-byte load per lane = one whole row segment per wave-instruction,
+    // four rows in flight; the four waves' partial sums meet in LDS.  (First form: thread = feature walking every pruned
+    // vertex in turn, one dependent 4-byte load each - 75 us for 100 classes x 360 vertices, more than the products it saves.)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ f32x4 part[4][64];
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int f0 = 0; f0 < E; f0 += 256) {
+        const int f = f0 + 4 * lane;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (f < E) {                                    // (E a multiple of 4)
+            for (int a0 = nk + wid; a0 < n; a0 += 16) {
+                f32x4 v[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int a = a0 + 4 * u;
+                    const int id = a < n ? id_s[a] : -1;
+                    w[u] = id >= 0 ? w_s[a] : 0.0f;
+                    v[u] = *reinterpret_cast<const f32x4 *>(iso + (int64_t)(id >= 0 ? id : 0) * E + f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[u], v[u][q], acc[q]);
+            }
+        }
+        __syncthreads();                                // (the previous slab's partial sums have been read)
+        part[wid][lane] = acc;
+        __syncthreads();
+        if (wid == 0 && f < E) {
+            const f32x4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+            *reinterpret_cast<f32x4 *>(pooled_iso + (int64_t)k * E + f) = t;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sn_atlas_normalize(const float *vertex_weights, float *edge_weights, int K, int n,
@@ -183,7 +289,7 @@ extern "C" int sn_atlas_normalize(const float *vertex_weights, float *edge_weigh
     const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
     sn_prof_start(3, (hipStream_t)stream);
     hipLaunchKernelGGL(atlas_normalize_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights,
-                       edge_weights, n, use_prune, prune_threshold, remove_self_loop, class_vertices, class_edges, (float *)nullptr);
+                       edge_weights, n, use_prune, prune_threshold, remove_self_loop, class_vertices, class_edges, (float *)nullptr, 0);
     sn_prof_stop(3, (hipStream_t)stream);
     SN_CHECK_LAUNCH("sn_atlas_normalize");
     return SN_OK;
@@ -192,9 +298,17 @@ extern "C" int sn_atlas_normalize(const float *vertex_weights, float *edge_weigh
 /* First half of the fused atlas -> adjacency route: vertices, in-place pruning and the row sums of the
  * clamped edge weights; the normalised edges themselves are never materialised
  * (sn_gcn_atlas_adjacency_planes applies the division while it builds the GCN operand). */
+static int g_skip_pruned_rows = 0;     // set by sn_atlas_skip_pruned_rows for the NEXT sn_atlas_prune_rowsum call of this thread's caller
+
+/* The next sn_atlas_prune_rowsum may leave the rows of pruned vertices unread (they are zero: an earlier call on the same
+ * versions of both parameters zeroed them).  One-shot: cleared by that call. */
+extern "C" void sn_atlas_skip_pruned_rows(int on) { g_skip_pruned_rows = on; }
+
 extern "C" int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,
                                      float prune_threshold, float *class_vertices, float *row_sum, void *stream)
 {
+    const int skip = g_skip_pruned_rows && use_prune;
+    g_skip_pruned_rows = 0;
     SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_atlas_prune_rowsum: bad K=%d n=%d", K, n);
     if (K == 0) return SN_OK;
     SN_REQUIRE(vertex_weights && edge_weights && row_sum, SN_ERR_BAD_ARG, "sn_atlas_prune_rowsum: NULL pointer");
@@ -204,7 +318,7 @@ extern "C" int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_we
     const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
     sn_prof_start(3, (hipStream_t)stream);
     hipLaunchKernelGGL(atlas_normalize_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights, edge_weights, n, use_prune,
-                       prune_threshold, 0, class_vertices, (float *)nullptr, row_sum);
+                       prune_threshold, 0, class_vertices, (float *)nullptr, row_sum, skip);
     sn_prof_stop(3, (hipStream_t)stream);
     SN_CHECK_LAUNCH("sn_atlas_prune_rowsum");
     return SN_OK;
@@ -227,5 +341,32 @@ extern "C" int sn_atlas_normalize_backward(const float *vertex_weights, const fl
     hipLaunchKernelGGL(atlas_normalize_backward_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights, edge_weights,
                        grad_class_edges, n, use_prune, prune_threshold, remove_self_loop, grad_edge_weights);
     SN_CHECK_LAUNCH("sn_atlas_normalize_backward");
+    return SN_OK;
+}
+
+/* A pruned atlas, compacted (see sn_gcn_atlas_adjacency_planes_compact): perm [K, n] int32 = class k's kept vertices
+ * (class_vertices[k][i] > prune_threshold) first, in their own order, then the pruned ones; n_kept [K].  n <= 1024. */
+extern "C" int sn_atlas_keep_perm(const float *class_vertices, int K, int n, float prune_threshold, int32_t *perm, int32_t *n_kept, void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0 && n <= 1024, SN_ERR_BAD_ARG, "sn_atlas_keep_perm: bad K=%d n=%d (n <= 1024)", K, n);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(class_vertices && perm && n_kept, SN_ERR_BAD_ARG, "sn_atlas_keep_perm: NULL pointer");
+    hipLaunchKernelGGL(atlas_keep_perm_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, class_vertices, n, prune_threshold, perm, n_kept);
+    SN_CHECK_LAUNCH("sn_atlas_keep_perm");
+    return SN_OK;
+}
+
+/* ids_c [K, n] int64 / w_c [K, n]: class_ingredients / node weights in the compacted operand's vertex order (w_c zero beyond
+ * n_kept[k]); pooled_iso [K, E]: sum over class k's pruned vertices of weight * iso[word] (iso [rows_iso, E] fp32: the
+ * per-word feature of an isolated vertex).  n <= 1024. */
+extern "C" int sn_class_compact(const int32_t *perm, const int32_t *n_kept, const float *nodes, const int64_t *ids, const float *iso, int K, int n,
+                                int E, int rows_iso, int64_t *ids_c, float *w_c, float *pooled_iso, void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0 && n <= 1024 && E > 0 && rows_iso > 0, SN_ERR_BAD_ARG, "sn_class_compact: bad K=%d n=%d E=%d", K, n, E);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(perm && n_kept && nodes && ids && iso && ids_c && w_c && pooled_iso, SN_ERR_BAD_ARG, "sn_class_compact: NULL pointer");
+    hipLaunchKernelGGL(class_compact_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, perm, n_kept, nodes, ids, iso, n, E, rows_iso,
+                       ids_c, w_c, pooled_iso);
+    SN_CHECK_LAUNCH("sn_class_compact");
     return SN_OK;
 }

@@ -62,6 +62,7 @@ constexpr int kRing = 3;                // LDS stages: two in flight behind the 
 constexpr int kGemmThreads = 256;
 constexpr int kDmaPerWave = (kChunksA + kChunksB) / (kGemmThreads / 64);     // 6
 constexpr int kBlockElems = 512;        // fp16 elements of one 32-row x 16-k block (1 KiB)
+constexpr int kMaxPerm = 1024;          // vertices per class graph the compacted atlas producer stages a permutation for
 
 // Operand planes are stored BLOCKED, in the order the MFMA consumes them: plane[g][row >> 5][k >> 4] is a
 // 1 KiB block holding element (row, k) at ((k >> 3 & 1) * 32 + (row & 31)) * 8 + (k & 7) - i.e. lane
@@ -117,19 +118,28 @@ __device__ __forceinline__ float saturate_f16_range(float x)
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
                                                                const int32_t *extent, const int32_t *n_valid, int pair_tiles, float scale,
-                                                               float *edges_out)
+                                                               float *edges_out, const int32_t *perm, int ext_stride)
 {
     __shared__ float te[64][65], tt[64][65];
     __shared__ float rs_i[64], rs_j[64];
+    // `perm` (compacted class graphs, round 4; n <= kMaxPerm): vertex a of the operand is vertex perm[g][a] of the stored graph
+    // - the kept vertices of a pruned IR-Atlas class first, in their own order -, extent / n_valid are then per graph
+    // (ext_stride 1): the operand is the n_kept x n_kept corner + identity, rows and k beyond the class's own extent are
+    // neither produced nor read by sn_gcn_gemm.  Staged once per workgroup.
+    __shared__ int perm_s[kMaxPerm];
     const int g = blockIdx.y;
+    if (perm) {
+        for (int i = threadIdx.x; i < n; i += 256) perm_s[i] = perm[(int64_t)g * n + i];
+        __syncthreads();
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float *e = edges + (int64_t)g * n * n;
     // elements outside the graph's own nv x nv corner count as 0 and are not read (their storage may be unwritten);
     // the identity below still covers all n rows
     const int nv = n_valid ? min(max(n_valid[g], 0), n) : n;
     int rows_lim = (n + 31) & ~31, k_lim = kb_count * 16;
-    if (extent) {                                              // nothing beyond the largest graph of the batch is ever read
-        const int ext = *extent;
+    if (extent) {                                              // nothing beyond the largest graph of the batch (ext_stride 1: of this graph) is ever read
+        const int ext = extent[(int64_t)g * ext_stride];
         rows_lim = min(rows_lim, (ext + 31) & ~31);
         k_lim = min(k_lim, (ext + 15) & ~15);
     }
@@ -170,18 +180,22 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
     auto fetch = [&](int I, int J) {
         const int bi = I * 64, bj = J * 64;
         if (rowsum && threadIdx.x < 64) {
-            rsi = bi + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bi + threadIdx.x] : 0.0f;
-            rsj = bj + (int)threadIdx.x < n ? rowsum[(int64_t)g * n + bj + threadIdx.x] : 0.0f;
+            const int ri = bi + (int)threadIdx.x, rj = bj + (int)threadIdx.x;
+            rsi = ri < n ? rowsum[(int64_t)g * n + (perm ? perm_s[ri] : ri)] : 0.0f;
+            rsj = rj < n ? rowsum[(int64_t)g * n + (perm ? perm_s[rj] : rj)] : 0.0f;
         }
+        const int pj = perm ? perm_s[min(bj + tx, n - 1)] : bj + tx, pj2 = perm ? perm_s[min(bi + tx, n - 1)] : bi + tx;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int rr = ty + 4 * it;
             const int i = bi + rr, j = bj + tx;
             const bool ok = i < nv && j < nv;
-            ve[it] = e[ok ? (int64_t)i * n + j : 0];                      // E[I][J] tile, [i - bi][j - bj]
+            const int pi = perm ? perm_s[min(i, n - 1)] : i;
+            ve[it] = e[ok ? (int64_t)pi * n + pj : 0];                    // E[I][J] tile, [i - bi][j - bj]
             const int i2 = bj + rr, j2 = bi + tx;
             const bool ok2 = i2 < nv && j2 < nv;
-            vt[it] = e[ok2 ? (int64_t)i2 * n + j2 : 0];                   // E[J][I] tile, [j - bj][i - bi]
+            const int pi2 = perm ? perm_s[min(i2, n - 1)] : i2;
+            vt[it] = e[ok2 ? (int64_t)pi2 * n + pj2 : 0];                 // E[J][I] tile, [j - bj][i - bi]
             ve[it] = ok ? ve[it] : 0.0f;
             vt[it] = ok2 ? vt[it] : 0.0f;
         }
@@ -477,6 +491,7 @@ struct GemmArgs {
     float *pooled;
     int batches, tiles_x, tiles_y;   // logical grid (the launch is 1-D, see the XCD remap in the kernel)
     const int32_t *m_extent, *k_extent;   // device scalars (or NULL): rows / k beyond them are never consumed downstream
+    int ext_stride;                       // 0: one value for the batch; 1: per graph (m_extent[batch], k_extent[batch])
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
     int nt_a, nt_b;                  // stream that operand past the caches (read once by one workgroup)
     // gathered B (GB kernels): Bt[g][f][j] = table[ids[g][j]][f] from row-major fp16 hi/lo tables [tab_rows + 1][256]
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     int fl_first = 0, fl_last = 2;
     if constexpr (FL) {
         if (p.m_extent && p.tiles_x == 1 && p.fl_twin) {
-            const int t_real = (*p.m_extent + kTileM - 1) / kTileM, ty = tile;
+            const int t_real = (p.m_extent[(int64_t)batch * p.ext_stride] + kTileM - 1) / kTileM, ty = tile;
             if (t_real > 0 && p.tiles_y >= 2 * t_real) {
                 if (ty < t_real) fl_last = 1;
                 else if (ty < 2 * t_real) { tile_m_ = (ty - t_real) * kTileM; fl_first = 1; }
@@ -546,7 +561,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         }
     }
     const int tile_m = tile_m_, tile_n = (tile % p.tiles_x) * kTileN;
-    if (p.m_extent && tile_m >= *p.m_extent) {                 // a row tile past the largest graph of the batch
+    if (p.m_extent && tile_m >= p.m_extent[(int64_t)batch * p.ext_stride]) {      // a row tile past the largest graph of the batch (ext_stride 1: past this graph)
         if (p.pooled && tid + tile_n < p.n) p.pooled[((int64_t)batch * p.tiles_y + tile / p.tiles_x) * p.n + tile_n + tid] = 0.0f;
         return;
     }
@@ -628,7 +643,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
     int n_stages = kb_count;
-    if (p.k_extent) { const int lim = (*p.k_extent + kStageK - 1) / kStageK; n_stages = lim < n_stages ? lim : n_stages; }
+    if (p.k_extent) { const int lim = (p.k_extent[(int64_t)batch * p.ext_stride] + kStageK - 1) / kStageK; n_stages = lim < n_stages ? lim : n_stages; }
     unsigned long long t_begin = 0, t_wait = 0, t_issue = 0, t_loop_end = 0;
     if (p.stamps) t_begin = __builtin_amdgcn_s_memtime();
 #pragma unroll
@@ -1057,7 +1072,7 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const i
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                        sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
-                       (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr);
+                       (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
@@ -1074,7 +1089,7 @@ extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, 
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr);
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
     return SN_OK;
 }
@@ -1092,8 +1107,31 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     adjacency_grid(n, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, pair_tiles, scale, class_edges_out);
+                       (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
+    return SN_OK;
+}
+
+/* The same for a PRUNED atlas, compacted: vertex a of class k's operand is vertex perm[k][a] of the stored graph (the kept
+ * vertices first), only its n_kept[k] x n_kept[k] corner (+ identity) is produced - rounded up to the 32 x 16 blocks, the
+ * rest of a block zero - and sn_gcn_gemm consumes it with per-graph extents (extent_stride 1). */
+extern "C" int sn_gcn_atlas_adjacency_planes_compact(const float *pruned_edge_weights, const float *row_sum, int K, int n, int remove_self_loop,
+                                                     float scale, const int32_t *perm, const int32_t *n_kept, void *adj_hi, void *adj_lo,
+                                                     void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes_compact: bad K=%d n=%d", K, n);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(pruned_edge_weights && row_sum && adj_hi && adj_lo && perm && n_kept, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes_compact: NULL pointer");
+    SN_REQUIRE(n <= kMaxPerm, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes_compact: n=%d > %d", n, kMaxPerm);
+    SN_REQUIRE(scale > 0.0f && scale <= 65536.0f, SN_ERR_BAD_ARG, "sn_gcn_atlas_adjacency_planes_compact: scale %g (a power of two in (0, 65536])", (double)scale);
+    SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes_compact: K=%d > 65535", K);
+    const int kb = (n + 15) / 16;
+    unsigned tiles; int pair_tiles;
+    adjacency_grid(n, tiles, pair_tiles);
+    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+                       kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, n_kept,
+                       n_kept, pair_tiles, scale, (float *)nullptr, perm, 1);
+    SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes_compact");
     return SN_OK;
 }
 
@@ -1214,7 +1252,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.bias = u->bias; a.gamma = u->gamma; a.beta = u->beta; a.eps = u->eps; a.relu = u->relu;
     a.rows_valid = u->rows_valid; a.pool_w = u->pool_w; a.pool_w_stride = u->pool_w_stride; a.pooled = u->pooled;
     a.stamps = g_gemm_stamps;
-    a.m_extent = u->m_extent; a.k_extent = u->k_extent;
+    a.m_extent = u->m_extent; a.k_extent = u->k_extent; a.ext_stride = u->extent_stride != 0 ? 1 : 0;
     a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
     a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows; a.tab_ld = u->n;
     a.w2_hi = (const _Float16 *)u->next_w_hi; a.w2_lo = (const _Float16 *)u->next_w_lo;

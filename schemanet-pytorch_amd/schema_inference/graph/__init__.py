@@ -142,7 +142,9 @@ class SchemaNetPredictor(nn.Module):
             # this path - from the same pass when the caller is going to look at it (requires_graph, `lazy_class_edges`
             # off), otherwise deferred until read (LazyOutputs: 105 MB less written per call at config [1])
             lazy_edges = self.lazy_class_edges and not requires_graph
-            mode = True if lazy_edges else "with_edges"
+            # (a pruned atlas: the operand compacted to the kept vertices of each class - SchemaNet.get_atlas; the fully fused
+            # GNN route only, and only where `class_edges` is not wanted from the same pass)
+            mode = ("compact" if self.matcher.gnn.embed_dim == 256 else True) if lazy_edges else "with_edges"
             get_atlas = lambda: self.schema_net.get_atlas(fused_adjacency=mode)       # noqa: E731
         # (S1: one call at a time the fp64 finish of the undecided tokens rides in the instance-graph kernel - `rerank` in
         # `output` -, with several batches in flight (`predict_batches`, side_stream False) it stays a launch of its own: the

@@ -173,7 +173,8 @@ class GNN(nn.Module):
         # weight-only operands: kept until one of the four weights changes (data_ptr / _version, like the packed codebook
         # of S1; `p.data.copy_` writes need `invalidate_prepared()`), so a forward pass launches no library GEMM
         srcs = (self.embedding.weight, l1.g_conv.linear.weight, l2.g_conv.linear.weight, self.fc.weight,
-                l1.norm.weight, l1.norm.bias, l2.norm.weight, l2.norm.bias)       # (the LayerNorm parameters: the operand scales)
+                l1.norm.weight, l1.norm.bias, l2.norm.weight, l2.norm.bias,       # (the LayerNorm parameters: the operand scales)
+                l1.g_conv.linear.bias, l2.g_conv.linear.bias)                     # (... and the biases: the isolated-vertex table)
         fused_gather = self.embed_dim % 256 == 0 and os.environ.get("SN_GCN_GATHER_FUSED", "1") == "1"
         fused_linear = self.embed_dim == 256 and os.environ.get("SN_GCN_FUSE_LINEAR", "1") == "1"
         key = tuple((t.data_ptr(), t._version, t.device) for t in srcs) + (fused_gather, fused_linear)
@@ -195,6 +196,17 @@ class GNN(nn.Module):
                "h1_scale": ops.pow2_scale(h1_bound), "h2_scale": ops.pow2_scale(ln_bound(l2.norm)),
                "zt2_scale": ops.pow2_scale(h1_bound * w2.abs().sum(dim=1).amax()),
                "fc_t": self.fc.weight.detach().t().contiguous()}                      # [E, E_out]: ops.pool_fc reads whole lines of it
+        # What an ISOLATED vertex of word w contributes to its graph's pooled feature, per unit of node weight: with no edge
+        # its adjacency row is the identity, so both products pass its own row through - H2 = act(LN2(W2 act(LN1(table[w] +
+        # b1)) + b2)), a function of the word only.  The pruned vertices of a trained IR-Atlas are such nodes
+        # (schema_net.py:152-166 zeroes their rows and columns): the compacted class branch (forward(..., compact=)) leaves
+        # them out of its products and adds sum_i w_i iso[word_i] instead.  [M + 1, E], once per weight version.
+        with torch.no_grad():
+            h = torch.nn.functional.layer_norm(table + l1.g_conv.linear.bias, (self.embed_dim,), l1.norm.weight, l1.norm.bias, l1.norm.eps)
+            h = torch.relu(h) if l1._is_relu else h
+            h = torch.nn.functional.linear(h, l2.g_conv.linear.weight, l2.g_conv.linear.bias)
+            h = torch.nn.functional.layer_norm(h, (self.embed_dim,), l2.norm.weight, l2.norm.bias, l2.norm.eps)
+            out["iso"] = (torch.relu(h) if l2._is_relu else h).contiguous()
         if fused_gather:
             # layer 1 gathers its B operand inside the GEMM: 170 MB less HBM traffic and 20 us less kernel time per step
             # (+4 % with four in-line steps in flight, +3 % one step at a time; SN_GCN_GATHER_FUSED=0 = the
@@ -210,7 +222,16 @@ class GNN(nn.Module):
     def invalidate_prepared(self):
         self._prepared = None
 
-    def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None):
+    @staticmethod
+    def _compacted(nodes, ingredients, compact, iso):
+        """class graphs whose operand holds their kept vertices only (SchemaNet.get_atlas(fused_adjacency="compact")):
+        -> (ids and node weights in the operand's vertex order - weights zero beyond a graph's extent -, the per-graph extents,
+        and the isolated vertices' share of the pooled feature [G, 1, E])"""
+        perm, n_kept = compact
+        ids_c, w_c, pooled_iso = ops.class_compact(perm, n_kept, nodes, ingredients, iso)
+        return ids_c, w_c, n_kept, pooled_iso[:, None, :]
+
+    def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None, compact=None):
         """Inference on the matrix cores: three GEMM launches per call, every elementwise step an
         epilogue (bias, pad-row mask, LayerNorm, ReLU, hi/lo split, node-weighted pooling).
             H1     = act(LN1(adj @ (Emb @ W1^T)[ids] + b1))
@@ -227,6 +248,10 @@ class GNN(nn.Module):
             adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)                       # A  [G, n, n]
         if prepared is None:
             prepared = self.prepare()
+        pooled_iso = None
+        if compact is not None:                          # (class graphs of a pruned atlas: per-graph extents)
+            ingredients, nodes, ext, pooled_iso = self._compacted(nodes, ingredients, compact, prepared["iso"])
+            n_valid = ext
         if "table_planes" in prepared and adj.kpad <= 1024:
             # Bt[g, f, j] = table[ids[g, j], f] gathered inside the kernel (no [G, E, n] copy through HBM)
             t_hi, t_lo = prepared["table_planes"]
@@ -248,9 +273,11 @@ class GNN(nn.Module):
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
                               rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext)["pooled"]   # [G, row tiles, E]
+        if pooled_iso is not None:
+            pooled = torch.cat([pooled, pooled_iso], dim=1)       # (one more partial sum: the isolated vertices)
         return ops.pool_fc(pooled, divisor if divisor is not None else n, self.fc.weight, self.fc.bias, weight_t=prepared.get("fc_t"))
 
-    def _forward_mfma_wide(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None):
+    def _forward_mfma_wide(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None, compact=None):
         """embed_dim != 256: a row of the result spans several 256-column tiles, so LayerNorm cannot be an epilogue of
         the GEMM.  Same three products on the matrix cores (split fp16, fp32-GEMM accuracy), fp32 results; mask + LayerNorm +
         activation run inside the pass that splits H1 for the next product, and inside the pooling pass for H2."""
@@ -261,6 +288,8 @@ class GNN(nn.Module):
             adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)
         if prepared is None:
             prepared = self.prepare()
+        if compact is not None:
+            raise RuntimeError("compacted class graphs need the fully fused route (embed_dim 256)")
         if "table_planes" in prepared and adj.kpad <= 1024:
             # Bt[g, f, j] = table[ids[g, j], f] gathered inside the product, each 256-column tile its own slice of the table rows
             # (round 4: the [G, E, n] planes - 2.1 GB at config [3] - are neither written nor read back)
@@ -282,7 +311,7 @@ class GNN(nn.Module):
 
     def forward(self, nodes: torch.Tensor, edges: torch.Tensor, ingredients: torch.LongTensor,
                 feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None,
-                divisor: Optional[torch.Tensor] = None, adjacency=None, prepared=None) -> torch.Tensor:
+                divisor: Optional[torch.Tensor] = None, adjacency=None, prepared=None, compact=None) -> torch.Tensor:
         """nodes [G, n], edges [G, n, n], ingredients [G, n] -> graph feature [G, embed_dim].
 
         feat_mask (bool [G, n], True = padding) is the reference argument (gnn.py:78-98).
@@ -294,7 +323,7 @@ class GNN(nn.Module):
             if not (nodes.is_cuda and self._mfma_ok()) or self._differentiable(nodes):
                 raise RuntimeError("adjacency planes need the inference MFMA path (2 Linear layers, embed_dim a multiple of 16, no autograd)")
             run = self._forward_mfma if self.embed_dim == 256 else self._forward_mfma_wide
-            return run(nodes, None, ingredients, n_valid, divisor, adj=adjacency, prepared=prepared)
+            return run(nodes, None, ingredients, n_valid, divisor, adj=adjacency, prepared=prepared, compact=compact)
         fused = nodes.is_cuda and not self._differentiable(nodes, edges)
         if n_valid is None and feat_mask is not None:
             n_valid = (~feat_mask).sum(dim=1).to(torch.int32)   # masks are suffix masks (match.py:48-51)

@@ -69,8 +69,9 @@ class Matcher(nn.Module):
     def atlas_features(self, class_dict: Dict[str, torch.Tensor], prepared=None) -> torch.Tensor:
         """GNN over the K class graphs -> [K, E]  (reference match.py:66-70)."""
         if "class_adjacency" in class_dict:          # fused atlas route (no class_edges tensor)
+            compact = (class_dict["class_perm"], class_dict["class_n_kept"]) if "class_perm" in class_dict else None
             return self.gnn(nodes=class_dict["class_vertices"], edges=None, ingredients=class_dict["class_ingredients"],
-                            adjacency=class_dict["class_adjacency"], prepared=prepared)
+                            adjacency=class_dict["class_adjacency"], prepared=prepared, compact=compact)
         return self.gnn(nodes=class_dict["class_vertices"], edges=class_dict["class_edges"],
                         ingredients=class_dict["class_ingredients"], prepared=prepared)
 

@@ -181,10 +181,25 @@ class SchemaNet(nn.Module):
         fused_adjacency=True (inference only) skips the [K, n, n] `class_edges` tensor: the dict
         then carries `class_adjacency` = the GCN operand (E + E^T)/2 + I as split-fp16 planes, built
         straight from the pruned parameters (same values, one pass less over the atlas); `Matcher`
-        consumes it directly.  fused_adjacency="with_edges": both - `class_edges` is written by the same pass (within
+        consumes it directly.  fused_adjacency="compact": the same for a pruned atlas with the operand compacted to the kept
+        vertices of each class (ops.atlas_adjacency_planes_compact; falls back to True where it does not apply).
+        fused_adjacency="with_edges": both - `class_edges` is written by the same pass (within
         one rounding of the unfused route: w * (1 / row sum) instead of w / row sum); what SchemaNetPredictor uses."""
         vw, ew = self.vertex_weights.tensor, self.edge_weights.tensor
         if fused_adjacency and vw.is_cuda and (detach or not self._needs_grad(vw, ew)):
+            if (fused_adjacency == "compact" and self.prune_node_threshold is not None and vw.shape[1] <= 1024
+                    and os.environ.get("SN_ATLAS_COMPACT", "1") != "0" and self._atlas_is_pruned()):
+                # a pruned atlas, compacted: the operand holds the kept vertices of every class only (class_perm / class_n_kept
+                # say which); `Matcher` adds the isolated vertices' share of the class feature without a product
+                # (the in-place pruning is idempotent: once it has run on these versions of the two parameters the rows of the
+                # pruned vertices are zero and are not read again - a weight-only fact like the packed codebook of S1)
+                pkey = (vw.data_ptr(), vw._version, ew.data_ptr(), ew._version, self.prune_node_threshold)
+                cv, adj, perm, n_kept = ops.atlas_adjacency_planes_compact(vw.detach(), ew.detach(), self.prune_node_threshold,
+                                                                           self.remove_self_loop,
+                                                                           pruned_rows_are_zero=getattr(self, "_pruned_in_place", None) == pkey)
+                self._pruned_in_place = pkey
+                return {"class_vertices": cv, "class_adjacency": adj, "class_ingredients": self.class_ingredients.tensor,
+                        "class_perm": perm, "class_n_kept": n_kept}
             if fused_adjacency == "with_edges":      # the reference's dictionary AND the GCN operand from one pass over the atlas
                 cv, adj, ce = ops.atlas_adjacency_planes(vw.detach(), ew.detach(), self.prune_node_threshold, self.remove_self_loop,
                                                          want_edges=True)
@@ -197,6 +212,25 @@ class SchemaNet(nn.Module):
         else:
             cv, ce = self.get_class_vertices(detach), self.get_class_edges(detach)
         return {"class_vertices": cv, "class_edges": ce, "class_ingredients": self.class_ingredients.tensor}
+
+    def _atlas_is_pruned(self) -> bool:
+        """Does any class have a vertex under prune_node_threshold?  (A freshly initialised atlas has none: the compacted
+        route would only add its bookkeeping launches.)  One host synchronisation per VERSION of vertex_weights - like the
+        packed codebook of S1 a weight-only fact, looked up from then on; `p.data` writes: `invalidate_pruned_flag()`."""
+        vw = self.vertex_weights.tensor
+        key = (vw.data_ptr(), vw._version, vw.device)
+        if getattr(self, "_pruned_flag", None) is None or self._pruned_flag[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return False                                    # (cannot ask the device now: the plain route is always right)
+            with torch.no_grad():
+                c = vw.detach().clamp_min(1.0e-5)
+                c = (c / c.sum(dim=-1, keepdim=True)).nan_to_num(0)
+                self._pruned_flag = (key, bool((c <= float(self.prune_node_threshold)).any().item()))
+        return self._pruned_flag[1]
+
+    def invalidate_pruned_flag(self):
+        self._pruned_flag = None
+        self._pruned_in_place = None
 
     # ------------------------------------------------------------------ initialisation path
     def _dev(self) -> torch.device:

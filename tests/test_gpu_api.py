@@ -547,6 +547,79 @@ def test_c5_real_size_forward_matches_cpu_pipeline(mods):
     _report("c5_real_size_forward.json", {"shape": {"B": B, "M": M, "K": K, "n_max": M, "E": E}, "max_rel_err_above_floor": rel, "vs_fp64": vs64})
 
 
+# =============================================================================== a pruned IR-Atlas, compacted
+@pytest.mark.parametrize("case", ["seventy_percent", "one_vertex_left_and_nothing_pruned"])
+def test_compacted_class_graphs_of_a_pruned_atlas(mods, case):
+    """A trained IR-Atlas is sparse: the loss's entropy terms push most vertices of a class under prune_node_threshold
+    (reference schema_net.py:152-166), their rows and columns of the class graph are zeroed - isolated nodes.
+    `get_atlas(fused_adjacency="compact")` builds the GCN operand from the kept vertices of each class only (per-class
+    extents), `GNN` adds the isolated vertices' share of the class feature from a per-word table.  Against the reference's
+    forward on the host in fp32 and fp64 (oracle/cpu_pipeline.py): scores within 1e-5 and no further from fp64 than the
+    reference's own fp32; and against the uncompacted route of this package."""
+    from oracle import cpu_pipeline
+    from test_gpu_parity import as_good_as_fp32_reference
+    graph = mods["graph"]
+    K, M, E, B, L = 8, 512, 256, 5, 196
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(3)
+    sn = graph.SchemaNet(num_vertices=M, num_classes=K, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0, prune_node_threshold=0.001)
+    sn.register_class_vertices(torch.stack([torch.randperm(M, generator=g) for _ in range(K)]))
+    with torch.no_grad():
+        vw = torch.rand(K, M, generator=g)
+        low = torch.rand(K, M, generator=g) < 0.7                           # ~70 % of every class under the threshold
+        if case == "one_vertex_left_and_nothing_pruned":
+            low[0] = True
+            low[0, 17] = False                                              # ONE vertex kept: the class is its isolated nodes + one
+            low[1] = False                                                  # nothing pruned (1 / 512 > threshold for equal weights)
+            vw[1] = 0.5
+        vw = torch.where(low, vw * 1.0e-4, vw)
+        sn.vertex_weights.tensor.copy_(vw)
+        sn.edge_weights.tensor.copy_(torch.rand(K, M, M, generator=g) * (torch.rand(K, M, M, generator=g) > 0.3))
+    m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu"))
+    with torch.no_grad():
+        for layer in m.gnn.layers:
+            layer.norm.weight.uniform_(0.5, 1.5); layer.norm.bias.uniform_(-0.5, 0.5)
+    sizes = [L, 1, 77, 130, 150][:B]
+    inst_ids = [torch.randperm(M, generator=g)[:s_].sort().values for s_ in sizes]
+    inst_v = [torch.rand(s_, generator=g) for s_ in sizes]
+    inst_e = []
+    for s_ in sizes:
+        e = torch.rand(s_, s_, generator=g) * (torch.rand(s_, s_, generator=g) > 0.5)
+        inst_e.append((e / e.sum(-1, keepdim=True)).nan_to_num(0))
+    P = {"gnn." + k: v.detach().clone() for k, v in m.gnn.state_dict().items()}
+    with torch.no_grad():
+        cv, ce = cpu_pipeline.get_atlas(sn.vertex_weights.tensor.detach().clone(), sn.edge_weights.tensor.detach().clone())
+        ci = sn.class_ingredients.tensor.clone()
+        frac = float((cv <= 0.001).float().mean())
+        assert frac > 0.5 if case == "seventy_percent" else bool((cv[0] > 0.001).sum() == 1 and (cv[1] > 0.001).all())
+
+        def host(dtype):
+            Pd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in P.items()}
+            return cpu_pipeline.matcher(Pd, [x.clone() for x in inst_ids], [x.to(dtype) for x in inst_v], [x.to(dtype) for x in inst_e],
+                                        cv.to(dtype), ce.to(dtype), ci, M)
+        ref32, ref64 = host(torch.float32), host(torch.float64)
+        sn, m = sn.to(DEV).eval(), m.to(DEV).eval()
+        inst = {"instance_ingredients": [x.to(DEV) for x in inst_ids], "instance_vertices": [x.to(DEV) for x in inst_v],
+                "instance_edges": [x.to(DEV) for x in inst_e]}
+        assert sn._atlas_is_pruned()
+        atlas_c = sn.get_atlas(fused_adjacency="compact")
+        assert "class_perm" in atlas_c and atlas_c["class_n_kept"].tolist() == (cv > 0.001).sum(1).tolist()
+        got_c = m(inst, atlas_c).cpu()
+        # a second pass on the same parameter versions leaves the rows of the pruned vertices unread (zeroed in place by the
+        # first): the same operand, the same scores
+        assert sn._pruned_in_place is not None
+        atlas_c2 = sn.get_atlas(fused_adjacency="compact")
+        assert torch.equal(atlas_c2["class_n_kept"], atlas_c["class_n_kept"]) and torch.equal(atlas_c2["class_perm"], atlas_c["class_perm"])
+        assert torch.equal(m(inst, atlas_c2).cpu(), got_c)                  # (blocks of the operand beyond a class's extent are never written: compare what is consumed)
+        got_p = m(inst, sn.get_atlas(fused_adjacency=True)).cpu()
+    scores_close(got_c, ref32, "compacted atlas vs the reference forward")
+    vs64 = as_good_as_fp32_reference(got_c, ref32, ref64, "compacted atlas")
+    scale = float(ref64.abs().max())
+    assert float((got_c - got_p).abs().max()) <= 2e-6 * scale                # the two routes of this package: fp32 summation order apart
+    _report(f"compacted_atlas_{case}.json", {"pruned_fraction": frac, "vs_fp64": vs64,
+                                             "max_diff_compact_vs_plain_over_scale": float((got_c - got_p).abs().max()) / scale})
+
+
 # =============================================================================== split-fp16 GCN outside its comfort zone
 def _stress_case(name):
     """(K, n_cls, M, B, E, make_params(m), make_class_edges(g)) of one stress shape"""
