@@ -6,6 +6,13 @@ import os
 from ctypes import byref, c_void_p, pointer
 
 import torch
+from torch.amp import custom_bwd, custom_fwd
+
+# Autocast policy of the autograd.Functions below (reference trainer: worker_schema_net.py:128-143, `use_amp`): the HIP
+# kernels compute in fp32 and take raw pointers, so under `torch.autocast` their floating-point inputs are cast to fp32 and
+# the op itself runs with autocast off (forward and backward) - the policy torch applies to its own fp32-only ops.
+_amp_fwd = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = custom_bwd(device_type="cuda")
 
 from . import _native as N
 
@@ -190,6 +197,7 @@ class _RowEntropy(torch.autograd.Function):
     gradient is zero."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, p, eps):
         lib = N.require_gpu()
         dev = _check_dev(p)
@@ -204,6 +212,7 @@ class _RowEntropy(torch.autograd.Function):
         return ent
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         (pc,) = ctx.saved_tensors
         lib = N.require_gpu()
@@ -436,6 +445,7 @@ class _ClassEdges(torch.autograd.Function):
     (2.6 ms at the Caltech configuration's 404 MB, a sixth of a training iteration)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, edge_weights, vertex_weights, prune_threshold, remove_self_loop):
         _, ce = atlas_normalize(vertex_weights, edge_weights.detach(), prune_threshold, remove_self_loop)
         ctx.save_for_backward(edge_weights, vertex_weights)
@@ -443,6 +453,7 @@ class _ClassEdges(torch.autograd.Function):
         return ce
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_ce):
         ew, vw = ctx.saved_tensors
         thr, rsl = ctx.opts
@@ -783,6 +794,7 @@ class _SymAdjMatmul(torch.autograd.Function):
     `adj_planes` = split_planes(adj) is passed in so that the layers of one forward pass share it."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, adj, x, adj_planes):
         G, n, _ = adj.shape
         xt = split_planes(x.detach(), transpose=True)
@@ -793,6 +805,7 @@ class _SymAdjMatmul(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         ap = ctx.adj_planes
@@ -819,6 +832,7 @@ class _EdgesAdjMatmul(torch.autograd.Function):
         backward   dX = adj . dY,      dE = (S + S^T) / 2  with  S = dY . X^T   (the chain rule through the symmetrisation)"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, edges, x, adj_planes):
         G = edges.shape[0]
         y = gcn_gemm(adj_planes, split_planes(x.detach(), transpose=True), G, want_c=True)["c"]
@@ -828,6 +842,7 @@ class _EdgesAdjMatmul(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         ap = ctx.adj_planes

@@ -43,12 +43,14 @@ class _LinearPerGraphWeightGrad(torch.autograd.Function):
     of inner length n and one reduction over G is a batched GEMM with G x (out / tile) x (in / tile) workgroups: 0.1 ms."""
 
     @staticmethod
+    @ops._amp_fwd
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
+    @ops._amp_bwd
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx = dw = db = None

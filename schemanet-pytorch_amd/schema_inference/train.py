@@ -42,15 +42,24 @@ def weighted_total(loss_dict: Dict[str, torch.Tensor], loss_weights: Dict[str, f
 
 
 def train_iter(forward: Callable[[], Dict[str, torch.Tensor]], schema_net, loss_fn, loss_weights: Dict[str, float],
-               optimizer: torch.optim.Optimizer, targets: Dict[str, torch.Tensor]):
+               optimizer: torch.optim.Optimizer, targets: Dict[str, torch.Tensor], scaler=None):
     """One optimisation step.  `forward()` runs the predictor on the batch (e.g. `lambda: predictor(x)`) and returns
-    its output dictionary (`pred`, `class_vertices`, `class_edges`, ...).  -> (total loss (detached), loss dict)."""
+    its output dictionary (`pred`, `class_vertices`, `class_edges`, ...).  -> (total loss (detached), loss dict).
+    scaler: a `torch.amp.GradScaler` = the reference's `use_amp: True` route (worker_schema_net.py:128-143): forward and loss
+    under `torch.autocast`, the scaled loss back-propagated, `scaler.step` / `scaler.update`.  The HIP-backed ops of this
+    package keep computing in fp32 under autocast (cpp_extension/ops.py: custom_fwd(cast_inputs=torch.float32))."""
     optimizer.zero_grad()
     schema_net.normalize()
-    output = forward()
-    loss_dict = loss_fn(output, targets)
-    loss = weighted_total(loss_dict, loss_weights)
-    loss.backward()
-    optimizer.step()
+    with torch.autocast("cuda", enabled=scaler is not None):
+        output = forward()
+        loss_dict = loss_fn(output, targets)
+        loss = weighted_total(loss_dict, loss_weights)
+    if scaler is not None:
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        loss.backward()
+        optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss.detach(), OrderedDict((k, v.detach()) for k, v in loss_dict.items())

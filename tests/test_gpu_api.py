@@ -393,6 +393,66 @@ def test_linear_with_per_graph_weight_gradient(mods):
     assert not type(gnn_mod._linear(lin, x[0]).grad_fn).__name__.startswith("_LinearPerGraphWeightGrad")       # 2-D input: the library
 
 
+# =============================================================================== the reference trainer's AMP route
+def test_train_iter_under_autocast_with_grad_scaler(mods):
+    """`use_amp: True` of the reference's trainer (worker_schema_net.py:128-143): forward + loss under `torch.autocast`, the
+    scaled loss back-propagated, `GradScaler.step`.  The HIP-backed autograd.Functions of this package (`ops._SymAdjMatmul`,
+    `_EdgesAdjMatmul`, `_ClassEdges`, `_RowEntropy`, `gnn._LinearPerGraphWeightGrad`) carry an autocast policy - inputs cast to
+    fp32, autocast off inside - so the raw-pointer kernels never see half tensors: three iterations run, finite, and stay
+    within fp16-matmul distance of the same three iterations without AMP."""
+    from schema_inference import loss as loss_mod
+    from schema_inference import train as train_mod
+    graph = mods["graph"]
+    B, L, M, K, E = 8, 196, 128, 5, 32
+    g = lambda s_: torch.Generator().manual_seed(s_)  # noqa: E731
+    ing = torch.randint(0, M, (B, L), generator=g(1))
+    attn, acls = torch.randn(B, L, L, generator=g(2)), torch.randn(B, L, generator=g(3))
+    label = torch.randint(0, K, (B,), generator=g(4))
+
+    def run(amp):
+        torch.manual_seed(11)
+        sn = graph.SchemaNet(num_vertices=M, num_classes=K, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0, prune_node_threshold=0.001).to(DEV)
+        sn.register_class_vertices(torch.arange(M, device=DEV).repeat(K, 1))
+        torch.manual_seed(12)
+        m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu")).to(DEV)
+        sn.train(); m.train()
+        params = list(sn.parameters()) + list(m.parameters())
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-4)
+        loss_fn = loss_mod.get_loss_fn({"name": "schema_inference_loss"})
+        weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0) if amp else None
+        seen = []
+
+        def forward():
+            inst = sn(ing.to(DEV), attn.to(DEV), acls.to(DEV))
+            atlas = sn.get_atlas()
+            out = {"pred": m(inst, atlas)}
+            out.update(atlas)
+            seen.append((torch.is_autocast_enabled(), out["class_edges"].dtype))
+            return out
+        losses = []
+        for _ in range(3):
+            total, _ = train_mod.train_iter(forward, sn, loss_fn, weights, opt, {"label": label.to(DEV)}, scaler=scaler)
+            losses.append(float(total))
+        assert all(a_ == amp for a_, _ in seen) and all(dt == torch.float32 for _, dt in seen)      # (the HIP class-edges op stays fp32 under autocast)
+        return losses, {n_: p_.detach().clone() for n_, p_ in list(sn.named_parameters()) + list(m.named_parameters())}
+
+    l_amp, p_amp = run(True)
+    l_ref, p_ref = run(False)
+    assert all(np.isfinite(l_amp)) and all(np.isfinite(l_ref))
+    for a_, b_ in zip(l_amp, l_ref):
+        assert abs(a_ - b_) <= 2e-2 * abs(b_), (l_amp, l_ref)
+    for n_ in p_ref:
+        pa, pr = p_amp[n_].nan_to_num(0), p_ref[n_].nan_to_num(0)
+        assert torch.isfinite(p_amp[n_]).all() or not torch.isfinite(p_ref[n_]).all(), n_
+        # (AdamW moves a parameter by ~lr per step whatever the size of its gradient: where a gradient is ~0 its sign, and so the
+        # step, may differ between fp16 and fp32 matmuls - the two runs cannot be further apart than the three steps)
+        # (the IR-Atlas parameters are also renormalised by schema_net.normalize() before every iteration, which scales such
+        # differences: the bound is held for the GNN's weights, the atlas only has to stay finite)
+        if n_.startswith("gnn."):
+            assert float((pa - pr).abs().max()) <= 3.2e-3, n_
+
+
 # =============================================================================== config [4] at its real size
 def test_c5_real_size_training_iterations(mods):
     """deit_small-l9-M_1024.yaml:22-47: B = 64, M = 1024, K = 101, n_max = 1024 (a 424 MB edge_weights with gradients),
