@@ -668,7 +668,7 @@ def main():
         copy_gbps = stream_copy_GBps(device)
         ev_floor = event_pair_floor_ms()
         traffic, traffic_s3, traffic_src = None, None, None      # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
-        for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     for row in json.load(fh)["kernels"]:

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = i0 + q < n ? i0 + q : n - 1;
+                if (skip_pruned_rows && rowk[q] == 0u) { x[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; continue; }      // (wave-uniform: a pruned row, known zero)
                 x[q] = *reinterpret_cast<const f32x4 *>(ew + ((int64_t)k * n + i) * n + (in ? j : 0));
             }
             u32x4 colk = {0u, 0u, 0u, 0u};

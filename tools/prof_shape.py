@@ -13,6 +13,7 @@ SHAPES = {"c4": (256, 768, 1024, 1000, 500, 1024, torch.bfloat16), "c5": (64, 38
           "c2": (256, 384, 512, 100, 512, 256, torch.float32)}
 name = sys.argv[1] if len(sys.argv) > 1 else "c4"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+defer = len(sys.argv) > 3 and sys.argv[3] == "defer"     # the one-at-a-time form of the step: S1's fp64 finish inside the instance-graph kernel
 Bc, Dc, Mc, Kc, n_max, Ec, dt = SHAPES[name]
 dev = torch.device("cuda", 0)
 g = lambda s_: torch.Generator().manual_seed(s_)  # noqa: E731
@@ -30,7 +31,7 @@ with torch.no_grad():
     disc.vocabulary.weight.copy_(codebook)
     tk = torch.randn(Bc, bench.L + 1, Dc, generator=g(200)).to(dev, dt)
     at = torch.randn(Bc, bench.L + 1, bench.L + 1, generator=g(203)).to(dev)
-    run = lambda: bench.step(disc, sn, m, tk, at, class_branch_first=False, side_stream=False)      # noqa: E731
+    run = lambda: bench.step(disc, sn, m, tk, at, class_branch_first=False, side_stream=False, defer=defer)      # noqa: E731
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -39,4 +40,4 @@ with torch.no_grad():
         last = run()
     torch.cuda.synchronize()
     dt_ms = 1e3 * (time.perf_counter() - t0) / n
-print(f"{name}: {n} eager steps in line, {dt_ms:.3f} ms per step, {Bc / dt_ms * 1e3:.0f} img/s", tuple(last.shape))
+print(f"{name}{' (deferred S1 finish)' if defer else ''}: {n} eager steps in line, {dt_ms:.3f} ms per step, {Bc / dt_ms * 1e3:.0f} img/s", tuple(last.shape))
