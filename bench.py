@@ -706,8 +706,13 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"image-parallel x{world}",
                        "resident_batches": n_batches, "steps_in_flight": depth, "feat_kg_cache": "off",
                        "caches_across_steps": ["packed_codebook (fp16 fragment image of the 512 words, per codebook version)",
-                                               "gnn_prepared (Emb . W1^T table, W2 planes, fc^T: weight-only operands, per weight version; "
-                                               "the reference runs linear(embedding) in every forward)"]},
+                                               "gnn_prepared (Emb . W1^T table, W2 planes, fc^T, the per-word feature of an isolated vertex: weight-only "
+                                               "operands, per weight version; the reference runs linear(embedding) in every forward)",
+                                               "atlas_facts (per version of the IR-Atlas parameters: whether any class vertex is under the prune "
+                                               "threshold - then the class branch runs compacted -, and that the in-place pruning has run on these "
+                                               "versions - then the rows it zeroed are not read again; the values of the atlas are re-read every step)"],
+                       "s1_finish": "one step at a time (value_depth1, value_api*): inside the instance-graph kernel; several steps in flight "
+                                    "(value, value_api_batches*): the stand-alone re-rank kernel - the faster form in either regime (DESIGN 3.1e)"},
             "roofline": {"bound": "hbm", "kernel": screen_name,
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
