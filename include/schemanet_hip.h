@@ -474,8 +474,27 @@ typedef struct sn_gemm_args {
      * magnitude the operand can hold lands at 2^13 .. 2^14: see "precision" above. */
     const float *a_scale, *b_scale, *out_scale, *next_w_scale, *next_h_scale;
     int extent_stride;            /* 0: m_extent / k_extent are one value for the batch; 1: one per graph ([batches]) */
+    int accumulate;               /* 1: the fp32 result is ADDED to what c holds (c += A . Bt^T; plain product only: no bias / LayerNorm /
+                                     ReLU): the layers of a training pass sum their dY . X^T into one adjacency gradient */
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * training-side streaming passes (csrc/sn_train.hip): one kernel each for chains of library launches
+ * ------------------------------------------------------------------------------------------ */
+/* *scale = the power of two s with s * max|x| in (top / 2, top] (clamped to 2^-60 .. 2^60; 1 for an all-zero or non-finite
+ * x): the operand scale of split-fp16 planes (top = 2^13), from ONE read of x and without a host synchronisation.
+ * partial: sn_pow2_scale_blocks(n) 32-bit words of scratch; amax_out (optional) receives max|x| (NaN if x holds one). */
+int sn_pow2_scale_blocks(int64_t n);
+int sn_pow2_scale(const float *x, int64_t n, float top, void *partial, float *scale, float *amax_out, void *stream);
+/* s [G, n, n] <- (s + s^T) / 2 per graph, in place: the chain rule through the GCN operand (E + E^T)/2 + I
+ * (reference schema_inference/graph/gnn.py:27-30), applied once to the sum of the layers' dY . X^T. */
+int sn_sym_half_inplace(float *s, int G, int n, void *stream);
+/* x [rows, n] <- nan_to_num(clamp_min(x, min_val) / sum(clamp_min(x, min_val), -1), 0), then x[r, r % diag_n] <- 0 when
+ * diag_n > 0 (x = a [K, n, n] tensor viewed as [K n, n]): `SchemaNet.normalize()` on one parameter in one pass
+ * (reference schema_net.py:133-142, graph/utils.py:7-13, :59-61).  The row sum is taken in fp32 in a fixed order
+ * (not torch's: the quotient can differ from the library chain in the last bit). */
+int sn_normalize_sum_rows(float *x, int64_t rows, int n, float min_val, int diag_n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Diagnostics (tools/ and the A/B parity tests; not part of the drop-in contract, no reference counterpart).

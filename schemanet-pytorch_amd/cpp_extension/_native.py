@@ -74,7 +74,7 @@ class GemmArgs(Structure):
         ("b_ids", c_void_p), ("b_ids_stride", c_int64), ("b_ids_n", c_int), ("b_table_rows", c_int),
         ("next_w_hi", c_void_p), ("next_w_lo", c_void_p),
         ("a_scale", c_void_p), ("b_scale", c_void_p), ("out_scale", c_void_p), ("next_w_scale", c_void_p), ("next_h_scale", c_void_p),
-        ("extent_stride", c_int),
+        ("extent_stride", c_int), ("accumulate", c_int),
     ]
 
 
@@ -138,6 +138,10 @@ _SIGNATURES = {
     "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes_transposed": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "sn_pow2_scale_blocks": (c_int, [c_int64]),
+    "sn_pow2_scale": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sn_sym_half_inplace": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "sn_normalize_sum_rows": (c_int, [c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     # diagnostics (include/schemanet_hip.h, last section)
     "sn_debug_set_assign_options": (None, [c_int, c_int]),
     "sn_debug_screen_occupancy": (c_int, [c_int]),

@@ -574,9 +574,44 @@ def pow2_scale(bound):
     """bound: tensor (its largest magnitude is taken) or 0-dim / [1] tensor holding a bound on |x| -> device scalar fp32 [1],
     the power of two s with s * bound in [2^13, 2^14) (clamped to 2^-60 .. 2^60; a zero / non-finite bound gives 1): what
     split-fp16 planes of x are scaled by (csrc/sn_gcn.hip, "What hi + lo holds").  No host synchronisation."""
-    b = bound.detach().abs().amax().to(torch.float32).reshape(1)
+    b = bound.detach()
+    if b.is_cuda and b.dtype == torch.float32 and b.numel() > 1 and b.is_contiguous():
+        # a whole operand: one read of it and one finishing launch (csrc/sn_train.hip) instead of abs, amax and nine scalar launches
+        lib = N.require_gpu()
+        partial = torch.empty(lib.sn_pow2_scale_blocks(b.numel()), dtype=torch.int32, device=b.device)
+        s = torch.empty(1, dtype=torch.float32, device=b.device)
+        with torch.cuda.device(b.device):
+            N.check(lib.sn_pow2_scale(N.ptr(b), b.numel(), _PLANE_TOP, N.ptr(partial), N.ptr(s), None, N.stream_ptr(b.device)), "sn_pow2_scale")
+        return s
+    b = b.abs().amax().to(torch.float32).reshape(1)
     s = torch.exp2(torch.floor(torch.log2(_PLANE_TOP / b)).clamp(-60.0, 60.0))
     return torch.where(torch.isfinite(s) & (b > 0), s, torch.ones_like(s))
+
+
+def sym_half_(s):
+    """s [G, n, n] fp32 contiguous (CUDA) <- (s + s^T) / 2 per graph, in place (sn_sym_half_inplace)."""
+    lib = N.require_gpu()
+    dev = _check_dev(s)
+    assert s.dtype == torch.float32 and s.is_contiguous() and s.dim() == 3 and s.shape[1] == s.shape[2]
+    with torch.cuda.device(dev):
+        N.check(lib.sn_sym_half_inplace(N.ptr(s), s.shape[0], s.shape[1], N.stream_ptr(dev)), "sn_sym_half_inplace")
+    return s
+
+
+def normalize_sum_rows_(x, min_val=0.0, zero_diagonal=False):
+    """In place on x [..., n] fp32 contiguous (CUDA): clamp_min(min_val), divide every row by its sum, NaN -> 0, and (x = [K, n, n],
+    zero_diagonal) the diagonal to 0 afterwards: `SchemaNet.normalize()` on one parameter as one pass (reference
+    schema_net.py:133-142, graph/utils.py:7-13)."""
+    lib = N.require_gpu()
+    dev = _check_dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() >= 1
+    n = x.shape[-1]
+    assert not zero_diagonal or (x.dim() == 3 and x.shape[1] == n)
+    if x.numel():
+        with torch.cuda.device(dev):
+            N.check(lib.sn_normalize_sum_rows(N.ptr(x), x.numel() // n, n, float(min_val), n if zero_diagonal else 0, N.stream_ptr(dev)),
+                    "sn_normalize_sum_rows")
+    return x
 
 
 class Planes:
@@ -585,10 +620,11 @@ class Planes:
     k of the blocks (multiple of 16); `scale`: None or a device scalar (fp32 [1], a power of two) - the planes hold
     x * scale."""
 
-    __slots__ = ("hi", "lo", "batches", "rows", "k", "kpad", "scale")
+    __slots__ = ("hi", "lo", "batches", "rows", "k", "kpad", "scale", "pending", "grad_sum")
 
     def __init__(self, hi, lo, batches, rows, k, scale=None):
         self.hi, self.lo, self.batches, self.rows, self.k, self.scale = hi, lo, batches, rows, k, scale
+        self.pending, self.grad_sum = 0, None       # training: products whose backward is still to come / the sum of their dY . X^T
         self.kpad = (k + 15) // 16 * 16
 
     @property
@@ -697,7 +733,7 @@ def next_layer_weight_planes(weight):
 
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
              want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False, b_table=None, next_w=None,
-             out_scale=None, h_scale=None):
+             out_scale=None, h_scale=None, accumulate_into=None):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
@@ -711,6 +747,7 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     Scales: the operands' `.scale` (b_table: an optional 4th entry) are divided out of the accumulators; out_scale
     (device scalar from pow2_scale(bound on the result)) is what the output planes are multiplied by and carry as their
     `.scale`; h_scale (with next_w): the bound-derived scale of the epilogue's H fragments.
+    accumulate_into: fp32 [batches, m, n] contiguous - the plain product is ADDED to it (and it is returned as "c").
     Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
     args = N.GemmArgs()
@@ -738,7 +775,13 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     args.m, args.n, args.k, args.batches = int(m), int(n), int(a.kpad), int(batches)
     out = {}
     keep = []
-    if want_c:
+    if accumulate_into is not None:
+        c = accumulate_into
+        assert c.dtype == torch.float32 and c.is_contiguous() and tuple(c.shape) == (batches, m, n) and c.device == dev
+        assert not want_planes and pool_w is None and bias is None and layernorm is None and not relu and rows_valid is None and m_extent is None
+        args.c, args.c_batch_stride, args.ldc, args.accumulate = _dp(c), m * n, n, 1
+        out["c"] = c
+    elif want_c:
         c = (torch.zeros if zero_c else torch.empty)((batches, m, n), dtype=torch.float32, device=dev)
         args.c, args.c_batch_stride, args.ldc = _dp(c), m * n, n
         out["c"] = c
@@ -833,12 +876,17 @@ class _EdgesAdjMatmul(torch.autograd.Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, edges, x, adj_planes):
+    def forward(ctx, edges, x, adj_planes, sum_edge_grads=False):
         G = edges.shape[0]
-        y = gcn_gemm(adj_planes, split_planes(x.detach(), transpose=True), G, want_c=True)["c"]
+        xt = split_planes(x.detach(), transpose=True)
+        y = gcn_gemm(adj_planes, xt, G, want_c=True)["c"]
         ctx.save_for_backward(x)
         ctx.adj_planes = adj_planes
+        ctx.x_scale = xt.scale                               # (the backward's planes of x: no second reduction over it)
         ctx.adj_like = torch.empty(edges.shape, dtype=edges.dtype, device="meta")
+        ctx.counted = bool(sum_edge_grads) and bool(ctx.needs_input_grad[0]) and os.environ.get("SN_GCN_SUM_DE", "1") != "0"
+        if ctx.counted:
+            adj_planes.pending += 1
         return y
 
     @staticmethod
@@ -850,21 +898,38 @@ class _EdgesAdjMatmul(torch.autograd.Function):
         dy = _f32c(dy)
         if dy.numel() == 0:
             return (torch.zeros(ctx.adj_like.shape, dtype=ctx.adj_like.dtype, device=x.device) if ctx.needs_input_grad[0] else None,
-                    torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None)
+                    torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None, None)
         d_e = d_x = None
+        dy_scale = pow2_scale(dy)                            # one reduction over dy for both of its plane forms
         if ctx.needs_input_grad[1]:
-            d_x = gcn_gemm(ap, split_planes(dy, transpose=True), G, want_c=True)["c"]
+            d_x = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True)["c"]
         if ctx.needs_input_grad[0]:
-            s_ = gcn_gemm(split_planes(dy), split_planes(x.detach()), G, want_c=True)["c"]
-            d_e = (s_ + s_.transpose(1, 2)) * 0.5
-        return d_e, d_x, None
+            dyp, xp = split_planes(dy, scale=dy_scale), split_planes(x.detach(), scale=ctx.x_scale)
+            if not ctx.counted:
+                s_ = gcn_gemm(dyp, xp, G, want_c=True)["c"]
+                return sym_half_(s_), d_x, None, None
+            # The layers of one forward pass share `ap` and the edge tensor: their S = dY . X^T are summed in ONE buffer (the
+            # product's epilogue adds) and symmetrised once, by the layer whose backward runs last; the others hand autograd
+            # no gradient for the edges (= zero).  Per layer this was a strided add, a scale and autograd's accumulation:
+            # three more passes over a [G, n, n] tensor (404 MB at config [4]'s real size).
+            if ap.grad_sum is None:
+                ap.grad_sum = gcn_gemm(dyp, xp, G, want_c=True)["c"]
+            else:
+                gcn_gemm(dyp, xp, G, accumulate_into=ap.grad_sum)
+            ap.pending -= 1
+            if ap.pending == 0:
+                d_e, ap.grad_sum = sym_half_(ap.grad_sum), None
+        return d_e, d_x, None, None
 
 
-def edges_adj_matmul(edges, x, adj_planes=None):
-    """edges [G, n, n] fp32, x [G, n, E] fp32 (CUDA, E a multiple of 16) -> ((edges + edges^T)/2 + I) @ x, differentiable in both."""
+def edges_adj_matmul(edges, x, adj_planes=None, sum_edge_grads=False):
+    """edges [G, n, n] fp32, x [G, n, E] fp32 (CUDA, E a multiple of 16) -> ((edges + edges^T)/2 + I) @ x, differentiable in both.
+    sum_edge_grads: the caller applies several of these products IN SEQUENCE to the same `edges` with the same `adj_planes` (the
+    layers of a GNN: every one of them is on the path to the loss if the last is) - their edge gradients are then summed in one
+    buffer and handed to autograd once, by the product whose backward runs last."""
     if adj_planes is None:
         adj_planes = gcn_adjacency_planes(edges.detach())
-    return _EdgesAdjMatmul.apply(edges, x, adj_planes)
+    return _EdgesAdjMatmul.apply(edges, x, adj_planes, sum_edge_grads)
 
 
 def sym_adj_matmul(adj, x, adj_planes=None):

@@ -492,6 +492,7 @@ struct GemmArgs {
     int batches, tiles_x, tiles_y;   // logical grid (the launch is 1-D, see the XCD remap in the kernel)
     const int32_t *m_extent, *k_extent;   // device scalars (or NULL): rows / k beyond them are never consumed downstream
     int ext_stride;                       // 0: one value for the batch; 1: per graph (m_extent[batch], k_extent[batch])
+    int accumulate;                       // c += result (plain products only)
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
     int nt_a, nt_b;                  // stream that operand past the caches (read once by one workgroup)
     // gathered B (GB kernels): Bt[g][f][j] = table[ids[g][j]][f] from row-major fp16 hi/lo tables [tab_rows + 1][256]
@@ -960,7 +961,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = tile_n + (4 * wn + j) * 32 + r;
-                    if (n < p.n) p.c[(int64_t)batch * p.c_batch_stride + (int64_t)m * p.ldc + n] = acc[i][j][q];
+                    if (n < p.n) {
+                        float *dst = p.c + (int64_t)batch * p.c_batch_stride + (int64_t)m * p.ldc + n;
+                        *dst = p.accumulate ? *dst + acc[i][j][q] : acc[i][j][q];
+                    }
                 }
             }
     }
@@ -1242,6 +1246,8 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     SN_REQUIRE(!u->layernorm || (u->n == kTileN && u->gamma && u->beta), SN_ERR_UNSUPPORTED,
                "sn_gcn_gemm: the LayerNorm epilogue needs n == 256 (got %d) and gamma/beta", u->n);
     SN_REQUIRE(!u->pooled || u->pool_w, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooling without weights");
+    SN_REQUIRE(!u->accumulate || (u->c && !u->c_hi && !u->pooled && !u->bias && !u->layernorm && !u->relu && !u->rows_valid && !u->m_extent), SN_ERR_UNSUPPORTED,
+               "sn_gcn_gemm: accumulate is for the plain fp32 product only");
     SN_REQUIRE(u->batches <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: batches=%d > 65535", u->batches);
     GemmArgs a;
     a.a_hi = (const _Float16 *)u->a_hi; a.a_lo = (const _Float16 *)u->a_lo; a.a_batch_stride = u->a_batch_stride;
@@ -1253,6 +1259,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.rows_valid = u->rows_valid; a.pool_w = u->pool_w; a.pool_w_stride = u->pool_w_stride; a.pooled = u->pooled;
     a.stamps = g_gemm_stamps;
     a.m_extent = u->m_extent; a.k_extent = u->k_extent; a.ext_stride = u->extent_stride != 0 ? 1 : 0;
+    a.accumulate = u->accumulate != 0 ? 1 : 0;
     a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
     a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows; a.tab_ld = u->n;
     a.w2_hi = (const _Float16 *)u->next_w_hi; a.w2_lo = (const _Float16 *)u->next_w_lo;

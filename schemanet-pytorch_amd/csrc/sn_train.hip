@@ -1,0 +1,260 @@
+// Training-side streaming passes (round 4): what a training iteration at config [4]'s real size (K = 101 class graphs of
+// 1024 vertices: a 404 MB edge_weights) spent in chains of library elementwise / reduce launches, one kernel each.
+//   sn_pow2_scale            the power-of-two operand scale of split-fp16 planes from the largest magnitude of a tensor
+//                            (ops.pow2_scale: abs, amax and nine scalar launches per operand, ten operands per iteration)
+//   sn_sym_half_inplace      S <- (S + S^T) / 2 per graph: the chain rule through the GCN's (E + E^T)/2 + I
+//                            (reference gnn.py:27-30) applied once to the SUM of the layers' dY . X^T products
+//   sn_normalize_sum_rows    SchemaNet.normalize(): x <- clamp_min(x, m); x <- x / sum(x, -1); NaN -> 0; diagonal <- 0
+//                            (reference schema_net.py:133-142, graph/utils.py:7-13; four passes over the parameter there)
+// All HBM-bound, no MFMA: whole-line accesses, one read and one write of the tensor.
+#include "sn_common.h"
+
+namespace {
+
+constexpr int kAmaxThreads = 256;
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, off, SN_WAVE);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// the bit pattern of |x| orders like the magnitude, and every NaN sorts above inf: the maximum over the patterns is
+// the amax of torch (NaN if any element is)
+__global__ __launch_bounds__(kAmaxThreads) void amax_partial_kernel(const float *x, int64_t n, unsigned *partial)
+{
+    __shared__ unsigned red[kAmaxThreads / SN_WAVE];
+    unsigned m = 0u;
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n / 4 : 0;
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * kAmaxThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kAmaxThreads) {
+        const uint4 v = x4[i];
+        const unsigned a = v.x & 0x7FFFFFFFu, b = v.y & 0x7FFFFFFFu, c = v.z & 0x7FFFFFFFu, d = v.w & 0x7FFFFFFFu;
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+        const unsigned q = ab > cd ? ab : cd;
+        m = q > m ? q : m;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kAmaxThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kAmaxThreads) {
+        const unsigned a = __float_as_uint(x[i]) & 0x7FFFFFFFu;
+        m = a > m ? a : m;
+    }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = red[0];
+#pragma unroll
+        for (int w = 1; w < kAmaxThreads / SN_WAVE; ++w) t = red[w] > t ? red[w] : t;
+        partial[blockIdx.x] = t;
+    }
+}
+
+// s = 2^clamp(floor(log2(top / b)), -60, 60), 1 for b == 0 or a non-finite b; floor(log2()) = the exponent field
+// (top / b is a normal number or +inf for every finite b > 0: top / FLT_MAX > FLT_MIN)
+__global__ __launch_bounds__(kAmaxThreads) void pow2_scale_finish_kernel(const unsigned *partial, int blocks, float top, float *scale, float *amax_out)
+{
+    __shared__ unsigned red[kAmaxThreads / SN_WAVE];
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < blocks; i += kAmaxThreads) m = partial[i] > m ? partial[i] : m;
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = red[0];
+#pragma unroll
+        for (int w = 1; w < kAmaxThreads / SN_WAVE; ++w) t = red[w] > t ? red[w] : t;
+        const float b = __uint_as_float(t);
+        float s = 1.0f;
+        if (b > 0.0f && t < 0x7F800000u) {
+            const float q = top / b;
+            int e = q > 3.0e38f ? 60 : (int)((__float_as_uint(q) >> 23) & 0xFFu) - 127;
+            e = e < -60 ? -60 : (e > 60 ? 60 : e);
+            s = ldexpf(1.0f, e);
+        }
+        scale[0] = s;
+        if (amax_out) amax_out[0] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// S <- (S + S^T) / 2, in place, per graph.  A workgroup holds the 64 x 64 tiles (I, J) and (J, I), J >= I, in LDS (row
+// stride 65: the transposed reads are conflict-free) and writes both; only the T (T + 1) / 2 tile pairs are launched.
+// n % 4 == 0 and a 16-byte aligned base: 16-byte accesses (a thread = 4 consecutive columns of 4 rows).
+constexpr int kSymTile = 64, kSymLd = kSymTile + 1;
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void sym_half_kernel(float *s, int n, int T)
+{
+    // pair index -> (I, J >= I): row I of the upper triangle starts at I T - I (I - 1) / 2
+    int I = 0, rest = blockIdx.x;
+    while (rest >= T - I) { rest -= T - I; ++I; }
+    const int J = I + rest;
+    __shared__ float ta[kSymTile * kSymLd], tb[kSymTile * kSymLd];
+    float *g = s + (int64_t)blockIdx.y * n * n;
+    const int ri = I * kSymTile, cj = J * kSymTile;
+    if constexpr (VEC) {
+        const int c = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;             // 16 threads per row, 16 rows per pass
+#pragma unroll
+        for (int r = r0; r < kSymTile; r += 16) {
+            float4 va = {0.0f, 0.0f, 0.0f, 0.0f}, vb = va;
+            if (ri + r < n && cj + c < n) va = *reinterpret_cast<const float4 *>(g + (int64_t)(ri + r) * n + cj + c);
+            if (I != J && cj + r < n && ri + c < n) vb = *reinterpret_cast<const float4 *>(g + (int64_t)(cj + r) * n + ri + c);
+            float *da = ta + r * kSymLd + c, *db = tb + r * kSymLd + c;
+            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
+            if (I != J) { db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w; }
+        }
+        __syncthreads();
+        const float *tt = I != J ? tb : ta;
+#pragma unroll
+        for (int r = r0; r < kSymTile; r += 16) {
+            if (ri + r < n && cj + c < n) {
+                const float *a = ta + r * kSymLd + c, *t = tt + c * kSymLd + r;
+                float4 o;
+                o.x = (a[0] + t[0]) * 0.5f; o.y = (a[1] + t[kSymLd]) * 0.5f; o.z = (a[2] + t[2 * kSymLd]) * 0.5f; o.w = (a[3] + t[3 * kSymLd]) * 0.5f;
+                *reinterpret_cast<float4 *>(g + (int64_t)(ri + r) * n + cj + c) = o;
+            }
+            if (I != J && cj + r < n && ri + c < n) {
+                const float *b = tb + r * kSymLd + c, *t = ta + c * kSymLd + r;
+                float4 o;
+                o.x = (b[0] + t[0]) * 0.5f; o.y = (b[1] + t[kSymLd]) * 0.5f; o.z = (b[2] + t[2 * kSymLd]) * 0.5f; o.w = (b[3] + t[3 * kSymLd]) * 0.5f;
+                *reinterpret_cast<float4 *>(g + (int64_t)(cj + r) * n + ri + c) = o;
+            }
+        }
+    } else {
+        const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+#pragma unroll 4
+        for (int r = r0; r < kSymTile; r += 4) {
+            const bool in_a = ri + r < n && cj + c < n, in_b = cj + r < n && ri + c < n;
+            ta[r * kSymLd + c] = in_a ? g[(int64_t)(ri + r) * n + cj + c] : 0.0f;
+            if (I != J) tb[r * kSymLd + c] = in_b ? g[(int64_t)(cj + r) * n + ri + c] : 0.0f;
+        }
+        __syncthreads();
+        const float *tt = I != J ? tb : ta;                      // the tile whose transpose pairs with (I, J)
+#pragma unroll 4
+        for (int r = r0; r < kSymTile; r += 4) {
+            if (ri + r < n && cj + c < n) g[(int64_t)(ri + r) * n + cj + c] = (ta[r * kSymLd + c] + tt[c * kSymLd + r]) * 0.5f;
+            if (I != J && cj + r < n && ri + c < n) g[(int64_t)(cj + r) * n + ri + c] = (tb[r * kSymLd + c] + ta[c * kSymLd + r]) * 0.5f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// x[r, :] <- nan_to_num(clamp_min(x[r, :], m) / sum(clamp_min(x[r, :], m)), 0); x[r, r % diag_n] <- 0 if diag_n.
+// One workgroup per row (grid-stride); a row of up to 4096 floats stays in registers between the sum and the division.
+constexpr int kNormThreads = 256, kNormKeep = 4;
+
+__device__ __forceinline__ float clamp_min_keep_nan(float v, float m) { return v < m ? m : v; }     // (NaN stays NaN: torch.clamp_min)
+__device__ __forceinline__ float nan_to_num0(float v)
+{
+    if (v != v) return 0.0f;
+    if (v > 3.4028234663852886e38f) return 3.4028234663852886e38f;
+    if (v < -3.4028234663852886e38f) return -3.4028234663852886e38f;
+    return v;
+}
+
+__global__ __launch_bounds__(kNormThreads) void normalize_sum_rows_kernel(float *x, int64_t rows, int n, float min_val, int diag_n)
+{
+    __shared__ float red[kNormThreads / SN_WAVE];
+    const int tid = threadIdx.x;
+    const bool vec = (n & 3) == 0 && n <= kNormThreads * 4 * kNormKeep && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        float *row = x + r * n;
+        float4 keep[kNormKeep];
+        float acc = 0.0f;
+        if (vec) {
+#pragma unroll
+            for (int u = 0; u < kNormKeep; ++u) {
+                const int j = (u * kNormThreads + tid) * 4;
+                if (j < n) {
+                    float4 v = *reinterpret_cast<const float4 *>(row + j);
+                    v.x = clamp_min_keep_nan(v.x, min_val); v.y = clamp_min_keep_nan(v.y, min_val);
+                    v.z = clamp_min_keep_nan(v.z, min_val); v.w = clamp_min_keep_nan(v.w, min_val);
+                    keep[u] = v;
+                    acc += (v.x + v.y) + (v.z + v.w);
+                }
+            }
+        } else {
+            for (int j = tid; j < n; j += kNormThreads) acc += clamp_min_keep_nan(row[j], min_val);
+        }
+        acc = sn_wave_sum(acc);
+        __syncthreads();                                         // (red[] of the previous row has been read)
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        const float total = (red[0] + red[1]) + (red[2] + red[3]);
+        const int dcol = diag_n > 0 ? (int)(r % diag_n) : -1;
+        if (vec) {
+#pragma unroll
+            for (int u = 0; u < kNormKeep; ++u) {
+                const int j = (u * kNormThreads + tid) * 4;
+                if (j < n) {
+                    float4 v = keep[u];
+                    v.x = nan_to_num0(v.x / total); v.y = nan_to_num0(v.y / total);
+                    v.z = nan_to_num0(v.z / total); v.w = nan_to_num0(v.w / total);
+                    if (dcol >= j && dcol < j + 4) {
+                        if (dcol == j) v.x = 0.0f;
+                        else if (dcol == j + 1) v.y = 0.0f;
+                        else if (dcol == j + 2) v.z = 0.0f;
+                        else v.w = 0.0f;
+                    }
+                    *reinterpret_cast<float4 *>(row + j) = v;
+                }
+            }
+        } else {
+            for (int j = tid; j < n; j += kNormThreads) {
+                const float v = nan_to_num0(clamp_min_keep_nan(row[j], min_val) / total);
+                row[j] = j == dcol ? 0.0f : v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sn_pow2_scale_blocks(int64_t n)
+{
+    const int64_t b = (n + (int64_t)kAmaxThreads * 16 - 1) / ((int64_t)kAmaxThreads * 16);
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+extern "C" int sn_pow2_scale(const float *x, int64_t n, float top, void *partial, float *scale, float *amax_out, void *stream)
+{
+    SN_REQUIRE(n > 0 && top > 0.0f, SN_ERR_BAD_ARG, "sn_pow2_scale: bad n=%lld top=%g", (long long)n, (double)top);
+    SN_REQUIRE(x && partial && scale, SN_ERR_BAD_ARG, "sn_pow2_scale: NULL pointer");
+    const int blocks = sn_pow2_scale_blocks(n);
+    hipLaunchKernelGGL(amax_partial_kernel, dim3(blocks), dim3(kAmaxThreads), 0, (hipStream_t)stream, x, n, (unsigned *)partial);
+    SN_CHECK_LAUNCH("sn_pow2_scale");
+    hipLaunchKernelGGL(pow2_scale_finish_kernel, dim3(1), dim3(kAmaxThreads), 0, (hipStream_t)stream, (const unsigned *)partial, blocks, top, scale, amax_out);
+    SN_CHECK_LAUNCH("sn_pow2_scale");
+    return SN_OK;
+}
+
+extern "C" int sn_sym_half_inplace(float *s, int G, int n, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n >= 0, SN_ERR_BAD_ARG, "sn_sym_half_inplace: bad G=%d n=%d", G, n);
+    if (G == 0 || n == 0) return SN_OK;
+    SN_REQUIRE(s, SN_ERR_BAD_ARG, "sn_sym_half_inplace: NULL pointer");
+    const int T = (n + kSymTile - 1) / kSymTile;
+    SN_REQUIRE(G <= 65535 && T <= 2048, SN_ERR_UNSUPPORTED, "sn_sym_half_inplace: G=%d or n=%d too large", G, n);
+    const unsigned pairs = (unsigned)(T * (T + 1) / 2);
+    if (n % 4 == 0 && ((uintptr_t)s & 15) == 0) hipLaunchKernelGGL(sym_half_kernel<true>, dim3(pairs, G), dim3(256), 0, (hipStream_t)stream, s, n, T);
+    else hipLaunchKernelGGL(sym_half_kernel<false>, dim3(pairs, G), dim3(256), 0, (hipStream_t)stream, s, n, T);
+    SN_CHECK_LAUNCH("sn_sym_half_inplace");
+    return SN_OK;
+}
+
+extern "C" int sn_normalize_sum_rows(float *x, int64_t rows, int n, float min_val, int diag_n, void *stream)
+{
+    SN_REQUIRE(rows >= 0 && n > 0 && diag_n >= 0 && diag_n <= n, SN_ERR_BAD_ARG, "sn_normalize_sum_rows: bad rows=%lld n=%d diag_n=%d",
+               (long long)rows, n, diag_n);
+    if (rows == 0) return SN_OK;
+    SN_REQUIRE(x, SN_ERR_BAD_ARG, "sn_normalize_sum_rows: NULL pointer");
+    const int64_t cap = (int64_t)sn_device_cus() * 32;
+    hipLaunchKernelGGL(normalize_sum_rows_kernel, dim3((unsigned)(rows < cap ? rows : cap)), dim3(kNormThreads), 0, (hipStream_t)stream, x, rows, n,
+                       min_val, diag_n);
+    SN_CHECK_LAUNCH("sn_normalize_sum_rows");
+    return SN_OK;
+}

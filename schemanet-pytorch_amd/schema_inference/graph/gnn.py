@@ -98,12 +98,12 @@ class GraphConv(nn.Module):
         eye = torch.eye(edges.shape[-1], dtype=edges.dtype, device=edges.device)
         return (edges + edges.transpose(1, 2)) / 2 + eye
 
-    def forward(self, edges: torch.Tensor, feat: torch.Tensor, adj: torch.Tensor = None, adj_planes=None) -> torch.Tensor:
+    def forward(self, edges: torch.Tensor, feat: torch.Tensor, adj: torch.Tensor = None, adj_planes=None, sum_edge_grads=False) -> torch.Tensor:
         if adj is None and adj_planes is None:
             adj = self.adjacency(edges)
         if adj_planes is not None:      # training on the matrix cores: adj @ feat and both of its gradients as split-fp16 MFMA GEMMs
             if adj is None:             # ... with the adjacency built straight from the edges as fp16 planes (never dense)
-                return _linear(self.linear, ops.edges_adj_matmul(edges, feat, adj_planes))
+                return _linear(self.linear, ops.edges_adj_matmul(edges, feat, adj_planes, sum_edge_grads))
             return _linear(self.linear, ops.sym_adj_matmul(adj, feat, adj_planes))
         return _linear(self.linear, torch.bmm(adj, feat))
 
@@ -118,8 +118,8 @@ class Layer(nn.Module):
         self._is_none = activation == "none"
 
     def forward(self, edges: torch.Tensor, feat: torch.Tensor, feat_mask: torch.BoolTensor = None,
-                adj: torch.Tensor = None, n_valid: torch.Tensor = None, fused: bool = False, adj_planes=None):
-        feat = self.g_conv(edges, feat, adj, adj_planes)
+                adj: torch.Tensor = None, n_valid: torch.Tensor = None, fused: bool = False, adj_planes=None, sum_edge_grads=False):
+        feat = self.g_conv(edges, feat, adj, adj_planes, sum_edge_grads)
         if fused and (self._is_relu or self._is_none) and feat.is_contiguous():
             # pad rows -> 0, LayerNorm, ReLU in one pass (reference gnn.py:43-46)
             return ops.mask_layernorm_act_(feat, self.norm.weight, self.norm.bias, self.norm.eps,
@@ -352,7 +352,8 @@ class GNN(nn.Module):
             feat = self.embedding(ingredients)
         adj_planes = ops.gcn_adjacency_planes(_contig(edges.detach())) if train_mfma else None      # shared by the layers (and by their backward passes)
         for layer in layers:
-            feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused, adj_planes=adj_planes)
+            # (the layers run in sequence on one `edges` / `adj_planes`: their edge gradients are summed before autograd sees them)
+            feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused, adj_planes=adj_planes, sum_edge_grads=train_mfma)
         if fused:
             pooled = ops.weighted_pool(feat, nodes, divisor)
         else:

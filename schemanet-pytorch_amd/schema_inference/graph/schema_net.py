@@ -143,9 +143,7 @@ class SchemaNet(nn.Module):
             self.edge_attribute_weights.tensor.clamp_(min=0.01, max=10)
         if self.apply_normalize:
             self.vertex_weights.normalize_sum_(dim=-1)
-            self.edge_weights.normalize_sum_(dim=-1)
-            if self.remove_self_loop:
-                self.edge_weights.tensor.diagonal(dim1=1, dim2=2).fill_(0)
+            self.edge_weights.normalize_sum_(dim=-1, zero_diagonal=self.remove_self_loop)
 
     # ------------------------------------------------------------------ atlas
     def _needs_grad(self, *tensors) -> bool:

@@ -1,4 +1,5 @@
 """Small tensor helpers of the IR-graph code (reference schema_inference/graph/utils.py)."""
+import os
 from typing import Iterable
 
 import torch
@@ -67,6 +68,17 @@ class MyParameter(nn.Module):
         with torch.no_grad():
             self.tensor.copy_(value)
 
-    def normalize_sum_(self, dim: int, min_val: float = 0):
+    def normalize_sum_(self, dim: int, min_val: float = 0, zero_diagonal: bool = False):
+        """reference utils.py:96-99; zero_diagonal: the `diagonal().fill_(0)` that schema_net.py:141-142 applies next, folded in."""
+        t = self.tensor
         with torch.no_grad():
-            normalize_sum_(self.tensor.clamp_min_(min_val), dim=dim)
+            if (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and dim in (-1, t.dim() - 1) and t.numel() >= (1 << 20)
+                    and os.environ.get("SN_NORMALIZE_FUSED", "1") != "0"):
+                # a large parameter (edge_weights: 404 MB at config [4]'s real size): one pass instead of four (csrc/sn_train.hip)
+                from cpp_extension import ops
+                ops.normalize_sum_rows_(t, min_val, zero_diagonal=zero_diagonal)
+                torch.autograd.graph.increment_version(t)        # (what an in-place torch op would have done: caches key on it)
+                return
+            normalize_sum_(t.clamp_min_(min_val), dim=dim)
+            if zero_diagonal:
+                t.diagonal(dim1=1, dim2=2).fill_(0)

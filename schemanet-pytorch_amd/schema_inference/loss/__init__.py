@@ -36,6 +36,13 @@ def entropy(p: torch.Tensor, eps: float = 1.0e-7, dim: int = -1, keepdim: bool =
 
 
 def rectify_linear(x: torch.Tensor, a: float = 0) -> torch.Tensor:
+    """x if x > a else a - 1 + 1 / (1 + a - x)   (reference schema_inference_loss.py:61-67: a python branch on a device scalar = a
+    host synchronisation per term).  On the GPU the same value and gradient as a select, so that a training iteration stays
+    asynchronous and can be captured into a hipGraph (train.GraphedTrainIter); the unselected branch's denominator is
+    replaced by 1 before the division (at x = 1 + a it would be 0 and its - masked - gradient 0 * inf)."""
+    if torch.is_tensor(x) and x.is_cuda:
+        above = x > a
+        return torch.where(above, x, a - 1 + 1.0 / torch.where(above, torch.ones_like(x), 1 + a - x))
     return x if x > a else a - 1 + 1.0 / (1 + a - x)
 
 

@@ -63,3 +63,61 @@ def train_iter(forward: Callable[[], Dict[str, torch.Tensor]], schema_net, loss_
         optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss.detach(), OrderedDict((k, v.detach()) for k, v in loss_dict.items())
+
+
+class GraphedTrainIter:
+    """`train_iter` for one batch shape as ONE hipGraph replay: `normalize -> forward -> loss -> backward -> optimizer.step` are
+    captured once (PyTorch's whole-network capture) and every later call copies the batch into the static input buffers
+    and replays - no python, no ~300 launches, no launch gaps between the many small kernels of the instance side.
+
+        step = GraphedTrainIter(lambda batch: predictor_part(batch), schema_net, loss_fn, loss_weights, optimizer, batch, targets)
+        loss, loss_dict = step(batch, targets)          # static tensors: valid until the next call
+
+    Conditions (checked where they can be): a CUDA optimizer built with `capturable=True` (e.g.
+    `torch.optim.AdamW(params, ..., capturable=True, fused=True)`); a `forward` free of host synchronisations - the padded
+    route `SchemaNet.instance_graph_padded` + `Matcher.forward_padded` that `SchemaNetPredictor` takes, not the reference's
+    python lists; fixed shapes and dtypes of every tensor in `batch` / `targets`.  `warmup` eager iterations run first on a
+    side stream (library workspaces, the optimizer's state): they are REAL optimisation steps on the example batch, as in
+    the PyTorch recipe - the step count of the trajectory includes them.
+    The values are those of `train_iter` (the same kernels in the same order)."""
+
+    def __init__(self, forward: Callable[[Dict[str, torch.Tensor]], Dict[str, torch.Tensor]], schema_net, loss_fn,
+                 loss_weights: Dict[str, float], optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor],
+                 targets: Dict[str, torch.Tensor], warmup: int = 2):
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainIter needs an optimizer built with capturable=True")
+        if warmup < 1 and not optimizer.state:
+            raise ValueError("GraphedTrainIter: the optimizer has no state yet - at least one warm-up iteration is needed")
+        self.batch = {k: v.clone() for k, v in batch.items()}
+        self.targets = {k: v.clone() for k, v in targets.items()}
+        self.optimizer, self.schema_net = optimizer, schema_net
+
+        def iteration():
+            schema_net.normalize()
+            output = forward(self.batch)
+            loss_dict = loss_fn(output, self.targets)
+            loss = weighted_total(loss_dict, loss_weights)
+            loss.backward()
+            optimizer.step()
+            return loss.detach(), OrderedDict((k, v.detach()) for k, v in loss_dict.items())
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                optimizer.zero_grad(set_to_none=True)
+                iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)                   # (the captured backward allocates the .grad tensors in the graph's pool)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.loss_dict = iteration()
+        self.warmup_steps = warmup
+
+    def __call__(self, batch: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor]):
+        for mine, theirs in ((self.batch, batch), (self.targets, targets)):
+            for k, v in mine.items():
+                if theirs[k] is not v:
+                    v.copy_(theirs[k], non_blocking=True)
+        self.graph.replay()
+        return self.loss, self.loss_dict

@@ -1,0 +1,266 @@
+"""GPU tests of the training-side streaming passes of round 4 (csrc/sn_train.hip) and of the summed edge gradient of the
+GCN layers: each against the chain of torch ops it replaces.  Reference ops: `SchemaNet.normalize`
+schema_inference/graph/schema_net.py:133-142 (graph/utils.py:7-13), the GCN operand schema_inference/graph/gnn.py:27-31 and
+its autograd chain rule."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "schemanet-pytorch_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from test_gpu_parity import DEV, mods  # noqa: E402,F401  (mods: fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_pow2_scale(x, top=8192.0):
+    b = x.abs().amax().to(torch.float32).reshape(1)
+    s = torch.exp2(torch.floor(torch.log2(top / b)).clamp(-60.0, 60.0))
+    return torch.where(torch.isfinite(s) & (b > 0), s, torch.ones_like(s))
+
+
+@pytest.mark.parametrize("shape", [(7,), (3, 1000), (101, 1024, 256), (5, 333, 17)])
+def test_pow2_scale_kernel(mods, shape):
+    """one read of the operand + one finishing launch == abs / amax / log2 / floor / exp2 of the library: the scale is the
+    power of two that puts the largest magnitude into (2^12, 2^13]; zeros, NaN, inf give 1; tiny / huge magnitudes clamp"""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(DEV)
+    for mul in (1.0, 1e-7, 3.3e5, 1e-30, 1e30, 2.0 ** -13, 0.0):
+        xs = x * mul
+        s = ops.pow2_scale(xs)
+        assert s.shape == (1,) and s.dtype == torch.float32
+        sv, amax = float(s), float(xs.abs().max())
+        if amax == 0.0:
+            assert sv == 1.0
+            continue
+        assert np.log2(sv) == np.floor(np.log2(sv)) and 2.0 ** -60 <= sv <= 2.0 ** 60
+        if 2.0 ** -47 < amax < 2.0 ** 73:
+            assert 4096.0 < sv * amax <= 8192.0, (mul, sv, amax)
+        # the library chain agrees except when 8192 / amax is within an ulp of a power of two (its log2 rounds up there)
+        want = float(_torch_pow2_scale(xs))
+        assert sv == want or sv == want / 2, (mul, sv, want)
+    xs = x.clone(); xs.view(-1)[xs.numel() // 2] = float("nan")
+    assert float(ops.pow2_scale(xs)) == 1.0
+    xs = x.clone(); xs.view(-1)[0] = float("inf")
+    assert float(ops.pow2_scale(xs)) == 1.0
+    exact = torch.zeros(shape, device=DEV); exact.view(-1)[-1] = -2.0        # 8192 / 2 = 2^12 exactly, negative element, last position
+    assert float(ops.pow2_scale(exact)) == 4096.0
+
+
+@pytest.mark.parametrize("G,n", [(1, 1), (3, 63), (2, 64), (3, 100), (2, 130), (2, 1024)])
+def test_sym_half_inplace(mods, G, n):
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(G * 100 + n)
+    s = torch.randn(G, n, n, generator=g).to(DEV)
+    want = (s + s.transpose(1, 2)) * 0.5
+    got = ops.sym_half_(s.clone())
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("K,n,diag", [(3, 1024, True), (2, 1024, False), (5, 100, True), (2, 4100, True), (4, 513, False), (3, 8192, False)])
+def test_normalize_sum_rows(mods, K, n, diag):
+    """`SchemaNet.normalize()` on one parameter as one pass: clamp_min, row sum, divide, NaN -> 0, diagonal -> 0; rows of
+    NaN (what AdamW leaves in the rows of pruned vertices, whose gradient is 0 / 0) and all-zero rows become zeros"""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(K * 10 + n)
+    shape = (K, n, n) if diag else (K * 7, n)
+    x = (torch.rand(*shape, generator=g) - 0.2).to(DEV)                      # some negatives: clamped
+    x2 = x.view(-1, n)
+    x2[1] = float("nan")
+    x2[2] = 0.0
+    x2[3, 5] = float("nan")
+    x2[4] = -1.0                                                             # clamps to an all-zero row: 0 / 0 -> 0
+    x2[5, 0] = float("inf")
+    want = x.clone().clamp_min_(0.0)
+    want.div_(want.sum(dim=-1, keepdim=True)).nan_to_num_(0)
+    if diag:
+        want.diagonal(dim1=1, dim2=2).fill_(0)
+    got = ops.normalize_sum_rows_(x.clone(), 0.0, zero_diagonal=diag)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got == 0, want == 0)
+    assert (got - want).abs().max().item() <= 4e-7 * want.abs().max().item()            # (the row sum is taken in another order)
+    rows = got.view(-1, n)
+    assert float(rows[1].abs().max()) == 0.0 and float(rows[2].abs().max()) == 0.0 and float(rows[4].abs().max()) == 0.0
+    # min_val > 0 (vertex weights use 0 too, but the argument is the reference's)
+    got2 = ops.normalize_sum_rows_(x.clone(), 0.25)
+    want2 = x.clone().clamp_min_(0.25)
+    want2.div_(want2.sum(dim=-1, keepdim=True)).nan_to_num_(0)
+    assert (got2 - want2).abs().max().item() <= 4e-7 * want2.abs().max().item()
+
+
+def test_schema_net_normalize_takes_the_fused_pass_and_bumps_the_version(mods):
+    graph = mods["graph"]
+    torch.manual_seed(5)
+    sn = graph.SchemaNet(num_vertices=1024, num_classes=3, prune_node_threshold=0.001).to(DEV)
+    with torch.no_grad():
+        sn.edge_weights.tensor.uniform_(-0.1, 1.0)
+        sn.edge_weights.tensor[1, 7] = float("nan")
+        sn.vertex_weights.tensor.uniform_(-0.1, 1.0)
+    ref_e = sn.edge_weights.tensor.detach().clone().clamp_min_(0)
+    ref_e.div_(ref_e.sum(-1, keepdim=True)).nan_to_num_(0)
+    if sn.remove_self_loop:
+        ref_e.diagonal(dim1=1, dim2=2).fill_(0)
+    v0 = sn.edge_weights.tensor._version
+    sn.normalize()
+    assert sn.edge_weights.tensor._version > v0
+    got = sn.edge_weights.tensor.detach()
+    assert (got - ref_e).abs().max().item() <= 4e-7 * ref_e.abs().max().item() and float(got[1, 7].abs().max()) == 0.0
+    old = os.environ.get("SN_NORMALIZE_FUSED")
+    os.environ["SN_NORMALIZE_FUSED"] = "0"
+    try:
+        with torch.no_grad():
+            sn.edge_weights.tensor.uniform_(-0.1, 1.0)
+        ref = sn.edge_weights.tensor.detach().clone()
+        sn.normalize()
+        lib_route = sn.edge_weights.tensor.detach().clone()
+    finally:
+        os.environ.pop("SN_NORMALIZE_FUSED") if old is None else os.environ.__setitem__("SN_NORMALIZE_FUSED", old)
+    with torch.no_grad():
+        sn.edge_weights.tensor.copy_(ref)
+    sn.normalize()
+    assert (sn.edge_weights.tensor.detach() - lib_route).abs().max().item() <= 4e-7 * lib_route.abs().max().item()
+
+
+@pytest.mark.parametrize("G,m,n,k", [(3, 200, 200, 256), (2, 1024, 1024, 64), (1, 70, 33, 48)])
+def test_gemm_accumulates_into_c(mods, G, m, n, k):
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(G, m, k, generator=g).to(DEV)
+    b = torch.randn(G, n, k, generator=g).to(DEV)
+    c0 = torch.randn(G, m, n, generator=g).to(DEV)
+    ap, bp = ops.split_planes(a), ops.split_planes(b)
+    prod = ops.gcn_gemm(ap, bp, G, want_c=True)["c"]
+    c = c0.clone()
+    out = ops.gcn_gemm(ap, bp, G, accumulate_into=c)["c"]
+    assert out.data_ptr() == c.data_ptr()
+    assert torch.equal(c, c0 + prod)
+
+
+@pytest.mark.parametrize("G,n,E", [(3, 196, 256), (2, 300, 64)])
+def test_summed_edge_gradient_of_a_gnn(mods, G, n, E):
+    """two GraphConv-like layers in sequence on one edge tensor: with sum_edge_grads the edge gradient reaches autograd once,
+    as sym(S1 + S2), and equals the float64 chain rule of (E + E^T)/2 + I; a third consumer of the edges (the loss's entropy
+    term) still adds its own gradient; the per-layer form (sum_edge_grads False) gives the same values"""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(G * 31 + n)
+    e = torch.rand(G, n, n, generator=g)
+    x = torch.randn(G, n, E, generator=g)
+    w = torch.randn(E, E, generator=g) / E ** 0.5
+    dy = torch.randn(G, n, E, generator=g) * 1e-4
+
+    def run(dtype, dev, prod):
+        ed = e.to(dev, dtype).requires_grad_(True)
+        xd = x.to(dev, dtype).requires_grad_(True)
+        wd = w.to(dev, dtype)
+        h1 = torch.relu(prod(ed, xd) @ wd)
+        h2 = prod(ed, h1) @ wd
+        extra = (ed * ed).sum() * 1e-6                               # another consumer of the same tensor
+        (h2 * dy.to(dev, dtype)).sum().add(extra).backward()
+        return ed.grad.detach().double().cpu(), xd.grad.detach().double().cpu()
+
+    def prod64(ed, xd):
+        return torch.bmm((ed + ed.transpose(1, 2)) / 2 + torch.eye(n, dtype=ed.dtype), xd)
+
+    want_e, want_x = run(torch.float64, "cpu", prod64)
+    for summed in (True, False):
+        planes = {}
+
+        def prod(ed, xd):
+            if "p" not in planes:
+                planes["p"] = ops.gcn_adjacency_planes(ed.detach())
+            return ops.edges_adj_matmul(ed, xd, planes["p"], sum_edge_grads=summed)
+        got_e, got_x = run(torch.float32, DEV, prod)
+        assert planes["p"].pending == 0 and planes["p"].grad_sum is None
+        for got, want, what in ((got_e, want_e, "d edges"), (got_x, want_x, "d x")):
+            err = (got - want).abs().max().item()
+            assert err <= 4e-6 * want.abs().max().item() * max(1.0, (n / 196) ** 0.5), (summed, what, err, want.abs().max().item())
+
+
+def test_graphed_train_iter_follows_the_eager_trajectory(mods):
+    """`train.GraphedTrainIter` (normalize -> forward -> loss -> backward -> AdamW as one hipGraph replay) against `train_iter`
+    called the same number of times from the same state with the same (capturable) optimizer: the losses of every step and
+    the parameters at the end agree; batches of different content go through the static buffers."""
+    from schema_inference import loss as loss_mod
+    from schema_inference import train as train_mod
+    graph = mods["graph"]
+    B, L, M, K, E = 8, 49, 512, 4, 64
+    g = lambda s: torch.Generator().manual_seed(s)  # noqa: E731
+    batches = []
+    for i in range(3):
+        ing = torch.randint(0, M, (B, L), generator=g(10 + i)); ing[:, ::3] = ing[:, :1]
+        batches.append(({"ingredients": ing.to(DEV), "attn": torch.randn(B, L, L, generator=g(20 + i)).to(DEV),
+                         "attn_cls": torch.randn(B, L, generator=g(30 + i)).to(DEV)},
+                        {"label": torch.randint(0, K, (B,), generator=g(40 + i)).to(DEV)}))
+
+    def build():
+        torch.manual_seed(3)
+        sn = graph.SchemaNet(num_vertices=M, num_classes=K, feat_h=7, feat_w=7, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0,
+                             prune_node_threshold=0.001).to(DEV)
+        sn.register_class_vertices(torch.arange(M, device=DEV).repeat(K, 1))
+        torch.manual_seed(4)
+        m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu")).to(DEV)
+
+        class _Model(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.schema_net, self.matcher = sn, m
+
+            def forward(self, batch):                                       # the route SchemaNetPredictor takes behind its wrapper
+                atlas = self.schema_net.get_atlas()
+                g_ = self.schema_net.instance_graph_padded(batch["ingredients"], batch["attn"].clone(), batch["attn_cls"].clone())
+                out = {"pred": self.matcher.forward_padded(g_, atlas)}
+                out.update(atlas)
+                return out
+        model = _Model().train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-4, capturable=True, fused=True)
+        return model, opt
+
+    loss_fn = loss_mod.get_loss_fn({"name": "schema_inference_loss"})
+    weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+    warm, steps = 2, 5
+    model_e, opt_e = build()
+    losses_e = []
+    for i in range(warm):
+        train_mod.train_iter(lambda: model_e(batches[0][0]), model_e.schema_net, loss_fn, weights, opt_e, batches[0][1])
+    for i in range(steps):
+        b, t = batches[i % 3]
+        total, _ = train_mod.train_iter(lambda: model_e(b), model_e.schema_net, loss_fn, weights, opt_e, t)
+        losses_e.append(float(total))
+    model_g, opt_g = build()
+    step = train_mod.GraphedTrainIter(model_g, model_g.schema_net, loss_fn, weights, opt_g, batches[0][0], batches[0][1], warmup=warm)
+    losses_g = []
+    for i in range(steps):
+        b, t = batches[i % 3]
+        total, ld = step(b, t)
+        losses_g.append(float(total))
+        assert set(ld) == {"cls", "entropy_vertex", "entropy_edge", "re_entropy_vertex", "re_entropy_edge"}
+    assert np.isfinite(losses_g).all() and len(set(losses_g)) > 1
+    np.testing.assert_allclose(losses_g, losses_e, rtol=2e-6)
+    for (name, pe), (_, pg) in zip(model_e.named_parameters(), model_g.named_parameters()):
+        pe, pg = pe.detach(), pg.detach()
+        assert torch.equal(torch.isfinite(pe), torch.isfinite(pg)), name
+        pe, pg = pe.nan_to_num(0), pg.nan_to_num(0)
+        assert (pe - pg).abs().max().item() <= 2e-6 * max(1e-30, pe.abs().max().item()), name
+    with pytest.raises(ValueError):
+        train_mod.GraphedTrainIter(model_e, model_e.schema_net, loss_fn, weights, torch.optim.AdamW(model_e.parameters()), *batches[0])
+
+
+def test_rectify_linear_select_form(mods):
+    """the GPU form of the loss's rectifier (a select instead of a python branch on a device scalar): values and gradients of
+    the reference's expression on both sides of `a` and at the pole of the unselected branch"""
+    from schema_inference import loss as loss_mod
+    for a in (0.0, 3.0):
+        for xv in (a - 2.0, a - 1e-3, a, a + 1e-3, a + 1.0, a + 5.0):
+            xc = torch.tensor(xv, dtype=torch.float32, requires_grad=True)
+            xd = torch.tensor(xv, dtype=torch.float32, device=DEV, requires_grad=True)
+            yc, yd = loss_mod.rectify_linear(xc, a), loss_mod.rectify_linear(xd, a)
+            yc.backward(); yd.backward()
+            assert float(yc) == pytest.approx(float(yd), rel=1e-6, abs=1e-7), (a, xv)
+            assert torch.isfinite(xd.grad) and float(xc.grad) == pytest.approx(float(xd.grad), rel=1e-6), (a, xv)

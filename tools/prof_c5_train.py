@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "schemanet-pytorch_amd"))
 import torch
 n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+ROUTE = sys.argv[4] if len(sys.argv) > 4 else "padded"
 os.environ["SN_GCN_MFMA"] = sys.argv[2] if len(sys.argv) > 2 else "1"
 import schema_inference.graph as graph
 from schema_inference import loss as loss_mod, train as train_mod
@@ -27,22 +28,31 @@ class Model(torch.nn.Module):
         self.schema_net, self.matcher = sn, m
 
     def forward(self, batch):
-        inst = self.schema_net(batch["ingredients"], batch["attn"].clone(), batch["attn_cls"].clone())
         atlas = self.schema_net.get_atlas()
-        out = {"pred": self.matcher(inst, atlas)}
+        if ROUTE == "lists":          # the reference's python lists (one host synchronisation for the sizes)
+            inst = self.schema_net(batch["ingredients"], batch["attn"].clone(), batch["attn_cls"].clone())
+            out = {"pred": self.matcher(inst, atlas)}
+        else:                         # what SchemaNetPredictor.forward takes: the padded batch, no synchronisation
+            g_ = self.schema_net.instance_graph_padded(batch["ingredients"], batch["attn"].clone(), batch["attn_cls"].clone())
+            out = {"pred": self.matcher.forward_padded(g_, atlas)}
         out.update(atlas)
         return out
 
 
 model = Model().train()
 loss_fn = loss_mod.get_loss_fn({"name": "schema_inference_loss"})
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-4)
+FUSED = (sys.argv[3] if len(sys.argv) > 3 else "1") != "0"
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=FUSED, capturable=ROUTE == "graphed")
 batch = {"ingredients": ing.to(DEV), "attn": attn.to(DEV), "attn_cls": acls.to(DEV)}
 target = {"label": label.to(DEV)}
 weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
 times = []
+step = train_mod.GraphedTrainIter(model, model.schema_net, loss_fn, weights, opt, batch, target) if ROUTE == "graphed" else None
 for it in range(n_it):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    total, _ = train_mod.train_iter(lambda: model(batch), model.schema_net, loss_fn, weights, opt, target)
+    if step is not None:
+        total, _ = step(batch, target)
+    else:
+        total, _ = train_mod.train_iter(lambda: model(batch), model.schema_net, loss_fn, weights, opt, target)
     torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-print("mfma", os.environ["SN_GCN_MFMA"], "ms per iteration", [round(1e3 * t, 2) for t in times], "loss", float(total))
+print("route", ROUTE, "mfma", os.environ["SN_GCN_MFMA"], "fused AdamW", FUSED, "ms per iteration", [round(1e3 * t, 2) for t in times], "loss", float(total))
