@@ -495,6 +495,12 @@ int sn_sym_half_inplace(float *s, int G, int n, void *stream);
  * (reference schema_net.py:133-142, graph/utils.py:7-13, :59-61).  The row sum is taken in fp32 in a fixed order
  * (not torch's: the quotient can differ from the library chain in the last bit). */
 int sn_normalize_sum_rows(float *x, int64_t rows, int n, float min_val, int diag_n, void *stream);
+/* `graph`: a captured, not yet instantiated hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Every
+ * one-dimensional memset node is replaced by a kernel node with the same predecessors and successors (a captured memset
+ * node was seen not to clear on replay on ROCm 7.2; a graph PyTorch captured holds the library's own: semaphores of
+ * multi-block reductions, the zero fill of embedding_dense_backward).  *n_replaced / *n_left (optional): nodes replaced /
+ * memset nodes left as they are (two-dimensional ones). */
+int sn_graph_replace_memsets(void *graph, int *n_replaced, int *n_left);
 
 /* ------------------------------------------------------------------------------------------
  * Diagnostics (tools/ and the A/B parity tests; not part of the drop-in contract, no reference counterpart).

@@ -142,6 +142,7 @@ _SIGNATURES = {
     "sn_pow2_scale": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_sym_half_inplace": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "sn_normalize_sum_rows": (c_int, [c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "sn_graph_replace_memsets": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     # diagnostics (include/schemanet_hip.h, last section)
     "sn_debug_set_assign_options": (None, [c_int, c_int]),
     "sn_debug_screen_occupancy": (c_int, [c_int]),

@@ -88,6 +88,102 @@ int sn_zero_async(void *ptr, size_t bytes, hipStream_t st)
     return SN_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// A captured memset node is not reliable on this ROCm (see sn_common.h, sn_zero_async): in a graph that PyTorch
+// captured (train.GraphedTrainIter: forward + backward + optimizer) the library's own memsets - the semaphores of its
+// multi-block reductions, the zero fill under embedding_dense_backward - are memset nodes.  This walks a captured
+// hipGraph_t BEFORE it is instantiated and puts a kernel node with the same predecessors and successors in the place of
+// every one-dimensional memset node.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void fill_words_kernel(unsigned *p, unsigned pattern, size_t n_words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = pattern;
+}
+__global__ void fill_elems_kernel(unsigned char *p, unsigned value, unsigned elem_size, size_t n_elems)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += (size_t)gridDim.x * blockDim.x)
+        for (unsigned b = 0; b < elem_size; ++b) p[i * elem_size + b] = (unsigned char)(value >> (8 * b));
+}
+}  // namespace
+
+extern "C" int sn_graph_replace_memsets(void *graph, int *n_replaced, int *n_left)
+{
+    SN_REQUIRE(graph, SN_ERR_BAD_ARG, "sn_graph_replace_memsets: NULL graph");
+    hipGraph_t g = (hipGraph_t)graph;
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(g, nullptr, &n);
+    SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphGetNodes: %s", hipGetErrorString(e));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) {
+        e = hipGraphGetNodes(g, nodes.data(), &n);
+        SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphGetNodes: %s", hipGetErrorString(e));
+    }
+    int done = 0, left = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType type;
+        e = hipGraphNodeGetType(nodes[i], &type);
+        SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphNodeGetType: %s", hipGetErrorString(e));
+        if (type != hipGraphNodeTypeMemset) continue;
+        hipMemsetParams mp;
+        e = hipGraphMemsetNodeGetParams(nodes[i], &mp);
+        SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphMemsetNodeGetParams: %s", hipGetErrorString(e));
+        if (mp.height > 1 || (mp.elementSize != 1 && mp.elementSize != 2 && mp.elementSize != 4) || !mp.dst) { ++left; continue; }
+        if (mp.width == 0) { ++left; continue; }
+        size_t n_in = 0, n_out = 0;
+        e = hipGraphNodeGetDependencies(nodes[i], nullptr, &n_in);
+        SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphNodeGetDependencies: %s", hipGetErrorString(e));
+        std::vector<hipGraphNode_t> in(n_in);
+        if (n_in) {
+            e = hipGraphNodeGetDependencies(nodes[i], in.data(), &n_in);
+            SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphNodeGetDependencies: %s", hipGetErrorString(e));
+        }
+        e = hipGraphNodeGetDependentNodes(nodes[i], nullptr, &n_out);
+        SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphNodeGetDependentNodes: %s", hipGetErrorString(e));
+        std::vector<hipGraphNode_t> out(n_out);
+        if (n_out) {
+            e = hipGraphNodeGetDependentNodes(nodes[i], out.data(), &n_out);
+            SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphNodeGetDependentNodes: %s", hipGetErrorString(e));
+        }
+        const size_t bytes = mp.width * mp.elementSize;
+        unsigned pattern = mp.value;
+        if (mp.elementSize == 1) { pattern &= 0xFFu; pattern |= pattern << 8; pattern |= pattern << 16; }
+        else if (mp.elementSize == 2) { pattern &= 0xFFFFu; pattern |= pattern << 16; }
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        void *dst = mp.dst;
+        size_t count;
+        unsigned value = mp.value, esz = mp.elementSize;
+        void *args_w[3] = {&dst, &pattern, &count};
+        void *args_e[4] = {&dst, &value, &esz, &count};
+        if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0 && (bytes & 3) == 0) {
+            count = bytes / 4;
+            kp.func = (void *)fill_words_kernel;
+            kp.kernelParams = args_w;
+        } else {
+            count = mp.width;
+            kp.func = (void *)fill_elems_kernel;
+            kp.kernelParams = args_e;
+        }
+        const size_t blocks = (count + 255) / 256;
+        kp.gridDim = dim3((unsigned)(blocks < 2048 ? blocks : 2048));
+        kp.blockDim = dim3(256);
+        hipGraphNode_t kn;
+        e = hipGraphAddKernelNode(&kn, g, n_in ? in.data() : nullptr, n_in, &kp);
+        SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphAddKernelNode: %s", hipGetErrorString(e));
+        for (size_t j = 0; j < n_out; ++j) {
+            e = hipGraphAddDependencies(g, &kn, &out[j], 1);
+            SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphAddDependencies: %s", hipGetErrorString(e));
+        }
+        e = hipGraphDestroyNode(nodes[i]);
+        SN_REQUIRE(e == hipSuccess, SN_ERR_LAUNCH, "sn_graph_replace_memsets: hipGraphDestroyNode: %s", hipGetErrorString(e));
+        ++done;
+    }
+    if (n_replaced) *n_replaced = done;
+    if (n_left) *n_left = left;
+    return SN_OK;
+}
+
 int sn_device_cus(void)
 {
     int dev = 0;

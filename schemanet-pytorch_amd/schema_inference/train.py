@@ -109,9 +109,19 @@ class GraphedTrainIter:
                 iteration()
         torch.cuda.current_stream().wait_stream(side)
         optimizer.zero_grad(set_to_none=True)                   # (the captured backward allocates the .grad tensors in the graph's pool)
-        self.graph = torch.cuda.CUDAGraph()
+        # keep_graph: the captured hipGraph_t is post-processed before it is instantiated - the memset nodes the library's own
+        # ops leave in it (semaphores of multi-block reductions, embedding_dense_backward's zero fill) become kernel nodes
+        # (sn_graph_replace_memsets: a captured memset node is not reliable on ROCm 7.2; seen here as reductions that keep the
+        # previous replay's result, i.e. a trajectory that drifts from the second replay on)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(self.graph):
             self.loss, self.loss_dict = iteration()
+        from ctypes import byref, c_int, c_void_p
+        from cpp_extension import _native as N
+        done, left = c_int(0), c_int(0)
+        N.check(N.require_gpu().sn_graph_replace_memsets(c_void_p(self.graph.raw_cuda_graph()), byref(done), byref(left)), "sn_graph_replace_memsets")
+        self.memsets_replaced, self.memsets_left = done.value, left.value
+        self.graph.instantiate()
         self.warmup_steps = warmup
 
     def __call__(self, batch: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor]):

@@ -491,13 +491,39 @@ def test_c5_real_size_training_iterations(mods):
                 return out
         return _Model()
 
-    def run(mfma):
+    def run(mfma, graphed=False):
         old = os.environ.get("SN_GCN_MFMA")
         os.environ["SN_GCN_MFMA"] = "1" if mfma else "0"
         try:
             model = build().train()
             loss_fn = loss_mod.get_loss_fn({"name": "schema_inference_loss"})
-            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-4)
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True, capturable=graphed)
+            if graphed:
+                # the iteration as one hipGraph replay (train.GraphedTrainIter) over the route SchemaNetPredictor takes (padded batch)
+                batch = {"ingredients": ing.to(DEV), "attn": attn.to(DEV), "attn_cls": acls.to(DEV)}
+                target = {"label": label.to(DEV)}
+                weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+                sn_, m_ = model.schema_net, model.matcher
+
+                def padded(b):
+                    atlas = sn_.get_atlas()
+                    out = {"pred": m_.forward_padded(sn_.instance_graph_padded(b["ingredients"], b["attn"].clone(), b["attn_cls"].clone()), atlas)}
+                    out.update(atlas)
+                    return out
+                if graphed == "eager":                                   # the same 2 + 6 steps as plain `train_iter` calls
+                    losses = [float(train_mod.train_iter(lambda: padded(batch), sn_, loss_fn, weights, opt, target)[0]) for _ in range(8)]
+                    return losses[2:], None, None, None
+                step = train_mod.GraphedTrainIter(padded, sn_, loss_fn, weights, opt, batch, target, warmup=2)
+                assert step.memsets_replaced > 0 and step.memsets_left == 0     # (the library's multi-block reductions at this size)
+                losses, times = [], []
+                for it in range(6):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    total, _ = step(batch, target)
+                    torch.cuda.synchronize()
+                    times.append(time.perf_counter() - t0)
+                    losses.append(float(total))
+                return losses, times, None, torch.cuda.max_memory_allocated() / 2 ** 30
             batch = {"ingredients": ing.to(DEV), "attn": attn.to(DEV), "attn_cls": acls.to(DEV)}
             target = {"label": label.to(DEV)}
             weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
@@ -548,11 +574,29 @@ def test_c5_real_size_training_iterations(mods):
     ge, gl = ge.masked_fill(nan_e, 0), gl.masked_fill(nan_l, 0)
     assert ge.abs().max() > 0 and (ge - gl).abs().max() <= 1e-3 * gl.abs().max()
     del ge, gl, g_mfma, g_lib
+    torch.cuda.empty_cache()
+    lg_mfma, tg_mfma, _, memg = run(True, graphed=True)
+    torch.cuda.empty_cache()
+    lg_lib, tg_lib, _, _ = run(False, graphed=True)
+    assert all(np.isfinite(lg_mfma)) and all(np.isfinite(lg_lib))
+    for i, (a, b) in enumerate(zip(lg_mfma, lg_lib)):            # (steps 3 .. 8 of the trajectory: the two routes drift apart slowly)
+        assert abs(a - b) <= (1e-4 if i < 3 else 2e-3) * abs(b), (lg_mfma, lg_lib)
+    # the replays follow the eager trajectory of the same route step for step (replay k = step k + 2: two warm-up steps).
+    # With the graph's memset nodes left in place they did not: from the second replay on the library's multi-block
+    # reductions kept the previous replay's result (12.18 instead of 12.07 at step 4).
+    torch.cuda.empty_cache()
+    le_mfma = run(True, graphed="eager")[0]
+    np.testing.assert_allclose(lg_mfma, le_mfma, rtol=5e-6)
     _report("c5_real_size_training.json", {
         "shape": {"B": B, "M": M, "K": K, "n_max": M, "E": E, "edge_weights_MB": K * M * M * 4 / 2 ** 20},
         "edge_weight_gradients_nan_rows_of_pruned_vertices": n_nan / n_all,
+        "optimizer": "torch.optim.AdamW(lr=1e-3, weight_decay=5e-4, fused=True)",
         "losses_mfma": l_mfma, "losses_library": l_lib, "iter_seconds_mfma": t_mfma, "iter_seconds_library": t_lib,
-        "peak_GiB_mfma": mem_mfma, "peak_GiB_library": mem_lib})
+        "route_eager": "train_iter over the reference's python lists (SchemaNet.forward -> Matcher.forward: one host synchronisation)",
+        "losses_mfma_graphed": lg_mfma, "losses_mfma_eager_same_route": le_mfma, "losses_library_graphed": lg_lib,
+        "iter_seconds_mfma_graphed": tg_mfma, "iter_seconds_library_graphed": tg_lib,
+        "route_graphed": "train.GraphedTrainIter over the padded batch (instance_graph_padded -> forward_padded), capturable AdamW: one hipGraph launch per iteration",
+        "peak_GiB_mfma": mem_mfma, "peak_GiB_library": mem_lib, "peak_GiB_mfma_graphed": memg})
 
 
 def test_c5_real_size_forward_matches_cpu_pipeline(mods):

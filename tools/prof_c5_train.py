@@ -46,7 +46,7 @@ opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=FU
 batch = {"ingredients": ing.to(DEV), "attn": attn.to(DEV), "attn_cls": acls.to(DEV)}
 target = {"label": label.to(DEV)}
 weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
-times = []
+times, losses = [], []
 step = train_mod.GraphedTrainIter(model, model.schema_net, loss_fn, weights, opt, batch, target) if ROUTE == "graphed" else None
 for it in range(n_it):
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -55,4 +55,6 @@ for it in range(n_it):
     else:
         total, _ = train_mod.train_iter(lambda: model(batch), model.schema_net, loss_fn, weights, opt, target)
     torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    losses.append(round(float(total), 5))
+print("losses", losses, "memset nodes replaced / left", (step.memsets_replaced, step.memsets_left) if step is not None else None)
 print("route", ROUTE, "mfma", os.environ["SN_GCN_MFMA"], "fused AdamW", FUSED, "ms per iteration", [round(1e3 * t, 2) for t in times], "loss", float(total))
