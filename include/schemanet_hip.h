@@ -384,9 +384,10 @@ int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float 
 int sn_atlas_keep_perm(const float *class_vertices, int K, int n, float prune_threshold, int32_t *perm, int32_t *n_kept,
                        void *stream);
 /* ids_c / w_c [K, n]: class_ingredients and node weights in the compacted operand's vertex order (w_c zero beyond
- * n_kept[k]); pooled_iso [K, E] = sum over class k's pruned vertices of weight * iso[word] (iso [rows_iso, E] fp32). */
+ * n_kept[k]); pooled_iso[k * pooled_iso_stride + f], f < E = sum over class k's pruned vertices of weight * iso[word]
+ * (iso [rows_iso, E] fp32; pooled_iso_stride >= E floats: the rows may be a slot of sn_gcn_gemm's `pooled`). */
 int sn_class_compact(const int32_t *perm, const int32_t *n_kept, const float *nodes, const int64_t *ids, const float *iso,
-                     int K, int n, int E, int rows_iso, int64_t *ids_c, float *w_c, float *pooled_iso, void *stream);
+                     int K, int n, int E, int rows_iso, int64_t *ids_c, float *w_c, float *pooled_iso, int64_t pooled_iso_stride, void *stream);
 int sn_gcn_atlas_adjacency_planes_compact(const float *pruned_edge_weights, const float *row_sum, int K, int n,
                                           int remove_self_loop, float scale, const int32_t *perm, const int32_t *n_kept,
                                           void *adj_hi, void *adj_lo, void *stream);
@@ -476,6 +477,8 @@ typedef struct sn_gemm_args {
     int extent_stride;            /* 0: m_extent / k_extent are one value for the batch; 1: one per graph ([batches]) */
     int accumulate;               /* 1: the fp32 result is ADDED to what c holds (c += A . Bt^T; plain product only: no bias / LayerNorm /
                                      ReLU): the layers of a training pass sum their dY . X^T into one adjacency gradient */
+    int pooled_parts;             /* 0, or the number of [n] partial sums per graph `pooled` is laid out with (>= ceil(m / 128): the
+                                     caller keeps the further slots, e.g. sn_class_compact's pooled_iso) */
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 

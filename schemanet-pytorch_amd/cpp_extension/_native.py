@@ -74,7 +74,7 @@ class GemmArgs(Structure):
         ("b_ids", c_void_p), ("b_ids_stride", c_int64), ("b_ids_n", c_int), ("b_table_rows", c_int),
         ("next_w_hi", c_void_p), ("next_w_lo", c_void_p),
         ("a_scale", c_void_p), ("b_scale", c_void_p), ("out_scale", c_void_p), ("next_w_scale", c_void_p), ("next_h_scale", c_void_p),
-        ("extent_stride", c_int), ("accumulate", c_int),
+        ("extent_stride", c_int), ("accumulate", c_int), ("pooled_parts", c_int),
     ]
 
 
@@ -129,7 +129,7 @@ _SIGNATURES = {
     "sn_gcn_atlas_adjacency_planes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_atlas_skip_pruned_rows": (None, [c_int]),
     "sn_atlas_keep_perm": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
-    "sn_class_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sn_class_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sn_gcn_atlas_adjacency_planes_compact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_plane_elems": (c_int64, [c_int, c_int]),
     "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),

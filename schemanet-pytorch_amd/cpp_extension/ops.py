@@ -526,18 +526,21 @@ def atlas_adjacency_planes_compact(vertex_weights, edge_weights, prune_threshold
     return cv, out, perm, n_kept
 
 
-def class_compact(perm, n_kept, nodes, ids, iso):
-    """-> (ids_c int64 [K, n], w_c [K, n], pooled_iso [K, E]): see sn_class_compact"""
+def class_compact(perm, n_kept, nodes, ids, iso, pooled_slot=None):
+    """-> (ids_c int64 [K, n], w_c [K, n], pooled_iso [K, E]): see sn_class_compact.  pooled_slot: a [K, E] view with row stride >= E
+    (a slot of the [K, parts, E] partial sums `gcn_gemm(..., pooled_out=)` fills) that receives pooled_iso instead of a new tensor."""
     lib = N.require_gpu()
     dev = _check_dev(perm, n_kept, nodes, ids, iso)
     K, n = ids.shape
     nodes, iso, ids = _f32c(nodes), _f32c(iso), ids.contiguous()
     ids_c = torch.empty((K, n), dtype=torch.int64, device=dev)
     w_c = torch.empty((K, n), dtype=torch.float32, device=dev)
-    pooled_iso = torch.empty((K, iso.shape[1]), dtype=torch.float32, device=dev)
+    pooled_iso = torch.empty((K, iso.shape[1]), dtype=torch.float32, device=dev) if pooled_slot is None else pooled_slot
+    assert pooled_iso.dtype == torch.float32 and tuple(pooled_iso.shape) == (K, iso.shape[1]) and pooled_iso.stride(1) == 1 and pooled_iso.device == dev
     with torch.cuda.device(dev):
         N.check(lib.sn_class_compact(N.ptr(perm), N.ptr(n_kept), N.ptr(nodes), N.ptr(ids), N.ptr(iso), K, n, iso.shape[1], iso.shape[0],
-                                     N.ptr(ids_c), N.ptr(w_c), N.ptr(pooled_iso), N.stream_ptr(dev)), "sn_class_compact")
+                                     N.ptr(ids_c), N.ptr(w_c), N.ptr(pooled_iso), pooled_iso.stride(0) if K > 1 else iso.shape[1],
+                                     N.stream_ptr(dev)), "sn_class_compact")
     return ids_c, w_c, pooled_iso
 
 
@@ -733,7 +736,7 @@ def next_layer_weight_planes(weight):
 
 def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=None,
              want_c=False, want_planes=0, pool_w=None, m_extent=None, k_extent=None, zero_c=False, b_table=None, next_w=None,
-             out_scale=None, h_scale=None, accumulate_into=None):
+             out_scale=None, h_scale=None, accumulate_into=None, pooled_out=None):
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
@@ -748,6 +751,8 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     (device scalar from pow2_scale(bound on the result)) is what the output planes are multiplied by and carry as their
     `.scale`; h_scale (with next_w): the bound-derived scale of the epilogue's H fragments.
     accumulate_into: fp32 [batches, m, n] contiguous - the plain product is ADDED to it (and it is returned as "c").
+    pooled_out: fp32 [batches, parts >= ceil(m / 128), n] contiguous that receives the partial sums in its first slots (the
+    further ones are the caller's: class_compact's pooled_iso) and is returned as "pooled".
     Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
     args = N.GemmArgs()
@@ -812,7 +817,13 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     if pool_w is not None:
         pw = _f32c(pool_w); keep.append(pw)
         assert pw.shape == (batches, m)
-        pooled = torch.empty((batches, (m + 127) // 128, n), dtype=torch.float32, device=dev)
+        if pooled_out is None:
+            pooled = torch.empty((batches, (m + 127) // 128, n), dtype=torch.float32, device=dev)
+        else:
+            pooled = pooled_out
+            assert pooled.dtype == torch.float32 and pooled.is_contiguous() and pooled.device == dev and pooled.dim() == 3
+            assert pooled.shape[0] == batches and pooled.shape[1] >= (m + 127) // 128 and pooled.shape[2] == n
+            args.pooled_parts = pooled.shape[1]
         args.pool_w, args.pool_w_stride, args.pooled = _dp(pw), m, _dp(pooled)
         out["pooled"] = pooled
     for name, t in (("m_extent", m_extent), ("k_extent", k_extent)):

@@ -220,15 +220,17 @@ __global__ __launch_bounds__(256) void atlas_keep_perm_kernel(const float *cv, i
 // beyond the class's extent - those vertices are not in the products) and the isolated vertices' share of the pooled
 // feature, pooled_iso[k][f] = sum over the pruned vertices a of class k, in perm order, of w_a * iso[word_a][f] (iso: what an
 // isolated vertex of a word contributes per unit of weight, GNN.prepare()).  One workgroup per class; thread = feature.
-__global__ __launch_bounds__(256) void class_compact_kernel(const int32_t *perm, const int32_t *n_kept, const float *nodes, const int64_t *ids,
+constexpr int kCompactWaves = 16, kCompactThreads = kCompactWaves * 64, kCompactInFlight = 4;
+
+__global__ __launch_bounds__(kCompactThreads) void class_compact_kernel(const int32_t *perm, const int32_t *n_kept, const float *nodes, const int64_t *ids,
                                                             const float *iso, int n, int E, int rows_iso, int64_t *ids_c, float *w_c,
-                                                            float *pooled_iso)
+                                                            float *pooled_iso, int64_t iso_stride)
 {
     __shared__ int id_s[1024];
     __shared__ float w_s[1024];
     const int k = blockIdx.x, tid = threadIdx.x;
     const int nk = min(max(n_kept[k], 0), n);
-    for (int a = tid; a < n; a += 256) {
+    for (int a = tid; a < n; a += kCompactThreads) {
         const int p = perm[(int64_t)k * n + a];
         const int64_t id = ids[(int64_t)k * n + p];
         const float w = nodes[(int64_t)k * n + p];
@@ -238,29 +240,30 @@ __global__ __launch_bounds__(256) void class_compact_kernel(const int32_t *perm,
         w_s[a] = w;
     }
     __syncthreads();
-    // wave w takes the pruned vertices nk + w, nk + w + 4, ... (a fixed order: the same sums in every launch), lane l the
+    // wave w takes the pruned vertices nk + w, nk + w + 16, ... (a fixed order: the same sums in every launch), lane l the
     // features 4 l .. 4 l + 3 of a 256-feature slab - one 16-byte load per lane = one whole row segment per wave-instruction,
-    // four rows in flight; the four waves' partial sums meet in LDS.  (First form: thread = feature walking every pruned
-    // vertex in turn, one dependent 4-byte load each - 75 us for 100 classes x 360 vertices, more than the products it saves.)
+    // four rows in flight per wave, sixteen waves: a class of 360 pruned vertices is six rounds of L2 latency (one workgroup
+    // per class and K ~ 100: latency, not bandwidth, is what this kernel waits for; with four waves it took 14.5 us, with
+    // thread = feature and one dependent 4-byte load per vertex 75 us); the waves' partial sums meet in LDS.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ f32x4 part[4][64];
+    __shared__ f32x4 part[kCompactWaves][64];
     const int lane = tid & 63, wid = tid >> 6;
     for (int f0 = 0; f0 < E; f0 += 256) {
         const int f = f0 + 4 * lane;
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         if (f < E) {                                    // (E a multiple of 4)
-            for (int a0 = nk + wid; a0 < n; a0 += 16) {
-                f32x4 v[4];
-                float w[4];
+            for (int a0 = nk + wid; a0 < n; a0 += kCompactWaves * kCompactInFlight) {
+                f32x4 v[kCompactInFlight];
+                float w[kCompactInFlight];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int a = a0 + 4 * u;
+                for (int u = 0; u < kCompactInFlight; ++u) {
+                    const int a = a0 + kCompactWaves * u;
                     const int id = a < n ? id_s[a] : -1;
                     w[u] = id >= 0 ? w_s[a] : 0.0f;
                     v[u] = *reinterpret_cast<const f32x4 *>(iso + (int64_t)(id >= 0 ? id : 0) * E + f);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < kCompactInFlight; ++u)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = fmaf(w[u], v[u][q], acc[q]);
             }
@@ -269,8 +272,10 @@ __global__ __launch_bounds__(256) void class_compact_kernel(const int32_t *perm,
         part[wid][lane] = acc;
         __syncthreads();
         if (wid == 0 && f < E) {
-            const f32x4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-            *reinterpret_cast<f32x4 *>(pooled_iso + (int64_t)k * E + f) = t;
+            f32x4 t = part[0][lane];
+#pragma unroll
+            for (int w2 = 1; w2 < kCompactWaves; ++w2) t += part[w2][lane];
+            *reinterpret_cast<f32x4 *>(pooled_iso + (int64_t)k * iso_stride + f) = t;
         }
     }
 }
@@ -361,13 +366,15 @@ extern "C" int sn_atlas_keep_perm(const float *class_vertices, int K, int n, flo
  * n_kept[k]); pooled_iso [K, E]: sum over class k's pruned vertices of weight * iso[word] (iso [rows_iso, E] fp32: the
  * per-word feature of an isolated vertex).  n <= 1024. */
 extern "C" int sn_class_compact(const int32_t *perm, const int32_t *n_kept, const float *nodes, const int64_t *ids, const float *iso, int K, int n,
-                                int E, int rows_iso, int64_t *ids_c, float *w_c, float *pooled_iso, void *stream)
+                                int E, int rows_iso, int64_t *ids_c, float *w_c, float *pooled_iso, int64_t pooled_iso_stride, void *stream)
 {
     SN_REQUIRE(K >= 0 && n > 0 && n <= 1024 && E > 0 && rows_iso > 0, SN_ERR_BAD_ARG, "sn_class_compact: bad K=%d n=%d E=%d", K, n, E);
     if (K == 0) return SN_OK;
     SN_REQUIRE(perm && n_kept && nodes && ids && iso && ids_c && w_c && pooled_iso, SN_ERR_BAD_ARG, "sn_class_compact: NULL pointer");
-    hipLaunchKernelGGL(class_compact_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, perm, n_kept, nodes, ids, iso, n, E, rows_iso,
-                       ids_c, w_c, pooled_iso);
+    SN_REQUIRE(E % 4 == 0 && pooled_iso_stride >= E && pooled_iso_stride % 4 == 0 && ((uintptr_t)pooled_iso & 15) == 0, SN_ERR_BAD_ARG,
+               "sn_class_compact: E=%d / pooled_iso_stride=%lld must be multiples of 4 (16-byte rows)", E, (long long)pooled_iso_stride);
+    hipLaunchKernelGGL(class_compact_kernel, dim3((unsigned)K), dim3(kCompactThreads), 0, (hipStream_t)stream, perm, n_kept, nodes, ids, iso, n, E, rows_iso,
+                       ids_c, w_c, pooled_iso, pooled_iso_stride);
     SN_CHECK_LAUNCH("sn_class_compact");
     return SN_OK;
 }

@@ -493,6 +493,7 @@ struct GemmArgs {
     const int32_t *m_extent, *k_extent;   // device scalars (or NULL): rows / k beyond them are never consumed downstream
     int ext_stride;                       // 0: one value for the batch; 1: per graph (m_extent[batch], k_extent[batch])
     int accumulate;                       // c += result (plain products only)
+    int pooled_parts;                     // partial sums per graph in `pooled` (>= tiles_y: the caller may keep further slots)
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
     int nt_a, nt_b;                  // stream that operand past the caches (read once by one workgroup)
     // gathered B (GB kernels): Bt[g][f][j] = table[ids[g][j]][f] from row-major fp16 hi/lo tables [tab_rows + 1][256]
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     }
     const int tile_m = tile_m_, tile_n = (tile % p.tiles_x) * kTileN;
     if (p.m_extent && tile_m >= p.m_extent[(int64_t)batch * p.ext_stride]) {      // a row tile past the largest graph of the batch (ext_stride 1: past this graph)
-        if (p.pooled && tid + tile_n < p.n) p.pooled[((int64_t)batch * p.tiles_y + tile / p.tiles_x) * p.n + tile_n + tid] = 0.0f;
+        if (p.pooled && tid + tile_n < p.n) p.pooled[((int64_t)batch * p.pooled_parts + tile / p.tiles_x) * p.n + tile_n + tid] = 0.0f;
         return;
     }
     const int kb_count = p.k / kStageK;
@@ -1036,7 +1037,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         __syncthreads();
         {   // one partial row per row tile: pooled[batch][tile_y][n] (summed in a fixed order by sn_pool_fc: deterministic)
             const int n = tile_n + tid;
-            if (n < p.n) p.pooled[((int64_t)batch * p.tiles_y + tile / p.tiles_x) * p.n + n] = pr[tid] + pr[256 + tid];
+            if (n < p.n) p.pooled[((int64_t)batch * p.pooled_parts + tile / p.tiles_x) * p.n + n] = pr[tid] + pr[256 + tid];
         }
     }
     if (p.stamps && lane == 0) {
@@ -1278,6 +1279,8 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     }
     const int cols = (u->c_hi && !fused2 && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
     a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + kTileM - 1) / kTileM;
+    SN_REQUIRE(u->pooled_parts == 0 || u->pooled_parts >= a.tiles_y, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooled_parts=%d < %d row tiles", u->pooled_parts, a.tiles_y);
+    a.pooled_parts = u->pooled_parts > 0 ? u->pooled_parts : a.tiles_y;
     const int64_t n_blocks = (int64_t)8 * ((u->batches + 7) / 8) * a.tiles_x * a.tiles_y;
     SN_REQUIRE(n_blocks <= 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: grid too large");
     const dim3 grid((unsigned)n_blocks);

@@ -228,10 +228,12 @@ class GNN(nn.Module):
     def _compacted(nodes, ingredients, compact, iso):
         """class graphs whose operand holds their kept vertices only (SchemaNet.get_atlas(fused_adjacency="compact")):
         -> (ids and node weights in the operand's vertex order - weights zero beyond a graph's extent -, the per-graph extents,
-        and the isolated vertices' share of the pooled feature [G, 1, E])"""
+        and the buffer of the pooled partial sums [G, row tiles + 1, E] whose LAST slot already holds the isolated vertices' share)"""
         perm, n_kept = compact
-        ids_c, w_c, pooled_iso = ops.class_compact(perm, n_kept, nodes, ingredients, iso)
-        return ids_c, w_c, n_kept, pooled_iso[:, None, :]
+        G, n = ingredients.shape
+        pooled = torch.empty((G, (n + 127) // 128 + 1, iso.shape[1]), dtype=torch.float32, device=iso.device)
+        ids_c, w_c, _ = ops.class_compact(perm, n_kept, nodes, ingredients, iso, pooled_slot=pooled[:, -1, :])
+        return ids_c, w_c, n_kept, pooled
 
     def _forward_mfma(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None, compact=None):
         """Inference on the matrix cores: three GEMM launches per call, every elementwise step an
@@ -250,9 +252,9 @@ class GNN(nn.Module):
             adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)                       # A  [G, n, n]
         if prepared is None:
             prepared = self.prepare()
-        pooled_iso = None
+        pooled_buf = None
         if compact is not None:                          # (class graphs of a pruned atlas: per-graph extents)
-            ingredients, nodes, ext, pooled_iso = self._compacted(nodes, ingredients, compact, prepared["iso"])
+            ingredients, nodes, ext, pooled_buf = self._compacted(nodes, ingredients, compact, prepared["iso"])
             n_valid = ext
         if "table_planes" in prepared and adj.kpad <= 1024:
             # Bt[g, f, j] = table[ids[g, j], f] gathered inside the kernel (no [G, E, n] copy through HBM)
@@ -274,9 +276,8 @@ class GNN(nn.Module):
             zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n, out_scale=prepared["zt2_scale"])["planes"]      # A = W2 planes [1, E, E] -> [G, E, n]
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
-                              rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext)["pooled"]   # [G, row tiles, E]
-        if pooled_iso is not None:
-            pooled = torch.cat([pooled, pooled_iso], dim=1)       # (one more partial sum: the isolated vertices)
+                              rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext,
+                              pooled_out=pooled_buf)["pooled"]   # [G, row tiles (+ 1: the isolated vertices' share), E]
         return ops.pool_fc(pooled, divisor if divisor is not None else n, self.fc.weight, self.fc.bias, weight_t=prepared.get("fc_t"))
 
     def _forward_mfma_wide(self, nodes, edges, ingredients, n_valid, divisor, adj=None, prepared=None, compact=None):
