@@ -288,6 +288,17 @@ int sn_atlas_normalize(const float *vertex_weights, float *edge_weights, int K, 
  * with the same values including the NaN rows of vertices whose row sum is 0.  edge_weights in its pruned state. */
 int sn_atlas_normalize_backward(const float *vertex_weights, const float *edge_weights, const float *grad_class_edges, int K, int n,
                                 int use_prune, float prune_threshold, int remove_self_loop, float *grad_edge_weights, void *stream);
+/* The training form (round 4): class_edges AND the entropy of each of its rows, row_entropy[k][i] = -sum_j y log(y + eps)
+ * (schema_inference/loss/schema_inference_loss.py:51-58: the sparsity term takes a maximum over them), from the pass that
+ * writes class_edges - the same bits as sn_row_entropy on the result - and, backwards, the gradient of BOTH outputs in one
+ * pass: grad_edge_weights from grad_class_edges (may be NULL: zero) + grad_row_entropy [K, n] (may be NULL); what autograd
+ * would add up from sn_row_entropy_backward and the other consumers of class_edges first. */
+int sn_atlas_normalize_entropy(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune, float prune_threshold,
+                               int remove_self_loop, float *class_vertices, float *class_edges, float *row_entropy, float entropy_eps,
+                               void *stream);
+int sn_atlas_normalize_entropy_backward(const float *vertex_weights, const float *edge_weights, const float *grad_class_edges,
+                                        const float *grad_row_entropy, float entropy_eps, int K, int n, int use_prune,
+                                        float prune_threshold, int remove_self_loop, float *grad_edge_weights, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * S4  graph matching
@@ -498,6 +509,15 @@ int sn_sym_half_inplace(float *s, int G, int n, void *stream);
  * (reference schema_net.py:133-142, graph/utils.py:7-13, :59-61).  The row sum is taken in fp32 in a fixed order
  * (not torch's: the quotient can differ from the library chain in the last bit). */
 int sn_normalize_sum_rows(float *x, int64_t rows, int n, float min_val, int diag_n, void *stream);
+/* The GNN layer's tail with autograd (reference gnn.py:43-46: pad rows -> 0, LayerNorm, ReLU): y = act(LN(mask(x))) out of place
+ * (the values of sn_mask_layernorm_act), and its backward as one pass over (x, dy): dx [G, n, E]; dgamma_dbeta [2, E] = the
+ * column sums, reduced in a fixed order through `partial` (sn_ln_act_blocks(G n) * 2 * E floats of scratch).  E <= 1024. */
+int sn_ln_act_blocks(int64_t rows);
+int sn_mask_layernorm_act_forward(const float *x, float *y, int G, int n, int E, const int32_t *n_valid, const float *gamma,
+                                  const float *beta, float eps, int relu, void *stream);
+int sn_mask_layernorm_act_backward(const float *x, const float *dy, int G, int n, int E, const int32_t *n_valid, const float *gamma,
+                                   const float *beta, float eps, int relu, float *dx, float *partial, float *dgamma_dbeta,
+                                   void *stream);
 /* `graph`: a captured, not yet instantiated hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Every
  * one-dimensional memset node is replaced by a kernel node with the same predecessors and successors (a captured memset
  * node was seen not to clear on replay on ROCm 7.2; a graph PyTorch captured holds the library's own: semaphores of

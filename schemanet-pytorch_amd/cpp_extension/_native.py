@@ -113,6 +113,8 @@ _SIGNATURES = {
     "sn_stats_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_atlas_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_atlas_normalize_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "sn_atlas_normalize_entropy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "sn_atlas_normalize_entropy_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "sn_gcn_adjacency": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sn_mask_layernorm_act": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     "sn_weighted_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -142,6 +144,10 @@ _SIGNATURES = {
     "sn_pow2_scale": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_sym_half_inplace": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "sn_normalize_sum_rows": (c_int, [c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "sn_ln_act_blocks": (c_int, [c_int64]),
+    "sn_mask_layernorm_act_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    "sn_mask_layernorm_act_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,
+                                               c_void_p, c_void_p, c_void_p]),
     "sn_graph_replace_memsets": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     # diagnostics (include/schemanet_hip.h, last section)
     "sn_debug_set_assign_options": (None, [c_int, c_int]),

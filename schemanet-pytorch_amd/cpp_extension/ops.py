@@ -438,40 +438,74 @@ def atlas_normalize(vertex_weights, edge_weights, prune_threshold=None, remove_s
     return cv, ce
 
 
+ENTROPY_EPS = 1.0e-7     # the eps of the loss's entropy terms (reference schema_inference_loss.py:51-58)
+
+
 class _ClassEdges(torch.autograd.Function):
     """class_edges = normalised, pruned edge_weights (reference schema_net.py:152-175) with autograd: the forward pass is
     sn_atlas_normalize (one pass, pruning the parameter in place as the reference does), the backward pass
     sn_atlas_normalize_backward (one pass) - instead of seven element-wise passes over [K, n, n] forward and as many back
-    (2.6 ms at the Caltech configuration's 404 MB, a sixth of a training iteration)."""
+    (2.6 ms at the Caltech configuration's 404 MB, a sixth of a training iteration).
+    entropy_eps (a number): the row entropies of class_edges (the loss's sparsity term takes a maximum over them) are a second
+    output of the same pass, and the backward pass takes both upstream gradients at once - no entropy pass over class_edges,
+    no [K, n, n] gradient of it that is zero outside K rows, and no pass of autograd adding that to the GCN's gradient
+    (three passes over 404 MB at the Caltech configuration)."""
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, edge_weights, vertex_weights, prune_threshold, remove_self_loop):
-        _, ce = atlas_normalize(vertex_weights, edge_weights.detach(), prune_threshold, remove_self_loop)
+    def forward(ctx, edge_weights, vertex_weights, prune_threshold, remove_self_loop, entropy_eps=None):
         ctx.save_for_backward(edge_weights, vertex_weights)
-        ctx.opts = (prune_threshold, remove_self_loop)
-        return ce
+        ctx.opts = (prune_threshold, remove_self_loop, entropy_eps)
+        if entropy_eps is None:
+            _, ce = atlas_normalize(vertex_weights, edge_weights.detach(), prune_threshold, remove_self_loop)
+            return ce
+        lib = N.require_gpu()
+        ew = edge_weights.detach()
+        dev = _check_dev(vertex_weights, ew)
+        K, n = vertex_weights.shape
+        ce = torch.empty((K, n, n), dtype=torch.float32, device=dev)
+        ent = torch.empty((K, n), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_atlas_normalize_entropy(N.ptr(vertex_weights), N.ptr(ew), K, n, int(prune_threshold is not None),
+                                                   float(prune_threshold or 0.0), int(remove_self_loop), None, N.ptr(ce), N.ptr(ent),
+                                                   float(entropy_eps), N.stream_ptr(dev)), "sn_atlas_normalize_entropy")
+        return ce, ent
 
     @staticmethod
     @_amp_bwd
-    def backward(ctx, grad_ce):
+    def backward(ctx, grad_ce, grad_ent=None):
         ew, vw = ctx.saved_tensors
-        thr, rsl = ctx.opts
+        thr, rsl, eps = ctx.opts
         lib = N.require_gpu()
-        dev = _check_dev(ew, vw, grad_ce)
+        dev = _check_dev(ew, vw)
         K, n = vw.shape
-        g = _f32c(grad_ce)
+        g = None if grad_ce is None else _f32c(grad_ce)
+        ge = None if grad_ent is None else _f32c(grad_ent)
+        if g is None and ge is None:
+            return None, None, None, None, None
         gx = torch.empty_like(ew)
         with torch.cuda.device(dev):
-            N.check(lib.sn_atlas_normalize_backward(N.ptr(vw), N.ptr(ew.detach()), N.ptr(g), K, n, int(thr is not None), float(thr or 0.0),
-                                                    int(rsl), N.ptr(gx), N.stream_ptr(dev)), "sn_atlas_normalize_backward")
-        return gx, None, None, None
+            if eps is None:
+                N.check(lib.sn_atlas_normalize_backward(N.ptr(vw), N.ptr(ew.detach()), N.ptr(g), K, n, int(thr is not None), float(thr or 0.0),
+                                                        int(rsl), N.ptr(gx), N.stream_ptr(dev)), "sn_atlas_normalize_backward")
+            else:
+                N.check(lib.sn_atlas_normalize_entropy_backward(N.ptr(vw), N.ptr(ew.detach()), N.ptr(g), N.ptr(ge), float(eps), K, n,
+                                                                int(thr is not None), float(thr or 0.0), int(rsl), N.ptr(gx),
+                                                                N.stream_ptr(dev)), "sn_atlas_normalize_entropy_backward")
+        return gx, None, None, None, None
 
 
-def class_edges_autograd(edge_weights, vertex_weights, prune_threshold=None, remove_self_loop=False):
-    """Differentiable class edges: edge_weights [K, n, n] (requires grad; pruned IN PLACE), vertex_weights [K, n] (detached)."""
+def class_edges_autograd(edge_weights, vertex_weights, prune_threshold=None, remove_self_loop=False, with_entropy=False):
+    """Differentiable class edges: edge_weights [K, n, n] (requires grad; pruned IN PLACE), vertex_weights [K, n] (detached).
+    with_entropy: the result carries its row entropies (eps = ENTROPY_EPS) as `class_edges._sn_row_entropy = (eps, [K, n]
+    tensor)`, a second differentiable output of the same pass: `schema_inference.loss.entropy` hands them out instead of
+    reading class_edges again (and their gradient is folded into this op's one backward pass)."""
     assert edge_weights.is_contiguous() and vertex_weights.is_contiguous()
-    return _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop)
+    if not with_entropy:
+        return _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop)
+    ce, ent = _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop, ENTROPY_EPS)
+    ce._sn_row_entropy = (ENTROPY_EPS, ent)
+    return ce
 
 
 def atlas_adjacency_planes(vertex_weights, edge_weights, prune_threshold=None, remove_self_loop=False, want_edges=False):
@@ -976,6 +1010,50 @@ def pool_fc(pooled_sum, divisor, weight, bias, weight_t=None):
         N.check(fn(N.ptr(p), G, parts, E, ddev, dhost, N.ptr(w), N.ptr(b), E_out, N.ptr(out), N.stream_ptr(dev)),
                 "sn_pool_fc_t" if transposed else "sn_pool_fc")
     return out
+
+
+class _MaskLayerNormAct(torch.autograd.Function):
+    """y = act(LayerNorm(x with the rows >= n_valid[g] set to 0)) on x [G, n, E] (reference gnn.py:43-46) with autograd: one HIP
+    pass forward (the values of mask_layernorm_act_), one back over (x, dy) that recomputes the row statistics and yields dx,
+    d gamma, d beta (csrc/sn_train.hip) - for the library's three passes forward and four back."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, gamma, beta, eps, n_valid, relu):
+        lib = N.require_gpu()
+        xc, gc, bc = _f32c(x.detach()), _f32c(gamma.detach()), _f32c(beta.detach())
+        dev = _check_dev(xc, gc, bc, n_valid)
+        G, n, E = xc.shape
+        y = torch.empty_like(xc)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_mask_layernorm_act_forward(N.ptr(xc), N.ptr(y), G, n, E, N.ptr(n_valid), N.ptr(gc), N.ptr(bc), float(eps), int(relu),
+                                                      N.stream_ptr(dev)), "sn_mask_layernorm_act_forward")
+        ctx.save_for_backward(xc, gc, bc, n_valid)
+        ctx.opts = (float(eps), int(relu))
+        return y
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, dy):
+        xc, gc, bc, n_valid = ctx.saved_tensors
+        eps, relu = ctx.opts
+        lib = N.require_gpu()
+        dev = xc.device
+        G, n, E = xc.shape
+        dyc = _f32c(dy)
+        dx = torch.empty_like(xc)
+        dgb = torch.empty((2, E), dtype=torch.float32, device=dev)
+        partial = torch.empty((max(1, lib.sn_ln_act_blocks(G * n)), 2, E), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_mask_layernorm_act_backward(N.ptr(xc), N.ptr(dyc), G, n, E, N.ptr(n_valid), N.ptr(gc), N.ptr(bc), eps, relu,
+                                                       N.ptr(dx), N.ptr(partial), N.ptr(dgb), N.stream_ptr(dev)), "sn_mask_layernorm_act_backward")
+        return dx, dgb[0], dgb[1], None, None, None
+
+
+def mask_layernorm_act(x, gamma, beta, eps, n_valid=None, relu=True):
+    """Differentiable, out of place: x [G, n, E] fp32 (CUDA, E <= 1024), n_valid int32 [G] or None."""
+    assert x.dim() == 3 and (n_valid is None or (n_valid.dtype == torch.int32 and n_valid.numel() == x.shape[0]))
+    return _MaskLayerNormAct.apply(x, gamma, beta, eps, n_valid, relu)
 
 
 def mask_layernorm_act_(x, gamma, beta, eps, n_valid=None, relu=True):

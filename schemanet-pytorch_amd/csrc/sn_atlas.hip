@@ -25,7 +25,8 @@ __device__ __forceinline__ float row_scale(float s) { return (s > 0.0f && s < IN
 // their row sum is 0.  70 % of a trained atlas.
 __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, float *ew, int n,
                                                               int use_prune, float thr,
-                                                              int remove_self_loop, float *cv, float *ce, float *rowsum, int skip_pruned_rows)
+                                                              int remove_self_loop, float *cv, float *ce, float *rowsum, int skip_pruned_rows,
+                                                              float *ent, float ent_eps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *keep = smem;                       // [n] vertex survives pruning
@@ -116,11 +117,37 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
         if (rowsum && lane == 0) rowsum[(int64_t)k * n + i] = row_scale(s);
         if (!ce) continue;
         float *out = ce + ((int64_t)k * n + i) * n;
-        for (int j = lane; j < n; j += SN_WAVE) {
-            float x = (use_prune && !(keep_i && keep[j])) ? 0.0f : row[j];
-            x = sn_nan_to_num(fmaxf(x, 0.0f) / s);
-            if (remove_self_loop && j == i) x = 0.0f;
-            out[j] = x;
+        // ent (training): the row entropy -sum y log(y + eps) of what is being written (schema_inference_loss.py:51-58), summed
+        // in the order of row_entropy_kernel (sn_loss.hip) - the same bits as that kernel run on `ce` afterwards
+        float ea = 0.0f;
+        if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(ce) | reinterpret_cast<uintptr_t>(ew)) & 15) == 0) {
+            for (int j = lane * 4; j < n; j += SN_WAVE * 4) {
+                const float4 raw = *reinterpret_cast<const float4 *>(row + j);
+                float x[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (use_prune && !(keep_i && keep[j + q])) x[q] = 0.0f;
+                    x[q] = sn_nan_to_num(fmaxf(x[q], 0.0f) / s);
+                    if (remove_self_loop && j + q == i) x[q] = 0.0f;
+                }
+                *reinterpret_cast<float4 *>(out + j) = float4{x[0], x[1], x[2], x[3]};
+                if (ent) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ea += x[q] * logf(x[q] + ent_eps);
+                }
+            }
+        } else {
+            for (int j = lane; j < n; j += SN_WAVE) {
+                float x = (use_prune && !(keep_i && keep[j])) ? 0.0f : row[j];
+                x = sn_nan_to_num(fmaxf(x, 0.0f) / s);
+                if (remove_self_loop && j == i) x = 0.0f;
+                out[j] = x;
+                if (ent) ea += x * logf(x + ent_eps);
+            }
+        }
+        if (ent) {
+            ea = sn_wave_sum(ea);
+            if (lane == 0) ent[(int64_t)k * n + i] = -ea;
         }
     }
 }
@@ -133,8 +160,11 @@ __global__ __launch_bounds__(256) void atlas_normalize_kernel(const float *vw, f
 //   cell);  g_m = g_c * [m >= 0] (clamp_min passes the gradient AT 0);  g_x = g_m * mask.
 // edge_weights is read in its pruned state (the forward pass has zeroed the masked cells in place).  One wave per row,
 // two passes over the row (its sum, then the gradients; the second from L2).
+// g_ent (optional): the upstream gradient of the row entropies the forward pass returned next to y; its share
+// -g_ent[i] (log(y + eps) + y / (y + eps)) (row_entropy_backward_kernel's expression) is added to g_y here - rows whose g_ent
+// is 0 (all but K of them: the loss takes a maximum over rows) skip it.  gy may then be NULL (no other consumer of y).
 __global__ __launch_bounds__(256) void atlas_normalize_backward_kernel(const float *vw, const float *ew, const float *gy, int n, int use_prune,
-                                                                       float thr, int remove_self_loop, float *gx)
+                                                                       float thr, int remove_self_loop, float *gx, const float *g_ent, float ent_eps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *keep = smem;                       // [n]
@@ -156,9 +186,10 @@ __global__ __launch_bounds__(256) void atlas_normalize_backward_kernel(const flo
         const int i = blockIdx.y * kRowsPerBlock + rr;
         if (i >= n) break;
         const float *row = ew + ((int64_t)k * n + i) * n;
-        const float *grow = gy + ((int64_t)k * n + i) * n;
+        const float *grow = gy ? gy + ((int64_t)k * n + i) * n : nullptr;
         float *orow = gx + ((int64_t)k * n + i) * n;
         const float mi = keep[i] ? 1.0f : 0.0f;
+        const float ge = g_ent ? g_ent[(int64_t)k * n + i] : 0.0f;       // (wave-uniform)
         float s = 0.0f;
         for (int j = lane; j < n; j += SN_WAVE) s += fmaxf(row[j] * (mi * (keep[j] ? 1.0f : 0.0f)), 0.0f);
         s = sn_wave_sum(s);
@@ -166,7 +197,11 @@ __global__ __launch_bounds__(256) void atlas_normalize_backward_kernel(const flo
             const float mask = mi * (keep[j] ? 1.0f : 0.0f);
             const float m = row[j] * mask;
             const float z = fmaxf(m, 0.0f) / s;
-            float g = grow[j];
+            float g = grow ? grow[j] : 0.0f;
+            if (ge != 0.0f) {
+                const float y = (remove_self_loop && j == i) ? 0.0f : sn_nan_to_num(z), q = y + ent_eps;
+                g = g + (-ge * (logf(q) + y / q));
+            }
             if (remove_self_loop && j == i) g = 0.0f;                     // masked_fill(eye, 0) after the normalisation
             const float gz = (z == z && fabsf(z) != INFINITY) ? g : 0.0f;   // nan_to_num: no gradient where z is not finite
             const float gc = gz / s;
@@ -282,28 +317,43 @@ __global__ __launch_bounds__(kCompactThreads) void class_compact_kernel(const in
 
 }  // namespace
 
+static int atlas_normalize_launch(const char *name, const float *vertex_weights, float *edge_weights, int K, int n, int use_prune,
+                                  float prune_threshold, int remove_self_loop, float *class_vertices, float *class_edges, float *row_entropy,
+                                  float entropy_eps, void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "%s: bad K=%d n=%d", name, K, n);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(vertex_weights && edge_weights, SN_ERR_BAD_ARG, "%s: NULL input", name);
+    SN_REQUIRE(!row_entropy || class_edges, SN_ERR_BAD_ARG, "%s: row entropies are a by-product of writing class_edges", name);
+    SN_REQUIRE(n <= 32768, SN_ERR_UNSUPPORTED, "%s: n=%d > 32768", name, n);
+    const dim3 grid((unsigned)K, (unsigned)((n + kRowsPerBlock - 1) / kRowsPerBlock));
+    SN_REQUIRE(grid.y <= 65535, SN_ERR_UNSUPPORTED, "%s: n too large", name);
+    const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
+    sn_prof_start(3, (hipStream_t)stream);
+    hipLaunchKernelGGL(atlas_normalize_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights,
+                       edge_weights, n, use_prune, prune_threshold, remove_self_loop, class_vertices, class_edges, (float *)nullptr, 0, row_entropy, entropy_eps);
+    sn_prof_stop(3, (hipStream_t)stream);
+    SN_CHECK_LAUNCH(name);
+    return SN_OK;
+}
+
 extern "C" int sn_atlas_normalize(const float *vertex_weights, float *edge_weights, int K, int n,
                                   int use_prune, float prune_threshold, int remove_self_loop,
                                   float *class_vertices, float *class_edges, void *stream)
 {
-    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_atlas_normalize: bad K=%d n=%d", K, n);
-    if (K == 0) return SN_OK;
-    SN_REQUIRE(vertex_weights && edge_weights, SN_ERR_BAD_ARG, "sn_atlas_normalize: NULL input");
-    SN_REQUIRE(n <= 32768, SN_ERR_UNSUPPORTED, "sn_atlas_normalize: n=%d > 32768", n);
-    const dim3 grid((unsigned)K, (unsigned)((n + kRowsPerBlock - 1) / kRowsPerBlock));
-    SN_REQUIRE(grid.y <= 65535, SN_ERR_UNSUPPORTED, "sn_atlas_normalize: n too large");
-    const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
-    sn_prof_start(3, (hipStream_t)stream);
-    hipLaunchKernelGGL(atlas_normalize_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights,
-                       edge_weights, n, use_prune, prune_threshold, remove_self_loop, class_vertices, class_edges, (float *)nullptr, 0);
-    sn_prof_stop(3, (hipStream_t)stream);
-    SN_CHECK_LAUNCH("sn_atlas_normalize");
-    return SN_OK;
+    return atlas_normalize_launch("sn_atlas_normalize", vertex_weights, edge_weights, K, n, use_prune, prune_threshold, remove_self_loop,
+                                  class_vertices, class_edges, nullptr, 0.0f, stream);
 }
 
-/* First half of the fused atlas -> adjacency route: vertices, in-place pruning and the row sums of the
- * clamped edge weights; the normalised edges themselves are never materialised
- * (sn_gcn_atlas_adjacency_planes applies the division while it builds the GCN operand). */
+extern "C" int sn_atlas_normalize_entropy(const float *vertex_weights, float *edge_weights, int K, int n, int use_prune, float prune_threshold,
+                                          int remove_self_loop, float *class_vertices, float *class_edges, float *row_entropy, float entropy_eps,
+                                          void *stream)
+{
+    SN_REQUIRE(class_edges && row_entropy, SN_ERR_BAD_ARG, "sn_atlas_normalize_entropy: NULL output");
+    return atlas_normalize_launch("sn_atlas_normalize_entropy", vertex_weights, edge_weights, K, n, use_prune, prune_threshold, remove_self_loop,
+                                  class_vertices, class_edges, row_entropy, entropy_eps, stream);
+}
+
 static int g_skip_pruned_rows = 0;     // set by sn_atlas_skip_pruned_rows for the NEXT sn_atlas_prune_rowsum call of this thread's caller
 
 /* The next sn_atlas_prune_rowsum may leave the rows of pruned vertices unread (they are zero: an earlier call on the same
@@ -324,7 +374,7 @@ extern "C" int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_we
     const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
     sn_prof_start(3, (hipStream_t)stream);
     hipLaunchKernelGGL(atlas_normalize_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights, edge_weights, n, use_prune,
-                       prune_threshold, 0, class_vertices, (float *)nullptr, row_sum, skip);
+                       prune_threshold, 0, class_vertices, (float *)nullptr, row_sum, skip, (float *)nullptr, 0.0f);
     sn_prof_stop(3, (hipStream_t)stream);
     SN_CHECK_LAUNCH("sn_atlas_prune_rowsum");
     return SN_OK;
@@ -333,25 +383,40 @@ extern "C" int sn_atlas_prune_rowsum(const float *vertex_weights, float *edge_we
 /* Backward of the normalised class edges (sn_atlas_normalize's class_edges as a function of edge_weights): grad_edge_weights
  * [K, n, n] from grad_class_edges, with the values - NaN rows of empty classes' vertices included - autograd gives for the
  * reference's chain of torch ops (schema_net.py:152-175). */
+static int atlas_backward_launch(const char *name, const float *vertex_weights, const float *edge_weights, const float *grad_class_edges,
+                                 const float *grad_row_entropy, float entropy_eps, int K, int n, int use_prune, float prune_threshold,
+                                 int remove_self_loop, float *grad_edge_weights, void *stream)
+{
+    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "%s: bad K=%d n=%d", name, K, n);
+    if (K == 0) return SN_OK;
+    SN_REQUIRE(vertex_weights && edge_weights && (grad_class_edges || grad_row_entropy) && grad_edge_weights, SN_ERR_BAD_ARG, "%s: NULL pointer", name);
+    SN_REQUIRE(n <= 32768, SN_ERR_UNSUPPORTED, "%s: n=%d > 32768", name, n);
+    const dim3 grid((unsigned)K, (unsigned)((n + kRowsPerBlock - 1) / kRowsPerBlock));
+    SN_REQUIRE(grid.y <= 65535, SN_ERR_UNSUPPORTED, "%s: n too large", name);
+    const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
+    hipLaunchKernelGGL(atlas_normalize_backward_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights, edge_weights,
+                       grad_class_edges, n, use_prune, prune_threshold, remove_self_loop, grad_edge_weights, grad_row_entropy, entropy_eps);
+    SN_CHECK_LAUNCH(name);
+    return SN_OK;
+}
+
 extern "C" int sn_atlas_normalize_backward(const float *vertex_weights, const float *edge_weights, const float *grad_class_edges, int K, int n,
                                            int use_prune, float prune_threshold, int remove_self_loop, float *grad_edge_weights,
                                            void *stream)
 {
-    SN_REQUIRE(K >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_atlas_normalize_backward: bad K=%d n=%d", K, n);
-    if (K == 0) return SN_OK;
-    SN_REQUIRE(vertex_weights && edge_weights && grad_class_edges && grad_edge_weights, SN_ERR_BAD_ARG, "sn_atlas_normalize_backward: NULL pointer");
-    SN_REQUIRE(n <= 32768, SN_ERR_UNSUPPORTED, "sn_atlas_normalize_backward: n=%d > 32768", n);
-    const dim3 grid((unsigned)K, (unsigned)((n + kRowsPerBlock - 1) / kRowsPerBlock));
-    SN_REQUIRE(grid.y <= 65535, SN_ERR_UNSUPPORTED, "sn_atlas_normalize_backward: n too large");
-    const size_t lds = ((size_t)(n + 15) & ~size_t(15)) + 16;
-    hipLaunchKernelGGL(atlas_normalize_backward_kernel, grid, dim3(256), lds, (hipStream_t)stream, vertex_weights, edge_weights,
-                       grad_class_edges, n, use_prune, prune_threshold, remove_self_loop, grad_edge_weights);
-    SN_CHECK_LAUNCH("sn_atlas_normalize_backward");
-    return SN_OK;
+    SN_REQUIRE(K == 0 || grad_class_edges, SN_ERR_BAD_ARG, "sn_atlas_normalize_backward: NULL pointer");
+    return atlas_backward_launch("sn_atlas_normalize_backward", vertex_weights, edge_weights, grad_class_edges, nullptr, 0.0f, K, n, use_prune,
+                                 prune_threshold, remove_self_loop, grad_edge_weights, stream);
 }
 
-/* A pruned atlas, compacted (see sn_gcn_atlas_adjacency_planes_compact): perm [K, n] int32 = class k's kept vertices
- * (class_vertices[k][i] > prune_threshold) first, in their own order, then the pruned ones; n_kept [K].  n <= 1024. */
+extern "C" int sn_atlas_normalize_entropy_backward(const float *vertex_weights, const float *edge_weights, const float *grad_class_edges,
+                                                   const float *grad_row_entropy, float entropy_eps, int K, int n, int use_prune,
+                                                   float prune_threshold, int remove_self_loop, float *grad_edge_weights, void *stream)
+{
+    return atlas_backward_launch("sn_atlas_normalize_entropy_backward", vertex_weights, edge_weights, grad_class_edges, grad_row_entropy, entropy_eps,
+                                 K, n, use_prune, prune_threshold, remove_self_loop, grad_edge_weights, stream);
+}
+
 extern "C" int sn_atlas_keep_perm(const float *class_vertices, int K, int n, float prune_threshold, int32_t *perm, int32_t *n_kept, void *stream)
 {
     SN_REQUIRE(K >= 0 && n > 0 && n <= 1024, SN_ERR_BAD_ARG, "sn_atlas_keep_perm: bad K=%d n=%d (n <= 1024)", K, n);

@@ -212,6 +212,125 @@ __global__ __launch_bounds__(kNormThreads) void normalize_sum_rows_kernel(float 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The GNN layer's tail in training: y = act(LayerNorm(mask(x))) (reference gnn.py:43-46) out of place - x is what the
+// backward pass keeps - and its backward in ONE pass over (x, dy): the statistics are recomputed from x (the row is in
+// registers anyway), dx written once, the column sums of d gamma / d beta kept in registers over the rows a wave walks
+// and reduced block by block in a fixed order (a [blocks, 2, E] scratch + a finishing launch: no atomics, bit-reproducible).
+// The library's chain was masked_fill, native_layer_norm, clamp forward and threshold_backward, two layer-norm backward
+// kernels, a masked_fill backward: three passes forward, four back, over [G n, E] (106 MB at the Caltech configuration).
+// One wave per row (sn_layernorm_row: the sums of the inference kernels), E <= 1024.
+__global__ __launch_bounds__(256) void ln_act_forward_kernel(const float *x, float *y, int64_t rows, int n, int E, const int32_t *n_valid,
+                                                             const float *gamma, const float *beta, float eps, int relu)
+{
+    const int lane = threadIdx.x & 63;
+    float gm[SN_LN_MAX], bt[SN_LN_MAX];
+    sn_layernorm_coeffs(gm, bt, lane, E, gamma, beta);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int g = (int)(row / n), r = (int)(row % n);
+        const bool masked = n_valid && r >= n_valid[g];
+        const float *p = x + row * E;
+        float v[SN_LN_MAX];
+#pragma unroll
+        for (int k = 0; k < SN_LN_MAX; ++k) {
+            const int c = lane + SN_WAVE * k;
+            v[k] = (c < E && !masked) ? p[c] : 0.0f;
+        }
+        sn_layernorm_row(v, lane, E, gm, bt, eps, relu);
+        float *o = y + row * E;
+#pragma unroll
+        for (int k = 0; k < SN_LN_MAX; ++k) {
+            const int c = lane + SN_WAVE * k;
+            if (c < E) o[c] = v[k];
+        }
+    }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void ln_act_backward_kernel(const float *x, const float *dy, int64_t rows, int n, int E, const int32_t *n_valid,
+                                                              const float *gamma, const float *beta, float eps, int relu, float *dx,
+                                                              float *partial)
+{
+    __shared__ float red[4][2][SN_WAVE * KMAX];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float gm[KMAX], bt[KMAX], dg[KMAX], db[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = lane + SN_WAVE * k;
+        gm[k] = c < E ? gamma[c] : 0.0f;
+        bt[k] = c < E ? beta[c] : 0.0f;
+        dg[k] = 0.0f; db[k] = 0.0f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const int g = (int)(row / n), r = (int)(row % n);
+        const bool masked = n_valid && r >= n_valid[g];
+        const float *p = x + row * E, *q = dy + row * E;
+        float v[KMAX], gy[KMAX];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + SN_WAVE * k;
+            v[k] = (c < E && !masked) ? p[c] : 0.0f;
+            gy[k] = c < E ? q[c] : 0.0f;
+            s += v[k];
+        }
+        const float mean = sn_wave_sum(s) / (float)E;              // (the sums of sn_layernorm_row)
+        float sq = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + SN_WAVE * k;
+            const float d = (c < E) ? v[k] - mean : 0.0f;
+            sq += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(sn_wave_sum(sq) / (float)E + eps);
+        float a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + SN_WAVE * k;
+            const float xh = (c < E) ? (v[k] - mean) * rstd : 0.0f;
+            const float yv = xh * gm[k] + bt[k];
+            const float gq = (relu && !(yv > 0.0f)) ? 0.0f : gy[k];       // threshold_backward: the gradient passes where y > 0
+            db[k] += gq;
+            dg[k] += gq * xh;
+            const float dxh = gq * gm[k];
+            a1 += dxh;
+            a2 += dxh * xh;
+            v[k] = xh; gy[k] = dxh;
+        }
+        const float m1 = sn_wave_sum(a1) / (float)E, m2 = sn_wave_sum(a2) / (float)E;
+        float *o = dx + row * E;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + SN_WAVE * k;
+            if (c < E) o[c] = masked ? 0.0f : rstd * (gy[k] - m1 - v[k] * m2);     // (masked_fill's backward: no gradient into a padded row)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        red[wid][0][lane + SN_WAVE * k] = dg[k];
+        red[wid][1][lane + SN_WAVE * k] = db[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * SN_WAVE * KMAX; i += 256) {
+        const int which = i / (SN_WAVE * KMAX), c = i % (SN_WAVE * KMAX);
+        if (c < E) partial[((int64_t)blockIdx.x * 2 + which) * E + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// out[which][c] = sum over blocks of partial[block][which][c], in block order per thread slice, the four slices in order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *partial, int blocks, int E, float *out)
+{
+    __shared__ float red[4][SN_WAVE];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x * SN_WAVE + lane, which = blockIdx.y;
+    float acc = 0.0f;
+    if (c < E)
+        for (int b = wid; b < blocks; b += 4) acc += partial[((int64_t)b * 2 + which) * E + c];
+    red[wid][lane] = acc;
+    __syncthreads();
+    if (wid == 0 && c < E) out[(int64_t)which * E + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 }  // namespace
 
 extern "C" int sn_pow2_scale_blocks(int64_t n)
@@ -256,5 +375,51 @@ extern "C" int sn_normalize_sum_rows(float *x, int64_t rows, int n, float min_va
     hipLaunchKernelGGL(normalize_sum_rows_kernel, dim3((unsigned)(rows < cap ? rows : cap)), dim3(kNormThreads), 0, (hipStream_t)stream, x, rows, n,
                        min_val, diag_n);
     SN_CHECK_LAUNCH("sn_normalize_sum_rows");
+    return SN_OK;
+}
+
+extern "C" int sn_ln_act_blocks(int64_t rows)
+{
+    const int64_t want = (rows + 3) / 4, cap = (int64_t)sn_device_cus() * 8;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+extern "C" int sn_mask_layernorm_act_forward(const float *x, float *y, int G, int n, int E, const int32_t *n_valid, const float *gamma,
+                                             const float *beta, float eps, int relu, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0 && E > 0, SN_ERR_BAD_ARG, "sn_mask_layernorm_act_forward: bad G=%d n=%d E=%d", G, n, E);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(x && y && gamma && beta, SN_ERR_BAD_ARG, "sn_mask_layernorm_act_forward: NULL pointer");
+    SN_REQUIRE(E <= SN_WAVE * SN_LN_MAX, SN_ERR_UNSUPPORTED, "sn_mask_layernorm_act_forward: E=%d > %d", E, SN_WAVE * SN_LN_MAX);
+    const int64_t rows = (int64_t)G * n;
+    const int64_t want = (rows + 3) / 4, cap = (int64_t)sn_device_cus() * 32;
+    hipLaunchKernelGGL(ln_act_forward_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, (hipStream_t)stream, x, y, rows, n, E, n_valid,
+                       gamma, beta, eps, relu);
+    SN_CHECK_LAUNCH("sn_mask_layernorm_act_forward");
+    return SN_OK;
+}
+
+extern "C" int sn_mask_layernorm_act_backward(const float *x, const float *dy, int G, int n, int E, const int32_t *n_valid, const float *gamma,
+                                              const float *beta, float eps, int relu, float *dx, float *partial, float *dgamma_dbeta,
+                                              void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0 && E > 0, SN_ERR_BAD_ARG, "sn_mask_layernorm_act_backward: bad G=%d n=%d E=%d", G, n, E);
+    SN_REQUIRE(dgamma_dbeta, SN_ERR_BAD_ARG, "sn_mask_layernorm_act_backward: NULL pointer");
+    if (G == 0) return sn_zero_async(dgamma_dbeta, (size_t)2 * E * sizeof(float), (hipStream_t)stream);
+    SN_REQUIRE(x && dy && gamma && beta && dx && partial, SN_ERR_BAD_ARG, "sn_mask_layernorm_act_backward: NULL pointer");
+    SN_REQUIRE(E <= SN_WAVE * SN_LN_MAX, SN_ERR_UNSUPPORTED, "sn_mask_layernorm_act_backward: E=%d > %d", E, SN_WAVE * SN_LN_MAX);
+    const int64_t rows = (int64_t)G * n;
+    const int blocks = sn_ln_act_blocks(rows);
+#define SN_LN_BWD(KM)                                                                                                                      \
+    hipLaunchKernelGGL(ln_act_backward_kernel<KM>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, rows, n, E, n_valid, gamma, \
+                       beta, eps, relu, dx, partial)
+    if (E <= 256) SN_LN_BWD(4);
+    else if (E <= 512) SN_LN_BWD(8);
+    else SN_LN_BWD(16);
+#undef SN_LN_BWD
+    SN_CHECK_LAUNCH("sn_mask_layernorm_act_backward");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((E + SN_WAVE - 1) / SN_WAVE), 2), dim3(256), 0, (hipStream_t)stream, partial, blocks, E,
+                       dgamma_dbeta);
+    SN_CHECK_LAUNCH("sn_mask_layernorm_act_backward");
     return SN_OK;
 }

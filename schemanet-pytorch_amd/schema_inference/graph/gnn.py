@@ -124,6 +124,12 @@ class Layer(nn.Module):
             # pad rows -> 0, LayerNorm, ReLU in one pass (reference gnn.py:43-46)
             return ops.mask_layernorm_act_(feat, self.norm.weight, self.norm.bias, self.norm.eps,
                                            n_valid=n_valid, relu=self._is_relu)
+        if (feat.is_cuda and feat.dim() == 3 and feat.dtype == torch.float32 and torch.is_grad_enabled() and (self._is_relu or self._is_none)
+                and feat.shape[-1] <= 1024 and (feat_mask is None or n_valid is not None) and self.norm.elementwise_affine
+                and self.norm.bias is not None and os.environ.get("SN_LN_ACT_FUSED", "1") != "0"):
+            # training on the GPU: mask, LayerNorm and activation as one differentiable op (one pass forward, one back)
+            return ops.mask_layernorm_act(feat, self.norm.weight, self.norm.bias, self.norm.eps,
+                                          n_valid=n_valid if feat_mask is not None else None, relu=self._is_relu)
         if feat_mask is not None:
             feat = feat.masked_fill(feat_mask[..., None], 0)
         return self.activation(self.norm(feat))

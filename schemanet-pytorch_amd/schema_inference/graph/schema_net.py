@@ -159,7 +159,9 @@ class SchemaNet(nn.Module):
         if ew.is_cuda and ew.is_contiguous() and self._needs_grad(ew) and os.environ.get("SN_ATLAS_AUTOGRAD_FUSED", "1") != "0":
             # one HIP pass forward (pruning the parameter in place, :164) and one back, the gradients - NaN rows included -
             # those of the chain of torch ops below
-            return ops.class_edges_autograd(ew, self.vertex_weights.tensor.detach(), self.prune_node_threshold, self.remove_self_loop)
+            # (training: the row entropies the loss's sparsity term wants ride along, SN_ATLAS_ENTROPY_FUSED=0 turns that off)
+            return ops.class_edges_autograd(ew, self.vertex_weights.tensor.detach(), self.prune_node_threshold, self.remove_self_loop,
+                                            with_entropy=os.environ.get("SN_ATLAS_ENTROPY_FUSED", "1") != "0")
         if self.prune_node_threshold is not None:
             with torch.no_grad():
                 keep = self.get_class_vertices(detach=True) > self.prune_node_threshold

@@ -262,5 +262,95 @@ def test_rectify_linear_select_form(mods):
             xd = torch.tensor(xv, dtype=torch.float32, device=DEV, requires_grad=True)
             yc, yd = loss_mod.rectify_linear(xc, a), loss_mod.rectify_linear(xd, a)
             yc.backward(); yd.backward()
-            assert float(yc) == pytest.approx(float(yd), rel=1e-6, abs=1e-7), (a, xv)
+            assert float(yc.detach()) == pytest.approx(float(yd.detach()), rel=1e-6, abs=1e-7), (a, xv)
             assert torch.isfinite(xd.grad) and float(xc.grad) == pytest.approx(float(xd.grad), rel=1e-6), (a, xv)
+
+
+@pytest.mark.parametrize("K,n,rsl", [(3, 1024, True), (4, 512, False), (2, 100, True), (3, 130, False)])
+def test_class_edges_with_row_entropies(mods, K, n, rsl):
+    """`class_edges_autograd(with_entropy=True)`: class_edges and, from the same pass, its row entropies; backwards one pass for
+    both upstream gradients.  Against the two separate ops (sn_atlas_normalize + sn_row_entropy and their backward passes joined
+    by autograd's add): the same bits forward, the same bits backward - also with only one of the two outputs used, with NaN
+    rows (a class vertex whose whole row is pruned: 0 / 0) and with a zero upstream entropy gradient in all rows but one."""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(K * 7 + n)
+    vw = torch.rand(K, n, generator=g).to(DEV)
+    vw[:, ::3] *= 1e-4                                                      # a third of the vertices under the threshold
+    ew0 = (torch.rand(K, n, n, generator=g) - 0.1).to(DEV)
+    w_ce = torch.randn(K, n, n, generator=g).to(DEV) * 1e-3
+    thr = 0.5 / n
+
+    def run(fused, use_ce=True, use_ent=True):
+        ew = ew0.clone().requires_grad_(True)
+        ce = ops.class_edges_autograd(ew, vw, thr, rsl, with_entropy=fused)
+        ent = getattr(ce, "_sn_row_entropy", (None, None))[1] if fused else ops.row_entropy(ce, 1.0e-7)
+        loss = 0.0
+        if use_ce:
+            loss = loss + (ce * w_ce).sum()
+        if use_ent:
+            loss = loss + ent.max(dim=1)[0].mean() * 0.75                  # the loss's form: a maximum over the rows of a class
+        loss.backward()
+        return ce.detach(), ent.detach(), ew.grad.detach()
+
+    for use_ce, use_ent in ((True, True), (False, True), (True, False)):
+        ce_a, ent_a, g_a = run(False, use_ce, use_ent)
+        ce_b, ent_b, g_b = run(True, use_ce, use_ent)
+        assert torch.equal(ce_a, ce_b)
+        assert torch.equal(ent_a, ent_b)
+        assert torch.equal(torch.isnan(g_a), torch.isnan(g_b)) and bool(torch.isnan(g_a).any())
+        assert torch.equal(g_a.nan_to_num(0), g_b.nan_to_num(0)), (use_ce, use_ent, (g_a.nan_to_num(0) - g_b.nan_to_num(0)).abs().max().item())
+    assert ent_b.shape == (K, n) and float(ent_b.max()) > 0
+
+
+def test_loss_takes_the_precomputed_row_entropies(mods):
+    from schema_inference import loss as loss_mod
+    graph = mods["graph"]
+    torch.manual_seed(9)
+    sn = graph.SchemaNet(num_vertices=256, num_classes=3, prune_node_threshold=0.001).to(DEV)
+    atlas = sn.get_atlas()
+    ce = atlas["class_edges"]
+    assert ce.requires_grad and hasattr(ce, "_sn_row_entropy")
+    ent = loss_mod.entropy(ce)
+    assert ent is ce._sn_row_entropy[1]
+    assert torch.equal(ent.detach(), mods["ops"].row_entropy(ce.detach(), 1.0e-7))
+    assert loss_mod.entropy(ce, eps=1e-5) is not ce._sn_row_entropy[1]     # another eps: computed
+    with torch.no_grad():
+        assert not hasattr(sn.get_atlas()["class_edges"], "_sn_row_entropy")
+
+
+@pytest.mark.parametrize("G,n,E,relu,masked", [(3, 196, 256, True, True), (101, 64, 256, True, False), (2, 70, 1024, True, True), (4, 33, 48, False, True),
+                                               (1, 1, 64, True, False), (5, 130, 512, False, False)])
+def test_mask_layernorm_act_with_autograd(mods, G, n, E, relu, masked):
+    """the GNN layer's tail as one differentiable op: the forward values are those of the inference kernel (bit for bit) and of
+    masked_fill + LayerNorm + ReLU in float64; dx, d gamma, d beta against float64 autograd of that chain, padded rows
+    included (no gradient into them, their share of d beta kept)"""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(G * 17 + n + E)
+    x = torch.randn(G, n, E, generator=g) * (0.5 + 2.0 * torch.rand(G, n, 1, generator=g))
+    gamma = 0.5 + torch.rand(E, generator=g)
+    beta = 0.3 * torch.randn(E, generator=g)
+    dy = torch.randn(G, n, E, generator=g) * 1e-3
+    n_valid = torch.randint(max(1, n // 2), n + 1, (G,), generator=g).to(torch.int32) if masked else None
+    xd = x.to(DEV).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    nv = None if n_valid is None else n_valid.to(DEV)
+    y = ops.mask_layernorm_act(xd, gd, bd, 1e-5, n_valid=nv, relu=relu)
+    y.backward(dy.to(DEV))
+    inplace = ops.mask_layernorm_act_(x.to(DEV).clone(), gamma.to(DEV), beta.to(DEV), 1e-5, n_valid=nv, relu=relu)
+    assert torch.equal(y.detach(), inplace)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    h = x64
+    if n_valid is not None:
+        h = h.masked_fill((torch.arange(n)[None, :] >= n_valid[:, None])[..., None], 0)
+    y64 = torch.nn.functional.layer_norm(h, (E,), g64, b64, 1e-5)
+    if relu:
+        y64 = torch.relu(y64)
+    y64.backward(dy.double())
+    for got, want, what, tol in ((y.detach(), y64.detach(), "y", 3e-6), (xd.grad, x64.grad, "dx", 2e-5), (gd.grad, g64.grad, "d gamma", 2e-5),
+                                 (bd.grad, b64.grad, "d beta", 2e-5)):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= tol * max(1e-30, want.abs().max().item()), (what, err, want.abs().max().item())
+    if n_valid is not None:
+        pad = (torch.arange(n)[None, :] >= n_valid[:, None]).to(DEV)
+        assert float(xd.grad[pad].abs().max()) == 0.0 if bool(pad.any()) else True
