@@ -317,18 +317,35 @@ __global__ __launch_bounds__(256) void ln_act_backward_kernel(const float *x, co
     }
 }
 
-// out[which][c] = sum over blocks of partial[block][which][c], in block order per thread slice, the four slices in order
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *partial, int blocks, int E, float *out)
+// out[which][c] = sum over blocks of partial[block][which][c]: sixteen slices of the blocks per column (a thread walks its
+// slice in block order, eight loads in flight), the slices added in order.  (Four slices over 2048 blocks: 120 us of
+// dependent-load latency per call, as much as the pass that produced the partial sums.)
+constexpr int kFinishSlices = 16;
+__global__ __launch_bounds__(kFinishSlices * SN_WAVE) void colsum_finish_kernel(const float *partial, int blocks, int E, float *out)
 {
-    __shared__ float red[4][SN_WAVE];
+    __shared__ float red[kFinishSlices][SN_WAVE];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = blockIdx.x * SN_WAVE + lane, which = blockIdx.y;
     float acc = 0.0f;
-    if (c < E)
-        for (int b = wid; b < blocks; b += 4) acc += partial[((int64_t)b * 2 + which) * E + c];
+    if (c < E) {
+        int b = wid;
+        for (; b + 7 * kFinishSlices < blocks; b += 8 * kFinishSlices) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = partial[((int64_t)(b + u * kFinishSlices) * 2 + which) * E + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; b < blocks; b += kFinishSlices) acc += partial[((int64_t)b * 2 + which) * E + c];
+    }
     red[wid][lane] = acc;
     __syncthreads();
-    if (wid == 0 && c < E) out[(int64_t)which * E + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wid == 0 && c < E) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < kFinishSlices; ++w) t += red[w][lane];
+        out[(int64_t)which * E + c] = t;
+    }
 }
 
 }  // namespace
@@ -380,7 +397,7 @@ extern "C" int sn_normalize_sum_rows(float *x, int64_t rows, int n, float min_va
 
 extern "C" int sn_ln_act_blocks(int64_t rows)
 {
-    const int64_t want = (rows + 3) / 4, cap = (int64_t)sn_device_cus() * 8;
+    const int64_t want = (rows + 3) / 4, cap = (int64_t)sn_device_cus() * 4;
     return (int)(want < 1 ? 1 : (want < cap ? want : cap));
 }
 
@@ -418,7 +435,7 @@ extern "C" int sn_mask_layernorm_act_backward(const float *x, const float *dy, i
     else SN_LN_BWD(16);
 #undef SN_LN_BWD
     SN_CHECK_LAUNCH("sn_mask_layernorm_act_backward");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((E + SN_WAVE - 1) / SN_WAVE), 2), dim3(256), 0, (hipStream_t)stream, partial, blocks, E,
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((E + SN_WAVE - 1) / SN_WAVE), 2), dim3(kFinishSlices * SN_WAVE), 0, (hipStream_t)stream, partial, blocks, E,
                        dgamma_dbeta);
     SN_CHECK_LAUNCH("sn_mask_layernorm_act_backward");
     return SN_OK;
