@@ -518,6 +518,12 @@ int sn_mask_layernorm_act_forward(const float *x, float *y, int G, int n, int E,
 int sn_mask_layernorm_act_backward(const float *x, const float *dy, int G, int n, int E, const int32_t *n_valid, const float *gamma,
                                    const float *beta, float eps, int relu, float *dx, float *partial, float *dgamma_dbeta,
                                    void *stream);
+/* Gradient of table[ids] with respect to the table for an index tensor sorted beforehand: order [N] = the positions of the
+ * flattened ids in ascending id order (stable), seg [rows + 1] = where each id's run starts in it; grad [rows, E] (every row
+ * written; row padding_idx, if in range, zero) from dy [N, E].  E % 4 == 0.  (reference gnn.py:83: nn.Embedding over the class
+ * graphs' words - constant between training iterations.) */
+int sn_embedding_grad_sorted(const float *dy, const int64_t *order, const int64_t *seg, int rows, int E, int padding_idx, float *grad,
+                             void *stream);
 /* `graph`: a captured, not yet instantiated hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Every
  * one-dimensional memset node is replaced by a kernel node with the same predecessors and successors (a captured memset
  * node was seen not to clear on replay on ROCm 7.2; a graph PyTorch captured holds the library's own: semaphores of

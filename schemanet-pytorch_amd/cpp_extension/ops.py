@@ -1012,6 +1012,46 @@ def pool_fc(pooled_sum, divisor, weight, bias, weight_t=None):
     return out
 
 
+class _EmbeddingSortedGrad(torch.autograd.Function):
+    """table[ids] whose backward takes the sort of `ids` from the caller (sorted_ids_of: done once for an index tensor that
+    stays the same from iteration to iteration) instead of sorting in every backward pass."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, weight, ids, order, seg, padding_idx):
+        ctx.save_for_backward(order, seg)
+        ctx.opts = (tuple(weight.shape), int(padding_idx) if padding_idx is not None else -1, tuple(ids.shape))
+        return torch.nn.functional.embedding(ids, weight.detach())
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, dy):
+        order, seg = ctx.saved_tensors
+        (rows, E), pad, _ = ctx.opts
+        lib = N.require_gpu()
+        dyc = _f32c(dy).reshape(-1, E)
+        dev = _check_dev(dyc, order, seg)
+        grad = torch.empty((rows, E), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_embedding_grad_sorted(N.ptr(dyc), N.ptr(order), N.ptr(seg), rows, E, pad, N.ptr(grad), N.stream_ptr(dev)),
+                    "sn_embedding_grad_sorted")
+        return grad, None, None, None, None
+
+
+def sorted_ids_of(ids, rows):
+    """-> (order int64 [N], seg int64 [rows + 1]) of an index tensor with values in [0, rows): see sn_embedding_grad_sorted"""
+    flat = ids.reshape(-1)
+    srt, order = torch.sort(flat, stable=True)
+    seg = torch.searchsorted(srt, torch.arange(rows + 1, device=ids.device, dtype=flat.dtype))
+    return order.contiguous(), seg.contiguous()
+
+
+def embedding_sorted(weight, ids, order, seg, padding_idx=None):
+    """weight[ids] (fp32 CUDA table [rows, E], E % 4 == 0), differentiable in `weight`; (order, seg) = sorted_ids_of(ids, rows)."""
+    assert weight.dtype == torch.float32 and weight.shape[1] % 4 == 0 and order.dtype == torch.int64 and seg.numel() == weight.shape[0] + 1
+    return _EmbeddingSortedGrad.apply(weight, ids, order, seg, padding_idx)
+
+
 class _MaskLayerNormAct(torch.autograd.Function):
     """y = act(LayerNorm(x with the rows >= n_valid[g] set to 0)) on x [G, n, E] (reference gnn.py:43-46) with autograd: one HIP
     pass forward (the values of mask_layernorm_act_), one back over (x, dy) that recomputes the row statistics and yields dx,

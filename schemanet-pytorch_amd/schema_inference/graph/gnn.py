@@ -151,6 +151,24 @@ class GNN(nn.Module):
         with torch.no_grad():
             nn.init.trunc_normal_(self.embedding.weight[:num_codes])
 
+    def _embed(self, ids: torch.Tensor) -> torch.Tensor:
+        """`self.embedding(ids)`.  Training on the GPU with an index tensor that is a module's buffer / Parameter (the class
+        graphs' words, `SchemaNet.class_ingredients`: the same in every iteration): its sort is taken once per version of the
+        tensor and kept ON it, and the backward pass is one gather-sum (ops.embedding_sorted) instead of the library's sort of
+        the 103 k ids in every iteration."""
+        w = self.embedding.weight
+        if (isinstance(ids, nn.Parameter) and not ids.requires_grad and ids.is_cuda and w.is_cuda and w.dtype == torch.float32
+                and w.requires_grad and torch.is_grad_enabled() and w.shape[1] % 4 == 0 and os.environ.get("SN_EMBED_SORTED", "1") != "0"):
+            srt = getattr(ids, "_sn_sorted", None)
+            if srt is None or srt[0] != (ids._version, w.shape[0]):
+                if torch.cuda.is_current_stream_capturing():
+                    return self.embedding(ids)               # (a sort cannot be captured: whoever captures warms up first)
+                with torch.no_grad():
+                    srt = ((ids._version, w.shape[0]),) + ops.sorted_ids_of(ids.detach().clamp(0, w.shape[0] - 1), w.shape[0])
+                ids._sn_sorted = srt
+            return ops.embedding_sorted(w, ids.detach(), srt[1], srt[2], self.embedding.padding_idx)
+        return self.embedding(ids)
+
     def _differentiable(self, *tensors) -> bool:
         if not torch.is_grad_enabled():
             return False
@@ -356,7 +374,7 @@ class GNN(nn.Module):
                                            n_valid=n_valid, relu=first._is_relu)
             layers = layers[1:]
         else:
-            feat = self.embedding(ingredients)
+            feat = self._embed(ingredients)
         adj_planes = ops.gcn_adjacency_planes(_contig(edges.detach())) if train_mfma else None      # shared by the layers (and by their backward passes)
         for layer in layers:
             # (the layers run in sequence on one `edges` / `adj_planes`: their edge gradients are summed before autograd sees them)

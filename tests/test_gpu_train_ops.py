@@ -354,3 +354,52 @@ def test_mask_layernorm_act_with_autograd(mods, G, n, E, relu, masked):
     if n_valid is not None:
         pad = (torch.arange(n)[None, :] >= n_valid[:, None]).to(DEV)
         assert float(xd.grad[pad].abs().max()) == 0.0 if bool(pad.any()) else True
+
+
+@pytest.mark.parametrize("rows,E,shape", [(1025, 256, (101, 1024)), (129, 64, (5, 300)), (33, 512, (2, 7)), (17, 48, (3, 40))])
+def test_embedding_backward_from_a_cached_sort(mods, rows, E, shape):
+    """table[ids] with the sort of `ids` taken once (ops.sorted_ids_of): the lookup equals F.embedding, the table gradient equals
+    its autograd (float64 sums), the padding row gets none, words that do not occur get zeros"""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(rows + E)
+    w = torch.randn(rows, E, generator=g)
+    ids = torch.randint(0, rows, shape, generator=g)
+    ids[0, 0] = rows - 1                                             # the padding index occurs
+    ids[ids == 3] = 4                                                # ... and word 3 never does
+    dy = torch.randn(*shape, E, generator=g)
+    wd = w.to(DEV).requires_grad_(True)
+    idd = ids.to(DEV)
+    order, seg = ops.sorted_ids_of(idd, rows)
+    y = ops.embedding_sorted(wd, idd, order, seg, padding_idx=rows - 1)
+    y.backward(dy.to(DEV))
+    w64 = w.double().requires_grad_(True)
+    y64 = torch.nn.functional.embedding(ids, w64, padding_idx=rows - 1)
+    y64.backward(dy.double())
+    assert torch.equal(y.detach().cpu(), y64.detach().float())
+    err = (wd.grad.double().cpu() - w64.grad).abs().max().item()
+    assert err <= 2e-6 * w64.grad.abs().max().item(), err
+    assert float(wd.grad[rows - 1].abs().max()) == 0.0 and float(wd.grad[3].abs().max()) == 0.0
+
+
+def test_gnn_uses_the_cached_sort_for_buffer_ids_only(mods):
+    graph = mods["graph"]
+    torch.manual_seed(2)
+    gnn = graph.GNN(num_codes=64, embed_dim=32, num_layers=2).to(DEV).train()
+    ids_buf = torch.nn.Parameter(torch.randint(0, 64, (3, 40), device=DEV), requires_grad=False)
+    ids_plain = ids_buf.detach().clone()
+    nodes = torch.rand(3, 40, device=DEV)
+    edges = torch.rand(3, 40, 40, device=DEV)
+    outs = []
+    for ids in (ids_buf, ids_plain):
+        gnn.zero_grad()
+        out = gnn(nodes, edges, ids)
+        out.sum().backward()
+        outs.append((out.detach().clone(), gnn.embedding.weight.grad.detach().clone()))
+    assert hasattr(ids_buf, "_sn_sorted") and not hasattr(ids_plain, "_sn_sorted")
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2e-6 * outs[1][1].abs().max().item()
+    v = ids_buf._sn_sorted[0]
+    with torch.no_grad():
+        ids_buf.copy_(torch.randint(0, 64, (3, 40), device=DEV))     # new content: the version moves, the sort is taken again
+    gnn(nodes, edges, ids_buf)
+    assert ids_buf._sn_sorted[0] != v
