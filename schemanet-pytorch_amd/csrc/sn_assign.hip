@@ -1630,8 +1630,33 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
 // Values, keys, error window, merge through LDS and the flag word / candidate record (format 3: slot 3 (2 q + h) + j) are
 // those of assign_screen3_kernel; the leftover tokens' keys of the four accumulator-row groups are merged pairwise
 // (lanes l, l ^ 32) so that what is left has the slot structure of a 32 x 32 tile (code bits: see kS4 comments below).
-// Probe (tools/proto_screen4.hip): intake alone 12.9 us (6 TB/s), with the MFMAs 21 us by the event pair's own clock.
+// Probe (tools/proto_screen4.hip): intake alone 12.9 us (6 TB/s), with the MFMAs 21 us of kernel time.
+// Measured (MI355X, 50 176 tokens): 34.5 us of kernel time (40.4 by the library's event pair; the default form: 30.4 / 36.3).
+// The main loop is ~19 us, but the keys of 448 accumulator values per lane are 2 300 dependent VALU instructions on a wave
+// that is ALONE on its SIMD - 9 us with nothing to overlap them with in a one-round form - and the merge another 4.5 us.
+// Opt-in; DESIGN 8.  What this kernel ran into, all because an asm MFMA is invisible to the compiler (hazard recogniser,
+// register allocator): (1) a VALU conversion scheduled right in front of the first MFMA of a group fed it a stale B register
+// (one tile in four of a set wrong): wait states are written into the asm; (2) VALU work dealt BETWEEN the four MFMAs of a
+// step (38 us, 2.4 us faster) gave whole sets of garbage - the queued MFMAs read their operands when they start, not when
+// they issue - so the next step's conversion runs behind the fourth MFMA; (3) any instrumentation between the phases (stamps)
+// made the compiler park whole accumulator sets in scratch - stamps 0 and 4 only; (4) a lambda nested in the kernel's generic
+// lambdas does not capture a variable that only appears as an asm operand (clang): the MFMA is a function.
 // ------------------------------------------------------------------------------------------
+// one MFMA of assign_screen4_kernel, accumulator in the AGPRs (AG) or the VGPRs, NOPS wait states in front
+template <bool AG, int NOPS>
+__device__ __forceinline__ void s4_mfma(f32x16 &ac, const half8 &a, const half8 &b)
+{
+    if constexpr (AG) {
+        if constexpr (NOPS == 3) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a), "v"(b));
+        else if constexpr (NOPS == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a), "v"(b));
+    } else {
+        if constexpr (NOPS == 3) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a), "v"(b));
+        else if constexpr (NOPS == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a), "v"(b));
+    }
+}
+
 constexpr int kS4Sets = 6, kS4Lo = 16;                          // full sets, leftover tokens
 constexpr int kS4Rows = kS4Sets * 32 + kS4Lo;                   // tokens a workgroup can hold (208)
 constexpr int kS4RowsPad = 224;                                 // token rows copied per chunk (28 x 8: seven 1 KiB copies per wave)
@@ -1773,38 +1798,67 @@ __global__ __launch_bounds__(256, 1) void assign_screen4_kernel(const AssignArgs
         unsigned rb = (unsigned)(kS4OffT + (c % 3) * kS4Tok);
         asm volatile("" : "+s"(rb));
         constexpr int sl = (c & 1) * kS4Slab;
+        // Software pipeline over the chunk's twelve steps (k-step, set): a wave alone on its SIMD issues in order, so the NEXT
+        // step's raw rows are requested in front of THIS step's four MFMAs and converted right behind them, in the shadow of the
+        // queued MFMAs (32 cycles of matrix pipe each) - with the request, the wait and the conversion of a step in front of its
+        // own MFMAs the loop ran at 1.75 us per chunk against 0.9 us of matrix pipe.  sched_barrier pins the order the source gives.
+        half8 a0[4], a1[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 a[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const half8 *>(smem + a_lane + (sl + t * 2048 + ks * 1024));
-            const unsigned char *plo = smem + rb + t_lo[ks], *phi = smem + rb + t_hi[ks];
-#pragma unroll
-            for (int s = 0; s < kS4Sets; ++s) {
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(plo + s * 4096);
-                const f32x4 hi = *reinterpret_cast<const f32x4 *>(phi + s * 4096);
-                float sq = 0.0f;
-                squares(sq, lo, hi);
-                sumsq0 = fmaf(sel0[s], sq, sumsq0);
-                sumsq1 = fmaf(sel1[s], sq, sumsq1);
-                asm volatile("" : "+v"(sumsq0), "+v"(sumsq1));     // (or the sums sink to the epilogue and every sq waits for them in scratch)
-                const half8 b = to_half8(lo, hi);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    // (t == 0: the B fragment has just been written by VALU conversions, and the hazard recogniser does not
-                    // look inside an asm statement: without the wait states the first tile's MFMA can read a stale register -
-                    // seen as one tile in four of a set wrong whenever the scheduler put a conversion right in front of it)
-                    f32x16 &ac = acc[s][t];
-                    if (s < 4) {
-                        if (t == 0) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a[t]), "v"(b));
-                        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a[t]), "v"(b));
-                    } else {
-                        if (t == 0) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a[t]), "v"(b));
-                        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a[t]), "v"(b));
-                    }
-                }
-            }
+        for (int t = 0; t < 4; ++t) a0[t] = *reinterpret_cast<const half8 *>(smem + a_lane + (sl + t * 2048));
+        const unsigned char *plo0 = smem + rb + t_lo[0], *phi0 = smem + rb + t_hi[0];
+        const unsigned char *plo1 = smem + rb + t_lo[1], *phi1 = smem + rb + t_hi[1];
+        f32x4 lo = *reinterpret_cast<const f32x4 *>(plo0), hi = *reinterpret_cast<const f32x4 *>(phi0);
+        // (an MFMA reads its A / B registers when it STARTS, and up to four of them queue in front of the matrix pipe: a register
+        // the compiler believes free right behind the asm statement - for the next LDS read, the next conversion - may be
+        // overwritten before the queued MFMA has read it.  Seen as whole sets of garbage.  So every operand is kept alive one
+        // step longer by an empty asm that "reads" it: bprev below, the A fragments behind their k-step.)
+        half8 bcur, bprev;
+        {
+            float sq = 0.0f;
+            squares(sq, lo, hi);
+            sumsq0 = fmaf(sel0[0], sq, sumsq0);
+            sumsq1 = fmaf(sel1[0], sq, sumsq1);
+            asm volatile("" : "+v"(sumsq0), "+v"(sumsq1));
+            bcur = to_half8(lo, hi);
+            bprev = bcur;
         }
+        static_for<2 * kS4Sets>([&](auto j_c) {
+            constexpr int j = decltype(j_c)::value, ks = j / kS4Sets, st = j % kS4Sets;
+            constexpr int jn = j + 1, ksn = jn / kS4Sets, sn = jn % kS4Sets;
+            constexpr bool more = jn < 2 * kS4Sets;
+            // the next step's raw rows (and, in the middle of k-step 0, the A fragments of k-step 1)
+            if constexpr (more) {
+                lo = *reinterpret_cast<const f32x4 *>((ksn ? plo1 : plo0) + sn * 4096);
+                hi = *reinterpret_cast<const f32x4 *>((ksn ? phi1 : phi0) + sn * 4096);
+            }
+            if constexpr (j == 2) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a1[t] = *reinterpret_cast<const half8 *>(smem + a_lane + (sl + t * 2048 + 1024));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr bool AG = st < 4;
+            constexpr int N0 = j == 0 ? 3 : 1;                    // (first MFMA of the chunk: its B fragment has just been packed)
+            float sq = 0.0f;
+            half8 bnext;
+            s4_mfma<AG, N0>(acc[st][0], ks ? a1[0] : a0[0], bcur);
+            s4_mfma<AG, 0>(acc[st][1], ks ? a1[1] : a0[1], bcur);
+            s4_mfma<AG, 0>(acc[st][2], ks ? a1[2] : a0[2], bcur);
+            s4_mfma<AG, 0>(acc[st][3], ks ? a1[3] : a0[3], bcur);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (more) {
+                squares(sq, lo, hi);
+                sumsq0 = fmaf(sel0[sn], sq, sumsq0);
+                sumsq1 = fmaf(sel1[sn], sq, sumsq1);
+                asm volatile("" : "+v"(sumsq0), "+v"(sumsq1));
+                bnext = to_half8(lo, hi);
+                asm volatile("" : "+v"(bnext));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" :: "v"(bprev));                       // (the previous step's B fragment may go now)
+            bprev = bcur;
+            if constexpr (more) bcur = bnext;
+            if constexpr (j == kS4Sets + 1) asm volatile("" :: "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]));
+        });
         asm volatile("s_nop 7" ::: "memory");                   // (the last MFMAs' operand registers are free game for the compiler from here on)
         {   // leftover tokens: one 16 x 16 x 32 step per block and chunk.  Lane (j16, kg) multiplies the image's (k-step kg >> 1, k half
             // kg & 1) = floats 16 (kg & 1) + 8 (kg >> 1) .. + 7 of the chunk = pieces pl, pl + 1
@@ -1816,13 +1870,18 @@ __global__ __launch_bounds__(256, 1) void assign_screen4_kernel(const AssignArgs
             asm volatile("" : "+v"(sumsq1));
             const half8 b = to_half8(lo, hi);
             // A fragment of block bl: words 16 (bl & 1) + j16 of tile bl >> 1, k = 8 kg .. + 7: k-step kg >> 1, k half kg & 1 of the image
+            // (all eight read up front into registers of their own, and everything kept alive behind the last MFMA: see above)
+            half8 a16[8];
+#pragma unroll
+            for (int bl = 0; bl < 8; ++bl) a16[bl] = *reinterpret_cast<const half8 *>(smem + a16_lane + (sl + (bl >> 1) * 2048 + (bl & 1) * 256));
 #pragma unroll
             for (int bl = 0; bl < 8; ++bl) {
-                const half8 a16 = *reinterpret_cast<const half8 *>(smem + a16_lane + (sl + (bl >> 1) * 2048 + (bl & 1) * 256));
                 f32x4 &al = accl[bl];
-                if (bl == 0) asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(al) : "v"(a16), "v"(b));
-                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(al) : "v"(a16), "v"(b));
+                if (bl == 0) asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(al) : "v"(a16[bl]), "v"(b));
+                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(al) : "v"(a16[bl]), "v"(b));
             }
+            asm volatile("s_nop 15\n\ts_nop 15" :: "v"(bprev), "v"(bcur), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]));
+            asm volatile("s_nop 15\n\ts_nop 15" :: "v"(b), "v"(a16[0]), "v"(a16[1]), "v"(a16[2]), "v"(a16[3]), "v"(a16[4]), "v"(a16[5]), "v"(a16[6]), "v"(a16[7]));
         }
     });
     // (the asm MFMAs are invisible to the hazard recogniser and their results are read below - first those of the LAST ones
