@@ -357,6 +357,57 @@ def shape_leg(device, name, Bc, Dc, Mc, Kc, n_max, Ec, token_dtype, n_steps):
                       "tokens": str(token_dtype).replace("torch.", "")}}
 
 
+def train_leg(device, n_iter=10):
+    """One optimisation step of the reference's SchemaNet trainer at config [4]'s real size (B = 64, M = 1024, K = 101 class graphs
+    of 1024 vertices - a 404 MB edge_weights -, E = 256; schema_inference/tasks/worker_schema_net.py:121-147): normalize -> forward ->
+    SchemaInferenceLoss -> backward -> AdamW as ONE hipGraph replay (`train.GraphedTrainIter`), and the same iteration as eager
+    `train_iter` calls over the same route.  Milliseconds per iteration; untimed by the driver."""
+    import schema_inference.graph as graph
+    from schema_inference import loss as loss_mod, train as train_mod
+    Bc, Mc, Kc, Ec = 64, 1024, 101, 256
+    g = lambda s_: torch.Generator().manual_seed(s_)  # noqa: E731
+    ing = torch.randint(0, Mc, (Bc, L), generator=g(1))
+    ing[:, ::3] = ing[:, :1]
+    batch = {"ingredients": ing.to(device), "attn": torch.randn(Bc, L, L, generator=g(2)).to(device), "attn_cls": torch.randn(Bc, L, generator=g(3)).to(device)}
+    target = {"label": torch.randint(0, Kc, (Bc,), generator=g(4)).to(device)}
+    weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+    loss_fn = loss_mod.get_loss_fn({"name": "schema_inference_loss"})
+    out = {}
+    for how in ("graphed", "eager"):
+        torch.manual_seed(11)
+        sn_t = graph.SchemaNet(num_vertices=Mc, num_classes=Kc, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0, prune_node_threshold=0.001).to(device)
+        sn_t.register_class_vertices(torch.arange(Mc, device=device).repeat(Kc, 1))
+        torch.manual_seed(12)
+        m_t = graph.Matcher("inner_product", Mc, dict(embed_dim=Ec, num_layers=2, identity_proj=False, activation="relu")).to(device).train()
+
+        def fwd(b):                                              # the route SchemaNetPredictor takes behind its wrapper
+            atlas = sn_t.get_atlas()
+            o = {"pred": m_t.forward_padded(sn_t.instance_graph_padded(b["ingredients"], b["attn"].clone(), b["attn_cls"].clone()), atlas)}
+            o.update(atlas)
+            return o
+        params = list(sn_t.parameters()) + list(m_t.parameters())
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-4, fused=True, capturable=how == "graphed")
+        if how == "graphed":
+            step_fn = train_mod.GraphedTrainIter(fwd, sn_t, loss_fn, weights, opt, batch, target, warmup=2)
+            run = lambda: step_fn(batch, target)                 # noqa: E731
+        else:
+            run = lambda: train_mod.train_iter(lambda: fwd(batch), sn_t, loss_fn, weights, opt, target)   # noqa: E731
+            for _ in range(2):
+                run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_iter):
+            total, _ = run()
+        torch.cuda.synchronize()
+        out["c5_train_iter_ms" + ("" if how == "graphed" else "_eager")] = 1e3 * (time.perf_counter() - t1) / n_iter
+        assert bool(torch.isfinite(total))
+        del sn_t, m_t, opt, run
+        torch.cuda.empty_cache()
+    out["c5_train_note"] = ("config [4] at its real size, one training iteration (normalize, forward, loss, backward, fused AdamW): `train.GraphedTrainIter` "
+                            "(one hipGraph launch) / eager `train_iter` over the same padded route; r03: 13.4 ms")
+    return out
+
+
 def pruned_atlas_leg(device, disc, m, batches, depth, n_steps):
     """The step of `value` with a PRUNED IR-Atlas: a trained atlas is sparse - the loss's entropy terms push most vertices of a
     class under prune_node_threshold (reference schema_net.py:152-166) - while the freshly initialised one of the main line
@@ -640,6 +691,8 @@ def main():
             c4 = shape_leg(device, "c4", 256, 768, 1024, 1000, 500, 1024, torch.bfloat16, 10)
             c5 = shape_leg(device, "c5", 64, 384, 1024, 101, 1024, 256, torch.float32, 20)
             extra.update(pruned_atlas_leg(device, disc, m, batches, depth, max(args.steps, 40)))
+            with torch.enable_grad():
+                extra.update(train_leg(device))
             extra.update({"c1_value": c1["value"], "c1": c1, "c4_value": c4["value"], "c4": c4, "c5_value": c5["value"], "c5": c5,
                           "roofline_c4": c4["roofline"], "roofline_c5": c5["roofline"]})
     t_max = torch.tensor(region_dt, device=device, dtype=torch.float64)

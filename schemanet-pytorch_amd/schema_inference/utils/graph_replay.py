@@ -30,7 +30,10 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        # keep_graph: the captured hipGraph_t stays accessible until it is instantiated below - any memset node in it (a
+        # `zeros`, a library reduction's semaphores) is replaced by a kernel node first: a captured memset node is not reliable on
+        # ROCm 7.2 (csrc/sn_common.h; seen in train.GraphedTrainIter as reductions that kept the previous replay's result)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         # capture_begin / capture_end by hand: the `torch.cuda.graph` context also empties the caching allocator, which
         # hands every LATER eager allocation of the process a new address - and a capture keyed on the addresses of its
         # inputs (SchemaNetPredictor) would then see them move after every other capture
@@ -45,6 +48,12 @@ class GraphedStep:
                     pass
                 raise
             self.graph.capture_end()
+        from ctypes import byref, c_int, c_void_p
+        from cpp_extension import _native as N
+        done, left = c_int(0), c_int(0)
+        N.check(N.require_gpu().sn_graph_replace_memsets(c_void_p(self.graph.raw_cuda_graph()), byref(done), byref(left)), "sn_graph_replace_memsets")
+        self.memsets_replaced, self.memsets_left = done.value, left.value
+        self.graph.instantiate()
         torch.cuda.current_stream().wait_stream(side)
 
     def replay(self):
