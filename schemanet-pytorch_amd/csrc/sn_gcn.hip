@@ -163,13 +163,26 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
     const int x0 = (int)blockIdx.x;
     int cI, cJ, chalf = 0;
     bool have;
+    // pair_tiles < 0 (large graphs, round 4): the T (T + 1) / 2 tile pairs of the graph are dealt round-robin over the graph's
+    // gridDim.x workgroups (pair p -> workgroup p % gridDim.x): a walk of T + 1 pairs per workgroup was T + 1 rounds of HBM latency
+    // with ~1.5 workgroups per CU (69 us for the 210 MB of the bench's class graphs, 3 TB/s); ~4 workgroups per CU walk a
+    // quarter of that each.
+    int cp = x0;
+    auto pair_of = [&](int p, int &I, int &J) -> bool {          // linear pair index -> (I, J >= I); false beyond the last pair
+        int i = 0;
+        while (i < T && p >= T - i) { p -= T - i; ++i; }
+        I = i; J = i + p;
+        return i < T;
+    };
     if (pair_tiles > 0) { cI = pair_I; cJ = pair_J; have = true; }
+    else if (pair_tiles < 0) { have = pair_of(cp, cI, cJ); }
     else {
         cI = x0; cJ = x0; have = cI < T;
         if (!have) { chalf = 1; cI = T - 1 - x0; cJ = cI; have = cI >= 0 && cI < T && cI > x0; }
     }
     auto advance = [&](int &I, int &J, int &half) -> bool {       // -> the pair after (I, J), false when the walk is over
         if (pair_tiles > 0) return false;
+        if (pair_tiles < 0) { cp += (int)gridDim.x; return pair_of(cp, I, J); }
         if (J + 1 < T) { ++J; return true; }
         if (half == 1) return false;
         half = 1; I = T - 1 - x0; J = I;
@@ -1058,11 +1071,18 @@ extern "C" int64_t sn_gcn_plane_elems(int rows, int k)
 }
 
 // grid of the adjacency producer: (workgroups per graph, pair_tiles).  Up to 4 tiles per side: one workgroup per tile pair.
-static void adjacency_grid(int n, unsigned &wgs, int &pair_tiles)
+static void adjacency_grid(int n, int G, unsigned &wgs, int &pair_tiles)
 {
     const int t_full = (((n + 31) & ~31) + 63) / 64;
-    if (t_full <= 4) { pair_tiles = t_full; wgs = (unsigned)(t_full * (t_full + 1) / 2); }
-    else { pair_tiles = 0; wgs = (unsigned)((t_full + 1) / 2); }                 // a workgroup owns row tiles x and T-1-x
+    if (t_full <= 4) { pair_tiles = t_full; wgs = (unsigned)(t_full * (t_full + 1) / 2); return; }
+    // larger graphs: the tile pairs dealt over W workgroups per graph, ~3.5 workgroups per CU in all (at least what the old walk
+    // launched, (T + 1) / 2: many graphs - 1000 classes - keep that; SN_ADJ_WALK=1: the old walk)
+    static const int old_walk = getenv("SN_ADJ_WALK") ? atoi(getenv("SN_ADJ_WALK")) : 0;
+    const int pairs = t_full * (t_full + 1) / 2, lo = (t_full + 1) / 2;
+    int w = (int)((7 * (int64_t)sn_device_cus() / 2 + G - 1) / (G > 0 ? G : 1));
+    w = w < lo ? lo : (w > pairs ? pairs : w);
+    if (old_walk) { pair_tiles = 0; wgs = (unsigned)lo; }
+    else { pair_tiles = -1; wgs = (unsigned)w; }
 }
 
 extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, float scale, void *adj_hi, void *adj_lo, void *stream)
@@ -1074,7 +1094,7 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const i
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
-    adjacency_grid(n, tiles, pair_tiles);
+    adjacency_grid(n, G, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                        sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
                        (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
@@ -1092,7 +1112,7 @@ extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, 
     SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes_masked: G=%d > 65535", G);
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
-    adjacency_grid(n, tiles, pair_tiles);
+    adjacency_grid(n, G, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                        sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
@@ -1109,7 +1129,7 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes: K=%d > 65535", K);
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
-    adjacency_grid(n, tiles, pair_tiles);
+    adjacency_grid(n, K, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
                        (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0);
@@ -1132,7 +1152,7 @@ extern "C" int sn_gcn_atlas_adjacency_planes_compact(const float *pruned_edge_we
     SN_REQUIRE(K <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_atlas_adjacency_planes_compact: K=%d > 65535", K);
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
-    adjacency_grid(n, tiles, pair_tiles);
+    adjacency_grid(n, K, tiles, pair_tiles);
     hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, n_kept,
                        n_kept, pair_tiles, scale, (float *)nullptr, perm, 1);

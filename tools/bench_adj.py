@@ -20,3 +20,5 @@ print("instance gather planes:    full %.1f us, extent 125: %.1f us" % (t(lambda
 vw = torch.rand(100, 512, device=dev); ew = torch.randn(100, 512, 512, device=dev)
 print("atlas prune + rowsum + fused adjacency: %.1f us; plain adjacency of [100,512,512]: %.1f us" % (
     t(lambda: ops.atlas_adjacency_planes(vw, ew, 0.001, False)), t(lambda: ops.gcn_adjacency_planes(ew))))
+ew2 = torch.randn(101, 1024, 1024, device=dev)
+print("plain adjacency of [101,1024,1024]: %.1f us" % t(lambda: ops.gcn_adjacency_planes(ew2)))
