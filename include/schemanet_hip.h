@@ -524,6 +524,10 @@ int sn_mask_layernorm_act_backward(const float *x, const float *dy, int G, int n
  * graphs' words - constant between training iterations.) */
 int sn_embedding_grad_sorted(const float *dy, const int64_t *order, const int64_t *seg, int rows, int E, int padding_idx, float *grad,
                              void *stream);
+/* Backward of sn_weighted_pool (pooled[g] = sum_i nodes[g][i] feat[g][i] / divisor, reference gnn.py:96) in one pass over feat:
+ * grad_feat [G, n, E], grad_nodes [G, n] from grad_pooled [G, E].  E % 4 == 0. */
+int sn_weighted_pool_backward(const float *feat, const float *nodes, const float *grad_pooled, int G, int n, int E,
+                              const int32_t *divisor_dev, float *grad_feat, float *grad_nodes, void *stream);
 /* `graph`: a captured, not yet instantiated hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Every
  * one-dimensional memset node is replaced by a kernel node with the same predecessors and successors (a captured memset
  * node was seen not to clear on replay on ROCm 7.2; a graph PyTorch captured holds the library's own: semaphores of

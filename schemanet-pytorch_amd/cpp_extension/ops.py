@@ -1121,6 +1121,38 @@ def weighted_pool(feat, nodes, divisor_dev=None):
     return out
 
 
+class _WeightedPool(torch.autograd.Function):
+    """weighted_pool with autograd (training): one pass forward, one back (sn_weighted_pool_backward) - the library's
+    `(feat * nodes[..., None]).sum(1) / div` is a product, a reduction and, backwards, two products and a reduction over [G, n, E]."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, feat, nodes, divisor_dev):
+        f, w = _f32c(feat.detach()), _f32c(nodes.detach())
+        ctx.save_for_backward(f, w, divisor_dev)
+        return weighted_pool(f, w, divisor_dev)
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        f, w, div = ctx.saved_tensors
+        lib = N.require_gpu()
+        dev = f.device
+        G, n, E = f.shape
+        gc = _f32c(g)
+        d_feat = torch.empty_like(f)
+        d_nodes = torch.empty_like(w)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_weighted_pool_backward(N.ptr(f), N.ptr(w), N.ptr(gc), G, n, E, N.ptr(div), N.ptr(d_feat), N.ptr(d_nodes),
+                                                  N.stream_ptr(dev)), "sn_weighted_pool_backward")
+        return d_feat, d_nodes, None
+
+
+def weighted_pool_autograd(feat, nodes, divisor_dev=None):
+    """Differentiable in feat [G, n, E] (E % 4 == 0) and nodes [G, n]; divisor_dev: int32 [1] device tensor or None (= n)."""
+    return _WeightedPool.apply(feat, nodes, divisor_dev)
+
+
 def layernorm_weighted_pool(x, gamma, beta, eps, nodes, n_valid=None, relu=True, divisor_dev=None):
     """weighted_pool(mask_layernorm_act_(x), nodes, divisor_dev) in one pass over x [G, n, E]; x is left as it is."""
     lib = N.require_gpu()

@@ -384,6 +384,30 @@ __global__ __launch_bounds__(256) void embedding_grad_sorted_kernel(const float 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward of the node-weighted mean pooling pooled[g] = sum_i nodes[g][i] feat[g][i] / div (reference gnn.py:96), one pass over
+// feat: d_feat[g][i] = nodes[g][i] g[g] / div, d_nodes[g][i] = feat[g][i] . g[g] / div.  One wave per row, 16-byte accesses.
+__global__ __launch_bounds__(256) void weighted_pool_backward_kernel(const float *feat, const float *nodes, const float *gout, int64_t rows, int n,
+                                                                    int E, const int32_t *div_dev, float *d_feat, float *d_nodes)
+{
+    const int lane = threadIdx.x & 63;
+    const float inv = 1.0f / (div_dev ? (float)(*div_dev) : (float)n);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const int g = (int)(row / n);
+        const float w = nodes[row] * inv;
+        const float *f = feat + row * E, *go = gout + (int64_t)g * E;
+        float *o = d_feat + row * E;
+        float acc = 0.0f;
+        for (int c = lane * 4; c < E; c += SN_WAVE * 4) {
+            const float4 fv = *reinterpret_cast<const float4 *>(f + c), gv = *reinterpret_cast<const float4 *>(go + c);
+            acc += (fv.x * gv.x + fv.y * gv.y) + (fv.z * gv.z + fv.w * gv.w);
+            *reinterpret_cast<float4 *>(o + c) = float4{w * gv.x, w * gv.y, w * gv.z, w * gv.w};
+        }
+        acc = sn_wave_sum(acc);
+        if (lane == 0) d_nodes[row] = acc * inv;
+    }
+}
+
 }  // namespace
 
 extern "C" int sn_pow2_scale_blocks(int64_t n)
@@ -486,5 +510,19 @@ extern "C" int sn_embedding_grad_sorted(const float *dy, const int64_t *order, c
     SN_REQUIRE((((uintptr_t)dy | (uintptr_t)grad) & 15) == 0, SN_ERR_BAD_ARG, "sn_embedding_grad_sorted: dy / grad must be 16-byte aligned");
     hipLaunchKernelGGL(embedding_grad_sorted_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, order, seg, E, padding_idx, grad);
     SN_CHECK_LAUNCH("sn_embedding_grad_sorted");
+    return SN_OK;
+}
+
+extern "C" int sn_weighted_pool_backward(const float *feat, const float *nodes, const float *grad_pooled, int G, int n, int E,
+                                         const int32_t *divisor_dev, float *grad_feat, float *grad_nodes, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0 && E > 0 && E % 4 == 0, SN_ERR_BAD_ARG, "sn_weighted_pool_backward: bad G=%d n=%d E=%d (E a multiple of 4)", G, n, E);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(feat && nodes && grad_pooled && grad_feat && grad_nodes, SN_ERR_BAD_ARG, "sn_weighted_pool_backward: NULL pointer");
+    SN_REQUIRE((((uintptr_t)feat | (uintptr_t)grad_pooled | (uintptr_t)grad_feat) & 15) == 0, SN_ERR_BAD_ARG, "sn_weighted_pool_backward: 16-byte alignment");
+    const int64_t rows = (int64_t)G * n, want = (rows + 3) / 4, cap = (int64_t)sn_device_cus() * 32;
+    hipLaunchKernelGGL(weighted_pool_backward_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, (hipStream_t)stream, feat, nodes,
+                       grad_pooled, rows, n, E, divisor_dev, grad_feat, grad_nodes);
+    SN_CHECK_LAUNCH("sn_weighted_pool_backward");
     return SN_OK;
 }

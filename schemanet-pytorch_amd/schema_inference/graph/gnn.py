@@ -381,6 +381,9 @@ class GNN(nn.Module):
             feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused, adj_planes=adj_planes, sum_edge_grads=train_mfma)
         if fused:
             pooled = ops.weighted_pool(feat, nodes, divisor)
+        elif (feat.is_cuda and feat.dtype == torch.float32 and feat.shape[-1] % 4 == 0 and (divisor is None or (torch.is_tensor(divisor) and divisor.dtype == torch.int32))
+              and os.environ.get("SN_POOL_FUSED", "1") != "0"):
+            pooled = ops.weighted_pool_autograd(feat, nodes, divisor)         # training: one pass forward, one back
         else:
             pooled = (feat * nodes[..., None]).sum(dim=1)
             pooled = pooled / (divisor.to(pooled.dtype) if divisor is not None else feat.shape[1])

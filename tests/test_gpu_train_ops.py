@@ -403,3 +403,23 @@ def test_gnn_uses_the_cached_sort_for_buffer_ids_only(mods):
         ids_buf.copy_(torch.randint(0, 64, (3, 40), device=DEV))     # new content: the version moves, the sort is taken again
     gnn(nodes, edges, ids_buf)
     assert ids_buf._sn_sorted[0] != v
+
+
+@pytest.mark.parametrize("G,n,E,with_div", [(3, 196, 256, True), (101, 64, 64, False), (2, 33, 48, True)])
+def test_weighted_pool_with_autograd(mods, G, n, E, with_div):
+    """the node-weighted mean pooling (reference gnn.py:96) as one differentiable op: value and both gradients against float64"""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(G + n + E)
+    feat = torch.randn(G, n, E, generator=g)
+    nodes = torch.rand(G, n, generator=g)
+    dy = torch.randn(G, E, generator=g)
+    div = torch.tensor([n - 3], dtype=torch.int32) if with_div else None
+    fd, nd = feat.to(DEV).requires_grad_(True), nodes.to(DEV).requires_grad_(True)
+    out = ops.weighted_pool_autograd(fd, nd, None if div is None else div.to(DEV))
+    out.backward(dy.to(DEV))
+    f64, n64 = feat.double().requires_grad_(True), nodes.double().requires_grad_(True)
+    o64 = (f64 * n64[..., None]).sum(1) / (float(div) if div is not None else n)
+    o64.backward(dy.double())
+    for got, want, what in ((out.detach(), o64.detach(), "pooled"), (fd.grad, f64.grad, "d feat"), (nd.grad, n64.grad, "d nodes")):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= 3e-6 * want.abs().max().item(), (what, err)
