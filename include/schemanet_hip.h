@@ -78,6 +78,10 @@ int sn_codebook_prepare(const float *codebook, int M, int D, void *packed, void 
  *   1  the same with 8-wave workgroups
  *   2  codebook-stationary: the fp16 codebook lives in the registers of each CU (M <= 512, D 192/384),
  *      token sets stream HBM -> LDS once; other shapes fall back to 0
+ *   3  K-outer token stream in rounds of 128 tokens per CU (codebooks of 8 or 16 tiles of 32 words, fp32 tokens)
+ *   4  K-outer in one round: the accumulators of up to 208 tokens per CU against the whole codebook resident in four
+ *      512-register waves (448 < M <= 512, D 192/384, fp32 tokens, n_tokens <= 208 x CUs); other shapes fall back to 0
+ * Forms 2-4 always use the stand-alone finish (sn_assign_defers == 0 where they apply).
  * Initial value: environment variable SN_ASSIGN_VARIANT (default 0). */
 int sn_assign_variant(void);
 int sn_assign_set_variant(int variant);
