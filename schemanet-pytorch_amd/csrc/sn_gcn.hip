@@ -115,6 +115,9 @@ __device__ __forceinline__ float saturate_f16_range(float x)
     return x != x ? x : c;
 }
 
+// VEC (round 4; no permutation, n % 4 == 0, 16-byte aligned tensors): the tile pair is read - and the by-product written - with
+// 16-byte accesses, thread = 4 consecutive columns of the rows r16, r16 + 16, ...; otherwise thread = one column of the rows ty, ty + 4, ...
+template <bool VEC>
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
                                                                const int32_t *extent, const int32_t *n_valid, int pair_tiles, float scale,
@@ -190,8 +193,33 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
     };
     float ve[16], vt[16], rsi = 0.0f, rsj = 0.0f;
     // branch-free loads (clamped index + select): a conditional load per element would serialise them
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int c4 = (threadIdx.x & 15) * 4, r16 = threadIdx.x >> 4;          // VEC: columns c4 .. c4 + 3 of the rows r16 + 16 it
+    f32x4 we[4], wt[4];
     auto fetch = [&](int I, int J) {
         const int bi = I * 64, bj = J * 64;
+        if constexpr (VEC) {
+            if (rowsum && threadIdx.x < 64) {
+                const int ri = bi + (int)threadIdx.x, rj = bj + (int)threadIdx.x;
+                rsi = ri < n ? rowsum[(int64_t)g * n + ri] : 0.0f;
+                rsj = rj < n ? rowsum[(int64_t)g * n + rj] : 0.0f;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = r16 + 16 * it;
+                const int i = bi + rr, j = bj + c4, i2 = bj + rr, j2 = bi + c4;
+                const bool in = i < nv && j < n, in2 = i2 < nv && j2 < n;         // (n % 4 == 0: a row's last piece is whole)
+                f32x4 a = *reinterpret_cast<const f32x4 *>(e + (in ? (int64_t)i * n + j : 0));
+                f32x4 b = *reinterpret_cast<const f32x4 *>(e + (in2 ? (int64_t)i2 * n + j2 : 0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[q] = (in && j + q < nv) ? a[q] : 0.0f;
+                    b[q] = (in2 && j2 + q < nv) ? b[q] : 0.0f;
+                }
+                we[it] = a; wt[it] = b;
+            }
+            return;
+        }
         if (rowsum && threadIdx.x < 64) {
             const int ri = bi + (int)threadIdx.x, rj = bj + (int)threadIdx.x;
             rsi = ri < n ? rowsum[(int64_t)g * n + (perm ? perm_s[ri] : ri)] : 0.0f;
@@ -219,6 +247,29 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
         __syncthreads();                                   // previous tile pair fully consumed
         if (rowsum && threadIdx.x < 64) { rs_i[threadIdx.x] = rsi; rs_j[threadIdx.x] = rsj; }
         __syncthreads();                                   // row scales visible
+        if constexpr (VEC) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = r16 + 16 * it;
+                f32x4 a = we[it], b = wt[it];
+                if (rowsum) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a[q] = fminf(fmaxf(a[q], 0.0f), 3.402823466e+38f) * rs_i[rr];      // row bi + rr
+                        b[q] = fminf(fmaxf(b[q], 0.0f), 3.402823466e+38f) * rs_j[rr];      // row bj + rr
+                        if (remove_self_loop && bi + rr == bj + c4 + q) a[q] = 0.0f;
+                        if (remove_self_loop && bj + rr == bi + c4 + q) b[q] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { te[rr][c4 + q] = a[q]; tt[rr][c4 + q] = b[q]; }
+                if (edges_out) {
+                    float *eo = edges_out + (int64_t)g * n * n;
+                    if (bi + rr < n && bj + c4 < n) *reinterpret_cast<f32x4 *>(eo + (int64_t)(bi + rr) * n + bj + c4) = a;
+                    if (J != I && bj + rr < n && bi + c4 < n) *reinterpret_cast<f32x4 *>(eo + (int64_t)(bj + rr) * n + bi + c4) = b;
+                }
+            }
+        } else {
         if (rowsum) {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
@@ -247,6 +298,7 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
                 if (bi + rr < n && bj + tx < n) eo[(int64_t)(bi + rr) * n + bj + tx] = ve[it];
                 if (J != I && bj + rr < n && bi + tx < n) eo[(int64_t)(bj + rr) * n + bi + tx] = vt[it];
             }
+        }
         }
         __syncthreads();
         have = advance(cI, cJ, chalf);
@@ -1095,9 +1147,14 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const i
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, G, tiles, pair_tiles);
-    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
-                       (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+    if (n % 4 == 0 && ((uintptr_t)edges & 15) == 0)
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
+                           (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+    else
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
+                           (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
@@ -1113,8 +1170,12 @@ extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, 
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, G, tiles, pair_tiles);
-    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+    if (n % 4 == 0 && ((uintptr_t)edges & 15) == 0)
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+    else
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
     return SN_OK;
 }
@@ -1130,9 +1191,14 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, K, tiles, pair_tiles);
-    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
-                       kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0);
+    if (n % 4 == 0 && (((uintptr_t)pruned_edge_weights | (uintptr_t)class_edges_out) & 15) == 0)
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+                           kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0);
+    else
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+                           kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }
@@ -1153,7 +1219,7 @@ extern "C" int sn_gcn_atlas_adjacency_planes_compact(const float *pruned_edge_we
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, K, tiles, pair_tiles);
-    hipLaunchKernelGGL(adjacency_planes_kernel, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+    hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, n_kept,
                        n_kept, pair_tiles, scale, (float *)nullptr, perm, 1);
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes_compact");
