@@ -130,7 +130,8 @@ class Matcher(nn.Module):
             class_dict = get_class_dict()
             return _AtlasHandle(class_dict, self.atlas_features(class_dict, prepared), None, prepared)
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != dev:
-            self._side_stream = torch.cuda.Stream(device=dev)
+            # (SN_CLASS_STREAM_PRIORITY: -1 = high; the class branch is the longer of the two chains of a step taken one at a time)
+            self._side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SN_CLASS_STREAM_PRIORITY", "0")))
         main = torch.cuda.current_stream(dev)
         self._side_stream.wait_stream(main)                 # parameters / earlier work are visible
         for v in (prepared or {}).values():                # allocated on the current stream, also read on the side stream

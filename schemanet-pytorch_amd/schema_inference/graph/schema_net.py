@@ -188,7 +188,7 @@ class SchemaNet(nn.Module):
         vw, ew = self.vertex_weights.tensor, self.edge_weights.tensor
         if fused_adjacency and vw.is_cuda and (detach or not self._needs_grad(vw, ew)):
             if (fused_adjacency == "compact" and self.prune_node_threshold is not None and vw.shape[1] <= 1024
-                    and os.environ.get("SN_ATLAS_COMPACT", "1") != "0" and self._atlas_is_pruned()):
+                    and os.environ.get("SN_ATLAS_COMPACT", "1") != "0" and self._atlas_compaction_pays()):
                 # a pruned atlas, compacted: the operand holds the kept vertices of every class only (class_perm / class_n_kept
                 # say which); `Matcher` adds the isolated vertices' share of the class feature without a product
                 # (the in-place pruning is idempotent: once it has run on these versions of the two parameters the rows of the
@@ -213,7 +213,7 @@ class SchemaNet(nn.Module):
             cv, ce = self.get_class_vertices(detach), self.get_class_edges(detach)
         return {"class_vertices": cv, "class_edges": ce, "class_ingredients": self.class_ingredients.tensor}
 
-    def _atlas_is_pruned(self) -> bool:
+    def _atlas_compaction_pays(self) -> bool:
         """Are enough class vertices under prune_node_threshold for the compacted route to pay (see below)?  One host
         synchronisation per VERSION of vertex_weights - like the
         packed codebook of S1 a weight-only fact, looked up from then on; `p.data` writes: `invalidate_pruned_flag()`."""

@@ -705,7 +705,7 @@ def test_compacted_class_graphs_of_a_pruned_atlas(mods, case):
         sn, m = sn.to(DEV).eval(), m.to(DEV).eval()
         inst = {"instance_ingredients": [x.to(DEV) for x in inst_ids], "instance_vertices": [x.to(DEV) for x in inst_v],
                 "instance_edges": [x.to(DEV) for x in inst_e]}
-        assert sn._atlas_is_pruned()
+        assert sn._atlas_compaction_pays()
         atlas_c = sn.get_atlas(fused_adjacency="compact")
         assert "class_perm" in atlas_c and atlas_c["class_n_kept"].tolist() == (cv > 0.001).sum(1).tolist()
         got_c = m(inst, atlas_c).cpu()

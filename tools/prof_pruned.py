@@ -21,4 +21,4 @@ with torch.no_grad():
     n = 10
     for _ in range(n): last = run()
     torch.cuda.synchronize()
-print("compact", os.environ.get("SN_ATLAS_COMPACT", "1"), "pruned flag", sn._atlas_is_pruned(), "%.1f us per eager step" % (1e6 * (time.perf_counter() - t0) / n))
+print("compact", os.environ.get("SN_ATLAS_COMPACT", "1"), "pruned flag", sn._atlas_compaction_pays(), "%.1f us per eager step" % (1e6 * (time.perf_counter() - t0) / n))
