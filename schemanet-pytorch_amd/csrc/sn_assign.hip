@@ -1634,6 +1634,8 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
 // Measured (MI355X, 50 176 tokens): 34.5 us of kernel time (40.4 by the library's event pair; the default form: 30.4 / 36.3).
 // The main loop is ~19 us, but the keys of 448 accumulator values per lane are 2 300 dependent VALU instructions on a wave
 // that is ALONE on its SIMD - 9 us with nothing to overlap them with in a one-round form - and the merge another 4.5 us.
+// (Two independent key chains per set in one asm statement: no faster - a lone wave issues ~one VALU instruction per 8 cycles
+// whatever their dependences; only a second wave on the SIMD would hide the keys.)
 // Opt-in; DESIGN 8.  What this kernel ran into, all because an asm MFMA is invisible to the compiler (hazard recogniser,
 // register allocator): (1) a VALU conversion scheduled right in front of the first MFMA of a group fed it a stale B register
 // (one tile in four of a set wrong): wait states are written into the asm; (2) VALU work dealt BETWEEN the four MFMAs of a
