@@ -423,3 +423,41 @@ def test_weighted_pool_with_autograd(mods, G, n, E, with_div):
     for got, want, what in ((out.detach(), o64.detach(), "pooled"), (fd.grad, f64.grad, "d feat"), (nd.grad, n64.grad, "d nodes")):
         err = (got.double().cpu() - want).abs().max().item()
         assert err <= 3e-6 * want.abs().max().item(), (what, err)
+
+
+def test_graphed_train_iter_over_the_predictor(mods):
+    """the documented use: `GraphedTrainIter(lambda batch: predictor(batch["x"]), ...)` over a `SchemaNetPredictor` in train() -
+    backbone taps (no grad) -> S1 -> instance graphs -> atlas -> matcher, the reference's output dictionary into
+    SchemaInferenceLoss - is capturable as it is (no host synchronisation on that route) and follows the eager iterations"""
+    import datagen
+    from schema_inference import loss as loss_mod
+    from schema_inference import train as train_mod
+    from test_gpu_api import _predictor
+    from test_gpu_parity import T
+    bs, H, L, D, M, K, E = 6, 3, 196, 192, 512, 5, 64
+    mid, ext = T(datagen.bellish((L + 1, bs, D), 500, 1.0)), T(datagen.bellish((bs * H, L + 1, L + 1), 501, 2.0))
+    x = torch.zeros(bs, 3, 4, 4, device=DEV)
+    target = {"label": torch.randint(0, K, (bs,), generator=torch.Generator().manual_seed(7)).to(DEV)}
+    loss_fn = loss_mod.get_loss_fn({"name": "schema_inference_loss"})
+    weights = {"cls": 1.0, "re_entropy_vertex": 0.5, "re_entropy_edge": 0.75}
+
+    def run(graphed):
+        pred, _ = _predictor(mods, [(mid, ext)], M, D, K, E, seed=3)
+        pred.train()
+        params = [p for n, p in pred.named_parameters() if p.requires_grad and not n.startswith("ingredient_wrapper")]
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=5e-4, fused=True, capturable=True)
+        fwd = lambda b: pred(b["x"])                                        # noqa: E731
+        losses = []
+        if graphed:
+            step = train_mod.GraphedTrainIter(fwd, pred.schema_net, loss_fn, weights, opt, {"x": x}, target, warmup=2)
+            for _ in range(4):
+                losses.append(float(step({"x": x}, target)[0]))
+        else:
+            for i in range(6):
+                total, _ = train_mod.train_iter(lambda: fwd({"x": x}), pred.schema_net, loss_fn, weights, opt, target)
+                if i >= 2:
+                    losses.append(float(total))
+        return losses
+    eager, graphed = run(False), run(True)
+    assert np.isfinite(graphed).all() and len(set(graphed)) > 1
+    np.testing.assert_allclose(graphed, eager, rtol=2e-6)
