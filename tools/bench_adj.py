@@ -22,3 +22,12 @@ print("atlas prune + rowsum + fused adjacency: %.1f us; plain adjacency of [100,
     t(lambda: ops.atlas_adjacency_planes(vw, ew, 0.001, False)), t(lambda: ops.gcn_adjacency_planes(ew))))
 ew2 = torch.randn(101, 1024, 1024, device=dev)
 print("plain adjacency of [101,1024,1024]: %.1f us" % t(lambda: ops.gcn_adjacency_planes(ew2)))
+# the compacted producer on a 70 % pruned atlas (bench shape)
+g = torch.Generator().manual_seed(44)
+vwp = torch.rand(100, 512, generator=g).to(dev)
+low = (torch.rand(100, 512, generator=g) < 0.7).to(dev)
+vwp = torch.where(low, vwp * 1e-4, vwp)
+ewp = torch.rand(100, 512, 512, generator=g).to(dev)
+ops.atlas_adjacency_planes_compact(vwp, ewp, 0.001, False)
+print("compacted atlas route (70 %% pruned): prune + rowsum + keep_perm + producer %.1f us; with the rows known zero %.1f us" % (
+    t(lambda: ops.atlas_adjacency_planes_compact(vwp, ewp, 0.001, False)), t(lambda: ops.atlas_adjacency_planes_compact(vwp, ewp, 0.001, False, pruned_rows_are_zero=True))))
