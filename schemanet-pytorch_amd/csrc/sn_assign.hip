@@ -1639,8 +1639,10 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
 // Opt-in; DESIGN 8.  What this kernel ran into, all because an asm MFMA is invisible to the compiler (hazard recogniser,
 // register allocator): (1) a VALU conversion scheduled right in front of the first MFMA of a group fed it a stale B register
 // (one tile in four of a set wrong): wait states are written into the asm; (2) VALU work dealt BETWEEN the four MFMAs of a
-// step (38 us, 2.4 us faster) gave whole sets of garbage although the instruction stream read correctly (hypothesis, not proven:
-// queued MFMAs read their operands when they start, not when they issue) - the next step's conversion runs behind the fourth MFMA; (3) any instrumentation between the phases (stamps)
+// step (38 us, 2.4 us faster) gave whole sets of garbage although the instruction stream read correctly (bisected: the eight
+// squares - reads only - between the MFMAs are harmless, the four v_cvt_pk that WRITE the next fragment's registers between the third
+// and the fourth MFMA are what breaks it, although those registers are nobody's operands yet; not understood) - the next step's
+// conversion runs behind the fourth MFMA; (3) any instrumentation between the phases (stamps)
 // made the compiler park whole accumulator sets in scratch - stamps 0 and 4 only; (4) a lambda nested in the kernel's generic
 // lambdas does not capture a variable that only appears as an asm operand (clang): the MFMA is a function.
 // ------------------------------------------------------------------------------------------
