@@ -1639,10 +1639,11 @@ __global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArg
 // Opt-in; DESIGN 8.  What this kernel ran into, all because an asm MFMA is invisible to the compiler (hazard recogniser,
 // register allocator): (1) a VALU conversion scheduled right in front of the first MFMA of a group fed it a stale B register
 // (one tile in four of a set wrong): wait states are written into the asm; (2) VALU work dealt BETWEEN the four MFMAs of a
-// step (38 us, 2.4 us faster) gave whole sets of garbage although the instruction stream read correctly (bisected: the eight
-// squares - reads only - between the MFMAs are harmless, the four v_cvt_pk that WRITE the next fragment's registers between the third
-// and the fourth MFMA are what breaks it, although those registers are nobody's operands yet; not understood) - the next step's
-// conversion runs behind the fourth MFMA; (3) any instrumentation between the phases (stamps)
+// step (38 us, 2.4 us faster) gave whole sets of garbage although the instruction stream read correctly (bisected: the eight squares
+// - reads only - between the MFMAs are harmless, the four v_cvt_pk in front of the fourth MFMA are what breaks it, although they
+// write nobody's operands; keeping every fragment alive three more steps changes nothing; `s_nop 3` in front of that MFMA cures it:
+// an asm MFMA right behind VALU writes needs wait states whatever the registers.  With them the interleaved loop is correct - and
+// no faster than this one: 40.2 us) - the next step's conversion runs behind the fourth MFMA; (3) any instrumentation between the phases (stamps)
 // made the compiler park whole accumulator sets in scratch - stamps 0 and 4 only; (4) a lambda nested in the kernel's generic
 // lambdas does not capture a variable that only appears as an asm operand (clang): the MFMA is a function.
 // ------------------------------------------------------------------------------------------
