@@ -53,6 +53,10 @@ class GraphedStep:
         done, left = c_int(0), c_int(0)
         N.check(N.require_gpu().sn_graph_replace_memsets(c_void_p(self.graph.raw_cuda_graph()), byref(done), byref(left)), "sn_graph_replace_memsets")
         self.memsets_replaced, self.memsets_left = done.value, left.value
+        if self.memsets_left:
+            import warnings
+            warnings.warn(f"{self.memsets_left} memset node(s) of the captured graph could not be replaced by kernel nodes (two-dimensional "
+                          "memsets): on ROCm 7.2 a captured memset node may not clear on replay - compare a replay with an eager call")
         self.graph.instantiate()
         torch.cuda.current_stream().wait_stream(side)
 
