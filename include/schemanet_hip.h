@@ -34,7 +34,10 @@ extern "C" {
 
 #define SN_MAX_TOKENS 196        /* L: 14x14 patch tokens; the graph kernels keep one image in LDS */
 
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any change of a signature or of a by-pointer struct (10: round 5, struct_size members).
+ * The three by-pointer argument structs below start with `struct_size`: the caller stores sizeof(the struct it was compiled
+ * against) there; a call whose struct_size differs from the library's own sizeof is rejected with SN_ERR_BAD_ARG before any
+ * member is read, so a caller built against an older header can never have the library read past the end of its struct. */
 int sn_abi_version(void);
 /* Thread-local, NUL-terminated description of the last non-zero return on this thread. */
 const char *sn_last_error(void);
@@ -170,6 +173,7 @@ int sn_head_mean_attention(const float *extracted, int B, int H, int L, float *a
  * consumer schema_net.py:278-305).  Applies to the edges kernel (attn != NULL) in its prediction configuration and to
  * D in {192, 384}, M <= 2048, L <= 210 (sn_assign_defers); sn_instance_graph returns SN_ERR_UNSUPPORTED otherwise. */
 typedef struct sn_rerank_args {
+    uint32_t struct_size;         /* sizeof(sn_rerank_args) of the caller's header (checked: see sn_abi_version)     */
     const void *x;                /* the tokens sn_assign_words screened: token (b, l) is the row at element offset
                                      b*x_stride_b + l*x_stride_l (fp32, or bf16 when x_bf16)                      */
     int64_t x_stride_b, x_stride_l;
@@ -190,6 +194,7 @@ typedef struct sn_rerank_args {
 int sn_assign_defers(int M, int D);
 
 typedef struct sn_graph_args {
+    uint32_t struct_size;         /* sizeof(sn_graph_args) of the caller's header (checked: see sn_abi_version) */
     /* inputs */
     const int64_t *ingredients;   /* word of token (b, l) at [b*ing_stride_b + l*ing_stride_l] */
     int64_t ing_stride_b, ing_stride_l;
@@ -456,6 +461,7 @@ int sn_layernorm_split_planes(const float *x, int G, int n, int E, const int32_t
  * ceil(m / 128): partial sums of the node-weighted pooling (gnn.py:96), added up in a fixed order
  * by sn_pool_fc (no atomics: results are bit-reproducible). */
 typedef struct sn_gemm_args {
+    uint32_t struct_size;                 /* sizeof(sn_gemm_args) of the caller's header (checked: see sn_abi_version) */
     const void *a_hi, *a_lo; int64_t a_batch_stride;
     const void *b_hi, *b_lo; int64_t b_batch_stride;
     int m, n, k, batches;

@@ -10,20 +10,30 @@ torch used only to own device memory and provide the current HIP stream.
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
-ABI_VERSION = 9
+ABI_VERSION = 10
 SN_MAX_TOKENS = 196
 _lib = None
 
 
-class RerankArgs(Structure):
+class _SizedArgs(Structure):
+    """A by-pointer argument struct of the C ABI: its first member carries sizeof(the struct) as this binding lays it out;
+    the library refuses a struct whose size is not its own (include/schemanet_hip.h, sn_abi_version)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.struct_size = ctypes.sizeof(type(self))
+
+
+class RerankArgs(_SizedArgs):
     """struct sn_rerank_args (include/schemanet_hip.h)."""
     _fields_ = [
+        ("struct_size", c_uint32),
         ("x", c_void_p), ("x_stride_b", c_int64), ("x_stride_l", c_int64), ("x_bf16", c_int),
         ("tok_stride_b", c_int64), ("tok_stride_l", c_int64), ("n_tokens", c_int64),
         ("codebook", c_void_p), ("packed", c_void_p), ("M", c_int), ("D", c_int),
@@ -31,9 +41,10 @@ class RerankArgs(Structure):
     ]
 
 
-class GraphArgs(Structure):
+class GraphArgs(_SizedArgs):
     """struct sn_graph_args (include/schemanet_hip.h)."""
     _fields_ = [
+        ("struct_size", c_uint32),
         ("ingredients", c_void_p), ("ing_stride_b", c_int64), ("ing_stride_l", c_int64),
         ("attn_cls", c_void_p), ("attn", c_void_p),
         ("acls_stride_b", c_int64), ("acls_stride_h", c_int64),
@@ -57,9 +68,10 @@ class GraphArgs(Structure):
     ]
 
 
-class GemmArgs(Structure):
+class GemmArgs(_SizedArgs):
     """struct sn_gemm_args (include/schemanet_hip.h)."""
     _fields_ = [
+        ("struct_size", c_uint32),
         ("a_hi", c_void_p), ("a_lo", c_void_p), ("a_batch_stride", c_int64),
         ("b_hi", c_void_p), ("b_lo", c_void_p), ("b_batch_stride", c_int64),
         ("m", c_int), ("n", c_int), ("k", c_int), ("batches", c_int),

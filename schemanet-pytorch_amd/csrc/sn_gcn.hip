@@ -1306,6 +1306,8 @@ extern "C" void sn_debug_set_gemm_stamps(void *device_buffer) { g_gemm_stamps = 
 extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
 {
     SN_REQUIRE(u, SN_ERR_BAD_ARG, "sn_gcn_gemm: NULL args");
+    SN_REQUIRE(u->struct_size == sizeof(sn_gemm_args), SN_ERR_BAD_ARG, "sn_gcn_gemm: sn_gemm_args.struct_size=%u, this library (ABI %d) expects %zu",
+               u->struct_size, sn_abi_version(), sizeof(sn_gemm_args));
     SN_REQUIRE(u->batches >= 0 && u->m > 0 && u->n > 0 && u->k > 0, SN_ERR_BAD_ARG, "sn_gcn_gemm: bad shape m=%d n=%d k=%d batches=%d",
                u->m, u->n, u->k, u->batches);
     if (u->batches == 0) return SN_OK;

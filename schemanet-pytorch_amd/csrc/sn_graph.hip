@@ -1791,6 +1791,8 @@ int ensure_lds(const void *fn, size_t bytes, const char *name)
 extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
 {
     SN_REQUIRE(args, SN_ERR_BAD_ARG, "sn_instance_graph: args is NULL");
+    SN_REQUIRE(args->struct_size == sizeof(sn_graph_args), SN_ERR_BAD_ARG, "sn_instance_graph: sn_graph_args.struct_size=%u, this library (ABI %d) expects %zu",
+               args->struct_size, sn_abi_version(), sizeof(sn_graph_args));
     sn_graph_args a = *args;
     SN_REQUIRE(a.B >= 0 && a.L > 0, SN_ERR_BAD_ARG, "sn_instance_graph: bad B=%d L=%d", a.B, a.L);
     if (a.B == 0) return SN_OK;
@@ -1832,6 +1834,8 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
         sn_s1::RerankView rv = {};
         int rr = 0;
         if (a.rerank) {
+            SN_REQUIRE(a.rerank->struct_size == sizeof(sn_rerank_args), SN_ERR_BAD_ARG, "sn_instance_graph: sn_rerank_args.struct_size=%u, this library (ABI %d) expects %zu",
+                       a.rerank->struct_size, sn_abi_version(), sizeof(sn_rerank_args));
             const sn_rerank_args &r = *a.rerank;
             SN_REQUIRE(fast, SN_ERR_UNSUPPORTED, "sn_instance_graph: the deferred S1 finish needs the prediction configuration of the edges kernel");
             SN_REQUIRE(r.x && r.codebook && r.packed && r.workspace && r.ids && r.n_tokens > 0, SN_ERR_BAD_ARG, "sn_instance_graph: incomplete rerank arguments");
