@@ -63,13 +63,12 @@ constexpr float kAccUlpPerMfma = 8.0f * 5.9604645e-8f;
 //                                           are |c|^2 / 2 (fp32) in accumulator-row order
 //   cn64    [M_pad] f64  |c|^2 (oracle summation order)
 //   scal    [0] max |c|_2  [1] max |c|_1  [2] max |c|^2  [3] max |c_mk|  [4] max |c - fp16(c)|_2   (uint bits of floats)
-//   frag2   [4 waves][nt2 tiles][ks2 k-steps][1 KiB]   (register-stationary screen, see assign_screen2_kernel)
-//                                           v_mfma_f32_32x32x16_f16 A-fragments of -c: wave q owns words
-//                                           [32 nt2 q, 32 nt2 (q+1)), tile a = 32 of them, lane (r, h) of k-step js
-//                                           holds word row r at k = 32 (js / 2) + {4g..4g+3, 16+4g..16+4g+3},
-//                                           g = 2 (js & 1) + h (the order the token converter produces)
-//   hn2     [4][nt2][2 halves][16] f32      |c|^2 / 2 in accumulator-register order (padding words: 1e30)
-constexpr float kPadHalfNorm = 1.0e30f;     // |c|^2/2 of the padding words of the frag2 image (finite: keys stay ordered floats)
+//   tiles5  [4 q][4 v][n_steps][1 KiB]    (one-round K-outer screen, assign_screen5_kernel; codebooks of 16 tiles only)
+//                                           the same fragments with the WORDS permuted: row i of virtual tile (q, v) is word
+//                                           32 (4 v + (i >> 3)) + 8 q + (i & 7), so that the lane (r, h) of the wave that owns
+//                                           quarter q holds exactly the words 32 t + 8 q + 4 h + e, t < 16: candidate slot
+//                                           group (h, g = q) of the record format below
+constexpr float kPadHalfNorm = 1.0e30f;     // |c|^2/2 of padding words where keys are compared as floats (finite: keys stay ordered)
 
 // ------------------------------------------------------------------------------------------
 // codebook_prepare
@@ -88,29 +87,22 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float *cb, int M, 
     frag[(i + 32 * h) * 8 + j] = (_Float16)(-v);
 }
 
-// frag2 image: one thread per (word of the padded codebook, k)
-__device__ __forceinline__ int hn2_index(int m, int nt2)     // word m -> slot of its |c|^2/2 in hn2
+// tiles5 image (see above): one thread per (word of the padded codebook, k); only for 16-tile codebooks
+__global__ __launch_bounds__(256) void pack_frag5_kernel(const float *cb, int M, int D, unsigned char *tiles5, int n_steps)
 {
-    const int q = m / (32 * nt2), a = (m / 32) % nt2, r = m & 31;
-    return ((q * nt2 + a) * 2 + ((r >> 2) & 1)) * 16 + (r & 3) + 4 * (r >> 3);       // accumulator row = (reg & 3) + 8 (reg >> 2) + 4 half
-}
-
-__global__ __launch_bounds__(256) void pack_frag2_kernel(const float *cb, int M, int D, unsigned char *frag2, float *hn2, int nt2, int ks2)
-{
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [128 nt2, D]
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // over [512, D]
     const int m = (int)(idx / D), k = (int)(idx % D);
-    const int q = m / (32 * nt2), a = (m / 32) % nt2, r = m & 31;
-    const int c = k >> 5, rem = k & 31;
-    const int g = (rem & 15) >> 2, e = (rem & 3) + 4 * (rem >> 4);
-    const int js = 2 * c + (g >> 1), h = g & 1;
-    const float v = m < M ? cb[(int64_t)m * D + k] : 0.0f;
-    _Float16 *frag = (_Float16 *)(frag2 + ((size_t)(q * nt2 + a) * ks2 + js) * 1024);
-    frag[(r + 32 * h) * 8 + e] = (_Float16)(-v);
-    if (k == 0 && m >= M) hn2[hn2_index(m, nt2)] = kPadHalfNorm;           // real words: pack_norm_kernel
+    const int t = m >> 5, row = m & 31;                           // word m = 32 t + 8 g + 4 hh + e
+    const int q = row >> 3, v = t >> 2, i = 8 * (t & 3) + (row & 7);
+    const int u = k >> 5, rem = k & 31, h = rem >> 4, e = (rem >> 3) & 1, j = rem & 7;     // (as pack_frag_kernel)
+    const int s = 2 * u + e;
+    const float val = m < M ? cb[(int64_t)m * D + k] : 0.0f;
+    _Float16 *frag = (_Float16 *)(tiles5 + ((size_t)(q * 4 + v) * n_steps + s) * 1024);
+    frag[(i + 32 * h) * 8 + j] = (_Float16)(-val);
 }
 
 __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, int D, int m_pad, unsigned char *tiles,
-                                                        int n_steps, int tile_bytes, double *cn64, unsigned *scal, float *hn2, int nt2)
+                                                        int n_steps, int tile_bytes, double *cn64, unsigned *scal)
 {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -140,7 +132,6 @@ __global__ __launch_bounds__(256) void pack_norm_kernel(const float *cb, int M, 
     if (lane == 0) {
         cn64[m] = p;
         *hc = (float)(0.5 * p);
-        if (nt2) hn2[hn2_index(m, nt2)] = (float)(0.5 * p);
         const float up = 1.0f + 1.0e-6f;
         atomicMax(&scal[0], __float_as_uint(sqrtf((float)p) * up));
         atomicMax(&scal[1], __float_as_uint(l1 * (1.0f + 1.0e-4f)));
@@ -166,11 +157,6 @@ struct AssignArgs {
     unsigned char *codes;   // per token 24 key codes (tile << 2 | e), written only for flagged tokens
     int *overflow;      // token ids that need a full scan
     unsigned long long *stamps;   // diagnostics only (sn_debug_set_stamps): 16 u64 slots per wave
-    // register-stationary screen (assign_screen2_kernel): the flag word has the same meaning (24-bit
-    // candidate mask, bit 3c+j = key j of lane slot c = 2 wave + accumulator half), the codes are 8
-    // dwords per token (slot c: code_j << 8j, code = tile << 4 | accumulator register)
-    unsigned *codes32;
-    int64_t n_sets;     // ceil(n_tokens / 32)
     // token-phase gate of the token-stationary screen (NULL = off): per CU {arrivals, waves whose tokens have
     // landed}; zeroed before every launch.  See assign_screen_kernel.
     unsigned *gate;
@@ -179,9 +165,8 @@ struct AssignArgs {
     // waves without tokens only keep the codebook ring going.  Default: full_waves = waves per workgroup.
     int full_waves;
     int64_t extra_base;
-    int tps;            // K-outer screen (assign_screen3_kernel): tokens per set (<= 32); set i holds tokens [i tps, (i + 1) tps)
-    int64_t n_sets3;    // ... number of sets, ceil(n_tokens / tps)
     int tps4;           // one-round K-outer screen (assign_screen4_kernel): tokens per workgroup (<= kS4Rows)
+    int dbg;            // diagnostics (SN_ASSIGN_DBG; results are WRONG with any bit set): bit 0 = every workgroup of the K-outer screen reads the first workgroup's tokens (no HBM stream)
     int x_bf16;         // tokens are bfloat16 (x points at 2-byte elements, strides in elements); results are defined on their fp32 values
 };
 
@@ -273,9 +258,8 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 // ------------------------------------------------------------------------------------------
 constexpr int kOverflowBlocks = 64;     // blocks reserved for the overflow list (4 tokens each per round)
 
-// FMT 0: records of assign_screen_kernel (24 code bytes per token); FMT 1: records of
-// assign_screen2_kernel (8 code dwords, slot c = 2 wave + accumulator half, key j: bit 3c + j);
-// FMT 2: 16-bit codes (M > 2048); FMT 3: records of assign_screen3_kernel (24 code bytes, its own slot order).
+// FMT 0: records of assign_screen_kernel / assign_screen5_kernel (24 code bytes per token); FMT 2: 16-bit codes (M > 2048);
+// FMT 3: records of assign_screen4_kernel (24 code bytes, slot = 3 (2 quarter + half) + j).
 template <int NT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void assign_rerank_kernel(const AssignArgs p)
 {
@@ -310,18 +294,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
                 }
             } else if constexpr (FMT == 3) {
-                // records of assign_screen3_kernel: slot c = 3 (2 q + h) + j, code = tile << 4 | accumulator register
+                // records of assign_screen4_kernel: slot c = 3 (2 q + h) + j, code = tile << 4 | accumulator register
                 if (lane < kMaxCand) {
                     const unsigned code = (unsigned)p.codes[n * kCodeBytes + lane];
                     const int qh = lane / 3, reg = (int)(code & 15u);
                     my_word = ((qh >> 1) * (lay.n_tiles / 4) + (int)(code >> 4)) * 32 + 8 * (reg >> 2) + 4 * (qh & 1) + (reg & 3);
-                }
-            } else {
-                if (lane < 24 && ((cmask >> lane) & 1ull)) {          // only slots with a candidate were written
-                    const int c = lane / 3, jj = lane % 3;
-                    const unsigned code = (p.codes32[n * 8 + c] >> (8 * jj)) & 0xFFu;
-                    const int reg = (int)(code & 15u);
-                    my_word = (c >> 1) * (32 * lay.nt2) + (int)(code >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (c & 1);
                 }
             }
             double x[NT];
@@ -879,739 +856,15 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// mode 0, pass 1, register-stationary form (M <= 512 at D = 384 / 192: the whole fp16 codebook fits the
-// register file of one CU).
-//
-// One persistent workgroup (4 waves, one per SIMD, 512 registers each) per CU.  Wave q keeps the A
-// fragments of its quarter of the codebook (NT tiles of 32 words x D: NT KS x 4 registers, 256 AGPRs +
-// the rest in VGPRs) for the whole kernel; token sets of 32 stream through:
-//   HBM --LDS-DMA (coalesced 128-B lines, piece-swizzled, two half sets of 16)--> raw fp32 slots
-//       --each wave converts a quarter of the 32-float chunks--> fp16 B fragments in LDS (+ |x|^2 by a Gram MFMA)
-//       --every wave: v_mfma_f32_32x32x16_f16 against its own words, one tile at a time--> keys (sorted triple per lane)
-//       --LDS min over the 8 lanes that hold a token--> window test, flag word, candidate codes.
-// The codebook is read from L2 once per CU and the tokens from HBM exactly once, in flight while
-// earlier sets are on the matrix pipe.  Values: u[word] = |c|^2/2 - x~.c~ (tokens and words rounded to
-// fp16, fp32 accumulate), keys = float bits with the low 8 mantissa bits replaced by (tile << 4 | reg),
-// compared as floats.  A lone wave per SIMD issues one instruction per ~4 cycles, so everything that
-// is not an MFMA is counted: the key arithmetic rides in the same asm statement as the MFMA it hides
-// behind, the other stages are dealt over the remaining gaps.
-//
-// Software pipeline, one barrier per iteration `it` (set indices local to the workgroup):
-//   DMA(it+2)  CVT(it+1)  MMA(it) [+ keys of the previous tile]  WIN(it)  CMP(it-2)  FLG(it-3)
-// ------------------------------------------------------------------------------------------
-constexpr int kS2RawSlots = 4;          // raw fp32 half sets (16 tokens) in LDS: set it+1 being converted, set it+2 in flight
-constexpr int kS2SmallSlots = 8;        // ring of per-set scalars
-constexpr int kS2StashSlots = 2;
 constexpr float kBigKey = 3.0e38f;      // "no key yet"
 constexpr float kKeyLimit = 1.0e29f;    // above this a best value is a padding word / nothing finite
 
-struct S2Tok {                          // per token of a set in flight (LDS)
-    float best;                         // smallest key of the token (ds_min over the 8 lanes that hold it)
-    float win;                          // 2E (NaN: the token cannot be screened)
-    unsigned mask;                      // candidate mask being assembled: bit 3c + j = key j of slot c = 2 wave + half (bit 31: overflow)
-    float nrm;                          // |x~|^2, summed over the four waves' chunks
-};
-struct S2Small { S2Tok tok[32]; };
-
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) as straight-line code
-// (the MFMA stream below is far beyond the size a `#pragma unroll` is allowed to expand)
+// (the chunk loops of the K-outer screens are far beyond the size a `#pragma unroll` is allowed to expand)
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-// One MFMA step and up to two key halves in ONE asm statement (nothing can be scheduled, and no s_nop
-// inserted, between them).  Key insert of value v with code c into the sorted triple m1 <= m2 <= m3:
-//   half A: k = (v & ~0xFF) | c;  m3 = med3(k, m2, m3)      half B: m2 = med3(k, m1, m2);  m1 = min(k, m1)
-// PAT 0: MFMA   1: MFMA, A   2: MFMA, B   3: MFMA, A, B   4: MFMA, B, A (B finishes the previous value)
-#define S2_MF "v_mfma_f32_32x32x16_f16 %[acc], %[a], %[b], %[acc]\n\t"
-#define S2_KA "v_and_or_b32 %[kk], %[v], %[km], %[code]\n\tv_med3_f32 %[m3], %[kk], %[m2], %[m3]\n\t"
-#define S2_KB "v_med3_f32 %[m2], %[kk], %[m1], %[m2]\n\tv_min_f32 %[m1], %[kk], %[m1]\n\t"
-#define S2_OUT [acc] "+v"(acc), [kk] "+v"(kk), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3)
-#define S2_IN(ACLS) [a] ACLS(a), [b] "v"(b), [v] "v"(v), [km] "v"(keymask), [code] "i"(CODE)
-template <bool AG, int PAT, int CODE>
-__device__ __forceinline__ void s2_step(f32x16 &acc, const half8 &a, const half8 &b, float &kk, float &m1, float &m2, float &m3,
-                                        float v, unsigned keymask)
-{
-    if constexpr (AG) {
-        if constexpr (PAT == 0) asm volatile(S2_MF : [acc] "+v"(acc) : [a] "a"(a), [b] "v"(b));
-        if constexpr (PAT == 1) asm volatile(S2_MF S2_KA : S2_OUT : S2_IN("a"));
-        if constexpr (PAT == 2) asm volatile(S2_MF S2_KB : S2_OUT : S2_IN("a"));
-        if constexpr (PAT == 3) asm volatile(S2_MF S2_KA S2_KB : S2_OUT : S2_IN("a"));
-        if constexpr (PAT == 4) asm volatile(S2_MF S2_KB S2_KA : S2_OUT : S2_IN("a"));
-    } else {
-        if constexpr (PAT == 0) asm volatile(S2_MF : [acc] "+v"(acc) : [a] "v"(a), [b] "v"(b));
-        if constexpr (PAT == 1) asm volatile(S2_MF S2_KA : S2_OUT : S2_IN("v"));
-        if constexpr (PAT == 2) asm volatile(S2_MF S2_KB : S2_OUT : S2_IN("v"));
-        if constexpr (PAT == 3) asm volatile(S2_MF S2_KA S2_KB : S2_OUT : S2_IN("v"));
-        if constexpr (PAT == 4) asm volatile(S2_MF S2_KB S2_KA : S2_OUT : S2_IN("v"));
-    }
-}
-template <int CODE>
-__device__ __forceinline__ void s2_key_a(float &kk, float &m2, float &m3, float v, unsigned keymask)
-{
-    asm volatile(S2_KA : [kk] "+v"(kk), [m2] "+v"(m2), [m3] "+v"(m3) : [v] "v"(v), [km] "v"(keymask), [code] "i"(CODE));
-}
-__device__ __forceinline__ void s2_key_b(float &kk, float &m1, float &m2)
-{
-    asm volatile(S2_KB : [kk] "+v"(kk), [m1] "+v"(m1), [m2] "+v"(m2));
-}
-#undef S2_MF
-#undef S2_KA
-#undef S2_KB
-#undef S2_OUT
-#undef S2_IN
-
-template <int NT, int KS>
-__global__ __launch_bounds__(256, 1) void assign_screen2_kernel(const AssignArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KC = KS / 2;                                  // 32-float chunks per token
-    constexpr int NA = NT * KS < 64 ? NT * KS : 64;             // fragments pinned in AGPRs
-    constexpr int kHalfRaw = KC * 2048, kSetFrag = KS * 1024;   // bytes: raw half set (16 tokens), fp16 fragments of a set
-    constexpr int kDmaPerWave = KC / 2;                         // 1 KiB LDS-DMA instructions per wave and half set
-    constexpr int kCvtPerHalf = (KC + 3) / 4;                   // chunks a wave converts per half set
-    constexpr int kSteps = NT * KS;                             // MFMA steps per set: (tile, k-step)
-    constexpr int kKeyStart = 2, kKeyEnd = KS - 5;              // k-steps of a tile phase that carry key halves of the previous tile
-    constexpr int kKeySteps = kKeyEnd - kKeyStart + 1;
-    static_assert(NT == 2 || NT == 4, "tiles per wave");
-    static_assert(KS == 12 || KS == 24, "k-steps");
-    unsigned char *raw = smem;
-    unsigned char *frag = smem + kS2RawSlots * kHalfRaw;
-    S2Small *small = reinterpret_cast<S2Small *>(frag + 2 * kSetFrag);
-    f32x4 *stash = reinterpret_cast<f32x4 *>(reinterpret_cast<unsigned char *>(small) + kS2SmallSlots * sizeof(S2Small));
-    f32x4 *hnl = stash + kS2StashSlots * 256;                     // [4 waves][NT tiles][2 halves][4] x 4 half norms
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tok = lane & 31, hh = lane >> 5;                   // MFMA side: token column, accumulator row half
-    const int tau = lane & 15, g = lane >> 4;                    // conversion side: token of the half set, piece pair
-    const PackLayout lay = pack_layout(p.M, p.D);
-    const unsigned char *frag2 = p.packed + lay.frag2_off;
-    const float *hn2 = reinterpret_cast<const float *>(p.packed + lay.hn2_off);
-    const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
-    const int wave_id = blockIdx.x * 4 + wid;
-    stamp(p, 0, lane, wave_id);
-
-    // this workgroup's sets: [sb, sb + ns)
-    const int64_t sb = (int64_t)blockIdx.x * p.n_sets / gridDim.x;
-    const int ns = (int)((int64_t)(blockIdx.x + 1) * p.n_sets / gridDim.x - sb);
-    const int n_inner32 = (int)p.n_inner;
-
-    // ---- per-set scalars
-    for (int i = tid; i < kS2SmallSlots * 32; i += 256) {
-        S2Tok &t0 = small[i >> 5].tok[i & 31];
-        t0.best = kBigKey; t0.win = 0.0f; t0.mask = 0u; t0.nrm = 0.0f;
-    }
-
-    // ---- token half sets: HBM -> LDS by LDS-DMA.  Instruction x = 2 c + h (32-float chunk c, token half h)
-    // copies the 128-B lines of 8 tokens; wave w issues x = w, w + 4, ...: always the same token half, so a
-    // lane needs one row pointer per half set.  Lane l: token 8 h + l / 8, LDS piece slot l % 8 holds
-    // piece slot ^ ((token >> 1) & 7) of the line (conflict-free ds_read_b128 of the fragments below).
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    int d_o, d_i;                                               // (outer, inner) of the first token of the next half set to copy
-    {
-        const int64_t n0 = sb * 32;
-        d_o = (int)(n0 / p.n_inner); d_i = (int)(n0 % p.n_inner);
-    }
-    int c_o = d_o, c_i = d_i;                                   // ... of the next set to compare (CMP)
-    const int last_o = (int)((p.n_tokens - 1) / p.n_inner), last_i = (int)((p.n_tokens - 1) % p.n_inner);
-    auto advance = [&](int &o, int &i, int by) {                 // (n_inner >= 32: at most one wrap)
-        i += by;
-        if (i >= n_inner32) { i -= n_inner32; ++o; }
-    };
-    auto issue_half = [&](int hs) {                              // hs = 2 set + half, local to the workgroup
-        const int d = 8 * (wid & 1) + (lane >> 3);
-        int o = d_o, i = d_i + d;
-        if (i >= n_inner32) { i -= n_inner32; ++o; }
-        const int64_t n = sb * 32 + (int64_t)hs * 16 + d;
-        if (n >= p.n_tokens) { o = last_o; i = last_i; }         // (tail of the last set: any valid row)
-        const int piece = (lane & 7) ^ ((d >> 1) & 7);
-        const float *src = p.x + (int64_t)o * p.xso + (int64_t)i * p.xsi + (wid >> 1) * 32 + piece * 4;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (hs & (kS2RawSlots - 1)) * kHalfRaw + (wid >> 1) * 2048 + (wid & 1) * 1024);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
-#pragma unroll
-        for (int x = 0; x < kDmaPerWave; ++x)                    // (the instruction offset moves the LDS address too)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
-                         :: "v"(src), "s"(dst + x * 4096 - x * 256), "i"(x * 256) : "memory");
-        asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
-        advance(d_o, d_i, 16);
-    };
-    if (tid < 4 * NT * 2 * 4) hnl[tid] = *reinterpret_cast<const f32x4 *>(hn2 + tid * 4);    // |c|^2/2: LDS, re-read per accumulator chain
-    float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]);
-    float CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
-    asm volatile("" : "+v"(C2), "+v"(C1), "+v"(CN), "+v"(CMAX));       // every ordinary load is consumed here, before ...
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // ... anything below is in flight (hipcc would drain it with vmcnt(0) at the first use)
-    for (int hs = 0; hs < 4 && hs < 2 * ns; ++hs) issue_half(hs);
-
-    // ---- this wave's quarter of the codebook -> registers (stays there).  The NT KS loads are issued here,
-    // tile by tile, and NOT waited for: 400 KB per CU out of L2 takes ~15 k cycles; the first set starts
-    // on tile 0 as soon as its fragments are in and waits per tile (counted vmcnt, first iteration below).
-    half8 A[NT][KS];
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const unsigned char *src = frag2 + ((size_t)(wid * NT + a) * KS + j) * 1024 + lane * 16;
-            if (a * KS + j < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(A[a][j]) : "v"(src) : "memory");
-            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(A[a][j]) : "v"(src) : "memory");
-        }
-    }
-    constexpr int kLoads = NT * KS;
-    // loads of tile a' <= a have landed when at most kLoads - KS (a + 1) operations are outstanding (younger
-    // operations only make this stricter); the counter saturates at 63
-    constexpr auto a_wait = [](int a) constexpr { return kLoads - KS * (a + 1) < 63 ? kLoads - KS * (a + 1) : 63; };
-    const f32x4 *hn_w = hnl + (wid * NT * 2 + hh) * 4;           // tile a: hn_w[8 a + i], i = 0..3: accumulator registers 4 i .. 4 i + 3
-
-    // ---- CVT: raw half set -> fp16 B fragments of chunks wid, wid + 4, ... (+ Gram diagonal = |x~|^2).
-    // Lane (tau, g) converts the floats {4g..4g+3, 16+4g..16+4g+3} of the chunk: k-step 2 c + (g >> 1), row half g & 1.
-    f32x4 c_lo, c_hi;
-    f32x4 nacc = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int swz = (tau >> 1) & 7;
-    const int rd_lo = tau * 128 + ((g ^ swz) << 4), rd_hi = tau * 128 + (((g + 4) ^ swz) << 4);
-    const int wr_off = (g >> 1) * 1024 + (tau + 32 * (g & 1)) * 16;
-    auto cvt_read = [&](int hs, int c) {
-        const int ch = wid + 4 * c;
-        if (KC % 4 == 0 || ch < KC) {
-            const unsigned char *base = raw + (hs & (kS2RawSlots - 1)) * kHalfRaw + ch * 2048;
-            c_lo = *reinterpret_cast<const f32x4 *>(base + rd_lo);
-            c_hi = *reinterpret_cast<const f32x4 *>(base + rd_hi);
-        }
-    };
-    auto cvt_write = [&](int hs, int c) {
-        const int ch = wid + 4 * c;
-        if (KC % 4 == 0 || ch < KC) {
-            half8 hb;
-            hb[0] = (_Float16)c_lo.x; hb[1] = (_Float16)c_lo.y; hb[2] = (_Float16)c_lo.z; hb[3] = (_Float16)c_lo.w;
-            hb[4] = (_Float16)c_hi.x; hb[5] = (_Float16)c_hi.y; hb[6] = (_Float16)c_hi.z; hb[7] = (_Float16)c_hi.w;
-            *reinterpret_cast<half8 *>(frag + ((hs >> 1) & 1) * kSetFrag + ch * 2048 + (hs & 1) * 256 + wr_off) = hb;
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(nacc) : "v"(hb));       // Gram matrix of the 16 tokens
-        }
-    };
-    auto cvt_norm = [&](int hs) {                            // diagonal (tau, tau): lane group tau >> 2, register tau & 3
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(nacc));                // MFMA -> VALU read distance (the asm MFMA is invisible to the hazard recogniser)
-        const float dg = (tau & 2) ? ((tau & 1) ? nacc[3] : nacc[2]) : ((tau & 1) ? nacc[1] : nacc[0]);
-        if (g == (tau >> 2))
-            __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)&small[(hs >> 1) & (kS2SmallSlots - 1)].tok[16 * (hs & 1) + tau].nrm, dg, 0, 0, false);
-        nacc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    };
-
-    // ---- WIN(s): error window of each token of the set (DESIGN.md "S1 error window"); lanes 0..31 of one wave
-    float w_nr = 0.0f;
-    auto win_read = [&](int s) { w_nr = small[s & (kS2SmallSlots - 1)].tok[tok].nrm; };
-    auto win_do = [&](int s) {
-        const float X2 = sqrtf(w_nr) * 1.002f + 1.0e-6f;              // |x|_2 from the fp16-rounded token
-        const float X1 = X2 * sqrtf((float)p.D);
-        const float vmax = 0.5f * CN + X2 * C2;                        // >= |any partial sum|
-        const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
-                                 + (float)KS * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
-        const bool ok = (w_nr < 1.0e30f) && (CMAX <= kHugeIn) && (vmax < 1.0e28f);       // false for NaN / inf
-        if (lane < 32) small[s & (kS2SmallSlots - 1)].tok[tok].win = ok ? 2.0f * E : __builtin_nanf("");
-    };
-
-    // ---- CMP(s): which of this lane's three keys are inside the window of the token's best
-    f32x4 c_t3;
-    float c_best = 0.0f, c_win = 0.0f;
-    auto cmp_read = [&](int s) {
-        c_t3 = stash[(s & (kS2StashSlots - 1)) * 256 + tid];
-        const S2Tok &tk = small[s & (kS2SmallSlots - 1)].tok[tok];
-        c_best = tk.best; c_win = tk.win;
-    };
-    auto cmp_do = [&](int s, bool en) {
-        const float cut = c_best + c_win;                              // NaN window -> no hit -> overflow
-        const int64_t n = (sb + s) * 32 + tok;
-        const bool live = en && n < p.n_tokens && cut < kKeyLimit;
-        const bool h1 = live && c_t3.x <= cut, h2 = live && c_t3.y <= cut, h3 = live && c_t3.z <= cut;
-        const unsigned k1 = __float_as_uint(c_t3.x), k2 = __float_as_uint(c_t3.y), k3 = __float_as_uint(c_t3.z);
-        int o = c_o, i = c_i + tok;
-        if (i >= n_inner32) { i -= n_inner32; ++o; }                   // (n_inner >= 32: at most one wrap)
-        if (h1) {
-            const int reg = (int)(k1 & 15u);                           // word row inside its 32 x 32 tile: (reg & 3) + 8 (reg >> 2) + 4 hh
-            p.out[(int64_t)o * p.oso + (int64_t)i * p.osi] = wid * (32 * NT) + (int)((k1 & 0xFFu) >> 4) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            const int c = wid * 2 + hh;
-            const unsigned bits = ((1u | (h2 ? 2u : 0u) | (h3 ? 4u : 0u)) << (3 * c)) | (h3 ? 0x80000000u : 0u);   // h3: a fourth key may hide behind the third
-            __hip_atomic_fetch_or(&small[s & (kS2SmallSlots - 1)].tok[tok].mask, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            p.codes32[n * 8 + c] = (k1 & 0xFFu) | ((k2 & 0xFFu) << 8) | ((k3 & 0xFFu) << 16);
-        }
-        if (en) advance(c_o, c_i, 32);
-    };
-
-    // ---- FLG(s): flag word of each token, overflow list, recycle the scalar slot; lanes 0..31 of one wave
-    unsigned f_mk = 0u;
-    auto flag_read = [&](int s) { f_mk = small[s & (kS2SmallSlots - 1)].tok[tok].mask; };
-    auto flag_do = [&](int s, bool en) {
-        if (lane < 32) {
-            S2Tok &tk = small[s & (kS2SmallSlots - 1)].tok[lane];
-            const int64_t n = (sb + s) * 32 + lane;
-            const unsigned cand = f_mk & 0xFFFFFFu;
-            const bool over = (f_mk >> 31) != 0u || cand == 0u;
-            const bool valid = en && n < p.n_tokens;
-            if (valid) p.flags[n] = over ? 0x80000000u : (__popc(cand) > 1 ? cand : 0u);
-            const bool need_b = valid && over;
-            const unsigned long long mask_b = __ballot(need_b);
-            if (mask_b) {
-                int base = 0;
-                const int leader = __ffsll((long long)mask_b) - 1;
-                if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
-                base = __shfl(base, leader, SN_WAVE);
-                if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;   // phase B writes out[]
-            }
-            tk.best = kBigKey; tk.mask = 0u; tk.nrm = 0.0f;
-        }
-    };
-
-    // ---- prologue: sets 0, 1 landed (their DMA is older than the fragment loads), set 0 converted
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kLoads < 63 ? kLoads : 63) : "memory");
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (ns > 0) {
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-            for (int c = 0; c < kCvtPerHalf; ++c) { cvt_read(h2, c); cvt_write(h2, c); }
-            cvt_norm(h2);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stamp(p, 1, lane, wave_id);
-
-    // accumulators: tile a uses buffer a & 1; a buffer is keyed while the next tile runs, then re-initialised
-    // to |c|^2/2 of the tile after that (4 ds_read_b128 straight into the accumulator registers)
-    f32x16 acc0, acc1;
-    auto load_hn = [&](f32x16 &acc, int a) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v4 = hn_w[8 * a + i];
-            acc[4 * i + 0] = v4.x; acc[4 * i + 1] = v4.y; acc[4 * i + 2] = v4.z; acc[4 * i + 3] = v4.w;
-        }
-    };
-    load_hn(acc0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = kBigKey;
-    float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey, kk = kBigKey;
-    unsigned keymask = 0xFFFFFF00u;
-    asm volatile("" : "+v"(keymask));
-    auto publish = [&](int s) {                                 // triple of set s is complete (s == -1: all keys are kBigKey, a no-op)
-        __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&small[s & (kS2SmallSlots - 1)].tok[tok].best, m1, 0, 0, false);
-        stash[(s & (kS2StashSlots - 1)) * 256 + tid] = f32x4{m1, m2, m3, 0.0f};
-        m1 = m2 = m3 = kBigKey;
-    };
-    half8 bq[4];
-    unsigned long long t_vm = 0, t_bar = 0, t_top = 0;           // diagnostics (only when stamps are on)
-    auto end_of_iteration = [&]() {
-        unsigned long long e0 = 0, e1 = 0;
-        if (p.stamps) e0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // set it+2 has landed (its DMA was issued at the start of this iteration)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (p.stamps) e1 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (p.stamps) { t_vm += e1 - e0; t_bar += __builtin_amdgcn_s_memtime() - e1; }
-    };
-    // step of the stream at which a stage runs (positions are given for 96 steps and scaled)
-    constexpr auto at = [](int x) constexpr { return x * kSteps / 96; };
-
-    // ---- main loop.  Everything except the DMA issue runs unconditionally (no per-step branches):
-    // in the first iterations the "previous" keys are kBigKey, CMP / FLG are predicated off by `en`,
-    // in the last one CVT converts stale slots nobody reads.
-    auto body = [&](auto first_c, const int it) {
-        constexpr bool FIRST = decltype(first_c)::value;        // iteration 0: the fragment loads are still in flight
-        const bool do_dma = it + 2 < ns;
-        const unsigned char *fb = frag + (it & 1) * kSetFrag + lane * 16;
-        bq[0] = *reinterpret_cast<const half8 *>(fb);
-        bq[1] = *reinterpret_cast<const half8 *>(fb + 1024);
-        bq[2] = *reinterpret_cast<const half8 *>(fb + 2048);
-        cmp_read(it - 2);
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned long long tt0 = 0;
-        if (p.stamps) tt0 = __builtin_amdgcn_s_memtime();
-        static_for<kSteps>([&](auto st_c) {
-            constexpr int st = decltype(st_c)::value;
-            constexpr int a = st / KS, j = st % KS;
-            constexpr int pa = (a + NT - 1) % NT;                    // the tile whose accumulators are being keyed
-            if (FIRST && j == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(a_wait(a)) : "memory");     // this tile's fragments are in
-            if (st == KS) publish(it - 1);                           // (keys of set it-1 ended with the previous tile phase)
-            // key halves of this step: half index hi = 2 * value + (0: A, 1: B), hi -> k-step kKeyStart + hi * kKeySteps / 32
-            constexpr int lo = j < kKeyStart || j > kKeyEnd ? 0 : ((j - kKeyStart) * 32 + kKeySteps - 1) / kKeySteps;
-            constexpr int hi_end = j < kKeyStart || j > kKeyEnd ? 0 : ((j + 1 - kKeyStart) * 32 + kKeySteps - 1) / kKeySteps;
-            constexpr int n = hi_end - lo;
-            constexpr int PAT = n == 0 ? 0 : (n == 1 ? ((lo & 1) ? 2 : 1) : ((lo & 1) ? 4 : 3));
-            constexpr int va = (lo + 1) / 2;                         // the value whose half A rides with this MFMA (if any)
-            constexpr int CODE = (pa << 4) | (va & 15);
-            f32x16 &acc = (a & 1) ? acc1 : acc0;
-            f32x16 &accp = (a & 1) ? acc0 : acc1;
-            const float v = accp[va & 15];
-            if (a * KS + j < NA) s2_step<true, PAT, CODE>(acc, A[a][j], bq[st & 3], kk, m1, m2, m3, v, keymask);
-            else s2_step<false, PAT, CODE>(acc, A[a][j], bq[st & 3], kk, m1, m2, m3, v, keymask);
-            if (st + 3 < kSteps) bq[(st + 3) & 3] = *reinterpret_cast<const half8 *>(fb + ((st + 3) % KS) * 1024);
-            // further halves of this step (only the D = 192 shapes have more than two per step)
-            static_for<(n > 2 ? n - 2 : 0)>([&](auto x_c) {
-                constexpr int hx = lo + 2 + decltype(x_c)::value;
-                if constexpr (hx & 1) s2_key_b(kk, m1, m2);
-                else s2_key_a<(pa << 4) | ((hx / 2) & 15)>(kk, m2, m3, accp[(hx / 2) & 15], keymask);
-            });
-            // the buffer just keyed starts its next chain (tile a + 1) at |c|^2/2
-            if (j == kKeyEnd + 1) load_hn(accp, (a + 1) % NT);
-            // the other stages, dealt over the steps
-            if (st == at(3)) cmp_do(it - 2, it >= 2);
-            if (st == at(6) && wid == (it & 3)) win_read(it);
-            if (st == at(9) && wid == (it & 3)) win_do(it);
-            if (st == at(6) && wid == ((it + 2) & 3)) flag_read(it - 3);
-            if (st == at(9) && wid == ((it + 2) & 3)) flag_do(it - 3, it >= 3);
-            // (first iteration: behind the last fragment wait, so that the counted waits see only fragment loads)
-            if (st == (FIRST ? (NT - 1) * KS + 1 : at(12)) && do_dma) issue_half(2 * it + 4);
-            if (st == (FIRST ? (NT - 1) * KS + 3 : at(15)) && do_dma) issue_half(2 * it + 5);
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-                for (int c = 0; c < kCvtPerHalf; ++c) {
-                    if (st == at(18) + (h2 * kCvtPerHalf + c) * (at(72) / (2 * kCvtPerHalf))) cvt_read(2 * it + 2 + h2, c);
-                    if (st == at(18) + (h2 * kCvtPerHalf + c) * (at(72) / (2 * kCvtPerHalf)) + 3) cvt_write(2 * it + 2 + h2, c);
-                }
-                if (st == at(18) + ((h2 + 1) * kCvtPerHalf) * (at(72) / (2 * kCvtPerHalf))) cvt_norm(2 * it + 2 + h2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if (p.stamps) t_top += __builtin_amdgcn_s_memtime() - tt0;
-        end_of_iteration();
-    };
-    if (ns > 0) body(std::true_type{}, 0);
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int it = 1; it < ns; ++it) body(std::false_type{}, it);
-    // ---- drain: keys of the very last tile, then the compare / flag stages of the last sets
-    for (int it = ns; it < ns + 3 && ns > 0; ++it) {
-        if (it == ns) {
-            f32x16 &accl = ((NT - 1) & 1) ? acc1 : acc0;
-            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accl));
-            static_for<16>([&](auto r_c) {
-                constexpr int r = decltype(r_c)::value;
-                s2_key_a<((NT - 1) << 4) | r>(kk, m2, m3, accl[r], keymask);
-                s2_key_b(kk, m1, m2);
-            });
-            publish(ns - 1);
-        }
-        if (it - 2 >= 0 && it - 2 < ns) { cmp_read(it - 2); cmp_do(it - 2, true); }
-        if (it - 3 >= 0 && it - 3 < ns && wid == ((it + 2) & 3)) { flag_read(it - 3); flag_do(it - 3, true); }
-        end_of_iteration();
-    }
-    stamp(p, 2, lane, wave_id);
-    if (p.stamps && lane == 0) {
-        p.stamps[(size_t)wave_id * 16 + 4] = t_top; p.stamps[(size_t)wave_id * 16 + 5] = t_vm; p.stamps[(size_t)wave_id * 16 + 6] = t_bar;
-        p.stamps[(size_t)wave_id * 16 + 7] = (unsigned long long)ns;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// mode 0, pass 1, K-outer form (opt-in, sn_assign_set_variant(3); codebooks of 8 or 16 tiles of 32 words: 192 < M <= 256,
-// 448 < M <= 512): the token stream and the matrix pipe overlap by construction.
-//
-// A workgroup = 16 waves = 4 token sets x 4 word quarters, one workgroup per CU, persistent over rounds (sets dealt
-// round-robin over the workgroups, so a last, partial round is spread over all CUs).  Wave
-// (set ps, quarter q) keeps the accumulators of its set (<= 32 tokens) against its quarter of the codebook - NTW
-// tiles of 32 words, 16 registers each - for a whole round, and K is the OUTER loop: a 32-float chunk of every
-// token row arrives from HBM by LDS-DMA (whole 128-byte lines, piece-swizzled: the token staging of
-// assign_screen_kernel) into a 3-deep ring per set, is converted to two fp16 B fragments by the four waves of the
-// set, and is multiplied against the two k-steps of the codebook image that belong to it: 2 x NTW MFMAs per wave
-// and chunk.  Those k-steps stream L2 -> LDS through a 3-slot ring (one slot = the two k-steps of a chunk of every
-// tile = the 1 KiB blocks the token-stationary form reads tile by tile) shared by the sixteen waves: one barrier
-// per chunk.  Nothing waits for a whole token: the first MFMA starts when the first 128 bytes of each row are in,
-// HBM stays busy until the last chunk of a round, and the first chunks of the NEXT round are requested before the
-// keys of this one are formed.
-// At the end of a round every wave turns its accumulators into keys (one sorted triple per lane) and the eight
-// lanes that hold a token merge through LDS (float min of the best key, or of the candidate masks) into the
-// same flag word / candidate-code record the re-rank kernel reads (format 3).
-//
-// Values: u[word] = |c|^2/2 - x~.c~ (accumulators start at |c|^2/2; no per-token shift: keys are compared as
-// floats, as in assign_screen2_kernel), window 2E from the fp32 sum of squares of the token.
-// vmcnt bookkeeping (LDS-DMA and loads retire in issue order): per wave, barrier(u) - between the two k-steps of
-// chunk u - is followed by the copies A(u+2) (two pieces) and tok(u+3) (one piece), and publishes A(u+1) and
-// tok(u+1): the only younger operation that may stay in flight across it is tok(u+2).
-//
-// Measured (MI355X, 50 176 tokens): 34.8 us against 36.2 us for the token-stationary form in isolation, but
-// 5 % fewer images/s in the replayed bench (it holds every CU's whole LDS and sixteen waves for the length of the launch):
-// opt-in.  History: with a rolled chunk loop (ring positions, wait counts and conditions computed at run time: 170
-// instructions per wave and chunk) the stream was bound by the INSTRUCTIONS the CU can issue - 45.8 us, and with the token
-// copies, the codebook copies, the barriers, the MFMAs and the fragment reads all compiled out the loop still took 85 % of
-// its time.  Fully unrolled (this version: ~70 instructions per wave and chunk, every ring position an immediate) the
-// loop is 15.9 k cycles per round against 12.3 k of matrix pipe; what bounds it now is the codebook stream (393 KB per CU
-// and round out of L2, ~27 B per cycle and CU), which a round with half of its sets missing does not shorten.
-// ------------------------------------------------------------------------------------------
-constexpr int kS3RingA = 3, kS3RingT = 3, kS3Sets = 4, kS3Quarters = 4;      // ring slots: codebook chunks (2 k-steps), token chunks
-
-// LDS-DMA pieces of assign_screen3_kernel with every ring position an immediate: the LDS address is M0 + instruction
-// offset + 16 x lane, the global address SGPR base + 32-bit lane offset + the same instruction offset (so M0 carries
-// the slot minus that offset).
-template <int LDS_OFF, int GOFF>
-__device__ __forceinline__ void s3_dma1(unsigned voff, const void *sbase, unsigned lds_dst)
-{
-    static_assert(GOFF >= 0 && GOFF < 4096, "instruction offset");
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4"
-                 :: "v"(voff), "s"(sbase), "s"(lds_dst), "n"(LDS_OFF - GOFF), "n"(GOFF) : "memory", "scc");
-}
-template <int LDS_OFF>
-__device__ __forceinline__ void s3_dma2(unsigned voff, const void *sbase, unsigned lds_dst)     // two consecutive KiB
-{
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
-                 :: "v"(voff), "s"(sbase), "s"(lds_dst), "n"(LDS_OFF) : "memory", "scc");
-}
-
-template <int NTW, int NCH>
-__global__ __launch_bounds__(1024, 4) void assign_screen3_kernel(const AssignArgs p)
-{
-    constexpr int NT = kS3Quarters * NTW;                       // tiles of the (padded) codebook: 8 or 16
-    constexpr int RG = 2;                                       // A fragments read ahead (registers)
-    constexpr int kSlotA = NT * 2048;                           // one chunk = two k-steps of every tile: [tile][k-step][1 KiB]
-    constexpr int kOffT = kS3RingA * kSlotA;                    // token rings  [4 sets][3][4 KiB]
-    constexpr int kOffHc = kOffT + kS3Sets * kS3RingT * 4096;   // |c|^2/2 of every word, accumulator-row order [NT][32]
-    constexpr int kOffBest = kOffHc + NT * 128;                 // [4][32] best key of a token
-    constexpr int kOffMask = kOffBest + kS3Sets * 32 * 4;       // [4][32] candidate mask being assembled
-    static_assert(NTW == 2 || NTW == 4, "tiles per wave");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *hcs = reinterpret_cast<float *>(smem + kOffHc);
-    float *tbest = reinterpret_cast<float *>(smem + kOffBest);
-    unsigned *tmask = reinterpret_cast<unsigned *>(smem + kOffMask);
-
-    const int wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int ps = wid >> 2, q = wid & 3;
-    const PackLayout lay = pack_layout(p.M, p.D);
-    const unsigned char *tiles = p.packed + lay.tiles_off;
-    const int wave_id = blockIdx.x * 16 + wid;
-    stamp(p, 0, (int)threadIdx.x & 63, wave_id);
-
-    if (threadIdx.x < kS3Sets * 32) { tbest[threadIdx.x] = kBigKey; tmask[threadIdx.x] = 0u; }
-
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned a_dst = __builtin_amdgcn_readfirstlane(lds_base + (wid % NT) * 2048);            // + slot
-    const unsigned t_dst = __builtin_amdgcn_readfirstlane(lds_base + kOffT + ps * (kS3RingT * 4096) + q * 1024);    // + buffer
-    unsigned keep_m0;
-    asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
-    // Sets are dealt round-robin: in round `rnd` workgroup b's slot ps holds set (4 rnd + ps) G + b (G = workgroups), so the
-    // last round's sets spread over ALL workgroups (50 176 tokens = 1 568 sets on 256 CUs: round 1 has four sets everywhere,
-    // round 2 two or three): a slot without a set only serves the codebook ring and the barriers, and a SIMD that hosts
-    // fewer computing waves finishes its chunk sooner (the loop is bound by the matrix pipe).
-    const int64_t G = gridDim.x;
-    const int64_t n_rounds = (p.n_sets3 + kS3Sets * G - 1) / (kS3Sets * G);
-
-    for (int64_t rnd = 0; rnd < n_rounds; ++rnd) {
-        // (everything that depends on the lane is formed again in every round, behind an opaque copy of the thread id:
-        // hoisted out of the round loop these values do not fit beside the accumulators and are spilled, and a spill reload
-        // waits for vmcnt(0), i.e. for the token chunks in flight)
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, r = lane & 31, h = lane >> 5;
-        // copies: codebook piece = tile (wid % NT), lane offset inside the image; token piece = rows 8 q + lane / 8 of the set
-        // (a row past the set or past the last token: the set's first row, or token 0: no wave skips a copy)
-        const unsigned a_voff = (unsigned)((wid % NT) * lay.tile_bytes + lane * 16);
-        auto set_of = [&](int64_t rd) -> int64_t { return (kS3Sets * rd + ps) * G + blockIdx.x; };
-        auto tok_voff = [&](int64_t rd) -> unsigned {
-            const int64_t tok0 = set_of(rd) * p.tps;
-            const int rq = 8 * q + (lane >> 3);
-            const int64_t nq = tok0 + rq;
-            const bool ok = rq < p.tps && nq < p.n_tokens;
-            const int64_t nn = ok ? nq : (tok0 < p.n_tokens ? tok0 : 0);
-            const unsigned ni = (unsigned)p.n_inner, o = (unsigned)nn / ni, i = (unsigned)nn - o * ni;
-            return (unsigned)(((int64_t)o * p.xso + (int64_t)i * p.xsi) * 4 + 16 * ((lane & 7) ^ ((rq >> 1) & 7)));
-        };
-        // issue order of a round's first copies: T0, A0, T1, A1, T2 (one barrier later: A2, T3, ...)
-        auto begin_round = [&](unsigned tv, bool act) {
-            if (act) s3_dma1<0 * 4096, 0>(tv, p.x, t_dst);
-            s3_dma2<0 * kSlotA>(a_voff, tiles, a_dst);
-            if (NCH > 1) { if (act) s3_dma1<1 * 4096, 128>(tv, p.x, t_dst); s3_dma2<1 * kSlotA>(a_voff, tiles + 2048, a_dst); }
-            if (NCH > 2 && act) s3_dma1<2 * 4096, 256>(tv, p.x, t_dst);
-        };
-        const bool active = set_of(rnd) < p.n_sets3;            // wave-uniform
-        unsigned t_voff = tok_voff(rnd);
-        if (rnd == 0) {
-            begin_round(t_voff, active);
-            // |c|^2/2 of every word -> LDS, once (behind the first copies: its wait is theirs).  Padding words: +inf in the
-            // image, kept finite here so that keys never become NaNs.
-            if (tid < NT * 32)
-                hcs[tid] = fminf(reinterpret_cast<const float *>(tiles + (size_t)(tid >> 5) * lay.tile_bytes + (size_t)lay.n_steps * 1024)[tid & 31], kPadHalfNorm);
-        }
-
-        // ---- accumulators start at |c|^2/2
-        f32x16 acc[NTW];
-        if (rnd == 0) { stamp(p, 6, lane, wave_id); __syncthreads(); stamp(p, 7, lane, wave_id); }                          // (hcs written above)
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (q * NTW + i) * 32 + (g * 2 + h) * 4);
-                acc[i][4 * g + 0] = c4.x; acc[i][4 * g + 1] = c4.y; acc[i][4 * g + 2] = c4.z; acc[i][4 * g + 3] = c4.w;
-            }
-        }
-        if (active) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH > 2 ? 4 : (NCH > 1 ? 3 : 0)) : "memory");     // T0 and A0 are in (younger: T1, A1 x 2, T2)
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NCH > 1 ? 2 : 0) : "memory");                           // A0 is in (younger: A1 x 2)
-        if (rnd == 0) stamp(p, 8, lane, wave_id);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (rnd == 0) stamp(p, 11, lane, wave_id);
-
-        // token chunk of this wave's set -> the lane's 16 floats (row r, k = 32 u + 16 h + 0..15)
-        const unsigned char *t_frag = smem + kOffT + ps * (kS3RingT * 4096) + (r >> 3) * 1024 + (r & 7) * 128;
-        const int sw = (r >> 1) & 7;
-        const unsigned char *tq0 = t_frag + ((4 * h + 0) ^ sw) * 16, *tq1 = t_frag + ((4 * h + 1) ^ sw) * 16;
-        const unsigned char *tq2 = t_frag + ((4 * h + 2) ^ sw) * 16, *tq3 = t_frag + ((4 * h + 3) ^ sw) * 16;
-        const unsigned char *a_frag = smem + (q * NTW) * 2048 + lane * 16;
-        f32x4 raw[4];
-        float sumsq = 0.0f;
-        auto convert = [&](half8 &b, const f32x4 &lo, const f32x4 &hi) {
-            sumsq = fmaf(lo.x, lo.x, sumsq); sumsq = fmaf(lo.y, lo.y, sumsq); sumsq = fmaf(lo.z, lo.z, sumsq); sumsq = fmaf(lo.w, lo.w, sumsq);
-            sumsq = fmaf(hi.x, hi.x, sumsq); sumsq = fmaf(hi.y, hi.y, sumsq); sumsq = fmaf(hi.z, hi.z, sumsq); sumsq = fmaf(hi.w, hi.w, sumsq);
-            b[0] = (_Float16)lo.x; b[1] = (_Float16)lo.y; b[2] = (_Float16)lo.z; b[3] = (_Float16)lo.w;
-            b[4] = (_Float16)hi.x; b[5] = (_Float16)hi.y; b[6] = (_Float16)hi.z; b[7] = (_Float16)hi.w;
-            asm volatile("" : "+v"(sumsq));                     // (otherwise the whole chain of squares sinks to the epilogue and every chunk's floats are spilled until then)
-        };
-        half8 bc0, bc1;
-        if (active) {
-            raw[0] = *reinterpret_cast<const f32x4 *>(tq0); raw[1] = *reinterpret_cast<const f32x4 *>(tq1);
-            raw[2] = *reinterpret_cast<const f32x4 *>(tq2); raw[3] = *reinterpret_cast<const f32x4 *>(tq3);
-            convert(bc0, raw[0], raw[1]);
-            convert(bc1, raw[2], raw[3]);
-        }
-        stamp(p, rnd == 0 ? 12 : 1, lane, wave_id);
-
-        // ---- main loop, fully unrolled (NCH chunks): one barrier per chunk, between its two k-steps; every ring position,
-        // wait count and condition is a constant.  Fragment c = e NTW + i of a chunk sits at (2 i + e) KiB of this wave's
-        // part of the slot; the register ring runs RG fragments ahead (the last RG of a chunk fetch the next chunk's first).
-        if (active) {
-        half8 ar[RG];
-#pragma unroll
-        for (int c = 0; c < RG; ++c) ar[c] = *reinterpret_cast<const half8 *>(a_frag + ((c % NTW) * 2 + c / NTW) * 1024);
-        static_for<NCH>([&](auto u_c) {
-            constexpr int u = decltype(u_c)::value;
-            constexpr int slot = (u % kS3RingA) * kSlotA, nslot = ((u + 1) % kS3RingA) * kSlotA;
-            auto k_step = [&](const half8 &b, auto e_c) {
-                constexpr int e = decltype(e_c)::value;
-#pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    const int c = e * NTW + i, cn = c + RG;
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[c % RG], b, acc[i], 0, 0, 0);
-                    if (cn < 2 * NTW) ar[c % RG] = *reinterpret_cast<const half8 *>(a_frag + slot + ((cn % NTW) * 2 + cn / NTW) * 1024);
-                    else if (u + 1 < NCH) ar[c % RG] = *reinterpret_cast<const half8 *>(a_frag + nslot + (((cn - 2 * NTW) % NTW) * 2 + (cn - 2 * NTW) / NTW) * 1024);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            k_step(bc0, std::integral_constant<int, 0>{});
-            if constexpr (u + 2 < NCH) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // (in flight across the barrier: T(u+2))
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                       // chunk u+1 (codebook and tokens) is in LDS for everybody; slot of chunk u-1 and buffer of chunk u are free
-            asm volatile("" ::: "memory");
-            if constexpr (u + 2 < NCH) s3_dma2<((u + 2) % kS3RingA) * kSlotA>(a_voff, tiles + (size_t)(u + 2) * 2048, a_dst);
-            if constexpr (u + 3 < NCH) s3_dma1<((u + 3) % kS3RingT) * 4096, 128 * (u + 3)>(t_voff, p.x, t_dst);
-            if constexpr (u + 1 < NCH) {
-                constexpr int rb = ((u + 1) % kS3RingT) * 4096;
-                raw[0] = *reinterpret_cast<const f32x4 *>(tq0 + rb); raw[1] = *reinterpret_cast<const f32x4 *>(tq1 + rb);
-                raw[2] = *reinterpret_cast<const f32x4 *>(tq2 + rb); raw[3] = *reinterpret_cast<const f32x4 *>(tq3 + rb);
-                convert(bc0, raw[0], raw[1]);                   // (bc0 of chunk u has been issued to the matrix pipe)
-            }
-            k_step(bc1, std::integral_constant<int, 1>{});
-            if constexpr (u + 1 < NCH) convert(bc1, raw[2], raw[3]);
-        });
-        } else {                                                // a slot without a set: its share of the codebook copies, and the barriers
-            static_for<NCH>([&](auto u_c) {
-                constexpr int u = decltype(u_c)::value;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if constexpr (u + 2 < NCH) s3_dma2<((u + 2) % kS3RingA) * kSlotA>(a_voff, tiles + (size_t)(u + 2) * 2048, a_dst);
-            });
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // nobody reads the rings any more
-        asm volatile("" ::: "memory");
-        stamp(p, rnd == 0 ? 13 : 2, lane, wave_id);
-        // ---- the next round's first chunks travel while this round's keys are formed
-        const int64_t tok0 = set_of(rnd) * p.tps;
-        if (rnd + 1 < n_rounds) { t_voff = tok_voff(rnd + 1); begin_round(t_voff, set_of(rnd + 1) < p.n_sets3); }
-
-        // ---- keys: one sorted triple per lane; code = tile << 4 | accumulator register
-        // (volatile asm, four instructions per value: left to itself hipcc forms the three chains one after the other and
-        // keeps every intermediate minimum alive - spills.  The asm reads MFMA results behind the hazard recogniser's
-        // back: the barrier and the copies above are far more than the last MFMA's write-back.)
-        float m1 = kBigKey, m2 = kBigKey, m3 = kBigKey;
-        unsigned keymask = 0xFFFFFF00u;
-        asm volatile("s_nop 15\n\ts_nop 15" : "+s"(keymask));
-        if (active)
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                float k;
-                asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
-                             "v_med3_f32 %3, %0, %2, %3\n\t"
-                             "v_med3_f32 %2, %0, %1, %2\n\t"
-                             "v_min_f32 %1, %0, %1"
-                             : "=&v"(k), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(acc[i][x]), "s"(keymask), "n"((i << 4) | x));
-            }
-        }
-        sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
-        // ---- per-token error window (DESIGN.md "S1 error window"): |key - exact value| <= E
-        const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
-        const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]), CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
-        const float X2 = sqrtf(sumsq) * 1.001f + 1.0e-6f, X1 = X2 * sqrtf((float)p.D);
-        const float vmax = 0.5f * CN + X2 * C2;                               // >= |any partial sum|
-        const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
-                                 + (float)(2 * NCH) * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
-        const bool bad = !(sumsq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e28f);   // NaN-safe; |x|_2 <= 3e4 bounds every component
-        const float window = 2.0f * E;
-        const int64_t n = tok0 + r;
-        const bool valid = active && r < p.tps && n < p.n_tokens;
-        const float kmin = fminf(m1, __shfl_xor(m1, 32, SN_WAVE));
-        if (valid && h == 0) __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&tbest[ps * 32 + r], kmin, 0, 0, false);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const float best = tbest[ps * 32 + r];
-        const bool any_finite = best < kKeyLimit;
-        const float cut = best + window;
-        const unsigned hmask = (m1 <= cut ? 1u : 0u) | (m2 <= cut ? 2u : 0u) | (m3 <= cut ? 4u : 0u);
-        const bool hover = m3 <= cut;                                         // a 4th may hide behind it
-        const unsigned contrib = (bad || !any_finite) ? 0x80000000u : ((hmask << (3 * (2 * q + h))) | (hover ? 0x80000000u : 0u));
-        if (valid && contrib) __hip_atomic_fetch_or(&tmask[ps * 32 + r], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned mk = tmask[ps * 32 + r];
-        const unsigned cand = mk & 0xFFFFFFu;
-        const bool overflow = (mk >> 31) != 0u || cand == 0u;
-        const int nc = __popc(cand);
-        if (valid && !overflow) {
-            if (nc == 1 && hmask != 0u) {                                     // the only candidate: final
-                const unsigned code = __float_as_uint(m1) & 0xFFu;
-                p.out[out_index(p, n)] = (q * NTW + (int)(code >> 4)) * 32 + 8 * (int)((code >> 2) & 3u) + 4 * h + (int)(code & 3u);
-            }
-            if (nc > 1) {                                       // the eight lanes of the token write their three codes
-                unsigned char *cd = p.codes + (int64_t)n * kCodeBytes + 3 * (2 * q + h);
-                cd[0] = (unsigned char)(__float_as_uint(m1) & 0xFFu);
-                cd[1] = (unsigned char)(__float_as_uint(m2) & 0xFFu);
-                cd[2] = (unsigned char)(__float_as_uint(m3) & 0xFFu);
-            }
-        }
-        const bool writer = valid && q == 0 && h == 0;
-        if (writer) p.flags[n] = overflow ? 0x80000000u : (nc > 1 ? cand : 0u);
-        const bool need_b = writer && overflow;
-        const unsigned long long mask_b = __ballot(need_b);
-        if (mask_b) {                                          // rare: tokens the screen cannot bound (phase B of the re-rank writes out[])
-            int base = 0;
-            const int leader = __ffsll((long long)mask_b) - 1;
-            if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
-            base = __shfl(base, leader, SN_WAVE);
-            if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // everybody has read the merged words: reset them for the next round
-        asm volatile("" ::: "memory");
-        if (q == 0 && h == 0) { tbest[ps * 32 + r] = kBigKey; tmask[ps * 32 + r] = 0u; }
-        stamp(p, rnd == 0 ? 14 : 3, lane, wave_id);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may be in flight when the LDS is released
-    asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));
-}
 
 // ------------------------------------------------------------------------------------------
 // mode 0, pass 1, one-round K-outer form (round 4; sn_assign_set_variant(4); codebooks of 16 tiles of 32 words - 448 < M <= 512 -,
@@ -2032,6 +1285,460 @@ __global__ __launch_bounds__(256, 1) void assign_screen4_kernel(const AssignArgs
     asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));
 }
 
+// ------------------------------------------------------------------------------------------
+// mode 0, pass 1, one-round K-outer form with TWO waves per SIMD (round 5; sn_assign_set_variant(5); codebooks of 16 tiles of
+// 32 words - 448 < M <= 512 -, D in {192, 384}, fp32 tokens, at most kS5Rows tokens per CU).
+//
+// Same idea as assign_screen4_kernel - the accumulators of every token of the workgroup against the whole codebook stay in
+// registers, K is the outer loop, so the token stream (HBM) runs under the matrix pipe and the codebook crosses the CU once -
+// but on EIGHT 256-register waves: wave (sg, q) = (tid >> 8, (tid >> 6) & 3) holds the accumulators of the three 32-token sets
+// 3 sg .. 3 sg + 2 against the quarter q of the words (4 tiles x 16 registers x 3 sets = 192) and of up to sixteen further
+// tokens ("leftover", v_mfma_f32_16x16x32_f16) against half of that quarter (4 blocks x 4 registers): 208 of its 256
+// registers, every one an architectural VGPR, so the MFMAs are plain builtins (the compiler sees their hazards and their
+// operands' lifetimes: none of assign_screen4_kernel's asm rules apply) and the key phase of one wave runs beside the other
+// wave of its SIMD instead of alone.
+// The quarter of a wave is not a run of four tiles but an accumulator-row group: the tiles5 image (pack_frag5_kernel)
+// permutes the words so that lane (r, h) of wave (sg, q) holds, of its token, exactly the words 32 t + 8 q + 4 h + e (t < 16,
+// e < 4) - the candidate-slot group (h, g = q) of the DEFAULT screen's record (sn_assign_shared.h): a sorted triple per lane
+// and set IS that group's triple, so this kernel writes the same flag words and 24-byte records as assign_screen_kernel and
+// both finishers (assign_rerank_kernel<., 0>, the deferred finish inside the instance-graph kernel) take them as they are.
+// The leftover tokens' words are split by accumulator-row half: wave (sg, q) multiplies them by the words 32 t + 8 q + 4 sg + e
+// - slot group (h = sg, g = q) again, spread over the four lanes (token, kg) that are merged with two shuffles.
+// Values u[word] = |c|^2/2 - x~.c~, keys compared as floats, window as in assign_screen4_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kS5Sets = 6, kS5Lo = 16;
+constexpr int kS5Rows = kS5Sets * 32 + kS5Lo;                   // tokens a workgroup can hold (208)
+constexpr int kS5RowsPad = 224;                                 // token rows copied per chunk: 28 copies of 8 rows
+constexpr int kS5Slab = 16 * 2048, kS5Tok = kS5RowsPad * 128;   // bytes per chunk: codebook (16 virtual tiles x 2 k-steps), token rows
+constexpr int kS5OffT = 2 * kS5Slab;
+constexpr int kS5OffHc = kS5OffT + 3 * kS5Tok;                  // |c|^2/2, [tile][accumulator-row order]
+constexpr int kS5OffBest = kS5OffHc + 16 * 128;                 // [7][32] best key of a token
+constexpr int kS5OffMask = kS5OffBest + 7 * 128;                // [7][32] candidate mask being assembled
+constexpr int kS5OffSum = kS5OffMask + 7 * 128;                 // [7][32] window (2 E) of a token, NaN: not screened
+constexpr int kS5OffTv = kS5OffSum + 7 * 128;                   // [4 waves][64 lanes] lane address of a wave's fourth token copy (one register less in the loop)
+constexpr int kS5Lds = kS5OffTv + 4 * 256;
+
+// one 1 KiB LDS-DMA piece: global address = scalar base + 32-bit lane offset + OFF, LDS address = lds_dst + 16 x lane (the
+// instruction's offset field moves both, so M0 carries the destination minus OFF).  A function, not a statement inside the
+// kernel's generic lambdas: clang does not count an asm operand there as a use of a captured variable.
+template <int OFF>
+__device__ __forceinline__ void s5_dma(unsigned voff, const void *sbase, unsigned lds_dst)
+{
+    static_assert(OFF >= 0 && OFF < 4096, "instruction offset");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" :: "v"(voff), "s"(sbase), "s"(lds_dst - (unsigned)OFF), "n"(OFF) : "memory");
+}
+
+// ABL (diagnostic builds, SN_S5_ABL; results are wrong): bit 0 = no squares / conversion, bit 1 = no 32 x 32 MFMAs, bit 2 = no copies behind chunk 0
+template <int NCH, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *hcs = reinterpret_cast<float *>(smem + kS5OffHc);
+    float *tbest = reinterpret_cast<float *>(smem + kS5OffBest);
+    unsigned *tmask = reinterpret_cast<unsigned *>(smem + kS5OffMask);
+    float *tsum = reinterpret_cast<float *>(smem + kS5OffSum);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sg = w >> 2, q = w & 3;
+    const int r = lane & 31, h = lane >> 5;                      // 32 x 32 side: token column, accumulator row half = k half of a fragment
+    const int j16 = lane & 15, kg = lane >> 4;                   // 16 x 16 side: token column, k group of a fragment = accumulator row group
+    const PackLayout lay = pack_layout(p.M, p.D);
+    const unsigned char *tiles = p.packed + lay.tiles_off;
+    const unsigned char *tiles5 = p.packed + lay.tiles5_off;
+    const int64_t tok0 = (int64_t)blockIdx.x * p.tps4;           // this workgroup's tokens: [tok0, tok0 + n_mine)
+    const int n_mine = (int)(p.n_tokens - tok0 < p.tps4 ? p.n_tokens - tok0 : p.tps4);
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int wave_id = blockIdx.x * 8 + w;
+    stamp(p, 0, lane, wave_id);
+
+    if (tid < 7 * 32) { tbest[tid] = kBigKey; tmask[tid] = 0u; tsum[tid] = 0.0f; }
+    // |c|^2/2 of every word, [tile][accumulator-row order] as in the image: two copies of eight tiles' 128 bytes (waves 0, 1),
+    // the first thing in flight; whoever reads them does so behind the first chunk's barrier
+    if (w < 2)
+        s5_dma<0>((unsigned)((8 * w + (lane >> 3)) * lay.tile_bytes + lay.n_steps * 1024 + (lane & 7) * 16), tiles, __builtin_amdgcn_readfirstlane(lds_base + kS5OffHc + w * 1024));
+
+    // ---- copies.  Token rows: copy i of wave w covers the rows 8 (w + 8 i) .. + 7 of the workgroup, i < 4 (w < 4) or 3 (a row
+    // past its tokens: its first token - nobody reads it); lane -> (row, piece slot), the slot holds piece slot ^ ((row >> 1) & 7).
+    unsigned tv[3];
+    unsigned *tv3 = reinterpret_cast<unsigned *>(smem + kS5OffTv) + (w & 3) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (w + 8 * i) + (lane >> 3);
+        const int64_t n = ((p.dbg & 1) ? 0 : tok0) + (row < n_mine ? row : 0);
+        const unsigned ni = (unsigned)p.n_inner, o = (unsigned)n / ni, ii = (unsigned)n - o * ni;
+        const unsigned tvi = (unsigned)(((int64_t)o * p.xso + (int64_t)ii * p.xsi) * 4 + 16 * ((lane & 7) ^ ((row >> 1) & 7)));
+        if (i < 3) tv[i] = tvi;
+        else if (w < 4) *tv3 = tvi;                              // (read back by the same lane only)
+    }
+    // (the chunk's 128 c bytes ride in the instruction's offset field, which moves the LDS address along with the global one:
+    // M0 = slot address - 128 c; no address arithmetic on the vector side)
+    auto issue_tok = [&](auto c_c) {
+        constexpr int c = decltype(c_c)::value;
+        const unsigned slot = (unsigned)(c % 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == 3 && w >= 4) break;                         // (wave-uniform)
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + kS5OffT + slot * kS5Tok + (w + 8 * i) * 1024);
+            s5_dma<c * 128>(i < 3 ? tv[i] : *tv3, p.x, dst);
+        }
+    };
+    const unsigned a_lane = (unsigned)(q * 4 * 2048 + lane * 16);   // A fragment of virtual tile (q, v), k-step ks: + v * 2048 + ks * 1024
+    // codebook: wave w copies the two k-steps of the virtual tiles 2 w, 2 w + 1 (4 KiB of the chunk's 32): scalar base, lane x 16
+    auto issue_slab = [&](int c) {
+        const unsigned slot = (unsigned)(c & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vt = 2 * w + (i >> 1);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kS5Slab + vt * 2048 + (i & 1) * 1024);
+            // (lane part = a_lane = 8192 q + 16 lane, the register the fragment reads use: the scalar base takes the - 8192 q)
+            const unsigned char *src = tiles5 + (ptrdiff_t)__builtin_amdgcn_readfirstlane((vt * lay.n_steps + 2 * c + (i & 1)) * 1024 - q * 8192);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(a_lane), "s"(src), "s"(dst) : "memory");
+        }
+    };
+    // issue order: slab(0), tok(0), slab(1), tok(1), tok(2); behind barrier c (which publishes chunk c + 1): slab(c + 2), tok(c + 3)
+    static_assert(NCH >= 3, "ring depths");
+    issue_slab(0); issue_tok(std::integral_constant<int, 0>{});
+    issue_slab(1); issue_tok(std::integral_constant<int, 1>{});
+    issue_tok(std::integral_constant<int, 2>{});
+    stamp(p, 1, lane, wave_id);
+
+    f32x16 acc[3][4];
+    f32x4 accl[4];
+    float sumsq = 0.0f;                                          // |x|^2 of the lane's share of set 3 sg + q (q < 3) or of the leftover tokens (w == 3)
+    auto squares = [&](const f32x4 &lo, const f32x4 &hi) {
+        float a = lo.x * lo.x;
+        a = fmaf(lo.y, lo.y, a); a = fmaf(lo.z, lo.z, a); a = fmaf(lo.w, lo.w, a);
+        a = fmaf(hi.x, hi.x, a); a = fmaf(hi.y, hi.y, a); a = fmaf(hi.z, hi.z, a); a = fmaf(hi.w, hi.w, a);
+        return a;
+    };
+    auto to_half8 = [](const f32x4 &lo, const f32x4 &hi) {
+        half8 b;
+        b[0] = (_Float16)lo.x; b[1] = (_Float16)lo.y; b[2] = (_Float16)lo.z; b[3] = (_Float16)lo.w;
+        b[4] = (_Float16)hi.x; b[5] = (_Float16)hi.y; b[6] = (_Float16)hi.z; b[7] = (_Float16)hi.w;
+        return b;
+    };
+    const int swz = (r >> 1) & 7;                                // (row 32 s + r: the set offset does not touch bits 1..3)
+    // lane parts of the LDS addresses.  B fragment of k-step ks: k half h of the image = floats 16 h + 8 ks .. + 7 of the chunk
+    // (pack_frag_kernel) = pieces 4 h + 2 ks, + 1 of the token's line
+    // piece slot of (k-step ks, 16-byte half b) = (4 h + 2 ks + b) ^ swz = (4 h ^ swz) ^ (2 ks + b): ONE lane register, the rest an
+    // xor with a constant folded into the address add (v_xad_u32)
+    const unsigned t_base = (unsigned)((96 * sg + r) * 128 + (((4 * h) ^ swz) << 4));
+    // (through an opaque copy at every use: left alone the compiler keeps all four t_base ^ const alive across the whole loop)
+    auto t_addr = [&](unsigned rb_, int ks, int b) {
+        unsigned tb = t_base;
+        asm volatile("" : "+v"(tb));
+        return (tb ^ (unsigned)((2 * ks + b) << 4)) + rb_;
+    };
+    // (the leftover step's two lane addresses are formed again in every chunk, from a lane register the loop keeps anyway: a dozen
+    // VALU instructions per chunk against two registers the loop does not have)
+    auto leftover_addr = [&](unsigned &l_lo, unsigned &a16_lane) {
+        unsigned al = a_lane;                                     // (= 8192 q + 16 lane, alive anyway; the empty asm keeps the arithmetic below inside its chunk)
+        asm volatile("" : "+v"(al));
+        const int ln = (int)((al >> 4) & 63u);
+        const int j16_ = ln & 15, kg_ = ln >> 4;
+        const int pl = 4 * (kg_ & 1) + 2 * (kg_ >> 1);
+        l_lo = (unsigned)((32 * kS5Sets + j16_) * 128 + ((pl ^ ((j16_ >> 1) & 7)) << 4));      // (pl is even: the second piece is this ^ 16)
+        // A fragment of leftover block b: row j16 of the block = virtual tile (q, b), row 8 (j16 >> 2) + 4 sg + (j16 & 3); k = 8 kg .. + 7:
+        // k-step kg >> 1, k half kg & 1 of the image
+        a16_lane = (unsigned)(q * 4 * 2048 + (kg_ >> 1) * 1024 + ((8 * (j16_ >> 2) + 4 * sg + (j16_ & 3)) + 32 * (kg_ & 1)) * 16);
+    };
+    unsigned long long tq[6] = {0, 0, 0, 0, 0, 0};               // diagnostics: s_memtime inside chunk 5 (scalar registers; written at the end)
+    // ---- main loop, fully unrolled.  The work of a chunk is seven steps: S0 .. S5 = (k-step ks, set st) - four 32 x 32 x 16 MFMAs, the
+    // wave's four virtual tiles against one B fragment - and L = the leftover tokens' four 16 x 16 x 32, in the order
+    //     S0 S1 S2 L S3 S4 | barrier c | S5
+    // as ONE software-pipelined stream over all chunks: the NEXT step's raw rows are requested in front of a step's MFMAs and squared /
+    // converted behind them (while the partner wave's MFMAs have the pipe), the A fragments of the next k-step / of the leftover
+    // blocks / of the next chunk take the registers of the current ones as each is used for the last time.
+    // The barrier does not open a chunk, it sits INSIDE one (stamps of the form with "wait, barrier, load, convert, multiply" per
+    // chunk: ~1 000 of its 2 700 cycles were the pipe waiting for the first LDS rows behind the barrier, on both waves of a SIMD at
+    // once).  Barrier c publishes chunk c + 1 - every wave has waited for its copies of it - and certifies that every LDS read of
+    // chunk c has been made (S5's operands are in registers), so the copies of slab(c + 2) / tok(c + 3) go into chunk c's slots
+    // right behind it, and S5 requests the first rows and fragments of chunk c + 1 with MFMAs on both sides of the barrier.
+    // The squares of a row are summed by ONE of the four quarter waves of its set (wave-uniform branches).
+    half8 a[4], bcur;
+    unsigned a16_lane = 0;
+    // one step: kind 0 .. 2 = set, 3 = leftover; reload: 0 none, else a[v] <- the fragment at reload_base + 2048 v behind MFMA v
+    auto run_step = [&](auto kind_c, auto reload_c, auto next_c, unsigned nlo, unsigned nhi, bool nsq, unsigned reload_base) {
+        constexpr int kind = decltype(kind_c)::value;
+        constexpr bool reload = decltype(reload_c)::value != 0, has_next = decltype(next_c)::value != 0;
+        f32x4 lo, hi;
+        if constexpr (has_next) {
+            lo = *reinterpret_cast<const f32x4 *>(smem + nlo);
+            hi = *reinterpret_cast<const f32x4 *>(smem + nhi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if constexpr (kind == 3) accl[v] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[v], bcur, accl[v], 0, 0, 0);
+            else if constexpr (ABL & 2) asm volatile("" :: "v"(a[v]), "v"(bcur));
+            else acc[kind][v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[v], bcur, acc[kind][v], 0, 0, 0);
+            if constexpr (reload) a[v] = *reinterpret_cast<const half8 *>(smem + (reload_base + v * 2048));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (has_next) {
+            if constexpr (ABL & 1) bcur = __builtin_bit_cast(half8, lo);
+            else {
+                if (nsq) {
+                    sumsq += squares(lo, hi);
+                    asm volatile("" : "+v"(sumsq));              // (pinned: left alone the chain of squares sinks to the epilogue, every raw row spilled until then)
+                }
+                bcur = to_half8(lo, hi);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    {   // static priority (diagnostics: SN_ASSIGN_DBG bit 1 = the younger half, bit 2 = the older half at priority 1)
+        if ((p.dbg & 2) && sg == 1) __builtin_amdgcn_s_setprio(1);
+        if ((p.dbg & 4) && sg == 0) __builtin_amdgcn_s_setprio(1);
+    }
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    {   // chunk 0 is in LDS: everything but slab(1), tok(1), tok(2) of this wave's copies
+        if (w < 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(p, 5, lane, wave_id);
+        // ---- accumulators start at |c|^2/2.  Register x of virtual tile v, lane half h: word 32 (4 v + (x >> 2)) + 8 q + 4 h + (x & 3)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            f32x16 c0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (4 * v + g) * 32 + (q * 2 + h) * 4);
+                c0[4 * g + 0] = fminf(c4.x, kPadHalfNorm); c0[4 * g + 1] = fminf(c4.y, kPadHalfNorm);
+                c0[4 * g + 2] = fminf(c4.z, kPadHalfNorm); c0[4 * g + 3] = fminf(c4.w, kPadHalfNorm);      // (padding words: +inf in the image, kept finite so that keys never become NaNs)
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc[s][v] = c0;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                            // block b, accumulator row 4 kg + e: word 32 (4 b + kg) + 8 q + 4 sg + e
+            const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (4 * b + kg) * 32 + (q * 2 + sg) * 4);
+            accl[b] = f32x4{fminf(c4.x, kPadHalfNorm), fminf(c4.y, kPadHalfNorm), fminf(c4.z, kPadHalfNorm), fminf(c4.w, kPadHalfNorm)};
+        }
+        // the first step's operands
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a[v] = *reinterpret_cast<const half8 *>(smem + a_lane + v * 2048);
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + t_addr((unsigned)kS5OffT, 0, 0));
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + t_addr((unsigned)kS5OffT, 0, 1));
+        if (q == 0) {
+            sumsq += squares(lo, hi);
+            asm volatile("" : "+v"(sumsq));
+        }
+        bcur = to_half8(lo, hi);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<NCH>([&](auto c_c) {
+        constexpr int c = decltype(c_c)::value;
+        constexpr bool last = c + 1 == NCH;
+        // (the token slot's base goes through an opaque scalar per chunk - with the loop unrolled the compiler otherwise keeps the
+        // addresses of every (set, k-step, slot) alive across chunks)
+        unsigned rb = (unsigned)(kS5OffT + (c % 3) * kS5Tok), rbn = (unsigned)(kS5OffT + ((c + 1) % 3) * kS5Tok);
+        asm volatile("" : "+s"(rb), "+s"(rbn));
+        constexpr unsigned sl = (c & 1) * kS5Slab, sln = ((c + 1) & 1) * kS5Slab;
+        if constexpr (c == 5) tq[0] = __builtin_amdgcn_s_memtime();
+        run_step(I0{}, I0{}, I1{}, t_addr(rb, 0, 0) + 4096, t_addr(rb, 0, 1) + 4096, q == 1, 0u);                       // S0; next: S1's rows
+        // the other wave of the SIMD issues the copies its partner issued right behind the barrier one step later
+        if constexpr (c >= 1 && !(ABL & 4)) {
+            if (sg == 1) {
+                if constexpr (c + 1 < NCH) issue_slab(c + 1);
+                if constexpr (c + 2 < NCH) issue_tok(std::integral_constant<int, c + 2 < NCH ? c + 2 : 0>{});
+            }
+        }
+        run_step(I1{}, I0{}, I1{}, t_addr(rb, 0, 0) + 8192, t_addr(rb, 0, 1) + 8192, q == 2, 0u);                       // S1; next: S2's
+        if constexpr (c == 5) tq[1] = __builtin_amdgcn_s_memtime();
+        unsigned l_lo;
+        leftover_addr(l_lo, a16_lane);
+        run_step(I2{}, I1{}, I1{}, l_lo + rb, (l_lo ^ 16u) + rb, w == 3, a16_lane + sl);                                   // S2; next: the leftover rows; A <- leftover blocks
+        if constexpr (c == 5) tq[2] = __builtin_amdgcn_s_memtime();
+        run_step(I3{}, I1{}, I1{}, t_addr(rb, 1, 0), t_addr(rb, 1, 1), q == 0, a_lane + sl + 1024);                       // L; next: S3's rows; A <- k-step 1
+        run_step(I0{}, I0{}, I1{}, t_addr(rb, 1, 0) + 4096, t_addr(rb, 1, 1) + 4096, q == 1, 0u);                       // S3
+        run_step(I1{}, I0{}, I1{}, t_addr(rb, 1, 0) + 8192, t_addr(rb, 1, 1) + 8192, q == 2, 0u);                       // S4; next: S5's rows - the last LDS read of chunk c
+        if constexpr (c == 5) tq[3] = __builtin_amdgcn_s_memtime();
+        if constexpr (!last) {
+            // barrier c.  Outstanding, oldest first: ..., slab(c + 1), tok(c + 1) | tok(c + 2): everything but the copies of tok(c + 2)
+            if constexpr (c + 2 < NCH) {
+                if (w < 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (this wave's reads of chunk c have returned)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (c + 2 == NCH) stamp(p, 6, lane, wave_id);
+            if constexpr (c == 5) tq[4] = __builtin_amdgcn_s_memtime();
+            if constexpr (!(ABL & 4)) {
+                if (sg == 0) {
+                    if constexpr (c + 2 < NCH) issue_slab(c + 2);
+                    if constexpr (c + 3 < NCH) issue_tok(std::integral_constant<int, c + 3 < NCH ? c + 3 : 0>{});
+                }
+            }
+            run_step(I2{}, I1{}, I1{}, t_addr(rbn, 0, 0), t_addr(rbn, 0, 1), q == 0, a_lane + sln);                       // S5; next: S0 of chunk c + 1; A <- its k-step 0
+        } else {
+            run_step(I2{}, I0{}, I0{}, 0u, 0u, false, 0u);                                                                // the very last step
+        }
+        if constexpr (c == 5) tq[5] = __builtin_amdgcn_s_memtime();
+    });
+    stamp(p, 2, lane, wave_id);
+    // (the epilogue's lane-derived values, formed again from the lane number the hardware counts (v_mbcnt): carried across the
+    // loop they cost eight registers the loop does not have - spilled in the prologue, a scratch segment at every dispatch)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned ni_e = (unsigned)p.n_inner;                         // (and the divisor of out_index: its reciprocal is formed again, not kept)
+    asm volatile("" : "+s"(ni_e));
+    auto out_index_e = [&](int64_t n) {
+        const unsigned o = (unsigned)n / ni_e, i = (unsigned)n - o * ni_e;
+        return (int64_t)o * p.oso + (int64_t)i * p.osi;
+    };
+    const int r_e = lane_e & 31, h_e = lane_e >> 5, j16_e = lane_e & 15, kg_e = lane_e >> 4;
+    // ---- keys: one sorted triple per lane and set; code = tile << 2 | e (the default screen's), tile = 4 v + (x >> 2), e = x & 3
+    float m1[4], m2[4], m3[4];
+    unsigned keymask = 0xFFFFFF00u;
+    asm volatile("" : "+s"(keymask));
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        m1[s] = kBigKey; m2[s] = kBigKey; m3[s] = kBigKey;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                float k;
+                const float val = acc[s][v][x];
+                asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
+                             "v_med3_f32 %3, %0, %2, %3\n\t"
+                             "v_med3_f32 %2, %0, %1, %2\n\t"
+                             "v_min_f32 %1, %0, %1"
+                             : "=&v"(k), "+v"(m1[s]), "+v"(m2[s]), "+v"(m3[s]) : "v"(val), "s"(keymask), "n"(((4 * v + (x >> 2)) << 2) | (x & 3)));
+            }
+        }
+    }
+    {   // leftover tokens.  Lane (j16, kg) holds, of block bl, the words 32 (4 bl + kg) + 8 q + 4 sg + e: code (4 bl + kg) << 2 | e in slot
+        // group (h = sg, g = q); the four lanes kg of a token share the group: their triples are merged (lane ^ 16, lane ^ 32), after
+        // which every one of them holds the group's triple
+        float a1 = kBigKey, a2 = kBigKey, a3 = kBigKey;
+        const unsigned lane_code = (unsigned)(kg_e << 2);
+        auto ins = [&](float k) {
+            a3 = __builtin_amdgcn_fmed3f(k, a2, a3);
+            a2 = __builtin_amdgcn_fmed3f(k, a1, a2);
+            a1 = fminf(k, a1);
+        };
+#pragma unroll
+        for (int bl = 0; bl < 4; ++bl) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                ins(__uint_as_float((__float_as_uint(accl[bl][e]) & 0xFFFFFF00u) | lane_code | (unsigned)((bl << 4) | e)));
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off *= 2) {
+            const float o1 = __shfl_xor(a1, off, SN_WAVE), o2 = __shfl_xor(a2, off, SN_WAVE), o3 = __shfl_xor(a3, off, SN_WAVE);
+            ins(o1); ins(o2); ins(o3);
+        }
+        m1[3] = a1; m2[3] = a2; m3[3] = a3;
+    }
+    stamp(p, 3, lane_e, wave_id);
+    // ---- the window of every token -> LDS, by the wave that summed its squares (wave (sg, q < 3): set 3 sg + q; wave 3: the leftover
+    // tokens as "set 6").  Per-token error window (DESIGN.md "S1 error window"): |key - exact value| <= E; stored: 2 E, NaN for a
+    // token the screen cannot bound
+    const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
+    const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]), CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
+    auto window_of = [&](float ssq) {
+        const float X2 = sqrtf(ssq) * 1.001f + 1.0e-6f, X1 = X2 * sqrtf((float)p.D);
+        const float vmax = 0.5f * CN + X2 * C2;                               // >= |any partial sum|
+        const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
+                                 + (float)(2 * NCH) * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
+        const bool bad = !(ssq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e28f);   // NaN-safe; |x|_2 <= 3e4 bounds every component
+        return bad ? __uint_as_float(0x7FC00000u) : 2.0f * E;
+    };
+    if (q < 3) {
+        sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
+        if (h_e == 0) tsum[(3 * sg + q) * 32 + r_e] = window_of(sumsq);
+    } else if (w == 3) {
+        sumsq += __shfl_xor(sumsq, 16, SN_WAVE);
+        sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
+        if (lane_e < 16) tsum[6 * 32 + lane_e] = window_of(sumsq);
+    }
+    // per slot of this wave: s < 3 = set 3 sg + s (lanes (r, h)), s == 3 = the leftover tokens (lanes < 16, row half sg)
+    auto slot_of = [&](int s, int &set, int &rr, int &hh, bool &valid) {
+        set = s < 3 ? 3 * sg + s : 6;
+        rr = s < 3 ? r_e : j16_e;
+        hh = s < 3 ? h_e : sg;
+        const int row = 32 * set + rr;
+        valid = (s < 3 || lane_e < 16) && row < n_mine;
+    };
+    // ---- per set: the best key of a token over the eight lanes that hold it
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        int set, rr, hh; bool valid;
+        slot_of(s, set, rr, hh, valid);
+        if (valid) __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&tbest[set * 32 + rr], m1[s], 0, 0, false);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp(p, 7, lane_e, wave_id);
+    unsigned hm[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        int set, rr, hh; bool valid;
+        slot_of(s, set, rr, hh, valid);
+        const float win = tsum[set * 32 + rr];
+        const bool bad = !(win == win);
+        const float best = tbest[set * 32 + rr];
+        const bool any_finite = best < kKeyLimit;
+        const float cut = best + win;
+        const unsigned hmask = (m1[s] <= cut ? 1u : 0u) | (m2[s] <= cut ? 2u : 0u) | (m3[s] <= cut ? 4u : 0u);
+        const bool hover = m3[s] <= cut;                                      // a 4th may hide behind it
+        const unsigned contrib = (bad || !any_finite) ? sn_s1::kFlagFullScan : ((hmask << (12 * hh + 3 * q)) | (hover ? sn_s1::kFlagOverflow : 0u));
+        if (valid && contrib) __hip_atomic_fetch_or(&tmask[set * 32 + rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        hm[s] = hmask;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stamp(p, 8, lane_e, wave_id);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        int set, rr, hh; bool valid;
+        slot_of(s, set, rr, hh, valid);
+        const int64_t n = tok0 + 32 * set + rr;
+        const unsigned mk = tmask[set * 32 + rr];
+        const unsigned cand = mk & 0xFFFFFFu;
+        const bool fullscan = ((mk >> 30) & 1u) != 0u || cand == 0u;
+        const bool overflow = fullscan || (mk >> 31) != 0u;
+        const int nc = __popc(cand);
+        const unsigned code = __float_as_uint(m1[s]) & 0xFFu;
+        // the only candidate: final (a flagged or overflow token's word is written by whoever finishes it)
+        if (valid && !overflow && nc == 1 && (hm[s] & 1u) != 0u)
+            p.out[out_index_e(n)] = (int)(code >> 2) * 32 + 8 * q + 4 * hh + (int)(code & 3u);
+        if (valid && !fullscan && (nc > 1 || overflow)) {        // the eight lanes of the token write their three codes
+            unsigned char *cd = p.codes + (int64_t)n * kCodeBytes + 12 * hh + 3 * q;
+            cd[0] = (unsigned char)code;
+            cd[1] = (unsigned char)(__float_as_uint(m2[s]) & 0xFFu);
+            cd[2] = (unsigned char)(__float_as_uint(m3[s]) & 0xFFu);
+        }
+        const bool writer = valid && q == 0 && hh == 0;
+        if (writer) {
+            p.flags[n] = fullscan ? sn_s1::kFlagFullScan : ((overflow ? sn_s1::kFlagOverflow : 0u) | ((nc > 1 || overflow) ? cand : 0u));
+            if (fullscan) p.out[out_index_e(n)] = 0;
+        }
+        const bool need_b = writer && overflow;
+        const unsigned long long mask_b = __ballot(need_b);
+        if (mask_b) {                                          // rare: tokens the screen cannot bound
+            int base = 0;
+            const int leader = __ffsll((long long)mask_b) - 1;
+            if (lane_e == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
+            base = __shfl(base, leader, SN_WAVE);
+            if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane_e) - 1ull))] = (int)n;
+        }
+    }
+    stamp(p, 4, lane_e, wave_id);
+    if (p.stamps && lane_e == 0) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) p.stamps[(size_t)wave_id * 16 + 9 + t] = tq[t];
+    }
+    asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));
+}
+
 template <int NT>
 int launch_exact(const AssignArgs &a, hipStream_t st)
 {
@@ -2103,45 +1810,6 @@ int launch_screen(const AssignArgs &a, hipStream_t st, bool defer = false)
     return 0;
 }
 
-template <int NT, int KS>
-int launch_screen2(const AssignArgs &a, hipStream_t st)
-{
-    const size_t lds = (size_t)kS2RawSlots * (KS / 2) * 2048 + (size_t)2 * KS * 1024 + kS2SmallSlots * sizeof(S2Small) + (size_t)kS2StashSlots * 256 * 16 + (size_t)4 * NT * 128;
-    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen2_kernel<NT, KS>, lds, "sn_assign_words")) return rc;
-    const int cus = device_cus();
-    const unsigned grid = (unsigned)(a.n_sets < cus ? a.n_sets : cus);     // one persistent workgroup per CU
-    sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen2_kernel<NT, KS>), dim3(grid), dim3(256), lds, st, a);
-    sn_prof_stop(0, st);
-    constexpr int NTR = KS / 4;                                             // fp64 re-rank: 64 k per lane-step
-    launch_rerank<NTR, 1>(a, st);
-    return 0;
-}
-
-template <int NTW, int NCH>
-int launch_screen3(const AssignArgs &a, hipStream_t st)
-{
-    constexpr int NTR = (NCH + 1) / 2;                          // fp64 re-rank: 64 k per lane-step
-    constexpr size_t lds = (size_t)kS3RingA * kS3Quarters * NTW * 2048 + (size_t)kS3Sets * kS3RingT * 4096 + (size_t)kS3Quarters * NTW * 128 + 1024;
-    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen3_kernel<NTW, NCH>, lds, "sn_assign_words")) return rc;
-    AssignArgs ag = a;
-    const int64_t cus = device_cus();
-    // full 32-token sets whenever there is more than one round of them (the loop is bound by the matrix pipe, which a
-    // smaller set does not relieve); a single partial round is spread over all CUs with smaller sets
-    int64_t tps = 32;
-    if (a.n_tokens < cus * kS3Sets * 32) tps = (a.n_tokens + cus * kS3Sets - 1) / (cus * kS3Sets);
-    if (const char *e = getenv("SN_ASSIGN_TPS")) tps = atoi(e);
-    tps = tps < 16 ? 16 : (tps > 32 ? 32 : tps);
-    ag.tps = (int)tps;
-    ag.n_sets3 = (a.n_tokens + tps - 1) / tps;
-    const unsigned grid = (unsigned)(ag.n_sets3 < cus ? ag.n_sets3 : cus);      // one persistent workgroup per CU; sets are dealt round-robin
-    sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen3_kernel<NTW, NCH>), dim3(grid), dim3(1024), lds, st, ag);
-    sn_prof_stop(0, st);
-    launch_rerank<NTR, 3>(ag, st);
-    return 0;
-}
-
 template <int NCH>
 int launch_screen4(const AssignArgs &a, hipStream_t st)
 {
@@ -2161,12 +1829,42 @@ int launch_screen4(const AssignArgs &a, hipStream_t st)
     return 0;
 }
 
-// form of the screen kernel: 0 (default) = token-stationary, 4 waves x 3-slot codebook ring, two
-// workgroups per CU; 1 = token-stationary, 8 waves x 5-slot ring; 2 = register-stationary codebook
-// (assign_screen2_kernel; shapes with M <= 512, D in {192, 384}, n_inner >= 32; else falls back to 0);
-// 3 = K-outer token stream (assign_screen3_kernel; 8 or 16 tiles of 32 words, i.e. 192 < M <= 256 or 448 < M <= 512,
-// fp32 tokens; else falls back to 0).
-// Initialised from SN_ASSIGN_VARIANT, changed with sn_assign_set_variant().
+template <int NCH>
+int launch_screen5(const AssignArgs &a, hipStream_t st, bool defer)
+{
+    constexpr int NTR = (NCH + 1) / 2;                          // fp64 re-rank: 64 k per lane-step
+    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen5_kernel<NCH>, kS5Lds, "sn_assign_words")) return rc;
+    AssignArgs ag = a;
+    const int64_t cus = device_cus();
+    int64_t tpw = (a.n_tokens + cus - 1) / cus;                 // one workgroup per CU, one round (the caller checked n_tokens <= cus kS5Rows)
+    if (const char *e = getenv("SN_ASSIGN_TPW")) tpw = atoi(e);
+    tpw = tpw < 1 ? 1 : (tpw > kS5Rows ? kS5Rows : tpw);
+    ag.tps4 = (int)tpw;
+    const unsigned grid = (unsigned)((a.n_tokens + tpw - 1) / tpw);
+    static const int abl = getenv("SN_S5_ABL") ? atoi(getenv("SN_S5_ABL")) : 0;
+    sn_prof_start(0, st);
+    if (abl == 0 || NCH != 12) hipLaunchKernelGGL((assign_screen5_kernel<NCH>), dim3(grid), dim3(512), kS5Lds, st, ag);
+    else {
+        const void *fn = abl == 1 ? (const void *)assign_screen5_kernel<12, 1> : abl == 2 ? (const void *)assign_screen5_kernel<12, 2> : abl == 3 ? (const void *)assign_screen5_kernel<12, 3>
+                       : abl == 4 ? (const void *)assign_screen5_kernel<12, 4> : abl == 6 ? (const void *)assign_screen5_kernel<12, 6> : (const void *)assign_screen5_kernel<12, 7>;
+        if (int rc = sn_ensure_dynamic_lds(fn, kS5Lds, "sn_assign_words")) return rc;
+        if (abl == 1) hipLaunchKernelGGL((assign_screen5_kernel<12, 1>), dim3(grid), dim3(512), kS5Lds, st, ag);
+        else if (abl == 2) hipLaunchKernelGGL((assign_screen5_kernel<12, 2>), dim3(grid), dim3(512), kS5Lds, st, ag);
+        else if (abl == 3) hipLaunchKernelGGL((assign_screen5_kernel<12, 3>), dim3(grid), dim3(512), kS5Lds, st, ag);
+        else if (abl == 4) hipLaunchKernelGGL((assign_screen5_kernel<12, 4>), dim3(grid), dim3(512), kS5Lds, st, ag);
+        else if (abl == 6) hipLaunchKernelGGL((assign_screen5_kernel<12, 6>), dim3(grid), dim3(512), kS5Lds, st, ag);
+        else hipLaunchKernelGGL((assign_screen5_kernel<12, 7>), dim3(grid), dim3(512), kS5Lds, st, ag);
+    }
+    sn_prof_stop(0, st);
+    if (!defer) launch_rerank<NTR, 0>(ag, st);                  // (its records are the default screen's)
+    return 0;
+}
+
+// form of the screen kernel: 0 = token-stationary (assign_screen_kernel: 4 waves x 3-slot codebook ring, two workgroups per CU);
+// 4 = one-round K-outer, four 512-register waves (assign_screen4_kernel); 5 = one-round K-outer, eight 256-register waves
+// (assign_screen5_kernel).  4 and 5 apply to codebooks of 16 tiles (448 < M <= 512), D in {192, 384}, fp32 tokens, at most
+// 208 tokens per CU; other shapes take form 0.  Initialised from SN_ASSIGN_VARIANT, changed with sn_assign_set_variant().
+// (The lab forms of rounds 1-3 - 8-wave workgroups, codebook-stationary, K-outer in rounds - are in the history and NOTES.md.)
 int g_variant = -1;
 int screen_variant()
 {
@@ -2198,12 +1896,12 @@ extern "C" int sn_codebook_prepare(const float *codebook, int M, int D, void *pa
     const int64_t elems = (int64_t)lay.m_pad * D;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)(elems / 256)), dim3(256), 0, st, codebook, M, D,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes);
-    if (lay.nt2)
-        hipLaunchKernelGGL(pack_frag2_kernel, dim3((unsigned)((int64_t)128 * lay.nt2 * D / 256)), dim3(256), 0, st, codebook, M, D,
-                           base + lay.frag2_off, (float *)(base + lay.hn2_off), lay.nt2, lay.ks2);
+    if (lay.tiles5_off)
+        hipLaunchKernelGGL(pack_frag5_kernel, dim3((unsigned)((int64_t)512 * D / 256)), dim3(256), 0, st, codebook, M, D,
+                           base + lay.tiles5_off, lay.n_steps);
     hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((lay.m_pad + 3) / 4)), dim3(256), 0, st, codebook, M, D, lay.m_pad,
                        base + lay.tiles_off, lay.n_steps, lay.tile_bytes, (double *)(base + lay.cn64_off),
-                       (unsigned *)(base + lay.scal_off), (float *)(base + lay.hn2_off), lay.nt2);
+                       (unsigned *)(base + lay.scal_off));
     SN_CHECK_LAUNCH("sn_codebook_prepare");
     return SN_OK;
 }
@@ -2214,14 +1912,13 @@ extern "C" int sn_assign_variant(void) { return screen_variant(); }
 extern "C" int sn_assign_defers(int M, int D)
 {
     const int v = screen_variant();
-    const bool dflt = v == 0 || (v == 2 && pack_layout(M, D).nt2 == 0) || (v == 3 && !(pack_layout(M, D).n_tiles == 8 || pack_layout(M, D).n_tiles == 16)) ||
-                      (v == 4 && pack_layout(M, D).n_tiles != 16);      // (variant 4 with 16 tiles may still fall back for a large batch: it then takes the stand-alone finish)
+    const bool dflt = v == 0 || v == 5 || (v == 4 && pack_layout(M, D).n_tiles != 16);      // (form 5 writes the default form's records; form 4 with 16 tiles may still fall back for a large batch: it then takes the stand-alone finish)
     return (dflt && M > 0 && M <= 2048 && (D == 192 || D == 384)) ? 1 : 0;      // (D = 768: the finish's state - three 12-register rows - does not fit the graph kernel's 128 registers)
 }
 
 extern "C" int sn_assign_set_variant(int variant)
 {
-    SN_REQUIRE(variant >= 0 && variant <= 4, SN_ERR_BAD_ARG, "sn_assign_set_variant: variant=%d", variant);
+    SN_REQUIRE(variant == 0 || variant == 4 || variant == 5, SN_ERR_BAD_ARG, "sn_assign_set_variant: variant=%d (0, 4 or 5)", variant);
     g_variant = variant;
     return SN_OK;
 }
@@ -2286,11 +1983,10 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
     a.codes = ws ? ws + 32 + (size_t)n_tokens * 4 : nullptr;
     a.overflow = ws ? (int *)(ws + 32 + (size_t)n_tokens * (4 + kCodeBytes)) : nullptr;
     a.stamps = g_stamps;
-    a.codes32 = ws ? (unsigned *)(ws + 32 + (size_t)n_tokens * 4) : nullptr;
-    a.n_sets = (n_tokens + 31) / 32;
     a.full_waves = kWavesPerBlock; a.extra_base = n_tokens;
     a.x_bf16 = x_bf16;
-    a.tps = 32; a.n_sets3 = 0; a.tps4 = 0;
+    a.tps4 = 0;
+    { static const int dbg = getenv("SN_ASSIGN_DBG") ? atoi(getenv("SN_ASSIGN_DBG")) : 0; a.dbg = dbg; }
     a.gate = ws ? (unsigned *)(ws + ((32 + (size_t)n_tokens * kWsPerToken2 + 15) & ~size_t(15))) : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const int per16 = x_bf16 ? 8 : 4;                            // elements per 16 bytes
@@ -2309,27 +2005,21 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
                    "sn_assign_words: workspace %zu < %zu bytes", workspace_bytes, sn_assign_workspace_bytes(n_tokens));
         if (int rc0 = sn_zero_async(workspace, 32, st)) return rc0;
         int rc = 0;
-        const bool wide = screen_variant() == 1;
         const PackLayout lay = pack_layout(M, D);
         // (K-outer form: fp32 tokens whose byte offsets fit 32 bits: the copies address them as base + 32-bit lane offset)
-        if (screen_variant() == 3 && !x_bf16 && (lay.n_tiles == 8 || lay.n_tiles == 16) &&
+        if (screen_variant() == 5 && !x_bf16 && lay.tiles5_off != 0 && n_tokens <= (int64_t)device_cus() * kS5Rows &&
             ((n_outer - 1) * x_stride_outer + (n_inner - 1) * x_stride_inner + D) * 4 < (int64_t)0xFFFFF000ll && x_stride_outer >= 0 && x_stride_inner >= 0) {
-            if (lay.n_tiles == 16) rc = D == 192 ? launch_screen3<4, 6>(a, st) : (D == 384 ? launch_screen3<4, 12>(a, st) : launch_screen3<4, 24>(a, st));
-            else rc = D == 192 ? launch_screen3<2, 6>(a, st) : (D == 384 ? launch_screen3<2, 12>(a, st) : launch_screen3<2, 24>(a, st));
+            rc = D == 192 ? launch_screen5<6>(a, st, deferred = want_defer) : launch_screen5<12>(a, st, deferred = want_defer);
         } else if (screen_variant() == 4 && !x_bf16 && lay.n_tiles == 16 && (D == 192 || D == 384) && n_tokens <= (int64_t)device_cus() * kS4Rows &&
                    ((n_outer - 1) * x_stride_outer + (n_inner - 1) * x_stride_inner + D) * 4 < (int64_t)0xFFFFF000ll && x_stride_outer >= 0 && x_stride_inner >= 0) {
             rc = D == 192 ? launch_screen4<6>(a, st) : launch_screen4<12>(a, st);
-        } else if (screen_variant() == 2 && lay.nt2 != 0 && n_inner >= 32 && !x_bf16) {
-            a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + 32));
-            if (lay.ks2 == 24) rc = lay.nt2 == 4 ? launch_screen2<4, 24>(a, st) : launch_screen2<2, 24>(a, st);
-            else rc = lay.nt2 == 4 ? launch_screen2<4, 12>(a, st) : launch_screen2<2, 12>(a, st);
         } else if (M > 2048) {               // more than 64 tiles: 10-bit word codes in the keys, 16-bit codes in the records
             a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + kCodeBytesWide));
             if (D == 192) rc = launch_screen<12, 4, 3, 10>(a, st);
             else if (D == 384) rc = launch_screen<24, 4, 3, 10>(a, st);
             else rc = launch_screen<48, 4, 3, 10>(a, st);
-        } else if (D == 192) rc = wide ? launch_screen<12, 8, 5>(a, st) : launch_screen<12, 4, 3>(a, st, deferred = want_defer);
-        else if (D == 384) rc = wide ? launch_screen<24, 8, 5>(a, st) : (assign_dual() ? launch_screen<24, 4, 3, 8, true>(a, st) : launch_screen<24, 4, 3>(a, st, deferred = want_defer));
+        } else if (D == 192) rc = launch_screen<12, 4, 3>(a, st, deferred = want_defer);
+        else if (D == 384) rc = (assign_dual() ? launch_screen<24, 4, 3, 8, true>(a, st) : launch_screen<24, 4, 3>(a, st, deferred = want_defer));
         else rc = launch_screen<48, 4, 3>(a, st);
         if (rc) return rc;
     } else {

@@ -23,9 +23,8 @@ constexpr unsigned kFlagOverflow = 0x80000000u;
 constexpr unsigned kFlagFullScan = 0xC0000000u;
 
 struct PackLayout {
-    size_t tiles_off, cn64_off, scal_off, frag2_off, hn2_off, total;
+    size_t tiles_off, cn64_off, scal_off, tiles5_off, total;      // tiles5_off == 0: no permuted image for this shape
     int n_tiles, n_steps, tile_bytes, m_pad;
-    int nt2, ks2;                       // nt2 == 0: no register-stationary image for this shape
 };
 
 __host__ __device__ inline PackLayout pack_layout(int M, int D)
@@ -38,14 +37,10 @@ __host__ __device__ inline PackLayout pack_layout(int M, int D)
     p.tiles_off = 0;
     p.cn64_off = (size_t)p.n_tiles * p.tile_bytes;
     p.scal_off = p.cn64_off + (((size_t)p.m_pad * 8 + 255) & ~size_t(255));
-    p.frag2_off = p.scal_off + 256;
-    // the whole fp16 codebook must fit the register file of one CU: 4 waves x nt2 x ks2 fragments of
-    // 4 registers, at most 96 fragments per wave
-    p.ks2 = D / 16;
-    p.nt2 = M <= 256 ? 2 : (M <= 512 ? 4 : 0);
-    if (D % 32 != 0 || (p.ks2 != 12 && p.ks2 != 24) || p.nt2 * p.ks2 > 96) p.nt2 = 0;
-    p.hn2_off = p.frag2_off + (size_t)4 * p.nt2 * p.ks2 * 1024;
-    p.total = p.hn2_off + (((size_t)4 * p.nt2 * 128 + 255) & ~size_t(255));
+    // the word-permuted fragment image of the one-round K-outer screen (csrc/sn_assign.hip, tiles5): codebooks of 16 tiles
+    const bool has5 = p.n_tiles == 16 && (D == 192 || D == 384);
+    p.tiles5_off = has5 ? p.scal_off + 256 : 0;
+    p.total = p.scal_off + 256 + (has5 ? (size_t)16 * p.n_steps * 1024 : 0);
     return p;
 }
 

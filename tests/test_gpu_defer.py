@@ -122,7 +122,7 @@ def test_deferred_finish_with_per_head_taps_and_fallbacks(mods):
     assert h3 is None and torch.equal(ids3, ops.assign_words(x3, cbt3, packed3))
     old = lib.sn_assign_variant()
     try:
-        lib.sn_assign_set_variant(2)
+        lib.sn_assign_set_variant(4)
         assert lib.sn_assign_defers(512, 384) == 0
         ids4, h4 = ops.assign_words(x, cbt, packed, defer=True)
         assert h4 is None and torch.equal(ids4, want)

@@ -31,13 +31,13 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.sn_abi_version() == N.ABI_VERSION
     assert lib.sn_last_error() is not None
     # size helpers are pure host code
-    # token-stationary tile image + norms + scalars, then the codebook-stationary fragment image + half norms
-    assert lib.sn_codebook_pack_bytes(512, 384) == (16 * 25 * 1024 + 4096 + 256) + (4 * 4 * 24 * 1024 + 4 * 4 * 128)
-    assert lib.sn_codebook_pack_bytes(1024, 384) == 32 * 25 * 1024 + 8192 + 256       # too large for the register file: no second image
+    # tile image + norms + scalars, then (codebooks of 16 tiles, D 192 / 384) the word-permuted image of the K-outer screen
+    assert lib.sn_codebook_pack_bytes(512, 384) == (16 * 25 * 1024 + 4096 + 256) + 16 * 24 * 1024
+    assert lib.sn_codebook_pack_bytes(1024, 384) == 32 * 25 * 1024 + 8192 + 256
     assert lib.sn_codebook_pack_bytes(512, 30) == 0
     # header + per-token records, rounded up to 16 bytes, + the per-CU gate table (4096 x 8 bytes)
     assert lib.sn_assign_workspace_bytes(50176) == ((32 + 50176 * 56 + 15) & ~15) + 4096 * 8
-    assert lib.sn_assign_variant() in (0, 1, 2, 3, 4)
+    assert lib.sn_assign_variant() in (0, 4, 5)
 
 
 def _struct_field_names(header, name):

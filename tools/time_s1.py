@@ -1,0 +1,58 @@
+"""GPU diagnostic: S1 screen / re-rank times (HIP events inside the library) on the bench shape for every screen form the
+library ships, in ONE process (same box, same clocks), with the flagged / overflow counts and the mismatches against the
+exact kernel.  python tools/time_s1.py [n_launches] [variants, e.g. 0,5]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "schemanet-pytorch_amd"))
+import torch
+from cpp_extension import ops, _native as N
+import bench
+
+dev = torch.device("cuda", 0)
+n_launch = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 4, 5]
+tokens, codebook, attn = bench.make_inputs(0, dev)
+lib = N.load()
+cb, packed = ops.PackedCodebook().get(codebook)
+near = torch.randint(0, bench.M, (bench.B, bench.L), device=dev)
+tok_km = tokens.clone(); tok_km[:, 1:, :] = codebook[near] + 0.3 * tokens[:, 1:, :]
+for rnd in range(2):
+    for variant in variants:
+        assert lib.sn_assign_set_variant(variant) == 0
+        for name, tok in (("randn", tokens), ("k-means-like", tok_km)):
+            x = tok[:, 1:, :]
+            n_tok = x.shape[0] * x.shape[1]
+            ws = torch.zeros(lib.sn_assign_workspace_bytes(n_tok), dtype=torch.uint8, device=dev)
+            out = torch.full((x.shape[0], x.shape[1]), -1, dtype=torch.int64, device=dev)
+
+            def run():
+                N.check(lib.sn_assign_words(N.ptr(x), x.shape[0], x.shape[1], x.stride(0), x.stride(1), N.ptr(cb), N.ptr(packed), bench.M, bench.D,
+                                            N.ptr(out), out.stride(0), out.stride(1), N.ptr(ws), ws.numel(), 0, N.stream_ptr(dev)), "assign")
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            lib.sn_profile_enable(n_launch)
+            for _ in range(n_launch):
+                run()
+            torch.cuda.synchronize()
+            res = {}
+            for kid, kname in ((0, "screen"), (1, "rerank")):
+                n = lib.sn_profile_count(kid); buf = (C.c_float * n)(); lib.sn_profile_elapsed_ms(kid, buf, n)
+                v = sorted(buf)
+                res[kname] = (v[n // 2] * 1e3, v[0] * 1e3)
+            lib.sn_profile_enable(0)
+            fl = ws[32:32 + 4 * n_tok].view(torch.int32)
+            over = int((fl < 0).sum()); flagged = int((fl > 0).sum())
+            exact = torch.empty_like(out)
+            N.check(lib.sn_assign_words(N.ptr(x), x.shape[0], x.shape[1], x.stride(0), x.stride(1), N.ptr(cb), N.ptr(packed), bench.M, bench.D,
+                                        N.ptr(exact), exact.stride(0), exact.stride(1), N.ptr(ws), ws.numel(), 1, N.stream_ptr(dev)), "assign exact")
+            torch.cuda.synchronize()
+            bad = int((exact != out).sum())
+            alg = n_tok * (bench.D * 4 + 8)
+            print(f"round {rnd} variant {variant} {name}: screen {res['screen'][0]:.1f} us (min {res['screen'][1]:.1f}) = {alg / res['screen'][0] / 1e3:.0f} GB/s "
+                  f"= {alg / res['screen'][0] / 1e3 / 80:.1f}% of 8 TB/s; rerank {res['rerank'][0]:.1f} us; flagged {flagged} ({100 * flagged / n_tok:.2f}%), "
+                  f"overflow {over}; mismatches vs exact kernel {bad}", flush=True)
+lib.sn_assign_set_variant(0)
