@@ -1308,24 +1308,25 @@ __global__ __launch_bounds__(256, 1) void assign_screen4_kernel(const AssignArgs
 // ------------------------------------------------------------------------------------------
 constexpr int kS5Sets = 6, kS5Lo = 16;
 constexpr int kS5Rows = kS5Sets * 32 + kS5Lo;                   // tokens a workgroup can hold (208)
-constexpr int kS5RowsPad = 224;                                 // token rows copied per chunk: 28 copies of 8 rows
+constexpr int kS5RowsPad = 208;                                 // token rows copied per chunk: 26 copies of 8 rows
 constexpr int kS5Slab = 16 * 2048, kS5Tok = kS5RowsPad * 128;   // bytes per chunk: codebook (16 virtual tiles x 2 k-steps), token rows
 constexpr int kS5OffT = 2 * kS5Slab;
 constexpr int kS5OffHc = kS5OffT + 3 * kS5Tok;                  // |c|^2/2, [tile][accumulator-row order]
 constexpr int kS5OffBest = kS5OffHc + 16 * 128;                 // [7][32] best key of a token
 constexpr int kS5OffMask = kS5OffBest + 7 * 128;                // [7][32] candidate mask being assembled
 constexpr int kS5OffSum = kS5OffMask + 7 * 128;                 // [7][32] window (2 E) of a token, NaN: not screened
-constexpr int kS5OffTv = kS5OffSum + 7 * 128;                   // [4 waves][64 lanes] lane address of a wave's fourth token copy (one register less in the loop)
-constexpr int kS5Lds = kS5OffTv + 4 * 256;
+constexpr int kS5OffTv = kS5OffSum + 7 * 128;                  // [4 copies][8 waves][64 lanes] lane addresses of a wave's token copies (no registers across the loop)
+constexpr int kS5Lds = kS5OffTv + 4 * 8 * 256;
 
 // one 1 KiB LDS-DMA piece: global address = scalar base + 32-bit lane offset + OFF, LDS address = lds_dst + 16 x lane (the
 // instruction's offset field moves both, so M0 carries the destination minus OFF).  A function, not a statement inside the
 // kernel's generic lambdas: clang does not count an asm operand there as a use of a captured variable.
-template <int OFF>
+template <int OFF, bool NT = false>
 __device__ __forceinline__ void s5_dma(unsigned voff, const void *sbase, unsigned lds_dst)
 {
     static_assert(OFF >= 0 && OFF < 4096, "instruction offset");
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" :: "v"(voff), "s"(sbase), "s"(lds_dst - (unsigned)OFF), "n"(OFF) : "memory");
+    if constexpr (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3 nt" :: "v"(voff), "s"(sbase), "s"(lds_dst - (unsigned)OFF), "n"(OFF) : "memory");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" :: "v"(voff), "s"(sbase), "s"(lds_dst - (unsigned)OFF), "n"(OFF) : "memory");
 }
 
 // ABL (diagnostic builds, SN_S5_ABL; results are wrong): bit 0 = no squares / conversion, bit 1 = no 32 x 32 MFMAs, bit 2 = no copies behind chunk 0
@@ -1358,29 +1359,30 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
     if (w < 2)
         s5_dma<0>((unsigned)((8 * w + (lane >> 3)) * lay.tile_bytes + lay.n_steps * 1024 + (lane & 7) * 16), tiles, __builtin_amdgcn_readfirstlane(lds_base + kS5OffHc + w * 1024));
 
-    // ---- copies.  Token rows: copy i of wave w covers the rows 8 (w + 8 i) .. + 7 of the workgroup, i < 4 (w < 4) or 3 (a row
+    // ---- copies.  Token rows: copy i of wave w covers the rows 8 (w + 8 i) .. + 7 of the workgroup, i < 4 (w < 2) or 3 (a row
     // past its tokens: its first token - nobody reads it); lane -> (row, piece slot), the slot holds piece slot ^ ((row >> 1) & 7).
-    unsigned tv[3];
-    unsigned *tv3 = reinterpret_cast<unsigned *>(smem + kS5OffTv) + (w & 3) * 64 + lane;
+    unsigned *tvl = reinterpret_cast<unsigned *>(smem + kS5OffTv) + w * 64 + lane;      // copy i: tvl[512 i] (written and read by this lane only)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * (w + 8 * i) + (lane >> 3);
         const int64_t n = ((p.dbg & 1) ? 0 : tok0) + (row < n_mine ? row : 0);
         const unsigned ni = (unsigned)p.n_inner, o = (unsigned)n / ni, ii = (unsigned)n - o * ni;
         const unsigned tvi = (unsigned)(((int64_t)o * p.xso + (int64_t)ii * p.xsi) * 4 + 16 * ((lane & 7) ^ ((row >> 1) & 7)));
-        if (i < 3) tv[i] = tvi;
-        else if (w < 4) *tv3 = tvi;                              // (read back by the same lane only)
+        tvl[512 * i] = tvi;
     }
     // (the chunk's 128 c bytes ride in the instruction's offset field, which moves the LDS address along with the global one:
     // M0 = slot address - 128 c; no address arithmetic on the vector side)
     auto issue_tok = [&](auto c_c) {
         constexpr int c = decltype(c_c)::value;
         const unsigned slot = (unsigned)(c % 3);
+        unsigned tv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = (i < 3 || w < 2) ? tvl[512 * i] : 0u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i == 3 && w >= 4) break;                         // (wave-uniform)
+            if (i == 3 && w >= 2) break;                         // (wave-uniform)
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + kS5OffT + slot * kS5Tok + (w + 8 * i) * 1024);
-            s5_dma<c * 128>(i < 3 ? tv[i] : *tv3, p.x, dst);
+            s5_dma<c * 128, SN_S1_TOKENS_NT != 0>(tv[i], p.x, dst);     // (read once: the non-temporal hint keeps the codebook and the finish's operands in L2)
         }
     };
     const unsigned a_lane = (unsigned)(q * 4 * 2048 + lane * 16);   // A fragment of virtual tile (q, v), k-step ks: + v * 2048 + ks * 1024
@@ -1405,17 +1407,31 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
 
     f32x16 acc[3][4];
     f32x4 accl[4];
-    float sumsq = 0.0f;                                          // |x|^2 of the lane's share of set 3 sg + q (q < 3) or of the leftover tokens (w == 3)
-    auto squares = [&](const f32x4 &lo, const f32x4 &hi) {
-        float a = lo.x * lo.x;
-        a = fmaf(lo.y, lo.y, a); a = fmaf(lo.z, lo.z, a); a = fmaf(lo.w, lo.w, a);
-        a = fmaf(hi.x, hi.x, a); a = fmaf(hi.y, hi.y, a); a = fmaf(hi.z, hi.z, a); a = fmaf(hi.w, hi.w, a);
-        return a;
-    };
-    auto to_half8 = [](const f32x4 &lo, const f32x4 &hi) {
+    // |x|^2 and |x - fp16(x)|^2 of a token (the measured rounding loss replaces the worst-case 2^-11 |x| in the window: half as many
+    // tokens to re-rank) are summed by ONE of the four quarter waves that convert its rows: wave (sg, q < 3) for set 3 sg + q, wave 3
+    // for the leftover tokens.  (As LDS float atomics - no registers across the loop - the loop took 2.8 x as long.)
+    auto to_half8 = [](const f32x4 &lo, const f32x4 &hi) {       // (pairs: v_cvt_pk_f16_f32, round to nearest)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 half2s __attribute__((ext_vector_type(2)));
+        const half2s p0 = __builtin_convertvector(f32x2{lo.x, lo.y}, half2s), p1 = __builtin_convertvector(f32x2{lo.z, lo.w}, half2s);
+        const half2s p2 = __builtin_convertvector(f32x2{hi.x, hi.y}, half2s), p3 = __builtin_convertvector(f32x2{hi.z, hi.w}, half2s);
         half8 b;
-        b[0] = (_Float16)lo.x; b[1] = (_Float16)lo.y; b[2] = (_Float16)lo.z; b[3] = (_Float16)lo.w;
-        b[4] = (_Float16)hi.x; b[5] = (_Float16)hi.y; b[6] = (_Float16)hi.z; b[7] = (_Float16)hi.w;
+        b[0] = p0.x; b[1] = p0.y; b[2] = p1.x; b[3] = p1.y; b[4] = p2.x; b[5] = p2.y; b[6] = p3.x; b[7] = p3.y;
+        return b;
+    };
+    float sumsq = 0.0f, sumd = 0.0f;
+    // the owner's form of to_half8: the same fragment (v_cvt_pk_f16_f32), and the two sums; the loss from the converted halves with a
+    // mixed-precision fma each (v_fma_mix_f32: x - fp16(x), exact) - 28 VALU instructions against 4 for the other three waves
+    auto tally_half8 = [&](const f32x4 &lo, const f32x4 &hi) {
+        const half8 b = to_half8(lo, hi);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sumsq = fmaf(v[e], v[e], sumsq);
+            const float dd = fmaf((float)b[e], -1.0f, v[e]);
+            sumd = fmaf(dd, dd, sumd);
+        }
+        asm volatile("" : "+v"(sumsq), "+v"(sumd));              // (pinned: left alone the chains sink to the epilogue, every raw row spilled until then)
         return b;
     };
     const int swz = (r >> 1) & 7;                                // (row 32 s + r: the set offset does not touch bits 1..3)
@@ -1459,7 +1475,7 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
     half8 a[4], bcur;
     unsigned a16_lane = 0;
     // one step: kind 0 .. 2 = set, 3 = leftover; reload: 0 none, else a[v] <- the fragment at reload_base + 2048 v behind MFMA v
-    auto run_step = [&](auto kind_c, auto reload_c, auto next_c, unsigned nlo, unsigned nhi, bool nsq, unsigned reload_base) {
+    auto run_step = [&](auto kind_c, auto reload_c, auto next_c, unsigned nlo, unsigned nhi, bool nsq, int nset, unsigned reload_base) {
         constexpr int kind = decltype(kind_c)::value;
         constexpr bool reload = decltype(reload_c)::value != 0, has_next = decltype(next_c)::value != 0;
         f32x4 lo, hi;
@@ -1479,11 +1495,8 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
         if constexpr (has_next) {
             if constexpr (ABL & 1) bcur = __builtin_bit_cast(half8, lo);
             else {
-                if (nsq) {
-                    sumsq += squares(lo, hi);
-                    asm volatile("" : "+v"(sumsq));              // (pinned: left alone the chain of squares sinks to the epilogue, every raw row spilled until then)
-                }
-                bcur = to_half8(lo, hi);
+                if (nsq) bcur = tally_half8(lo, hi);
+                else bcur = to_half8(lo, hi);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1495,12 +1508,19 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     {   // chunk 0 is in LDS: everything but slab(1), tok(1), tok(2) of this wave's copies
-        if (w < 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (w < 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stamp(p, 5, lane, wave_id);
-        // ---- accumulators start at |c|^2/2.  Register x of virtual tile v, lane half h: word 32 (4 v + (x >> 2)) + 8 q + 4 h + (x & 3)
+        // ---- accumulators start at |c|^2/2.  Leftover block b, accumulator row 4 kg + e: word 32 (4 b + kg) + 8 q + 4 sg + e
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (4 * b + kg) * 32 + (q * 2 + sg) * 4);
+            accl[b] = f32x4{fminf(c4.x, kPadHalfNorm), fminf(c4.y, kPadHalfNorm), fminf(c4.z, kPadHalfNorm), fminf(c4.w, kPadHalfNorm)};
+            asm volatile("" : "+v"(accl[b]));
+        }
+        // Register x of virtual tile v, lane half h: word 32 (4 v + (x >> 2)) + 8 q + 4 h + (x & 3)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             f32x16 c0;
@@ -1513,21 +1533,13 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
 #pragma unroll
             for (int s = 0; s < 3; ++s) acc[s][v] = c0;
         }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {                            // block b, accumulator row 4 kg + e: word 32 (4 b + kg) + 8 q + 4 sg + e
-            const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (4 * b + kg) * 32 + (q * 2 + sg) * 4);
-            accl[b] = f32x4{fminf(c4.x, kPadHalfNorm), fminf(c4.y, kPadHalfNorm), fminf(c4.z, kPadHalfNorm), fminf(c4.w, kPadHalfNorm)};
-        }
         // the first step's operands
 #pragma unroll
         for (int v = 0; v < 4; ++v) a[v] = *reinterpret_cast<const half8 *>(smem + a_lane + v * 2048);
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + t_addr((unsigned)kS5OffT, 0, 0));
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + t_addr((unsigned)kS5OffT, 0, 1));
-        if (q == 0) {
-            sumsq += squares(lo, hi);
-            asm volatile("" : "+v"(sumsq));
-        }
-        bcur = to_half8(lo, hi);
+        if (q == 0) bcur = tally_half8(lo, hi);
+        else bcur = to_half8(lo, hi);
         __builtin_amdgcn_sched_barrier(0);
     }
     static_for<NCH>([&](auto c_c) {
@@ -1539,7 +1551,7 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
         asm volatile("" : "+s"(rb), "+s"(rbn));
         constexpr unsigned sl = (c & 1) * kS5Slab, sln = ((c + 1) & 1) * kS5Slab;
         if constexpr (c == 5) tq[0] = __builtin_amdgcn_s_memtime();
-        run_step(I0{}, I0{}, I1{}, t_addr(rb, 0, 0) + 4096, t_addr(rb, 0, 1) + 4096, q == 1, 0u);                       // S0; next: S1's rows
+        run_step(I0{}, I0{}, I1{}, t_addr(rb, 0, 0) + 4096, t_addr(rb, 0, 1) + 4096, q == 1, 3 * sg + 1, 0u);           // S0; next: S1's rows
         // the other wave of the SIMD issues the copies its partner issued right behind the barrier one step later
         if constexpr (c >= 1 && !(ABL & 4)) {
             if (sg == 1) {
@@ -1547,20 +1559,20 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
                 if constexpr (c + 2 < NCH) issue_tok(std::integral_constant<int, c + 2 < NCH ? c + 2 : 0>{});
             }
         }
-        run_step(I1{}, I0{}, I1{}, t_addr(rb, 0, 0) + 8192, t_addr(rb, 0, 1) + 8192, q == 2, 0u);                       // S1; next: S2's
+        run_step(I1{}, I0{}, I1{}, t_addr(rb, 0, 0) + 8192, t_addr(rb, 0, 1) + 8192, q == 2, 3 * sg + 2, 0u);           // S1; next: S2's
         if constexpr (c == 5) tq[1] = __builtin_amdgcn_s_memtime();
         unsigned l_lo;
         leftover_addr(l_lo, a16_lane);
-        run_step(I2{}, I1{}, I1{}, l_lo + rb, (l_lo ^ 16u) + rb, w == 3, a16_lane + sl);                                   // S2; next: the leftover rows; A <- leftover blocks
+        run_step(I2{}, I1{}, I1{}, l_lo + rb, (l_lo ^ 16u) + rb, w == 3, 6, a16_lane + sl);                                   // S2; next: the leftover rows; A <- leftover blocks
         if constexpr (c == 5) tq[2] = __builtin_amdgcn_s_memtime();
-        run_step(I3{}, I1{}, I1{}, t_addr(rb, 1, 0), t_addr(rb, 1, 1), q == 0, a_lane + sl + 1024);                       // L; next: S3's rows; A <- k-step 1
-        run_step(I0{}, I0{}, I1{}, t_addr(rb, 1, 0) + 4096, t_addr(rb, 1, 1) + 4096, q == 1, 0u);                       // S3
-        run_step(I1{}, I0{}, I1{}, t_addr(rb, 1, 0) + 8192, t_addr(rb, 1, 1) + 8192, q == 2, 0u);                       // S4; next: S5's rows - the last LDS read of chunk c
+        run_step(I3{}, I1{}, I1{}, t_addr(rb, 1, 0), t_addr(rb, 1, 1), q == 0, 3 * sg, a_lane + sl + 1024);                       // L; next: S3's rows; A <- k-step 1
+        run_step(I0{}, I0{}, I1{}, t_addr(rb, 1, 0) + 4096, t_addr(rb, 1, 1) + 4096, q == 1, 3 * sg + 1, 0u);           // S3
+        run_step(I1{}, I0{}, I1{}, t_addr(rb, 1, 0) + 8192, t_addr(rb, 1, 1) + 8192, q == 2, 3 * sg + 2, 0u);           // S4; next: S5's rows - the last LDS read of chunk c
         if constexpr (c == 5) tq[3] = __builtin_amdgcn_s_memtime();
         if constexpr (!last) {
             // barrier c.  Outstanding, oldest first: ..., slab(c + 1), tok(c + 1) | tok(c + 2): everything but the copies of tok(c + 2)
             if constexpr (c + 2 < NCH) {
-                if (w < 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (w < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (this wave's reads of chunk c have returned)
@@ -1574,9 +1586,9 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
                     if constexpr (c + 3 < NCH) issue_tok(std::integral_constant<int, c + 3 < NCH ? c + 3 : 0>{});
                 }
             }
-            run_step(I2{}, I1{}, I1{}, t_addr(rbn, 0, 0), t_addr(rbn, 0, 1), q == 0, a_lane + sln);                       // S5; next: S0 of chunk c + 1; A <- its k-step 0
+            run_step(I2{}, I1{}, I1{}, t_addr(rbn, 0, 0), t_addr(rbn, 0, 1), q == 0, 3 * sg, a_lane + sln);                       // S5; next: S0 of chunk c + 1; A <- its k-step 0
         } else {
-            run_step(I2{}, I0{}, I0{}, 0u, 0u, false, 0u);                                                                // the very last step
+            run_step(I2{}, I0{}, I0{}, 0u, 0u, false, 0, 0u);                                                                // the very last step
         }
         if constexpr (c == 5) tq[5] = __builtin_amdgcn_s_memtime();
     });
@@ -1641,21 +1653,24 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
     // token the screen cannot bound
     const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
     const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]), CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
-    auto window_of = [&](float ssq) {
+    const float DC = __uint_as_float(scal[4]);                                // max |c - fp16(c)|_2
+    auto window_of = [&](float ssq, float sloss) {
         const float X2 = sqrtf(ssq) * 1.001f + 1.0e-6f, X1 = X2 * sqrtf((float)p.D);
+        const float DX = sqrtf(sloss) * 1.001f + 1.0e-30f;                    // |x - fp16(x)|_2
         const float vmax = 0.5f * CN + X2 * C2;                               // >= |any partial sum|
-        const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
+        // x.c - x~.c~ = x.(c - c~) + (x - x~).c~ (exactly), each term by Cauchy-Schwarz; |c~| <= (1 + u) |c|
+        const float E = 1.01f * (1.001f * (X2 * DC + DX * C2 * 1.0005f) + 5.96e-8f * (X1 + C1)
                                  + (float)(2 * NCH) * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
         const bool bad = !(ssq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e28f);   // NaN-safe; |x|_2 <= 3e4 bounds every component
         return bad ? __uint_as_float(0x7FC00000u) : 2.0f * E;
     };
     if (q < 3) {
-        sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
-        if (h_e == 0) tsum[(3 * sg + q) * 32 + r_e] = window_of(sumsq);
+        sumsq += __shfl_xor(sumsq, 32, SN_WAVE); sumd += __shfl_xor(sumd, 32, SN_WAVE);
+        if (h_e == 0) tsum[(3 * sg + q) * 32 + r_e] = window_of(sumsq, sumd);
     } else if (w == 3) {
-        sumsq += __shfl_xor(sumsq, 16, SN_WAVE);
-        sumsq += __shfl_xor(sumsq, 32, SN_WAVE);
-        if (lane_e < 16) tsum[6 * 32 + lane_e] = window_of(sumsq);
+        sumsq += __shfl_xor(sumsq, 16, SN_WAVE); sumd += __shfl_xor(sumd, 16, SN_WAVE);
+        sumsq += __shfl_xor(sumsq, 32, SN_WAVE); sumd += __shfl_xor(sumd, 32, SN_WAVE);
+        if (lane_e < 16) tsum[6 * 32 + lane_e] = window_of(sumsq, sumd);
     }
     // per slot of this wave: s < 3 = set 3 sg + s (lanes (r, h)), s == 3 = the leftover tokens (lanes < 16, row half sg)
     auto slot_of = [&](int s, int &set, int &rr, int &hh, bool &valid) {
