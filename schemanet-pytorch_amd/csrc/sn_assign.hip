@@ -50,7 +50,6 @@ using sn_s1::dot64;
 constexpr int kWsPerToken2 = 4 + 48 + 4;          // the largest record format: flag word + 24 16-bit codes + overflow-list slot
 constexpr int kMaxTilesScreen = 256;    // tile code in the keys: 6 bits (M <= 2048, byte codes) or 8 bits (M <= 8192, 16-bit codes)
 constexpr int kCodeBytesWide = 48;      // candidate record with 16-bit codes
-constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
 // fp32 accumulate of v_mfma_f32_32x32x16_f16: measured (tools/mfma_probe.hip, MI355X) total error
 // after 24 chained MFMAs <= 12.3 x 2^-24 x max|partial sum| (about 0.5 per instruction).  The
@@ -165,7 +164,7 @@ struct AssignArgs {
     // waves without tokens only keep the codebook ring going.  Default: full_waves = waves per workgroup.
     int full_waves;
     int64_t extra_base;
-    int tps4;           // one-round K-outer screen (assign_screen4_kernel): tokens per workgroup (<= kS4Rows)
+    int tps4;           // one-round K-outer screen (assign_screen5_kernel): tokens per workgroup (<= kS5Rows)
     int dbg;            // diagnostics (SN_ASSIGN_DBG; results are WRONG with any bit set): bit 0 = every workgroup of the K-outer screen reads the first workgroup's tokens (no HBM stream)
     int x_bf16;         // tokens are bfloat16 (x points at 2-byte elements, strides in elements); results are defined on their fp32 values
 };
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(256) void assign_exact_kernel(const AssignArgs p)
 constexpr int kOverflowBlocks = 64;     // blocks reserved for the overflow list (4 tokens each per round)
 
 // FMT 0: records of assign_screen_kernel / assign_screen5_kernel (24 code bytes per token); FMT 2: 16-bit codes (M > 2048);
-// FMT 3: records of assign_screen4_kernel (24 code bytes, slot = 3 (2 quarter + half) + j).
+
 template <int NT, int FMT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void assign_rerank_kernel(const AssignArgs p)
 {
@@ -292,13 +291,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                    : (unsigned)reinterpret_cast<const unsigned short *>(p.codes)[n * kMaxCand + lane];
                     const int hh = lane / 12, g = (lane % 12) / 3;
                     my_word = (int)(code >> 2) * 32 + 8 * g + 4 * hh + (int)(code & 3u);
-                }
-            } else if constexpr (FMT == 3) {
-                // records of assign_screen4_kernel: slot c = 3 (2 q + h) + j, code = tile << 4 | accumulator register
-                if (lane < kMaxCand) {
-                    const unsigned code = (unsigned)p.codes[n * kCodeBytes + lane];
-                    const int qh = lane / 3, reg = (int)(code & 15u);
-                    my_word = ((qh >> 1) * (lay.n_tiles / 4) + (int)(code >> 4)) * 32 + 8 * (reg >> 2) + 4 * (qh & 1) + (reg & 3);
                 }
             }
             double x[NT];
@@ -867,444 +859,35 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // ------------------------------------------------------------------------------------------
-// mode 0, pass 1, one-round K-outer form (round 4; sn_assign_set_variant(4); codebooks of 16 tiles of 32 words - 448 < M <= 512 -,
-// D in {192, 384}, fp32 tokens, at most kS4Rows tokens per CU): the accumulators of EVERY token of the workgroup against the
-// whole codebook stay in registers for the length of the launch, so the codebook crosses a CU's memory path once and the
-// token stream runs under the matrix pipe.
+// mode 0, pass 1, one-round K-outer form (round 5; opt-in, sn_assign_set_variant(5); codebooks of 16 tiles of 32 words - 448 < M <= 512 -,
+// D in {192, 384}, fp32 tokens, at most kS5Rows tokens per CU).
 //
-// One workgroup of four 512-register waves per CU.  Wave q holds, for its quarter of the words (4 tiles), the accumulators of
-// six 32-token sets (24 tiles x 16 registers: sets 0-3 in the 256 AGPRs, sets 4-5 in VGPRs - the compiler keeps the
-// MFMAs of a function in one register file, so the instruction is written out) and of up to sixteen further tokens
-// ("leftover": v_mfma_f32_16x16x32_f16, 8 blocks of 16 words x 4 registers): 196 tokens per CU = 50 176 / 256 is 6 x 32 + 4.
-// K is the outer loop: per 32-float chunk the token rows (LDS-DMA, whole 128-byte lines, piece-swizzled; three slots, two
-// chunks ahead - HBM has the long latency) and the two k-steps of every tile of the codebook image (two slots, one ahead,
-// L2) arrive while the previous chunk is multiplied; one barrier per chunk.  A wave forms the fp16 B fragments it multiplies
-// from the raw fp32 rows itself, right before their MFMAs (no fragment buffer, no second barrier).
-// Values, keys, error window, merge through LDS and the flag word / candidate record (format 3: slot 3 (2 q + h) + j) are
-// those of assign_screen3_kernel; the leftover tokens' keys of the four accumulator-row groups are merged pairwise
-// (lanes l, l ^ 32) so that what is left has the slot structure of a 32 x 32 tile (code bits: see kS4 comments below).
-// Probe (tools/proto_screen4.hip): intake alone 12.9 us (6 TB/s), with the MFMAs 21 us of kernel time.
-// Measured (MI355X, 50 176 tokens): 34.5 us of kernel time (40.4 by the library's event pair; the default form: 30.4 / 36.3).
-// The main loop is ~19 us, but the keys of 448 accumulator values per lane are 2 300 dependent VALU instructions on a wave
-// that is ALONE on its SIMD - 9 us with nothing to overlap them with in a one-round form - and the merge another 4.5 us.
-// (Two independent key chains per set in one asm statement: no faster - a lone wave issues ~one VALU instruction per 8 cycles
-// whatever their dependences; only a second wave on the SIMD would hide the keys.)
-// Opt-in; DESIGN 8.  What this kernel ran into, all because an asm MFMA is invisible to the compiler (hazard recogniser,
-// register allocator): (1) a VALU conversion scheduled right in front of the first MFMA of a group fed it a stale B register
-// (one tile in four of a set wrong): wait states are written into the asm; (2) VALU work dealt BETWEEN the four MFMAs of a
-// step (38 us, 2.4 us faster) gave whole sets of garbage although the instruction stream read correctly (bisected: the eight squares
-// - reads only - between the MFMAs are harmless, the four v_cvt_pk in front of the fourth MFMA are what breaks it, although they
-// write nobody's operands; keeping every fragment alive three more steps changes nothing; `s_nop 3` in front of that MFMA cures it:
-// an asm MFMA right behind VALU writes needs wait states whatever the registers.  With them the interleaved loop is correct - and
-// no faster than this one: 40.2 us) - the next step's conversion runs behind the fourth MFMA; (3) any instrumentation between the phases (stamps)
-// made the compiler park whole accumulator sets in scratch - stamps 0 and 4 only; (4) a lambda nested in the kernel's generic
-// lambdas does not capture a variable that only appears as an asm operand (clang): the MFMA is a function.
-// ------------------------------------------------------------------------------------------
-// one MFMA of assign_screen4_kernel, accumulator in the AGPRs (AG) or the VGPRs, NOPS wait states in front
-template <bool AG, int NOPS>
-__device__ __forceinline__ void s4_mfma(f32x16 &ac, const half8 &a, const half8 &b)
-{
-    if constexpr (AG) {
-        if constexpr (NOPS == 3) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a), "v"(b));
-        else if constexpr (NOPS == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a), "v"(b));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(ac) : "v"(a), "v"(b));
-    } else {
-        if constexpr (NOPS == 3) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a), "v"(b));
-        else if constexpr (NOPS == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a), "v"(b));
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ac) : "v"(a), "v"(b));
-    }
-}
-
-constexpr int kS4Sets = 6, kS4Lo = 16;                          // full sets, leftover tokens
-constexpr int kS4Rows = kS4Sets * 32 + kS4Lo;                   // tokens a workgroup can hold (208)
-constexpr int kS4RowsPad = 224;                                 // token rows copied per chunk (28 x 8: seven 1 KiB copies per wave)
-constexpr int kS4Slab = 16 * 2048, kS4Tok = kS4RowsPad * 128;   // bytes per chunk: codebook (16 tiles x 2 k-steps), token rows
-constexpr int kS4OffT = 2 * kS4Slab;
-constexpr int kS4OffHc = kS4OffT + 3 * kS4Tok;                  // |c|^2/2, accumulator-row order [16][32]
-constexpr int kS4OffBest = kS4OffHc + 16 * 128;                 // [7][32] best key of a token
-constexpr int kS4OffMask = kS4OffBest + 7 * 128;                // [7][32] candidate mask being assembled
-constexpr int kS4OffSum = kS4OffMask + 7 * 128;                 // [7][32] |x|^2 of a token
-constexpr int kS4Lds = kS4OffSum + 7 * 128;
-
-template <int NCH>
-__global__ __launch_bounds__(256, 1) void assign_screen4_kernel(const AssignArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *hcs = reinterpret_cast<float *>(smem + kS4OffHc);
-    float *tbest = reinterpret_cast<float *>(smem + kS4OffBest);
-    unsigned *tmask = reinterpret_cast<unsigned *>(smem + kS4OffMask);
-    float *tsum = reinterpret_cast<float *>(smem + kS4OffSum);
-    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;                      // 32 x 32 side: token column, accumulator row half = k half of a fragment
-    const int j16 = lane & 15, kg = lane >> 4;                   // 16 x 16 side: token column, k group of a fragment = accumulator row group
-    const PackLayout lay = pack_layout(p.M, p.D);
-    const unsigned char *tiles = p.packed + lay.tiles_off;
-    const int64_t tok0 = (int64_t)blockIdx.x * p.tps4;           // this workgroup's tokens: [tok0, tok0 + n_mine)
-    const int n_mine = (int)(p.n_tokens - tok0 < p.tps4 ? p.n_tokens - tok0 : p.tps4);
-    unsigned keep_m0;
-    asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const int wave_id = blockIdx.x * 4 + q;
-    stamp(p, 0, lane, wave_id);
-
-    if (tid < 7 * 32) { tbest[tid] = kBigKey; tmask[tid] = 0u; tsum[tid] = 0.0f; }
-    // |c|^2/2 of every word (padding words: +inf in the image, kept finite so that keys never become NaNs)
-    for (int i = tid; i < 16 * 32; i += 256)
-        hcs[i] = fminf(reinterpret_cast<const float *>(tiles + (size_t)(i >> 5) * lay.tile_bytes + (size_t)lay.n_steps * 1024)[i & 31], kPadHalfNorm);
-
-    // ---- copies.  Token rows: copy i of wave q covers the rows 8 (q + 4 i) .. + 7 of the workgroup (a row past its tokens: its
-    // first token - nobody reads it); lane -> (row, piece slot), the slot holds piece slot ^ ((row >> 1) & 7) of the line.
-    unsigned tv[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int row = 8 * (q + 4 * i) + (lane >> 3);
-        const int64_t n = tok0 + (row < n_mine ? row : 0);
-        const unsigned ni = (unsigned)p.n_inner, o = (unsigned)n / ni, ii = (unsigned)n - o * ni;
-        tv[i] = (unsigned)(((int64_t)o * p.xso + (int64_t)ii * p.xsi) * 4 + 16 * ((lane & 7) ^ ((row >> 1) & 7)));
-    }
-    auto issue_tok = [&](int c) {
-        const unsigned slot = (unsigned)(c % 3);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + kS4OffT + slot * kS4Tok + (q + 4 * i) * 1024);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(tv[i] + (unsigned)c * 128u), "s"(p.x), "s"(dst) : "memory");
-        }
-    };
-    // codebook: wave q copies the two k-steps of its four tiles (8 KiB of the chunk's 32)
-    const unsigned av = (unsigned)(lane * 16);
-    auto issue_slab = [&](int c) {
-        const unsigned slot = (unsigned)(c & 1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int tile = 4 * q + (i >> 1);
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kS4Slab + tile * 2048 + (i & 1) * 1024);
-            const unsigned src = __builtin_amdgcn_readfirstlane((unsigned)(tile * lay.tile_bytes + c * 2048 + (i & 1) * 1024));
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(av + src), "s"(tiles), "s"(dst) : "memory");
-        }
-    };
-    // issue order: slab(0), tok(0), tok(1); per chunk c: slab(c + 1), tok(c + 2)
-    issue_slab(0); issue_tok(0);
-    if (NCH > 1) issue_tok(1);
-    __syncthreads();                                            // hcs / the merge words are written
-
-    // ---- accumulators start at |c|^2/2
-    f32x16 acc[kS4Sets][4];
-    f32x4 accl[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f32x16 c0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (q * 4 + i) * 32 + (g * 2 + h) * 4);
-            c0[4 * g + 0] = c4.x; c0[4 * g + 1] = c4.y; c0[4 * g + 2] = c4.z; c0[4 * g + 3] = c4.w;
-        }
-#pragma unroll
-        for (int s = 0; s < kS4Sets; ++s) acc[s][i] = c0;
-    }
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {                                // block b = words 16 b .. + 15 of the quarter; lane: rows 4 kg .. + 3 of it
-        const int rho = 16 * (b & 1) + 4 * kg;                   // row inside the tile b >> 1 (a multiple of 4)
-        const float4 c4 = *reinterpret_cast<const float4 *>(hcs + (q * 4 + (b >> 1)) * 32 + (2 * (rho >> 3) + ((rho >> 2) & 1)) * 4);
-        accl[b] = f32x4{c4.x, c4.y, c4.z, c4.w};
-    }
-    float sumsq0 = 0.0f, sumsq1 = 0.0f;                          // |x|^2 of the lane's share of the sets q, q + 4 (set 6 = the leftover tokens)
-    auto squares = [&](float &acc_, const f32x4 &lo, const f32x4 &hi) {
-        acc_ = fmaf(lo.x, lo.x, acc_); acc_ = fmaf(lo.y, lo.y, acc_); acc_ = fmaf(lo.z, lo.z, acc_); acc_ = fmaf(lo.w, lo.w, acc_);
-        acc_ = fmaf(hi.x, hi.x, acc_); acc_ = fmaf(hi.y, hi.y, acc_); acc_ = fmaf(hi.z, hi.z, acc_); acc_ = fmaf(hi.w, hi.w, acc_);
-        asm volatile("" : "+v"(acc_));
-    };
-    auto to_half8 = [](const f32x4 &lo, const f32x4 &hi) {
-        half8 b;
-        b[0] = (_Float16)lo.x; b[1] = (_Float16)lo.y; b[2] = (_Float16)lo.z; b[3] = (_Float16)lo.w;
-        b[4] = (_Float16)hi.x; b[5] = (_Float16)hi.y; b[6] = (_Float16)hi.z; b[7] = (_Float16)hi.w;
-        return b;
-    };
-    const int swz = (r >> 1) & 7, swz16 = (j16 >> 1) & 7;        // (rows 32 s + r and 192 + j16: the set offset does not touch bits 1..3)
-    // lane parts of the LDS addresses.  B fragment of k-step ks: k half h of the image = floats 16 h + 8 ks .. + 7 of the chunk
-    // (pack_frag_kernel) = pieces 4 h + 2 ks, + 1 of the token's line
-    const unsigned a_lane = (unsigned)(q * 4 * 2048 + lane * 16);
-    unsigned t_lo[2], t_hi[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        t_lo[ks] = (unsigned)(r * 128 + (((4 * h + 2 * ks) ^ swz) << 4));
-        t_hi[ks] = (unsigned)(r * 128 + (((4 * h + 2 * ks + 1) ^ swz) << 4));
-    }
-    const int pl = 4 * (kg & 1) + 2 * (kg >> 1);
-    const unsigned l_lo = (unsigned)((32 * kS4Sets + j16) * 128 + ((pl ^ swz16) << 4));
-    const unsigned l_hi = (unsigned)((32 * kS4Sets + j16) * 128 + (((pl + 1) ^ swz16) << 4));
-    const unsigned a16_lane = (unsigned)(q * 4 * 2048 + (kg >> 1) * 1024 + (j16 + 32 * (kg & 1)) * 16);
-
-    // (which of the sets this wave sums the squares of, as factors: a branch inside the loop makes the compiler move every
-    // accumulator through scratch at the loop's back edge - 200 registers per chunk)
-    float sel0[kS4Sets], sel1[kS4Sets];
-#pragma unroll
-    for (int s = 0; s < kS4Sets; ++s) { sel0[s] = s == q ? 1.0f : 0.0f; sel1[s] = s == q + 4 ? 1.0f : 0.0f; }
-    const float sel_lo = q == 2 ? 1.0f : 0.0f;
-
-    // ---- main loop, fully unrolled (no back edge: the accumulators never move)
-    static_for<NCH>([&](auto c_c) {
-        constexpr int c = decltype(c_c)::value;
-        // outstanding, oldest first: tok(c), slab(c), tok(c + 1): everything but the seven copies of tok(c + 1)
-        if constexpr (c + 1 < NCH) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // chunk c is in LDS for everybody; the slots of chunk c - 1 are free
-        asm volatile("" ::: "memory");
-        if constexpr (c + 1 < NCH) issue_slab(c + 1);
-        if constexpr (c + 2 < NCH) issue_tok(c + 2);
-        // (LDS addresses: lane part + an immediate; the token slot's base goes through an opaque scalar per chunk - with the loop
-        // unrolled the compiler otherwise keeps the addresses of every (set, k-step, slot) alive across chunks, in scratch)
-        unsigned rb = (unsigned)(kS4OffT + (c % 3) * kS4Tok);
-        asm volatile("" : "+s"(rb));
-        constexpr int sl = (c & 1) * kS4Slab;
-        // Software pipeline over the chunk's twelve steps (k-step, set): a wave alone on its SIMD issues in order, so the NEXT
-        // step's raw rows are requested in front of THIS step's four MFMAs and converted right behind them, in the shadow of the
-        // queued MFMAs (32 cycles of matrix pipe each) - with the request, the wait and the conversion of a step in front of its
-        // own MFMAs the loop ran at 1.75 us per chunk against 0.9 us of matrix pipe.  sched_barrier pins the order the source gives.
-        half8 a0[4], a1[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a0[t] = *reinterpret_cast<const half8 *>(smem + a_lane + (sl + t * 2048));
-        const unsigned char *plo0 = smem + rb + t_lo[0], *phi0 = smem + rb + t_hi[0];
-        const unsigned char *plo1 = smem + rb + t_lo[1], *phi1 = smem + rb + t_hi[1];
-        f32x4 lo = *reinterpret_cast<const f32x4 *>(plo0), hi = *reinterpret_cast<const f32x4 *>(phi0);
-        // (an MFMA reads its A / B registers when it STARTS, and up to four of them queue in front of the matrix pipe: a register
-        // the compiler believes free right behind the asm statement - for the next LDS read, the next conversion - may be
-        // overwritten before the queued MFMA has read it.  Seen as whole sets of garbage.  So every operand is kept alive one
-        // step longer by an empty asm that "reads" it: bprev below, the A fragments behind their k-step.)
-        half8 bcur, bprev;
-        {
-            float sq = 0.0f;
-            squares(sq, lo, hi);
-            sumsq0 = fmaf(sel0[0], sq, sumsq0);
-            sumsq1 = fmaf(sel1[0], sq, sumsq1);
-            asm volatile("" : "+v"(sumsq0), "+v"(sumsq1));
-            bcur = to_half8(lo, hi);
-            bprev = bcur;
-        }
-        static_for<2 * kS4Sets>([&](auto j_c) {
-            constexpr int j = decltype(j_c)::value, ks = j / kS4Sets, st = j % kS4Sets;
-            constexpr int jn = j + 1, ksn = jn / kS4Sets, sn = jn % kS4Sets;
-            constexpr bool more = jn < 2 * kS4Sets;
-            // the next step's raw rows (and, in the middle of k-step 0, the A fragments of k-step 1)
-            if constexpr (more) {
-                lo = *reinterpret_cast<const f32x4 *>((ksn ? plo1 : plo0) + sn * 4096);
-                hi = *reinterpret_cast<const f32x4 *>((ksn ? phi1 : phi0) + sn * 4096);
-            }
-            if constexpr (j == 2) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) a1[t] = *reinterpret_cast<const half8 *>(smem + a_lane + (sl + t * 2048 + 1024));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr bool AG = st < 4;
-            constexpr int N0 = j == 0 ? 3 : 1;                    // (first MFMA of the chunk: its B fragment has just been packed)
-            float sq = 0.0f;
-            half8 bnext;
-            s4_mfma<AG, N0>(acc[st][0], ks ? a1[0] : a0[0], bcur);
-            s4_mfma<AG, 0>(acc[st][1], ks ? a1[1] : a0[1], bcur);
-            s4_mfma<AG, 0>(acc[st][2], ks ? a1[2] : a0[2], bcur);
-            s4_mfma<AG, 0>(acc[st][3], ks ? a1[3] : a0[3], bcur);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (more) {
-                squares(sq, lo, hi);
-                sumsq0 = fmaf(sel0[sn], sq, sumsq0);
-                sumsq1 = fmaf(sel1[sn], sq, sumsq1);
-                asm volatile("" : "+v"(sumsq0), "+v"(sumsq1));
-                bnext = to_half8(lo, hi);
-                asm volatile("" : "+v"(bnext));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" :: "v"(bprev));                       // (the previous step's B fragment may go now)
-            bprev = bcur;
-            if constexpr (more) bcur = bnext;
-            if constexpr (j == kS4Sets + 1) asm volatile("" :: "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]));
-        });
-        asm volatile("s_nop 7" ::: "memory");                   // (the last MFMAs' operand registers are free game for the compiler from here on)
-        {   // leftover tokens: one 16 x 16 x 32 step per block and chunk.  Lane (j16, kg) multiplies the image's (k-step kg >> 1, k half
-            // kg & 1) = floats 16 (kg & 1) + 8 (kg >> 1) .. + 7 of the chunk = pieces pl, pl + 1
-            const f32x4 lo = *reinterpret_cast<const f32x4 *>(smem + rb + l_lo);
-            const f32x4 hi = *reinterpret_cast<const f32x4 *>(smem + rb + l_hi);
-            float sq = 0.0f;
-            squares(sq, lo, hi);
-            sumsq1 = fmaf(sel_lo, sq, sumsq1);
-            asm volatile("" : "+v"(sumsq1));
-            const half8 b = to_half8(lo, hi);
-            // A fragment of block bl: words 16 (bl & 1) + j16 of tile bl >> 1, k = 8 kg .. + 7: k-step kg >> 1, k half kg & 1 of the image
-            // (all eight read up front into registers of their own, and everything kept alive behind the last MFMA: see above)
-            half8 a16[8];
-#pragma unroll
-            for (int bl = 0; bl < 8; ++bl) a16[bl] = *reinterpret_cast<const half8 *>(smem + a16_lane + (sl + (bl >> 1) * 2048 + (bl & 1) * 256));
-#pragma unroll
-            for (int bl = 0; bl < 8; ++bl) {
-                f32x4 &al = accl[bl];
-                if (bl == 0) asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(al) : "v"(a16[bl]), "v"(b));
-                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(al) : "v"(a16[bl]), "v"(b));
-            }
-            asm volatile("s_nop 15\n\ts_nop 15" :: "v"(bprev), "v"(bcur), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]));
-            asm volatile("s_nop 15\n\ts_nop 15" :: "v"(b), "v"(a16[0]), "v"(a16[1]), "v"(a16[2]), "v"(a16[3]), "v"(a16[4]), "v"(a16[5]), "v"(a16[6]), "v"(a16[7]));
-        }
-    });
-    // (the asm MFMAs are invisible to the hazard recogniser and their results are read below - first those of the LAST ones
-    // issued: up to twelve of them are still queued in front of the matrix pipe when the loop ends, ~250 cycles of work)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-
-    // ---- keys: one sorted triple per lane and set; code = tile << 4 | accumulator register
-    float m1[7], m2[7], m3[7];
-    unsigned keymask = 0xFFFFFF00u;
-    asm volatile("" : "+s"(keymask));
-#pragma unroll
-    for (int s = 0; s < kS4Sets; ++s) {
-        m1[s] = kBigKey; m2[s] = kBigKey; m3[s] = kBigKey;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                float k;
-                const float v = acc[s][i][x];
-                asm volatile("v_and_or_b32 %0, %4, %5, %6\n\t"
-                             "v_med3_f32 %3, %0, %2, %3\n\t"
-                             "v_med3_f32 %2, %0, %1, %2\n\t"
-                             "v_min_f32 %1, %0, %1"
-                             : "=&v"(k), "+v"(m1[s]), "+v"(m2[s]), "+v"(m3[s]) : "v"(v), "s"(keymask), "n"((i << 4) | x));
-            }
-        }
-    }
-    {   // leftover tokens.  Lane (j16, kg) holds, of block bl, the words 16 bl + 4 kg + e: in the frame of a 32 x 32 tile that is
-        // tile bl >> 1, accumulator row 16 (bl & 1) + 4 kg + e = 8 A + 4 H + e with A = 2 (bl & 1) + (kg >> 1), H = kg & 1: the code
-        // (bl >> 1) << 4 | A << 2 | e in the slot of row half H decodes like every other code.  The lanes kg and kg ^ 2 share H:
-        // their triples are merged (lane ^ 32) and the lanes kg < 2 carry on as (r = j16, h = kg).
-        float a1 = kBigKey, a2 = kBigKey, a3 = kBigKey;
-        const unsigned lane_code = (unsigned)((kg >> 1) << 2);
-#pragma unroll
-        for (int bl = 0; bl < 8; ++bl) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned code = lane_code | (unsigned)(((bl >> 1) << 4) | ((2 * (bl & 1)) << 2) | e);
-                const float k = __uint_as_float((__float_as_uint(accl[bl][e]) & 0xFFFFFF00u) | code);
-                a3 = __builtin_amdgcn_fmed3f(k, a2, a3);
-                a2 = __builtin_amdgcn_fmed3f(k, a1, a2);
-                a1 = fminf(k, a1);
-            }
-        }
-        const float o1 = __shfl_xor(a1, 32, SN_WAVE), o2 = __shfl_xor(a2, 32, SN_WAVE), o3 = __shfl_xor(a3, 32, SN_WAVE);
-        const float ks3[3] = {o1, o2, o3};
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const float k = ks3[u];
-            a3 = __builtin_amdgcn_fmed3f(k, a2, a3);
-            a2 = __builtin_amdgcn_fmed3f(k, a1, a2);
-            a1 = fminf(k, a1);
-        }
-        m1[6] = a1; m2[6] = a2; m3[6] = a3;
-    }
-    // ---- |x|^2 of every token -> LDS (wave q summed the sets q and q + 4; wave 2 the leftover tokens as its "set 6")
-    sumsq0 += __shfl_xor(sumsq0, 32, SN_WAVE);
-    if (q == 2) { sumsq1 += __shfl_xor(sumsq1, 16, SN_WAVE); sumsq1 += __shfl_xor(sumsq1, 32, SN_WAVE); }
-    else sumsq1 += __shfl_xor(sumsq1, 32, SN_WAVE);
-    if (h == 0) tsum[q * 32 + r] = sumsq0;
-    if (q < 2 && h == 0) tsum[(q + 4) * 32 + r] = sumsq1;
-    if (q == 2 && lane < 16) tsum[6 * 32 + lane] = sumsq1;
-    // ---- per set: the best key of a token over the eight lanes that hold it
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const bool lane_on = s < kS4Sets || lane < 32;           // (leftover: the lanes kg < 2, as r = j16 = lane & 15, h = kg = lane >> 4)
-        const int rr = s < kS4Sets ? r : j16, hh = s < kS4Sets ? h : (kg & 1);
-        const int row = 32 * s + rr;
-        const bool valid = lane_on && (s < kS4Sets || rr < kS4Lo) && row < n_mine;
-        const float other = __shfl_xor(m1[s], s < kS4Sets ? 32 : 16, SN_WAVE);
-        const float kmin = fminf(m1[s], other);
-        if (valid && hh == 0) __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)&tbest[s * 32 + rr], kmin, 0, 0, false);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const unsigned *scal = reinterpret_cast<const unsigned *>(p.packed + lay.scal_off);
-    const float C2 = __uint_as_float(scal[0]), C1 = __uint_as_float(scal[1]), CN = __uint_as_float(scal[2]), CMAX = __uint_as_float(scal[3]);
-    unsigned hm[7];
-    bool badv[7];
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const bool lane_on = s < kS4Sets || lane < 32;
-        const int rr = s < kS4Sets ? r : j16, hh = s < kS4Sets ? h : (kg & 1);
-        const int row = 32 * s + rr;
-        const bool valid = lane_on && (s < kS4Sets || rr < kS4Lo) && row < n_mine;
-        // per-token error window (DESIGN.md "S1 error window"): |key - exact value| <= E
-        const float sumsq = tsum[s * 32 + rr];
-        const float X2 = sqrtf(sumsq) * 1.001f + 1.0e-6f, X1 = X2 * sqrtf((float)p.D);
-        const float vmax = 0.5f * CN + X2 * C2;                               // >= |any partial sum|
-        const float E = 1.01f * (2.01f * kU16 * X2 * C2 + 5.96e-8f * (X1 + C1)
-                                 + (float)(2 * NCH) * kAccUlpPerMfma * vmax + vmax * (3.0f * 5.96e-8f + 3.1e-5f));
-        const bool bad = !(sumsq <= kHugeIn * kHugeIn) || !(CMAX <= kHugeIn) || !(vmax < 1.0e28f);   // NaN-safe; |x|_2 <= 3e4 bounds every component
-        const float best = tbest[s * 32 + rr];
-        const bool any_finite = best < kKeyLimit;
-        const float cut = best + 2.0f * E;
-        const unsigned hmask = (m1[s] <= cut ? 1u : 0u) | (m2[s] <= cut ? 2u : 0u) | (m3[s] <= cut ? 4u : 0u);
-        const bool hover = m3[s] <= cut;                                      // a 4th may hide behind it
-        const unsigned contrib = (bad || !any_finite) ? 0x80000000u : ((hmask << (3 * (2 * q + hh))) | (hover ? 0x80000000u : 0u));
-        if (valid && contrib) __hip_atomic_fetch_or(&tmask[s * 32 + rr], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        hm[s] = hmask; badv[s] = bad;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < 7; ++s) {
-        const bool lane_on = s < kS4Sets || lane < 32;
-        const int rr = s < kS4Sets ? r : j16, hh = s < kS4Sets ? h : (kg & 1);
-        const int row = 32 * s + rr;
-        const bool valid = lane_on && (s < kS4Sets || rr < kS4Lo) && row < n_mine;
-        const int64_t n = tok0 + row;
-        const unsigned mk = tmask[s * 32 + rr];
-        const unsigned cand = mk & 0xFFFFFFu;
-        const bool overflow = (mk >> 31) != 0u || cand == 0u;
-        const int nc = __popc(cand);
-        if (valid && !overflow) {
-            if (nc == 1 && hm[s] != 0u) {                                     // the only candidate: final
-                const unsigned code = __float_as_uint(m1[s]) & 0xFFu;
-                p.out[out_index(p, n)] = (q * 4 + (int)(code >> 4)) * 32 + 8 * (int)((code >> 2) & 3u) + 4 * hh + (int)(code & 3u);
-            }
-            if (nc > 1) {                                       // the eight lanes of the token write their three codes
-                unsigned char *cd = p.codes + (int64_t)n * kCodeBytes + 3 * (2 * q + hh);
-                cd[0] = (unsigned char)(__float_as_uint(m1[s]) & 0xFFu);
-                cd[1] = (unsigned char)(__float_as_uint(m2[s]) & 0xFFu);
-                cd[2] = (unsigned char)(__float_as_uint(m3[s]) & 0xFFu);
-            }
-        }
-        const bool writer = valid && q == 0 && hh == 0;
-        if (writer) p.flags[n] = overflow ? 0x80000000u : (nc > 1 ? cand : 0u);
-        const bool need_b = writer && overflow;
-        const unsigned long long mask_b = __ballot(need_b);
-        if (mask_b) {                                          // rare: tokens the screen cannot bound (phase B of the re-rank writes out[])
-            int base = 0;
-            const int leader = __ffsll((long long)mask_b) - 1;
-            if (lane == leader) base = atomicAdd(&p.work[1], __popcll(mask_b));
-            base = __shfl(base, leader, SN_WAVE);
-            if (need_b) p.overflow[base + __popcll(mask_b & ((1ull << lane) - 1ull))] = (int)n;
-        }
-    }
-    stamp(p, 4, lane, wave_id);
-    asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0));
-}
-
-// ------------------------------------------------------------------------------------------
-// mode 0, pass 1, one-round K-outer form with TWO waves per SIMD (round 5; sn_assign_set_variant(5); codebooks of 16 tiles of
-// 32 words - 448 < M <= 512 -, D in {192, 384}, fp32 tokens, at most kS5Rows tokens per CU).
-//
-// Same idea as assign_screen4_kernel - the accumulators of every token of the workgroup against the whole codebook stay in
-// registers, K is the outer loop, so the token stream (HBM) runs under the matrix pipe and the codebook crosses the CU once -
-// but on EIGHT 256-register waves: wave (sg, q) = (tid >> 8, (tid >> 6) & 3) holds the accumulators of the three 32-token sets
-// 3 sg .. 3 sg + 2 against the quarter q of the words (4 tiles x 16 registers x 3 sets = 192) and of up to sixteen further
-// tokens ("leftover", v_mfma_f32_16x16x32_f16) against half of that quarter (4 blocks x 4 registers): 208 of its 256
-// registers, every one an architectural VGPR, so the MFMAs are plain builtins (the compiler sees their hazards and their
-// operands' lifetimes: none of assign_screen4_kernel's asm rules apply) and the key phase of one wave runs beside the other
-// wave of its SIMD instead of alone.
-// The quarter of a wave is not a run of four tiles but an accumulator-row group: the tiles5 image (pack_frag5_kernel)
-// permutes the words so that lane (r, h) of wave (sg, q) holds, of its token, exactly the words 32 t + 8 q + 4 h + e (t < 16,
-// e < 4) - the candidate-slot group (h, g = q) of the DEFAULT screen's record (sn_assign_shared.h): a sorted triple per lane
-// and set IS that group's triple, so this kernel writes the same flag words and 24-byte records as assign_screen_kernel and
-// both finishers (assign_rerank_kernel<., 0>, the deferred finish inside the instance-graph kernel) take them as they are.
+// The accumulators of EVERY token of the workgroup against the whole codebook stay in registers for the length of the launch and
+// K is the outer loop, so the token stream (HBM) runs under the matrix pipe and the codebook crosses the CU's memory path once.
+// One workgroup of eight 256-register waves per CU: wave (sg, q) = (tid >> 8, (tid >> 6) & 3) holds the accumulators of the three
+// 32-token sets 3 sg .. 3 sg + 2 against the quarter q of the words (4 tiles x 16 registers x 3 sets = 192) and of up to sixteen
+// further tokens ("leftover", v_mfma_f32_16x16x32_f16; 196 tokens per CU = 50 176 / 256 is 6 x 32 + 4) against half of that quarter
+// (4 blocks x 4 registers): 208 of its 256 registers, every one an architectural VGPR, so the MFMAs are plain builtins (the compiler
+// sees their hazards and their operands' lifetimes) and two waves share a SIMD.  (Round 4's form of the same idea ran four
+// 512-register waves with asm MFMAs on AGPRs: 34.5 us - a lone wave issues its 2 300 key instructions at one per 8 cycles.)
+// The quarter of a wave is not a run of four tiles but an accumulator-row group: the tiles5 image (pack_frag5_kernel) permutes the
+// words so that lane (r, h) of wave (sg, q) holds, of its token, exactly the words 32 t + 8 q + 4 h + e (t < 16, e < 4) - the
+// candidate-slot group (h, g = q) of the DEFAULT screen's record (sn_assign_shared.h): a sorted triple per lane and set IS that
+// group's triple, so this kernel writes the same flag words and 24-byte records as assign_screen_kernel and both finishers
+// (assign_rerank_kernel<., 0>, the deferred finish inside the instance-graph kernel) take them as they are.
 // The leftover tokens' words are split by accumulator-row half: wave (sg, q) multiplies them by the words 32 t + 8 q + 4 sg + e
 // - slot group (h = sg, g = q) again, spread over the four lanes (token, kg) that are merged with two shuffles.
-// Values u[word] = |c|^2/2 - x~.c~, keys compared as floats, window as in assign_screen4_kernel.
+// Values u[word] = |c|^2/2 - x~.c~ (accumulators start at |c|^2/2, no per-token shift: |x|^2 is only known at the end), keys = float
+// bits with the low byte replaced by the word code, compared as floats; window from the token's measured fp16 rounding loss.
+//
+// Measured (MI355X, 50 176 tokens, rocprofv3 kernel trace): 31.2 us against 33.7 us for assign_screen_kernel in the same process
+// (32.6 / 35.2 by the library's event pair), same ids, 6.4 % of the tokens flagged (6.6 %).  In the replayed bench (four steps in
+// flight) the step is 1.5 % SLOWER with it: it owns every CU's registers and LDS for the length of the launch, and the kernels of
+// the other steps cannot fill in - hence opt-in.  Where its 59 k cycles go (in-kernel stamps, tools/diag_s5.py): prologue to first
+// MFMA 6 k, the eleven steady chunks 32.4 k = 2 950 per chunk against 1 790 of matrix pipe and 2 070 of HBM (ablation builds: the
+// LDS-read skeleton alone 1 080 per chunk, + the fp32 -> fp16 conversion 2 010, + the MFMAs 2 750: an in-order wave with ONE partner
+// on its SIMD overlaps the three only partly; two steps of lead for the raw rows would need eight registers the waves do not have),
+// last chunk 2 k, keys 4.6 - 7.7 k (832 VALU instructions per wave), merge + records 5 k.
 // ------------------------------------------------------------------------------------------
 constexpr int kS5Sets = 6, kS5Lo = 16;
 constexpr int kS5Rows = kS5Sets * 32 + kS5Lo;                   // tokens a workgroup can hold (208)
@@ -1341,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void assign_screen5_kernel(const AssignArgs
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sg = w >> 2, q = w & 3;
     const int r = lane & 31, h = lane >> 5;                      // 32 x 32 side: token column, accumulator row half = k half of a fragment
-    const int j16 = lane & 15, kg = lane >> 4;                   // 16 x 16 side: token column, k group of a fragment = accumulator row group
+    const int kg = lane >> 4;                                    // 16 x 16 side: lane = (token column j16 = lane & 15, k group of a fragment = accumulator row group kg)
     const PackLayout lay = pack_layout(p.M, p.D);
     const unsigned char *tiles = p.packed + lay.tiles_off;
     const unsigned char *tiles5 = p.packed + lay.tiles5_off;
@@ -1826,25 +1409,6 @@ int launch_screen(const AssignArgs &a, hipStream_t st, bool defer = false)
 }
 
 template <int NCH>
-int launch_screen4(const AssignArgs &a, hipStream_t st)
-{
-    constexpr int NTR = (NCH + 1) / 2;                          // fp64 re-rank: 64 k per lane-step
-    if (int rc = sn_ensure_dynamic_lds((const void *)assign_screen4_kernel<NCH>, kS4Lds, "sn_assign_words")) return rc;
-    AssignArgs ag = a;
-    const int64_t cus = device_cus();
-    int64_t tpw = (a.n_tokens + cus - 1) / cus;                 // one workgroup per CU, one round (the caller checked n_tokens <= cus kS4Rows)
-    if (const char *e = getenv("SN_ASSIGN_TPW")) tpw = atoi(e);
-    tpw = tpw < 1 ? 1 : (tpw > kS4Rows ? kS4Rows : tpw);
-    ag.tps4 = (int)tpw;
-    const unsigned grid = (unsigned)((a.n_tokens + tpw - 1) / tpw);
-    sn_prof_start(0, st);
-    hipLaunchKernelGGL((assign_screen4_kernel<NCH>), dim3(grid), dim3(256), kS4Lds, st, ag);
-    sn_prof_stop(0, st);
-    launch_rerank<NTR, 3>(ag, st);
-    return 0;
-}
-
-template <int NCH>
 int launch_screen5(const AssignArgs &a, hipStream_t st, bool defer)
 {
     constexpr int NTR = (NCH + 1) / 2;                          // fp64 re-rank: 64 k per lane-step
@@ -1856,10 +1420,10 @@ int launch_screen5(const AssignArgs &a, hipStream_t st, bool defer)
     tpw = tpw < 1 ? 1 : (tpw > kS5Rows ? kS5Rows : tpw);
     ag.tps4 = (int)tpw;
     const unsigned grid = (unsigned)((a.n_tokens + tpw - 1) / tpw);
-    static const int abl = getenv("SN_S5_ABL") ? atoi(getenv("SN_S5_ABL")) : 0;
     sn_prof_start(0, st);
-    if (abl == 0 || NCH != 12) hipLaunchKernelGGL((assign_screen5_kernel<NCH>), dim3(grid), dim3(512), kS5Lds, st, ag);
-    else {
+#ifdef SN_S5_ABLATION      // diagnostic builds (make FLAGS+=-DSN_S5_ABLATION): SN_S5_ABL selects an ablated form of the D = 384 kernel; results are wrong
+    static const int abl = getenv("SN_S5_ABL") ? atoi(getenv("SN_S5_ABL")) : 0;
+    if (abl != 0 && NCH == 12) {
         const void *fn = abl == 1 ? (const void *)assign_screen5_kernel<12, 1> : abl == 2 ? (const void *)assign_screen5_kernel<12, 2> : abl == 3 ? (const void *)assign_screen5_kernel<12, 3>
                        : abl == 4 ? (const void *)assign_screen5_kernel<12, 4> : abl == 6 ? (const void *)assign_screen5_kernel<12, 6> : (const void *)assign_screen5_kernel<12, 7>;
         if (int rc = sn_ensure_dynamic_lds(fn, kS5Lds, "sn_assign_words")) return rc;
@@ -1869,17 +1433,21 @@ int launch_screen5(const AssignArgs &a, hipStream_t st, bool defer)
         else if (abl == 4) hipLaunchKernelGGL((assign_screen5_kernel<12, 4>), dim3(grid), dim3(512), kS5Lds, st, ag);
         else if (abl == 6) hipLaunchKernelGGL((assign_screen5_kernel<12, 6>), dim3(grid), dim3(512), kS5Lds, st, ag);
         else hipLaunchKernelGGL((assign_screen5_kernel<12, 7>), dim3(grid), dim3(512), kS5Lds, st, ag);
-    }
+    } else
+#endif
+    hipLaunchKernelGGL((assign_screen5_kernel<NCH>), dim3(grid), dim3(512), kS5Lds, st, ag);
     sn_prof_stop(0, st);
     if (!defer) launch_rerank<NTR, 0>(ag, st);                  // (its records are the default screen's)
     return 0;
 }
 
-// form of the screen kernel: 0 = token-stationary (assign_screen_kernel: 4 waves x 3-slot codebook ring, two workgroups per CU);
-// 4 = one-round K-outer, four 512-register waves (assign_screen4_kernel); 5 = one-round K-outer, eight 256-register waves
-// (assign_screen5_kernel).  4 and 5 apply to codebooks of 16 tiles (448 < M <= 512), D in {192, 384}, fp32 tokens, at most
-// 208 tokens per CU; other shapes take form 0.  Initialised from SN_ASSIGN_VARIANT, changed with sn_assign_set_variant().
-// (The lab forms of rounds 1-3 - 8-wave workgroups, codebook-stationary, K-outer in rounds - are in the history and NOTES.md.)
+// form of the screen kernel: 0 = token-stationary (assign_screen_kernel: 4 waves x 3-slot codebook ring, two workgroups per CU: the
+// default - it leaves half of every CU to the kernels of the other steps in flight); 5 = one-round K-outer on eight 256-register
+// waves (assign_screen5_kernel: 7.5 % less kernel time alone, but it owns the CU; codebooks of 16 tiles - 448 < M <= 512 -, D in
+// {192, 384}, fp32 tokens, at most 208 tokens per CU; other shapes take form 0).  Both write the same records.
+// Initialised from SN_ASSIGN_VARIANT, changed with sn_assign_set_variant().
+// (The lab forms of rounds 1-4 - 8-wave workgroups, codebook-stationary, K-outer in rounds, K-outer on four 512-register waves - are
+// in the history and in NOTES.md / DESIGN.md section 8.)
 int g_variant = -1;
 int screen_variant()
 {
@@ -1927,13 +1495,13 @@ extern "C" int sn_assign_variant(void) { return screen_variant(); }
 extern "C" int sn_assign_defers(int M, int D)
 {
     const int v = screen_variant();
-    const bool dflt = v == 0 || v == 5 || (v == 4 && pack_layout(M, D).n_tiles != 16);      // (form 5 writes the default form's records; form 4 with 16 tiles may still fall back for a large batch: it then takes the stand-alone finish)
+    const bool dflt = v == 0 || v == 5;                          // (form 5 writes the default form's records)
     return (dflt && M > 0 && M <= 2048 && (D == 192 || D == 384)) ? 1 : 0;      // (D = 768: the finish's state - three 12-register rows - does not fit the graph kernel's 128 registers)
 }
 
 extern "C" int sn_assign_set_variant(int variant)
 {
-    SN_REQUIRE(variant == 0 || variant == 4 || variant == 5, SN_ERR_BAD_ARG, "sn_assign_set_variant: variant=%d (0, 4 or 5)", variant);
+    SN_REQUIRE(variant == 0 || variant == 5, SN_ERR_BAD_ARG, "sn_assign_set_variant: variant=%d (0 or 5)", variant);
     g_variant = variant;
     return SN_OK;
 }
@@ -2025,9 +1593,6 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
         if (screen_variant() == 5 && !x_bf16 && lay.tiles5_off != 0 && n_tokens <= (int64_t)device_cus() * kS5Rows &&
             ((n_outer - 1) * x_stride_outer + (n_inner - 1) * x_stride_inner + D) * 4 < (int64_t)0xFFFFF000ll && x_stride_outer >= 0 && x_stride_inner >= 0) {
             rc = D == 192 ? launch_screen5<6>(a, st, deferred = want_defer) : launch_screen5<12>(a, st, deferred = want_defer);
-        } else if (screen_variant() == 4 && !x_bf16 && lay.n_tiles == 16 && (D == 192 || D == 384) && n_tokens <= (int64_t)device_cus() * kS4Rows &&
-                   ((n_outer - 1) * x_stride_outer + (n_inner - 1) * x_stride_inner + D) * 4 < (int64_t)0xFFFFF000ll && x_stride_outer >= 0 && x_stride_inner >= 0) {
-            rc = D == 192 ? launch_screen4<6>(a, st) : launch_screen4<12>(a, st);
         } else if (M > 2048) {               // more than 64 tiles: 10-bit word codes in the keys, 16-bit codes in the records
             a.overflow = (int *)(ws + 32 + (size_t)n_tokens * (4 + kCodeBytesWide));
             if (D == 192) rc = launch_screen<12, 4, 3, 10>(a, st);

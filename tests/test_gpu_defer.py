@@ -47,9 +47,20 @@ def _case(D, M, B, L, seed, hard=True):
     return cb, tok
 
 
-@pytest.mark.parametrize("D,M", [(384, 512), (192, 128), (384, 1000)])
+@pytest.fixture(params=[0, 5], ids=["token-stationary", "k-outer"])
+def screen_form(request, mods):
+    """both forms of the screen write the records the finish reads (the K-outer form applies to 16-tile codebooks; elsewhere it
+    falls back to the default form)"""
+    lib = mods["cx"].load()
+    old = lib.sn_assign_variant()
+    assert lib.sn_assign_set_variant(request.param) == 0
+    yield request.param
+    lib.sn_assign_set_variant(old)
+
+
+@pytest.mark.parametrize("D,M", [(384, 512), (192, 128), (384, 1000), (192, 480)])
 @pytest.mark.parametrize("layout", ["batch_first", "sequence_first"])
-def test_deferred_finish_equals_mode0_and_oracle(mods, D, M, layout):
+def test_deferred_finish_equals_mode0_and_oracle(mods, D, M, layout, screen_form):
     ops, lib = mods["ops"], mods["cx"].load()
     B, L, K = 8, 196, 5
     cb, tok = _case(D, M, B, L, seed=900 + D + M)
@@ -120,12 +131,14 @@ def test_deferred_finish_with_per_head_taps_and_fallbacks(mods):
     x3 = T(datagen.bellish((2, L, 768), 6, 1.0))
     ids3, h3 = ops.assign_words(x3, cbt3, packed3, defer=True)
     assert h3 is None and torch.equal(ids3, ops.assign_words(x3, cbt3, packed3))
+    # the K-outer screen writes the default screen's records: the same deferred finish
     old = lib.sn_assign_variant()
     try:
-        lib.sn_assign_set_variant(4)
-        assert lib.sn_assign_defers(512, 384) == 0
+        lib.sn_assign_set_variant(5)
+        assert lib.sn_assign_defers(512, 384) == 1
         ids4, h4 = ops.assign_words(x, cbt, packed, defer=True)
-        assert h4 is None and torch.equal(ids4, want)
+        g4 = sn.instance_graph_padded(ids4, *args, mutate_inputs=False, zero_padding=False, rerank=h4)
+        assert h4 is not None and h4.done and torch.equal(ids4, want) and torch.equal(g4["ids"], g_ref["ids"])
     finally:
         lib.sn_assign_set_variant(old)
 
