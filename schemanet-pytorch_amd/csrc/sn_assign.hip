@@ -50,6 +50,7 @@ using sn_s1::dot64;
 constexpr int kWsPerToken2 = 4 + 48 + 4;          // the largest record format: flag word + 24 16-bit codes + overflow-list slot
 constexpr int kMaxTilesScreen = 256;    // tile code in the keys: 6 bits (M <= 2048, byte codes) or 8 bits (M <= 8192, 16-bit codes)
 constexpr int kCodeBytesWide = 48;      // candidate record with 16-bit codes
+[[maybe_unused]] constexpr float kU16 = 4.8828125e-4f;  // 2^-11, fp16 unit round-off (SN_S1_EXACT_LOSS 0)
 constexpr float kHugeIn = 3.0e4f;      // |value| above this does not go through fp16
 // fp32 accumulate of v_mfma_f32_32x32x16_f16: measured (tools/mfma_probe.hip, MI355X) total error
 // after 24 chained MFMAs <= 12.3 x 2^-24 x max|partial sum| (about 0.5 per instruction).  The
