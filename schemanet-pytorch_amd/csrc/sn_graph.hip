@@ -812,7 +812,7 @@ __device__ __forceinline__ bool group_positions_sorted(const Lds &s, int L, int 
     for (int e = 0; e < 4; ++e) {
         if (!valid[e]) continue;
         const int pos = (int)(key[e] & 255u);
-        if (kLean) { s.flag[pos] = (unsigned char)(4 * lane + e); continue; }
+        if (kLean) { s.flag[pos] = (unsigned char)(4 * lane + e); stage[pos] = 1.0f / (float)cnt[e]; continue; }      // (stage: now 1 / positions of the position's word - the edges phase's per-position weight)
         s.pless[pos] = (unsigned short)gs[e];
         s.pcnt[pos] = (unsigned short)cnt[e];
         s.flag[pos] = (unsigned char)(1 | (head[e] ? 2 : 0) | 4);
@@ -1395,6 +1395,11 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     float tk[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) tk[i] = ((take >> i) & 1u) ? 1.0f : 0.0f;
+    // lean form: 1 / (positions of the word of the lane's k-th POSITION) (group_positions_sorted<true> leaves it in s.T): the weight
+    // that turns column sums into the summands of the cell means before the scan (see the fused row below)
+    float rq[kCellsPerLane];
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) rq[k] = (lean && qok[k]) ? s.T[lane + SN_WAVE * k] : 0.0f;
     float rcnt[kCellsPerLane];                             // 1 / (positions of the column's word)
 #pragma unroll
     for (int k = 0; k < kCellsPerLane; ++k) rcnt[k] = 1.0f / (float)(cc.cnt[k] > 0 ? cc.cnt[k] : 1);
@@ -1473,6 +1478,64 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
             // b) stage the column sums, in SORTED position order, in the group's first row; the positions of
             // an output column's word are then a contiguous run: independent, pipelined LDS reads
             char *stage = reinterpret_cast<char *>(s.A + __builtin_amdgcn_readfirstlane((int)s.pos_sorted[ia]) * L);
+            if constexpr (kFast) {
+                // Fused row (round 5).  Means, row normalisation and the weighting by w_e are linear in the column sums, so they are
+                // applied BEFORE the scan: u = column sum / positions of its word; the row totals T0, T1 of the cell means are then
+                // plain wave sums of u (every position belongs to one word; the row's own 1 / n_i cancels), and the output row is ONE
+                // segmented scan of z = (w_e0 / T0) u0 + (w_e1 / T1) u1 - instead of two scans and a pass of multiplies over the
+                // cells behind them.  Same cells to fp32 rounding (another association: 1e-7).  Rows whose totals are not positive and
+                // finite (an all-clamped attention row: NaN) keep the two-scan form with nan_to_num below.
+                if (lean) {
+                    float u0[kCellsPerLane], u1[kCellsPerLane];
+#pragma unroll
+                    for (int k = 0; k < kCellsPerLane; ++k) { u0[k] = csg[k] * rq[k]; u1[k] = csa[k] * rq[k]; }
+                    const float T0 = wave_sum_fast((u0[0] + u0[1]) + (u0[2] + u0[3]));
+                    const float T1 = wave_sum_fast((u1[0] + u1[1]) + (u1[2] + u1[3]));
+                    if (T0 > 0.0f && T0 < INFINITY && T1 > 0.0f && T1 < INFINITY) {             // wave-uniform
+                        const float a0 = w0 * __builtin_amdgcn_rcpf(T0), a1 = w1 * __builtin_amdgcn_rcpf(T1);
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int k = 0; k < kCellsPerLane; ++k)
+                            if (qok[k]) *reinterpret_cast<float *>(stage + qsidx4[k]) = fmaf(a0, u0[k], a1 * u1[k]);
+                        __builtin_amdgcn_wave_barrier();
+                        f32x4 v4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (4 * lane < L) v4 = *reinterpret_cast<const f32x4 *>(stage + 16 * lane);
+                        const float s0 = v4.x;
+                        const float s1 = fmaf(s0, nh1, v4.y);
+                        const float s2 = fmaf(s1, nh2, v4.z);
+                        const float s3 = fmaf(s2, nh3, v4.w);
+                        float run = s3;
+#define SN_SCAN_STEP(i, ctrl, rows)                                                                                            \
+                        asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " ctrl " row_mask:" rows " bank_mask:0xf bound_ctrl:0" : "+v"(run) : "v"(tk[i]));
+                        SN_SCAN_STEP(0, "row_shr:1", "0xf")
+                        SN_SCAN_STEP(1, "row_shr:2", "0xf")
+                        SN_SCAN_STEP(2, "row_shr:4", "0xf")
+                        SN_SCAN_STEP(3, "row_shr:8", "0xf")
+                        SN_SCAN_STEP(4, "row_bcast:15", "0xa")
+                        SN_SCAN_STEP(5, "row_bcast:31", "0xc")
+#undef SN_SCAN_STEP
+                        float carry;
+                        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(carry) : "v"(run));
+                        v4.x = fmaf(carry, cf0, s0);
+                        v4.y = fmaf(carry, cf1, s1);
+                        v4.z = fmaf(carry, cf2, s2);
+                        v4.w = fmaf(carry, cf3, s3);
+                        __builtin_amdgcn_wave_barrier();
+                        if (4 * lane < L) *reinterpret_cast<f32x4 *>(stage + 16 * lane) = v4;
+                        __builtin_amdgcn_wave_barrier();
+                        const int64_t rowbase_f = ((int64_t)b * a.n_pad + r_this) * a.n_pad;
+#pragma unroll
+                        for (int k = 0; k < KC; ++k) {
+                            const int c = lane + SN_WAVE * k;
+                            const int last = cc.cnt[k] > 0 ? cc.ja[k] + cc.cnt[k] - 1 : 0;
+                            const float v = *reinterpret_cast<const float *>(stage + last * 4);
+                            if (c < n_out && c < a.n_pad) a.out_e[rowbase_f + c] = v;
+                        }
+                        if (stamps) { ts2 = __builtin_amdgcn_s_memtime(); dt_a += ts1 - ts0; dt_b += ts2 - ts1; }
+                        continue;
+                    }
+                }
+            }
             float sa[kCellsPerLane], sg[kCellsPerLane];
             if (scan_ok) {
                 // cell(gj) = sum of a contiguous run of the staged vector -> ONE segmented inclusive scan of the
@@ -1609,460 +1672,6 @@ __global__ __launch_bounds__(1024) void instance_graph_kernel(const sn_graph_arg
     __syncthreads();
     SN_GSTAMP(5);
     if (stamps && threadIdx.x == 0) { stamps[(size_t)blockIdx.x * 16 + 6] = dt_a; stamps[(size_t)blockIdx.x * 16 + 7] = dt_b; stamps[(size_t)blockIdx.x * 16 + 8] = dt_c; stamps[(size_t)blockIdx.x * 16 + 9] = dt_pre; }
-}
-
-// ------------------------------------------------------------------------------------------
-// S2 + S3, group-streamed form (round 5; the prediction configuration with one attention map per image)
-//
-// An edge cell is cell(gi, gj) = sum_{p in gi} sum_{q in gj} A[p][q]: output row gi only ever needs the attention rows of the
-// positions of word gi.  So the map never has to lie in LDS (instance_graph_kernel: 153.7 KB per image, a rows phase the VALU sits
-// out - 22 k cycles - and an edges phase HBM sits out - 33 k): once the positions are grouped by word, a wave owns a contiguous run
-// of the SORTED position order (whole groups, balanced by cost) and streams exactly those rows from HBM through a register ring,
-// soft-maxes each, adds it to the group's column sums in registers (attention: straight from the row; grid similarity: the signed
-// table), and at the last row of a group turns the column sums into the output row: per-position weight 1 / count(word), ONE
-// segmented scan over the sorted order of z = (w_e0 / T0) u0 + (w_e1 / T1) u1 (T = the row totals, plain wave sums of u: the
-// normalisation and the weighting by w_e are linear, so they are applied BEFORE the scan instead of two scans and a pass over the
-// cells behind them), gather, store.  HBM reads of some waves run under the VALU work of the others from start to end, 20 KB of LDS.
-// Sum order per cell: p-major over the group's rows, inside a row a scan tree over q (fp32; the reference: p-major, q sequential,
-// large_scale_feat_to_e.cpp:99-125) - 1e-7 relative like the two-phase kernel's q-major order; rows whose totals are not positive
-// and finite (an all-clamped attention row: NaN) take the two-scan form with nan_to_num, value for value the two-phase kernel's.
-// Grouping, vertices, the word sort: the sorting wave of the two-phase kernel (group_positions_sorted), while the other fifteen
-// waves build the signed grid table.
-// ------------------------------------------------------------------------------------------
-constexpr int kStreamDepth = 4;                 // attention rows in flight per wave
-template <class F>
-__device__ __forceinline__ void static_for_stream(F &&f)
-{
-    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
-}
-
-// The ring of rows in flight lives in the ACCUMULATOR registers a[48 + 4 d .. + 3] of slot d, named literally: a row that is still
-// on its way must not be copied, and a value the compiler can see it does copy (register coalescing at the loop's edges moved the
-// "=v" outputs of asm loads into the loop's registers before the data had landed).  With 1024 threads the kernel's 128 registers
-// are split 64 : 64 as soon as an AGPR is used; the compiler parks the VGPRs that do not fit in AGPRs from a0 upwards (19 of
-// them), so the ring sits at the top of the file: audit `AGPRs: 64` and the compiler's own v_accvgpr_* below a48 after any edit.
-template <int D>
-__device__ __forceinline__ void stream_load_row(const float *ptr)
-{
-    static_assert(D >= 0 && D < kStreamDepth, "ring slot");
-    if constexpr (D == 0) asm volatile("global_load_dwordx4 a[48:51], %0, off nt" :: "v"(ptr) : "memory", "a48", "a49", "a50", "a51");
-    if constexpr (D == 1) asm volatile("global_load_dwordx4 a[52:55], %0, off nt" :: "v"(ptr) : "memory", "a52", "a53", "a54", "a55");
-    if constexpr (D == 2) asm volatile("global_load_dwordx4 a[56:59], %0, off nt" :: "v"(ptr) : "memory", "a56", "a57", "a58", "a59");
-    if constexpr (D == 3) asm volatile("global_load_dwordx4 a[60:63], %0, off nt" :: "v"(ptr) : "memory", "a60", "a61", "a62", "a63");
-}
-// wait until at most N vector memory operations are outstanding, then move slot D into x (one statement: nothing in between)
-template <int D, int N>
-__device__ __forceinline__ void stream_take_row(float (&x)[4])
-{
-#define SN_TAKE(r0, r1, r2, r3)                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a" #r0 "\n\tv_accvgpr_read_b32 %1, a" #r1 "\n\tv_accvgpr_read_b32 %2, a" #r2       \
-                 "\n\tv_accvgpr_read_b32 %3, a" #r3 : "=v"(x[0]), "=v"(x[1]), "=v"(x[2]), "=v"(x[3]) : "n"(N) : "memory")
-    if constexpr (D == 0) SN_TAKE(48, 49, 50, 51);
-    if constexpr (D == 1) SN_TAKE(52, 53, 54, 55);
-    if constexpr (D == 2) SN_TAKE(56, 57, 58, 59);
-    if constexpr (D == 3) SN_TAKE(60, 61, 62, 63);
-#undef SN_TAKE
-}
-template <int D>
-__device__ __forceinline__ void stream_take_row_n(float (&x)[4], int n_after)      // n_after: wave-uniform, 0 is always safe
-{
-    if (n_after >= 7) stream_take_row<D, 7>(x);
-    else if (n_after == 6) stream_take_row<D, 6>(x);
-    else if (n_after == 5) stream_take_row<D, 5>(x);
-    else if (n_after == 4) stream_take_row<D, 4>(x);
-    else if (n_after == 3) stream_take_row<D, 3>(x);
-    else if (n_after == 2) stream_take_row<D, 2>(x);
-    else if (n_after == 1) stream_take_row<D, 1>(x);
-    else stream_take_row<D, 0>(x);
-}
-
-__host__ __device__ inline size_t stream_lds_bytes(int L, int feat_h, int feat_w, int nw)
-{
-    return lds_bytes(L, false) + up16((size_t)(2 * feat_h - 1) * (2 * feat_w - 1) * 4) + up16((size_t)L) + (size_t)nw * up16((size_t)L * 4);
-}
-
-__global__ __launch_bounds__(1024) void instance_graph_stream_kernel(const sn_graph_args a, unsigned long long *stamps)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int L = a.L, b = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-    const Lds s = carve(smem, L, false);
-    const int fh = L / a.feat_w, ts_S = 2 * a.feat_w - 1;
-    unsigned char *xp = smem + lds_bytes(L, false);
-    float *TS = reinterpret_cast<float *>(xp);          xp += up16((size_t)(2 * fh - 1) * ts_S * 4);
-    unsigned char *gidx = xp;                           xp += up16((size_t)L);
-    char *stage = reinterpret_cast<char *>(xp) + (size_t)wid * up16((size_t)L * 4);
-    const bool do_v = a.attn_cls != nullptr;
-    const bool sorter = wid == nw - 1;
-    SN_GSTAMP(0);
-    if (tid == 0) s.misc[2] = 0;
-
-    // ---- phase 0: the sorting wave groups the positions by word (and soft-maxes the cls attention); the others build the tables
-    SortedGroups sg;
-    sg.n_groups = 0;
-    bool done = false;
-    float wv0 = 0.0f, wv1 = 0.0f;
-    if (sorter) {
-        __builtin_amdgcn_s_setprio(3);
-        int64_t w4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int q = lane + SN_WAVE * e;
-            w4[e] = q < L ? a.ingredients[(int64_t)b * a.ing_stride_b + (int64_t)q * a.ing_stride_l] : 0;
-        }
-        if (do_v && a.out_v) { wv0 = a.w_v[0]; wv1 = a.w_v[1]; }
-        if (do_v) {                                                  // clamp / softmax / nan_to_num(0)  (schema_net.py:295-297), exact form
-            const float *row = a.attn_cls + (int64_t)b * a.acls_stride_b;
-            float x[4];
-            load_row4<false>(row, L, lane, x);
-            for (int hh = 1; hh < a.acls_heads; ++hh) {
-                float y[4];
-                load_row4<false>(row + hh * a.acls_stride_h, L, lane, y);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] += y[k];
-            }
-            if (a.acls_heads > 1) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = x[k] / (float)a.acls_heads;
-            }
-            if (a.attn_cls_is_logits) {
-                if (a.attn_cls_masked) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c = lane + SN_WAVE * k;
-                        if (c < L) a.attn_cls_masked[(int64_t)b * L + c] = (a.use_clamp_v && x[k] < a.clamp_v) ? -INFINITY : x[k];
-                    }
-                }
-                softmax_row4<false>(x, L, lane, a.use_clamp_v != 0, a.clamp_v);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = sn_nan_to_num(x[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = lane + SN_WAVE * k;
-                if (c < L) s.acls[c] = x[k];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memtime();      // diagnostics: words + cls attention in
-        done = group_positions_sorted<true>(s, L, lane, w4, do_v, sg, reinterpret_cast<float *>(stage));
-        if (stamps && lane == 0) stamps[(size_t)blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memtime();      // ... sorted, records written
-        if (done) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * lane + e;
-                if (sg.key[e] != 0xFFFFFFFFu) gidx[i] = (unsigned char)sg.g[e];       // sorted index -> group
-            }
-            if (lane == 0) s.misc[2] = 1;
-        }
-        __builtin_amdgcn_s_setprio(0);
-    } else {
-        build_grid_prc(s, L, a.feat_w, tid);
-        if (lane < ts_S) {
-            const int dc = lane - (a.feat_w - 1), adc = dc < 0 ? -dc : dc;
-            for (int dr = wid; dr < fh; dr += nw - 1) {           // table rows fh - 1 +- dr hold the same values
-                const float v = grid_table_entry(dr, adc, fh, a.feat_w, a.dist_alpha, a.dist_pow);
-                TS[(fh - 1 + dr) * ts_S + lane] = v;
-                TS[(fh - 1 - dr) * ts_S + lane] = v;
-            }
-        }
-        // The image's map is touched once, a 128-byte line per lane, while the sorting wave sorts (8 us - the 39 MB of a batch take
-        // 7 at the HBM rate): the row stream behind the barrier then reads from L2 / the Infinity Cache instead of starting the
-        // HBM burst of 256 images at a point where every wave of the chip waits for its first rows.
-        {
-            const char *base = reinterpret_cast<const char *>(a.attn + (int64_t)b * a.attn_stride_b);
-            const int64_t row_bytes = (int64_t)L * 4, stride_bytes = a.attn_stride_r * 4;
-            const int lines_per_row = (int)((row_bytes + 127) / 128);
-            const int n_lines = L * lines_per_row;
-            float sink = 0.0f;
-            for (int t = wid * SN_WAVE + lane; t < n_lines; t += (nw - 1) * SN_WAVE) {
-                const int r_ = t / lines_per_row, c_ = t - r_ * lines_per_row;
-                const int64_t off = (int64_t)r_ * stride_bytes + (int64_t)(c_ * 128 < row_bytes - 4 ? c_ * 128 : row_bytes - 4);
-                sink += *reinterpret_cast<const float *>(base + (off & ~(int64_t)3));
-            }
-            asm volatile("" :: "v"(sink));                            // (the values are not used; the loads are waited for here, under the sort)
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    SN_GSTAMP(1);
-    if (s.misc[2] == 0) {
-        // a word that does not fit the sort key (>= 2^24 - 1): this form does not apply; the host never selects it for such ids
-        // (sn_instance_graph checks pad_id), and a caller that passes them anyway gets NaN edges, not silently wrong ones
-        const int n_pad = a.n_pad;
-        for (int64_t i = tid; i < (int64_t)n_pad * n_pad; i += blockDim.x) a.out_e[(int64_t)b * n_pad * n_pad + i] = NAN;
-        if (tid == 0 && a.out_n) a.out_n[b] = 0;
-        return;
-    }
-
-    // ---- vertices (large_scale_feat_to_v.cpp:100-125): the sorting wave holds every word's count and cls-attention sum
-    if (sorter) {
-        const int n_groups = sg.n_groups;
-        if (a.out_n && lane == 0) a.out_n[b] = n_groups;
-        if (a.out_n_max && lane == 0) atomicMax(a.out_n_max, n_groups);
-        if (do_v) {
-            float a0[4], a1[4], m0 = -INFINITY, m1 = -INFINITY;
-            bool nan0 = false, nan1 = false;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a0[e] = (float)sg.cnt[e];
-                a1[e] = a.mean ? sg.sum[e] / (float)sg.cnt[e] : sg.sum[e];
-                if (sg.head[e]) {                                 // max over the words, NaN propagating like at::max (:124)
-                    nan0 = nan0 || (a0[e] != a0[e]); nan1 = nan1 || (a1[e] != a1[e]);
-                    m0 = (a0[e] != a0[e]) ? m0 : fmaxf(m0, a0[e]);
-                    m1 = (a1[e] != a1[e]) ? m1 : fmaxf(m1, a1[e]);
-                }
-            }
-            m0 = __any(nan0) ? NAN : sn_wave_max(m0);
-            m1 = __any(nan1) ? NAN : sn_wave_max(m1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (!sg.head[e] || sg.g[e] >= a.n_pad) continue;
-                const float v0 = sn_nan_to_num(a0[e] / m0), v1 = sn_nan_to_num(a1[e] / m1);
-                const int64_t o = (int64_t)b * a.n_pad + sg.g[e];
-                if (a.out_v2) { a.out_v2[2 * o] = v0; a.out_v2[2 * o + 1] = v1; }
-                if (a.out_v) {
-                    const float t0 = v0 * wv0, t1 = v1 * wv1;
-                    a.out_v[o] = t0 + t1;
-                }
-            }
-            for (int c = n_groups + lane; c < a.n_pad; c += SN_WAVE) {
-                const int64_t o = (int64_t)b * a.n_pad + c;
-                if (a.out_v2) { a.out_v2[2 * o] = 0.0f; a.out_v2[2 * o + 1] = 0.0f; }
-                if (a.out_v) a.out_v[o] = 0.0f;
-            }
-        }
-        if (a.out_ids) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (sg.head[e] && sg.g[e] < a.n_pad) a.out_ids[(int64_t)b * a.n_pad + sg.g[e]] = (int64_t)(sg.key[e] >> 8);
-            for (int c = n_groups + lane; c < a.n_pad; c += SN_WAVE) a.out_ids[(int64_t)b * a.n_pad + c] = a.pad_id;
-        }
-    }
-
-    // ---- phase 1: this wave's run of the sorted order.  Cost of a row 2, of a group 3 more (its scan, gather, store: ~75 and ~115 VALU instructions): wave w starts at
-    // the first group head whose cost-before reaches w / nw of the total
-    const int n_groups = s.misc[0], n_kept = s.misc[1];
-    int i_beg, i_end;
-    {
-        const int ctot = 2 * n_kept + 3 * n_groups;
-        auto first_head_at = [&](int target) {                    // smallest head index i with 2 i + 3 gidx[i] >= target (n_kept: none)
-            int best = n_kept;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = 4 * lane + e;
-                bool pred = false;
-                if (i < n_kept) {
-                    const int g = gidx[i];
-                    const bool head = i == 0 || (int)gidx[i - 1] != g;
-                    pred = head && 2 * i + 3 * g >= target;
-                }
-                const unsigned long long m = __ballot(pred);
-                if (m) { const int i0 = 4 * (__ffsll((long long)m) - 1) + e; best = i0 < best ? i0 : best; }
-            }
-            return best;
-        };
-        i_beg = wid == 0 ? 0 : first_head_at((ctot * wid + nw - 1) / nw);
-        i_end = wid == nw - 1 ? n_kept : first_head_at((ctot * (wid + 1) + nw - 1) / nw);
-    }
-    // lane constants.  A row is held as in memory: lane l has the positions q = 4 l + k
-    const bool lane_ok = 4 * lane < L;
-    int qsidx4[4], qts[4];
-    float rcq[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int q = lane_ok ? 4 * lane + k : 0;
-        const int si = s.flag[q];                                 // position -> sorted index
-        const int g = gidx[si];
-        qsidx4[k] = si * 4;
-        rcq[k] = lane_ok ? 1.0f / (float)((int)s.gstart[g + 1] - (int)s.gstart[g]) : 0.0f;
-        const int rc = s.prc[q];
-        qts[k] = ((fh - 1 - (rc >> 8)) * ts_S + (a.feat_w - 1 - (rc & 255))) * 4;
-    }
-    // this wave's rows: lane j holds the position, the signed-table base and the last-of-group flag of sorted index i_beg + j
-    // (a run longer than 64 rows - an image of very few words - is walked in pieces)
-    const float w0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.w_e[0])));
-    const float w1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a.w_e[1])));
-    // segment heads of the sorted order for the lane's four sorted indices 4 lane + e, and the cross-lane flags of the scan (see
-    // instance_graph_kernel: Hillis-Steele on the DPP network, the flag half run once)
-    unsigned hd = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = 4 * lane + e;
-        bool head = true;
-        if (i > 0 && i < n_kept) head = gidx[i] != gidx[i - 1];
-        hd |= head ? (1u << e) : 0u;
-    }
-    unsigned take = 0;
-    {
-        int fl = hd != 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int fup = __shfl_up(fl, 1 << i, SN_WAVE);
-            if ((lane & 15) >= (1 << i)) { take |= fl ? 0u : (1u << i); fl |= fup; }
-        }
-        {
-            const int fup = __shfl(fl, (lane & 48) - 1, SN_WAVE);
-            if ((lane >> 4) & 1) { take |= fl ? 0u : (1u << 4); fl |= fup; }
-        }
-        {
-            const int fup = __shfl(fl, 31, SN_WAVE);
-            if (lane >= 32) { take |= fl ? 0u : (1u << 5); fl |= fup; }
-        }
-    }
-    const float nh1 = (hd & 2) ? 0.0f : 1.0f, nh2 = (hd & 4) ? 0.0f : 1.0f, nh3 = (hd & 8) ? 0.0f : 1.0f;
-    const float cf0 = (hd & 1) ? 0.0f : 1.0f, cf1 = (hd & 3) ? 0.0f : 1.0f, cf2 = (hd & 7) ? 0.0f : 1.0f, cf3 = (hd & 15) ? 0.0f : 1.0f;
-    float tk[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) tk[i] = ((take >> i) & 1u) ? 1.0f : 0.0f;
-    // output columns of a lane: c = 4 lane + k (one 16-byte store per lane and row) or lane + 64 k; a cell is the scan value at the last sorted index of word c
-    int last4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = (a.n_pad & 3) == 0 ? 4 * lane + k : lane + SN_WAVE * k;
-        last4[k] = c < n_groups ? ((int)s.gstart[c + 1] - 1) * 4 : 0;
-    }
-    const int n_cols = a.n_pad < n_groups ? a.n_pad : n_groups;
-    const float *src = a.attn + (int64_t)b * a.attn_stride_b;
-    const bool is_logits = a.attn_is_logits != 0, use_clamp = a.use_clamp_e != 0;
-    const float clamp = a.clamp_e;
-
-    // one inclusive segmented scan of the wave over the staged vector (sorted order), in place
-    auto scan_stage = [&](const float (&z)[4]) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane_ok) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<float *>(stage + qsidx4[k]) = z[k];
-        }
-        __builtin_amdgcn_wave_barrier();
-        f32x4 v4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (lane_ok) v4 = *reinterpret_cast<const f32x4 *>(stage + 16 * lane);
-        const float s0 = v4.x;
-        const float s1 = fmaf(s0, nh1, v4.y);
-        const float s2 = fmaf(s1, nh2, v4.z);
-        const float s3 = fmaf(s2, nh3, v4.w);
-        float run = s3;
-#define SN_SCAN_STEP(i, ctrl, rows)                                                                                            \
-        asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " ctrl " row_mask:" rows " bank_mask:0xf bound_ctrl:0" : "+v"(run) : "v"(tk[i]));
-        SN_SCAN_STEP(0, "row_shr:1", "0xf")
-        SN_SCAN_STEP(1, "row_shr:2", "0xf")
-        SN_SCAN_STEP(2, "row_shr:4", "0xf")
-        SN_SCAN_STEP(3, "row_shr:8", "0xf")
-        SN_SCAN_STEP(4, "row_bcast:15", "0xa")
-        SN_SCAN_STEP(5, "row_bcast:31", "0xc")
-#undef SN_SCAN_STEP
-        float carry;
-        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(carry) : "v"(run));
-        v4.x = fmaf(carry, cf0, s0);
-        v4.y = fmaf(carry, cf1, s1);
-        v4.z = fmaf(carry, cf2, s2);
-        v4.w = fmaf(carry, cf3, s3);
-        __builtin_amdgcn_wave_barrier();
-        if (lane_ok) *reinterpret_cast<f32x4 *>(stage + 16 * lane) = v4;
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    // The row stream.  Loads and stores of the loop are written out (asm) and waited for by hand: hipcc counts every vector memory
-    // operation it issues itself and, with a store of unknown presence between the loads of a ring, waits for all but the ring's
-    // three youngest operations - stores included - i.e. for rows that were requested last: one row in flight per wave instead
-    // of four (measured: 3.4 k cycles per row).  Here a shift register of "this iteration stored" bits gives the exact number of
-    // operations younger than the row about to be used.
-    const bool vec_store = (a.n_pad & 3) == 0;                   // one dwordx4 per lane and output row (the row's start is 16-byte aligned)
-    float csa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, csg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    unsigned st_hist = 0;                                        // bit t: the iteration t + 1 before this one issued a store
-    for (int piece = i_beg; piece < i_end; piece += SN_WAVE) {
-        const int n_here = i_end - piece < SN_WAVE ? i_end - piece : SN_WAVE;
-        int prow = 0, ptp = 0, plast = 0, pgrp = 0;
-        if (lane < n_here) {
-            const int i = piece + lane;
-            prow = s.pos_sorted[i];
-            const int rc = s.prc[prow];
-            ptp = ((rc >> 8) * ts_S + (rc & 255)) * 4;
-            pgrp = gidx[i];
-            plast = (i + 1 >= n_kept || (int)gidx[i + 1] != pgrp) ? 1 : 0;
-        }
-        const int cq = min(lane * 4, L - 4);                      // (lanes past the row re-read its end: masked by the soft-max)
-        auto row_ptr = [&](int j) { return src + (int64_t)__builtin_amdgcn_readlane(prow, j) * a.attn_stride_r + cq; };
-        st_hist = 0;
-        // (iterations j < 0 only request: the ring is primed by the loop itself)
-        for (int j0 = -kStreamDepth; j0 < n_here; j0 += kStreamDepth) {
-            static_for_stream([&](auto d_c) {
-                constexpr int d = decltype(d_c)::value;
-                const int j = j0 + d;
-                if (j >= n_here) return;                          // wave-uniform
-                if (j < 0) {
-                    if (j + kStreamDepth < n_here) stream_load_row<d>(row_ptr(j + kStreamDepth));
-                    return;
-                }
-                // row j has landed when at most (loads issued after it) + (stores issued after it) operations are outstanding
-                const int loads_after = (n_here - 1 - j) < (kStreamDepth - 1) ? (n_here - 1 - j) : (kStreamDepth - 1);
-                float x[4];
-                stream_take_row_n<d>(x, loads_after + __builtin_popcount(st_hist & ((1u << kStreamDepth) - 1u)));
-                if (j + kStreamDepth < n_here) stream_load_row<d>(row_ptr(j + kStreamDepth));
-                st_hist <<= 1;
-                if (is_logits) softmax_row4<true, true>(x, L, lane, use_clamp, clamp);
-                const char *tp = reinterpret_cast<const char *>(TS) + __builtin_amdgcn_readlane(ptp, j);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    csa[k] += x[k];
-                    csg[k] += *reinterpret_cast<const float *>(tp + qts[k]);
-                }
-                if (!__builtin_amdgcn_readlane(plast, j)) return;
-                // ---- the group is complete: its output row
-                const int gi = __builtin_amdgcn_readlane(pgrp, j);
-                float u0[4], u1[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { u0[k] = csg[k] * rcq[k]; u1[k] = csa[k] * rcq[k]; csa[k] = 0.0f; csg[k] = 0.0f; }
-                const float T0 = wave_sum_fast((u0[0] + u0[1]) + (u0[2] + u0[3]));          // instance_edges.sum(1, keepdim)  :135 (up to the row's 1 / n_i, which cancels)
-                const float T1 = wave_sum_fast((u1[0] + u1[1]) + (u1[2] + u1[3]));
-                const bool plain = T0 > 0.0f && T0 < INFINITY && T1 > 0.0f && T1 < INFINITY;      // wave-uniform
-                if (gi >= a.n_pad) return;
-                float *orow = a.out_e + ((int64_t)b * a.n_pad + gi) * a.n_pad;
-                float e4[4];                                      // the lane's cells: columns 4 lane + k (vec_store) or lane + 64 k
-                if (plain) {
-                    const float a0 = w0 * __builtin_amdgcn_rcpf(T0), a1 = w1 * __builtin_amdgcn_rcpf(T1);
-                    float z[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) z[k] = fmaf(a0, u0[k], a1 * u1[k]);
-                    scan_stage(z);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) e4[k] = *reinterpret_cast<const float *>(stage + last4[k]);
-                } else {                                         // a total that is 0, inf or NaN: the general form, value for value
-                    float e0[4], e1[4];
-                    scan_stage(u0);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) e0[k] = *reinterpret_cast<const float *>(stage + last4[k]);
-                    scan_stage(u1);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) e1[k] = *reinterpret_cast<const float *>(stage + last4[k]);
-                    const float i0 = __builtin_amdgcn_rcpf(T0), i1 = __builtin_amdgcn_rcpf(T1);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float p0 = sn_nan_to_num(e0[k] * i0) * w0, p1 = sn_nan_to_num(e1[k] * i1) * w1;
-                        e4[k] = p0 + p1;
-                    }
-                }
-                if (vec_store) {
-                    // columns 4 lane .. + 3 (the cells past the image's vertex count inside the last quad: zeros - the consumer masks by n)
-                    if (4 * lane < n_cols) {
-                        const f32x4 v = {e4[0], 4 * lane + 1 < n_cols ? e4[1] : 0.0f, 4 * lane + 2 < n_cols ? e4[2] : 0.0f, 4 * lane + 3 < n_cols ? e4[3] : 0.0f};
-                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(orow + 4 * lane), "v"(v) : "memory");
-                    }
-                    st_hist |= 1u;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c = lane + SN_WAVE * k;
-                        if (c < n_cols) orow[c] = e4[k];
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (stores the loop does not count: drained)
-                }
-            });
-        }
-    }
-    if (stamps && lane == 0 && wid >= 4) stamps[(size_t)blockIdx.x * 16 + wid] = __builtin_amdgcn_s_memtime();      // diagnostics: slot w = wave w is done (w >= 2; slots 0, 1: start, barrier)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2309,17 +1918,6 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
             rv.ids = r.ids; rv.isb = r.ids_stride_b; rv.isl = r.ids_stride_l;
             rv.M = r.M; rv.D = r.D; rv.n_tiles = lay.n_tiles;
             rr = r.D / 64;                                        // (sn_assign_defers: D in {192, 384})
-        }
-        // the group-streamed form: the prediction configuration, one map per image, no deferred finish, ids that fit the sort key
-        static const int stream_on = getenv("SN_S3_STREAM") ? atoi(getenv("SN_S3_STREAM")) : 1;
-        if (stream_on && fast && rr == 0 && a.attn_heads <= 1 && 2 * a.feat_w - 1 <= SN_WAVE && a.pad_id >= 0 && a.pad_id < (1 << 24) - 1 && a.n_pad <= kMaxCols) {
-            const size_t lds_s = stream_lds_bytes(a.L, a.feat_h, a.feat_w, 16);
-            if (int rc = ensure_lds((const void *)instance_graph_stream_kernel, lds_s, "sn_instance_graph")) return rc;
-            sn_prof_start(2, st);
-            hipLaunchKernelGGL(instance_graph_stream_kernel, dim3(a.B), dim3(1024), lds_s, st, a, g_graph_stamps);
-            sn_prof_stop(2, st);
-            SN_CHECK_LAUNCH("sn_instance_graph");
-            return SN_OK;
         }
         const void *fn = rr == 3 ? (const void *)instance_graph_kernel<true, true, 3>
                        : rr == 6 ? (const void *)instance_graph_kernel<true, true, 6>
