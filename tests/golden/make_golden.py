@@ -349,11 +349,11 @@ def predictor_graph():
 TRAJ = dict(B=8, L=196, M=128, K=5, n_max=48, E=32, iters=30, seed0=500, eval_seed=990, lr=1.0e-2, wd=0.05, wd_schema_net=5.0e-4)
 
 
-def _trajectory_run(perturb=0.0):
-    """-> (predictor, sn, losses, cls_losses): TRAJ["iters"] reference iterations; perturb: relative size of a random
-    perturbation of the initial GNN / attribute weights (what a different summation order does to them after one step)"""
+def _trajectory_run(perturb=0.0, c=None):
+    """-> (predictor, sn, losses, cls_losses): c["iters"] reference iterations (c: TRAJ by default); perturb: relative size of a
+    random perturbation of the initial GNN / attribute weights (what a different summation order does to them after one step)"""
     from schema_inference.utils.customs_param_group import customs_param_group
-    c = TRAJ
+    c = c or TRAJ
     B, L, M, K, n_max, E = c["B"], c["L"], c["M"], c["K"], c["n_max"], c["E"]
     sn = make_schema_net(M, K, n_max=n_max, seed=21)
     torch.manual_seed(22)
@@ -439,6 +439,52 @@ def trajectory():
     save("trajectory.npz", **rec)
 
 
+# --------------------------------------------------------------------------- a second trajectory, at a size where the HIP
+# package takes its matrix-core route in training (GNN width 256, 512 words, class graphs of 128 vertices, 10 classes; VERDICT
+# r04 item 8).  The state is 3 MB, so the fixture holds what pins it instead of the tensors: the construction seeds (the
+# package's constructors draw the reference's RNG sequence),
+# float64 checksums of every initial tensor (the test re-creates the state from the seeds and must hit them), the reference's loss of every iteration, 2048 seeded samples of every final tensor
+# and the scores of a held-out batch.
+TRAJ2 = dict(B=8, L=196, M=512, K=10, n_max=128, E=256, iters=10, seed0=700, eval_seed=1990, lr=1.0e-3, wd=0.05, wd_schema_net=5.0e-4)
+
+
+def trajectory_mfma():
+    c = TRAJ2
+    B, L, M, K, n_max, E = c["B"], c["L"], c["M"], c["K"], c["n_max"], c["E"]
+    predictor, sn, init, losses, cls_losses = _trajectory_run(c=c)
+    rec = dict(case=np.asarray([B, L, M, K, n_max, E, c["iters"], c["seed0"], c["eval_seed"]]),
+               hyper=np.asarray([c["lr"], c["wd"], c["wd_schema_net"]]), seeds=np.asarray([21, 22, 23]))
+    # (the initial state is re-created by the test from the seeds; these checksums pin it)
+    for k, v in init.items():
+        rec["init_sum:" + k] = np.float64(v.double().sum()) if v.dtype.is_floating_point else np.float64(v.sum())
+        rec["init_abs:" + k] = np.float64(v.double().abs().sum()) if v.dtype.is_floating_point else np.float64(v.abs().sum())
+    twin, _, _, twin_losses, _ = _trajectory_run(perturb=6.0e-8, c=c)
+    rec["selfdev_loss"] = np.abs(np.asarray(losses) - np.asarray(twin_losses)) / np.abs(np.asarray(losses))
+    print("trajectory_mfma: the reference against itself under a 6e-8 perturbation: loss drift max %.2e" % rec["selfdev_loss"].max())
+    rec["loss"] = np.asarray(losses, np.float64)
+    rec["loss_cls"] = np.asarray(cls_losses, np.float64)
+    rng = np.random.default_rng(4242)
+    for (k, v), (_, tw) in zip(predictor.state_dict().items(), twin.state_dict().items()):
+        flat = v.detach().reshape(-1).numpy()
+        idx = np.sort(rng.choice(flat.size, size=min(2048, flat.size), replace=False))
+        rec["final_idx:" + k] = idx.astype(np.int64)
+        rec["final_val:" + k] = flat[idx].copy()
+        if v.dtype.is_floating_point:
+            d = (v - tw).abs().flatten()
+            d = d[~torch.isnan(d)]
+            rec["selfdev_p99:" + k] = np.float64(torch.quantile(d.double(), 0.99)) if d.numel() else np.float64(0)
+    ing, attn, attn_cls, label = datagen.labelled_case(B, L, M, K, c["eval_seed"])
+    predictor.eval()
+    with torch.no_grad():
+        sn.normalize()
+        pred = predictor({"ingredients": T(ing), "attn": T(attn), "attn_cls": T(attn_cls)})["pred"]
+    rec["eval_pred"] = pred.numpy()
+    rec["eval_top1"] = pred.argmax(1).numpy()
+    rec["eval_label"] = label
+    print("trajectory_mfma: loss", " ".join(f"{x:.5f}" for x in losses), "| eval top-1", rec["eval_top1"].tolist(), "labels", label.tolist())
+    save("trajectory_mfma.npz", **rec)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # e.g. `make_golden.py trajectory`: regenerate one fixture
         for name in sys.argv[1:]:
@@ -452,3 +498,4 @@ if __name__ == "__main__":
     train_step()
     predictor_graph()
     trajectory()
+    trajectory_mfma()
