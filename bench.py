@@ -715,13 +715,12 @@ def main():
         graph_bytes = B * (L * L * 4 + L * 4 + L * 8) + int((g["n"].long() ** 2).sum().item()) * 4 + B * L * 12
         g_ach = (graph_bytes / (avg["instance_graph"] * 1e-3) / 1e9) if avg["instance_graph"] else None
         variant = lib.sn_assign_variant()
-        screen_name = {2: "assign_screen2_kernel<4,24> (S1 fp16-MFMA screen, codebook-stationary)",
-                       3: "assign_screen3_kernel<8> (S1 fp16-MFMA screen, K-outer token stream)"}.get(
-                           variant, "assign_screen_kernel<24,4,3,8,false> (S1 fp16-MFMA screen, token-stationary)")
+        screen_name = {5: "assign_screen5_kernel<12,0> (S1 fp16-MFMA screen, K-outer one-round form: opt-in, SN_ASSIGN_VARIANT=5)"}.get(
+            variant, "assign_screen_kernel<24,4,3,8,false> (S1 fp16-MFMA screen, token-stationary)")
         copy_gbps = stream_copy_GBps(device)
         ev_floor = event_pair_floor_ms()
         traffic, traffic_s3, traffic_src = None, None, None      # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
-        for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     for row in json.load(fh)["kernels"]:
