@@ -984,6 +984,159 @@ def sym_adj_matmul(adj, x, adj_planes=None):
     return _SymAdjMatmul.apply(adj, x, adj_planes)
 
 
+def _plane_batches(p, g0, g1):
+    """the planes of the batch entries g0 .. g1 - 1 (views)"""
+    return Planes(p.hi[g0:g1], p.lo[g0:g1], g1 - g0, p.rows, p.k, p.scale)
+
+
+_DW_TEMP_BYTES = 256 << 20     # largest [group, out, in] fp32 temporary of a per-graph weight gradient
+
+
+def _weight_grad_per_graph(dyt, xt):
+    """sum_g dY[g]^T X[g] from the planes of dY^T [G, out, n] and X^T [G, in, n]: G products of inner length n and one sum over G
+    (one [out, in] product of inner length G n would be (out / 128) x (in / 256) workgroups walking 100 k rows each); graphs in
+    groups when the [G, out, in] temporary would pass _DW_TEMP_BYTES (config [3]: 1000 class graphs of width 1024 = 4.2 GB)."""
+    G, out_f, in_f = dyt.batches, dyt.rows, xt.rows
+    group = max(1, min(G, _DW_TEMP_BYTES // max(1, 4 * out_f * in_f)))
+    if group >= G:
+        return gcn_gemm(dyt, xt, G, want_c=True)["c"].sum(dim=0)
+    dw = None
+    for g0 in range(0, G, group):
+        g1 = min(G, g0 + group)
+        part = gcn_gemm(_plane_batches(dyt, g0, g1), _plane_batches(xt, g0, g1), g1 - g0, want_c=True)["c"].sum(dim=0)
+        dw = part if dw is None else dw.add_(part)
+    return dw
+
+
+class _LinearMfma(torch.autograd.Function):
+    """y = x W^T (+ b) on x [G, n, in] (or [rows, in]) with all three products - forward, dX = dY W, dW = sum_g dY[g]^T X[g] - as
+    split-fp16 MFMA GEMMs (sn_gcn_gemm: fp32-GEMM accuracy): the training side's Linear layers (reference gnn.py:31,
+    `self.linear(torch.bmm(adj, feat))`) without a library GEMM.
+        forward   A = planes of X [G, n, in],        Bt = planes of W [out, in] (shared by the graphs), bias in the epilogue
+        dX        A = planes of dY [G, n, out],      Bt = planes of W^T [in, out]
+        dW        A = planes of dY^T [G, out, n],    Bt = planes of X^T [G, in, n]: per graph, summed over G"""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, weight, bias):
+        x3 = _f32c(x.detach())
+        x3 = x3[None] if x3.dim() == 2 else x3
+        G = x3.shape[0]
+        xp, wp = split_planes(x3), split_planes(weight.detach())
+        y = gcn_gemm(xp, wp, G, bias=bias, want_c=True)["c"]
+        ctx.save_for_backward(x, weight)
+        ctx.scales = (xp.scale, wp.scale)
+        ctx.has_bias = bias is not None
+        return y[0] if x.dim() == 2 else y
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        x_scale, w_scale = ctx.scales
+        dx = dw = db = None
+        dy3, x3 = _f32c(dy), _f32c(x.detach())
+        if x.dim() == 2:
+            dy3, x3 = dy3[None], x3[None]
+        G = x3.shape[0]
+        if dy3.numel() == 0:
+            return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None, torch.zeros_like(weight) if ctx.needs_input_grad[1] else None,
+                    torch.zeros(weight.shape[0], dtype=weight.dtype, device=weight.device) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+        dy_scale = pow2_scale(dy3)                              # one reduction over dY for both of its plane forms
+        if ctx.needs_input_grad[0]:
+            dx = gcn_gemm(split_planes(dy3, scale=dy_scale), split_planes(weight.detach(), scale=w_scale, transpose=True), G, want_c=True)["c"]
+            dx = dx[0] if x.dim() == 2 else dx
+        if ctx.needs_input_grad[1]:
+            dw = _weight_grad_per_graph(split_planes(dy3, scale=dy_scale, transpose=True), split_planes(x3, scale=x_scale, transpose=True))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy3.sum(dim=(0, 1))
+        return dx, dw, db
+
+
+def linear_mfma(x, weight, bias=None):
+    """x [G, n, in] or [rows, in] fp32 (CUDA; in and out multiples of 16), weight [out, in], bias [out] or None -> x W^T + b,
+    differentiable in all three, every product on the matrix cores (no library GEMM)."""
+    return _LinearMfma.apply(x, weight, bias)
+
+
+class _GatherAdjMatmul(torch.autograd.Function):
+    """Y = ((E + E^T)/2 + I) @ table[ids] + bias from the edge tensor E [G, n, n], a table [rows, F] and ids [G, n]: layer 1 of
+    the GCN in training with its Linear folded into the embedding table (`table` = embedding.weight @ W1^T, a [rows, F] product
+    instead of the [G n, F] one of reference gnn.py:31 - the same re-association the inference route makes, gnn.py `prepare`).
+    The gathered operand only ever exists as fp16 planes (sn_gcn_gather_planes); no [G, n, F] fp32 embedding is written.
+        backward   dTable = scatter-add by ids of adj . dY   (a cached sort of the ids, or the library's embedding backward)
+                   dE = (S + S^T)/2, S = dY . table[ids]^T   (summed over the layers that share `adj_planes`, as _EdgesAdjMatmul)
+                   dBias = sum of dY over graphs and vertices"""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, edges, table, ids, bias, adj_planes, sort, padding_idx, sum_edge_grads):
+        G = edges.shape[0]
+        tab = _f32c(table.detach())
+        t_scale = pow2_scale(tab)
+        zt = gcn_gather_planes(tab, ids, scale=t_scale)
+        y = gcn_gemm(adj_planes, zt, G, bias=bias, want_c=True)["c"]
+        ctx.save_for_backward(tab, ids, *(sort if sort is not None else ()))
+        ctx.adj_planes, ctx.t_scale, ctx.has_bias = adj_planes, t_scale, bias is not None
+        ctx.pad = int(padding_idx) if padding_idx is not None else -1
+        ctx.adj_like = torch.empty(edges.shape, dtype=edges.dtype, device="meta")
+        ctx.counted = bool(sum_edge_grads) and bool(ctx.needs_input_grad[0]) and os.environ.get("SN_GCN_SUM_DE", "1") != "0"
+        if ctx.counted:
+            adj_planes.pending += 1
+        return y
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, dy):
+        tab, ids, *sort = ctx.saved_tensors
+        ap = ctx.adj_planes
+        G, n = ids.shape
+        rows, F = tab.shape
+        dy = _f32c(dy)
+        d_e = d_tab = d_b = None
+        if dy.numel() == 0:
+            return (torch.zeros(ctx.adj_like.shape, dtype=ctx.adj_like.dtype, device=tab.device) if ctx.needs_input_grad[0] else None,
+                    torch.zeros_like(tab) if ctx.needs_input_grad[1] else None, None,
+                    torch.zeros(F, dtype=tab.dtype, device=tab.device) if ctx.has_bias and ctx.needs_input_grad[3] else None, None, None, None, None)
+        dy_scale = pow2_scale(dy)
+        if ctx.needs_input_grad[1]:
+            dz = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True)["c"].reshape(-1, F)
+            if sort:
+                lib = N.require_gpu()
+                d_tab = torch.empty((rows, F), dtype=torch.float32, device=dz.device)
+                with torch.cuda.device(dz.device):
+                    N.check(lib.sn_embedding_grad_sorted(N.ptr(dz), N.ptr(sort[0]), N.ptr(sort[1]), rows, F, ctx.pad, N.ptr(d_tab), N.stream_ptr(dz.device)),
+                            "sn_embedding_grad_sorted")
+            else:
+                d_tab = torch.ops.aten.embedding_dense_backward(dz, ids, rows, ctx.pad, False)
+        if ctx.needs_input_grad[0]:
+            dyp = split_planes(dy, scale=dy_scale)
+            zp = split_planes(torch.nn.functional.embedding(ids, tab), scale=ctx.t_scale)
+            if not ctx.counted:
+                d_e = sym_half_(gcn_gemm(dyp, zp, G, want_c=True)["c"])
+            else:
+                if ap.grad_sum is None:
+                    ap.grad_sum = gcn_gemm(dyp, zp, G, want_c=True)["c"]
+                else:
+                    gcn_gemm(dyp, zp, G, accumulate_into=ap.grad_sum)
+                ap.pending -= 1
+                if ap.pending == 0:
+                    d_e, ap.grad_sum = sym_half_(ap.grad_sum), None
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            d_b = dy.sum(dim=(0, 1))
+        return d_e, d_tab, None, d_b, None, None, None, None
+
+
+def gather_adj_matmul(edges, table, ids, bias=None, adj_planes=None, sort=None, padding_idx=None, sum_edge_grads=False):
+    """edges [G, n, n], table [rows, F] (F a multiple of 16), ids int64 [G, n] with values in [0, rows) -> ((edges + edges^T)/2 + I) @
+    table[ids] + bias [G, n, F], differentiable in edges, table and bias.  sort = sorted_ids_of(ids, rows) when the caller keeps it
+    (ids that stay the same over the iterations); padding_idx: that row of the table gets no gradient (nn.Embedding's rule).
+    sum_edge_grads: as edges_adj_matmul."""
+    if adj_planes is None:
+        adj_planes = gcn_adjacency_planes(edges.detach())
+    return _GatherAdjMatmul.apply(edges, table, ids.contiguous(), bias, adj_planes, sort, padding_idx, sum_edge_grads)
+
+
 def pool_fc(pooled_sum, divisor, weight, bias, weight_t=None):
     """fc(pooled / divisor) with pooled = pooled_sum [G, E] or the sum over dim 1 of [G, parts, E]
     (the per-row-tile partial sums of gcn_gemm); divisor: int32 [1] device tensor or a number.

@@ -1018,21 +1018,48 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     }
     // ---- stores
     if (p.c) {
+        bool added = false;
+        if constexpr (!LN && !GB) {
+            if (p.accumulate) {
+                // c += result: the old values of four rows (16 per lane) are ALL requested before the first sum is stored (the stores go
+                // through the same pointer, so the compiler keeps every later load behind them: a chain of 128 load - add - store round
+                // trips per lane ran the 424 MB read-modify-write of config [4]'s edge gradient at 1 TB/s: 620 us against 206 us for the
+                // plain store)
+                added = true;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int m = tile_m + (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (m >= p.m) continue;
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float old[4][4];
+                        float *row = p.c + (int64_t)batch * p.c_batch_stride + (int64_t)(tile_m + (2 * wm + i) * 32 + 8 * q4 + 4 * h) * p.ldc + tile_n + 4 * wn * 32 + r;
+                        const int m0 = tile_m + (2 * wm + i) * 32 + 8 * q4 + 4 * h, n0 = tile_n + 4 * wn * 32 + r;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = tile_n + (4 * wn + j) * 32 + r;
-                    if (n < p.n) {
-                        float *dst = p.c + (int64_t)batch * p.c_batch_stride + (int64_t)m * p.ldc + n;
-                        *dst = p.accumulate ? *dst + acc[i][j][q] : acc[i][j][q];
+                        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                old[qq][j] = (m0 + qq < p.m && n0 + 32 * j < p.n) ? __builtin_nontemporal_load(row + (int64_t)qq * p.ldc + 32 * j) : 0.0f;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (m0 + qq < p.m && n0 + 32 * j < p.n) row[(int64_t)qq * p.ldc + 32 * j] = old[qq][j] + acc[i][j][4 * q4 + qq];
+                    }
+            }
+        }
+        if (!added) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = tile_m + (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (m >= p.m) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = tile_n + (4 * wn + j) * 32 + r;
+                        if (n < p.n) p.c[(int64_t)batch * p.c_batch_stride + (int64_t)m * p.ldc + n] = acc[i][j][q];
                     }
                 }
-            }
+        }
     }
     // Blocked hi/lo planes of the result (row m, k = n).  The accumulator holds a column per lane; the
     // planes want 8 consecutive k per 16-byte piece, so each wave transposes its 32 x 128 sub-tile through
@@ -1335,7 +1362,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     SN_REQUIRE(!u->layernorm || (u->n == kTileN && u->gamma && u->beta), SN_ERR_UNSUPPORTED,
                "sn_gcn_gemm: the LayerNorm epilogue needs n == 256 (got %d) and gamma/beta", u->n);
     SN_REQUIRE(!u->pooled || u->pool_w, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooling without weights");
-    SN_REQUIRE(!u->accumulate || (u->c && !u->c_hi && !u->pooled && !u->bias && !u->layernorm && !u->relu && !u->rows_valid && !u->m_extent), SN_ERR_UNSUPPORTED,
+    SN_REQUIRE(!u->accumulate || (u->c && !u->c_hi && !u->pooled && !u->bias && !u->layernorm && !u->relu && !u->rows_valid && !u->m_extent && !gathered), SN_ERR_UNSUPPORTED,
                "sn_gcn_gemm: accumulate is for the plain fp32 product only");
     SN_REQUIRE(u->batches <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: batches=%d > 65535", u->batches);
     GemmArgs a;

@@ -8,7 +8,8 @@ epilogues (csrc/sn_gcn.hip; `_forward_mfma`, `_forward_mfma_wide`), fp32-GEMM ac
 within the 1e-5 budget; other configurations use the library GEMMs with HIP kernels in between.
 Training (any input or parameter requires grad): the same maths as differentiable torch ops, with the
 adjacency products adj @ X - forward and both gradients, the 27 GFLOP per step of the class graphs - on the
-same MFMA GEMM through `ops.sym_adj_matmul` (an autograd.Function); the Linear layers stay library GEMMs.
+same MFMA GEMM through `ops.edges_adj_matmul` (an autograd.Function); layer 1's Linear folded into the embedding table as in
+inference (`ops.gather_adj_matmul`), the other Linear layers and `fc` through `ops.linear_mfma`: no library GEMM in an iteration.
 """
 import math
 import os
@@ -76,10 +77,15 @@ _DW_TEMP_BYTES = 256 << 20     # largest [group, out, in] fp32 temporary of _Lin
 
 
 def _linear(lin, x):
-    """`lin(x)`; for a batch of graphs on the GPU under autograd: the form above."""
-    if isinstance(lin, nn.Linear) and x.dim() == 3 and x.is_cuda and torch.is_grad_enabled() and lin.weight.requires_grad \
-            and x.shape[0] > 1 and os.environ.get("SN_LINEAR_PER_GRAPH_DW", "1") != "0":
-        return _LinearPerGraphWeightGrad.apply(x, lin.weight, lin.bias)
+    """`lin(x)`; for a batch of graphs on the GPU under autograd: on the matrix cores (ops.linear_mfma: forward and both gradients
+    as split-fp16 MFMA GEMMs, no library GEMM in a training iteration), or - SN_LINEAR_MFMA=0 - the library's GEMMs with the
+    per-graph weight gradient above."""
+    if isinstance(lin, nn.Linear) and x.is_cuda and torch.is_grad_enabled() and lin.weight.requires_grad and x.dim() in (2, 3) and x.shape[0] > 0:
+        if (x.dtype == torch.float32 and lin.in_features % 16 == 0 and lin.out_features % 16 == 0 and os.environ.get("SN_GCN_MFMA", "1") != "0"
+                and os.environ.get("SN_LINEAR_MFMA", "1") != "0"):
+            return ops.linear_mfma(x, lin.weight, lin.bias)
+        if x.dim() == 3 and x.shape[0] > 1 and os.environ.get("SN_LINEAR_PER_GRAPH_DW", "1") != "0":
+            return _LinearPerGraphWeightGrad.apply(x, lin.weight, lin.bias)
     return lin(x)
 
 
@@ -119,9 +125,11 @@ class Layer(nn.Module):
 
     def forward(self, edges: torch.Tensor, feat: torch.Tensor, feat_mask: torch.BoolTensor = None,
                 adj: torch.Tensor = None, n_valid: torch.Tensor = None, fused: bool = False, adj_planes=None, sum_edge_grads=False):
-        feat = self.g_conv(edges, feat, adj, adj_planes, sum_edge_grads)
+        return self.post(self.g_conv(edges, feat, adj, adj_planes, sum_edge_grads), feat_mask, n_valid, fused)
+
+    def post(self, feat: torch.Tensor, feat_mask: torch.BoolTensor = None, n_valid: torch.Tensor = None, fused: bool = False):
+        """what follows the graph convolution: pad rows -> 0, LayerNorm, activation (reference gnn.py:43-46)"""
         if fused and (self._is_relu or self._is_none) and feat.is_contiguous():
-            # pad rows -> 0, LayerNorm, ReLU in one pass (reference gnn.py:43-46)
             return ops.mask_layernorm_act_(feat, self.norm.weight, self.norm.bias, self.norm.eps,
                                            n_valid=n_valid, relu=self._is_relu)
         if (feat.is_cuda and feat.dim() == 3 and feat.dtype == torch.float32 and torch.is_grad_enabled() and (self._is_relu or self._is_none)
@@ -151,22 +159,29 @@ class GNN(nn.Module):
         with torch.no_grad():
             nn.init.trunc_normal_(self.embedding.weight[:num_codes])
 
+    def _cached_sort(self, ids: torch.Tensor, rows: int):
+        """(order, seg) of an index tensor that is a module's buffer / Parameter (the class graphs' words,
+        `SchemaNet.class_ingredients`: the same in every iteration): its sort is taken once per version of the tensor and kept ON
+        it; None for any other index tensor, or when a sort would be needed while a stream capture is running."""
+        if not (isinstance(ids, nn.Parameter) and not ids.requires_grad and ids.is_cuda and os.environ.get("SN_EMBED_SORTED", "1") != "0"):
+            return None
+        srt = getattr(ids, "_sn_sorted", None)
+        if srt is None or srt[0] != (ids._version, rows):
+            if torch.cuda.is_current_stream_capturing():
+                return None                                  # (a sort cannot be captured: whoever captures warms up first)
+            with torch.no_grad():
+                srt = ((ids._version, rows),) + ops.sorted_ids_of(ids.detach().clamp(0, rows - 1), rows)
+            ids._sn_sorted = srt
+        return srt[1], srt[2]
+
     def _embed(self, ids: torch.Tensor) -> torch.Tensor:
-        """`self.embedding(ids)`.  Training on the GPU with an index tensor that is a module's buffer / Parameter (the class
-        graphs' words, `SchemaNet.class_ingredients`: the same in every iteration): its sort is taken once per version of the
-        tensor and kept ON it, and the backward pass is one gather-sum (ops.embedding_sorted) instead of the library's sort of
-        the 103 k ids in every iteration."""
+        """`self.embedding(ids)`.  Training on the GPU with an index tensor whose sort is cached: the backward pass is one
+        gather-sum (ops.embedding_sorted) instead of the library's sort of the 103 k ids in every iteration."""
         w = self.embedding.weight
-        if (isinstance(ids, nn.Parameter) and not ids.requires_grad and ids.is_cuda and w.is_cuda and w.dtype == torch.float32
-                and w.requires_grad and torch.is_grad_enabled() and w.shape[1] % 4 == 0 and os.environ.get("SN_EMBED_SORTED", "1") != "0"):
-            srt = getattr(ids, "_sn_sorted", None)
-            if srt is None or srt[0] != (ids._version, w.shape[0]):
-                if torch.cuda.is_current_stream_capturing():
-                    return self.embedding(ids)               # (a sort cannot be captured: whoever captures warms up first)
-                with torch.no_grad():
-                    srt = ((ids._version, w.shape[0]),) + ops.sorted_ids_of(ids.detach().clamp(0, w.shape[0] - 1), w.shape[0])
-                ids._sn_sorted = srt
-            return ops.embedding_sorted(w, ids.detach(), srt[1], srt[2], self.embedding.padding_idx)
+        if w.is_cuda and w.dtype == torch.float32 and w.requires_grad and torch.is_grad_enabled() and w.shape[1] % 4 == 0:
+            srt = self._cached_sort(ids, w.shape[0])
+            if srt is not None:
+                return ops.embedding_sorted(w, ids.detach(), srt[0], srt[1], self.embedding.padding_idx)
         return self.embedding(ids)
 
     def _differentiable(self, *tensors) -> bool:
@@ -364,6 +379,7 @@ class GNN(nn.Module):
         adj = None if train_mfma else (ops.gcn_adjacency(edges) if fused else GraphConv.adjacency(edges))
         layers = list(self.layers)
         first = layers[0] if layers else None
+        feat = None
         if fused and first is not None and isinstance(first.g_conv.linear, nn.Linear) and (first._is_relu or first._is_none):
             # layer 1 re-associated: (adj @ Emb[ids]) @ W^T + b == adj @ (Emb @ W^T)[ids] + b, so the
             # [G*n, E] x [E, E] Linear becomes one [(M+1), E] x [E, E] GEMM shared by every graph
@@ -373,9 +389,20 @@ class GNN(nn.Module):
             feat = ops.mask_layernorm_act_(feat, first.norm.weight, first.norm.bias, first.norm.eps,
                                            n_valid=n_valid, relu=first._is_relu)
             layers = layers[1:]
-        else:
-            feat = self._embed(ingredients)
         adj_planes = ops.gcn_adjacency_planes(_contig(edges.detach())) if train_mfma else None      # shared by the layers (and by their backward passes)
+        if (feat is None and train_mfma and first is not None and isinstance(first.g_conv.linear, nn.Linear) and ingredients.dtype == torch.int64
+                and self.embedding.weight.dtype == torch.float32 and edges.dtype == torch.float32 and os.environ.get("SN_TRAIN_FOLD", "1") != "0"):
+            # training, layer 1 re-associated the same way: the Linear of the first convolution acts on the embedding TABLE (a [M + 1, E] x
+            # [E, E] product with autograd) and the graph product gathers its operand from that table as fp16 planes - no [G n, E] x [E, E]
+            # GEMM in the forward or the backward pass, no fp32 embedding of the graphs
+            lin = first.g_conv.linear
+            table = ops.linear_mfma(self.embedding.weight, lin.weight)
+            srt = self._cached_sort(ingredients, table.shape[0])
+            feat = ops.gather_adj_matmul(edges, table, ingredients.detach(), lin.bias, adj_planes, srt, self.embedding.padding_idx, sum_edge_grads=True)
+            feat = first.post(feat, feat_mask, n_valid, fused)
+            layers = layers[1:]
+        if feat is None:
+            feat = self._embed(ingredients)
         for layer in layers:
             # (the layers run in sequence on one `edges` / `adj_planes`: their edge gradients are summed before autograd sees them)
             feat = layer(edges, feat, feat_mask, adj=adj, n_valid=n_valid, fused=fused, adj_planes=adj_planes, sum_edge_grads=train_mfma)
@@ -387,4 +414,4 @@ class GNN(nn.Module):
         else:
             pooled = (feat * nodes[..., None]).sum(dim=1)
             pooled = pooled / (divisor.to(pooled.dtype) if divisor is not None else feat.shape[1])
-        return self.fc(pooled)
+        return _linear(self.fc, pooled)

@@ -156,9 +156,36 @@ class Matcher(nn.Module):
             # written without its zero padding, and this GNN route reads all of it: mask by the vertex counts here
             valid = torch.arange(edges.shape[-1], device=edges.device)[None, :] < graph["n"][:, None]
             edges = torch.where(valid[:, :, None] & valid[:, None, :], edges, torch.zeros((), dtype=edges.dtype, device=edges.device))
-        feat_instance = self.gnn(nodes=graph["vertices"], edges=edges, ingredients=graph["ids"],
-                                 n_valid=graph["n"], divisor=graph["n_max"],
-                                 prepared=feat_kg.prepared if isinstance(feat_kg, _AtlasHandle) else None)
+        run_instance = lambda: self.gnn(nodes=graph["vertices"], edges=edges, ingredients=graph["ids"],     # noqa: E731
+                                        n_valid=graph["n"], divisor=graph["n_max"],
+                                        prepared=feat_kg.prepared if isinstance(feat_kg, _AtlasHandle) else None)
+        if (feat_kg is None and edges.is_cuda and torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters())
+                and os.environ.get("SN_TRAIN_SIDE_STREAM", "1") != "0"):
+            # Training: the two GNN passes of an iteration meet at the similarity only.  The instance pass is a chain of ~25 small
+            # launches forward and ~50 backward (64 graphs of <= 196 vertices: ~20 us each whatever their size), the class pass a chain
+            # of large ones: the instance pass runs on a second stream, forward AND backward (autograd runs a node's backward on the
+            # stream of its forward and orders the streams where gradients cross), so its launches fill the gaps of the class pass -
+            # eagerly and inside a captured iteration (train.GraphedTrainIter) alike.
+            dev = edges.device
+            if getattr(self, "_train_stream", None) is None or self._train_stream.device != dev:
+                self._train_stream = torch.cuda.Stream(device=dev)
+                # (the GNN's parameters receive gradients from both streams: the engine orders them; its warning about the
+                # mismatch is about an unintended one)
+                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if quiet is not None:
+                    quiet(False)
+            main, side = torch.cuda.current_stream(dev), self._train_stream
+            side.wait_stream(main)
+            for t in (graph["vertices"], edges, graph["ids"], graph["n"], graph["n_max"]):
+                if torch.is_tensor(t):
+                    t.record_stream(side)                    # allocated on the current stream, read on the side stream
+            with torch.cuda.stream(side):
+                feat_instance = run_instance()
+            feat_kg = self.atlas_features(class_dict)
+            main.wait_stream(side)
+            feat_instance.record_stream(main)
+            return self.similarity(feat_instance, feat_kg, votes)
+        feat_instance = run_instance()
         if isinstance(feat_kg, _AtlasHandle):
             feat_kg = feat_kg.join()
         elif feat_kg is None:

@@ -369,11 +369,13 @@ def test_class_edges_with_fused_backward(mods, monkeypatch, rsl):
     assert float(g_t[ok].abs().max()) > 0
 
 
-def test_linear_with_per_graph_weight_gradient(mods):
-    """Training route of the GCN: the Linear of a layer takes its weight gradient as G per-graph products + one sum (the
-    library's single [out, in] product over G n rows runs on 256 tiny tiles): same y, same three gradients as nn.Linear
-    up to the order of the fp32 sums; taken on the GPU under autograd only."""
+def test_linear_with_per_graph_weight_gradient(mods, monkeypatch):
+    """Training route of the GCN with the library's GEMMs (SN_LINEAR_MFMA=0; the default since round 5 is the matrix-core form,
+    tests/test_gpu_train_ops.py::test_linear_on_the_matrix_cores): the Linear of a layer takes its weight gradient as G per-graph
+    products + one sum (the library's single [out, in] product over G n rows runs on 256 tiny tiles): same y, same three
+    gradients as nn.Linear up to the order of the fp32 sums; taken on the GPU under autograd only."""
     from schema_inference.graph import gnn as gnn_mod
+    monkeypatch.setenv("SN_LINEAR_MFMA", "0")
     torch.manual_seed(3)
     lin = torch.nn.Linear(96, 64).to(DEV)
     x = torch.randn(7, 50, 96, device=DEV, requires_grad=True)

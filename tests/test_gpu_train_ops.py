@@ -461,3 +461,128 @@ def test_graphed_train_iter_over_the_predictor(mods):
     eager, graphed = run(False), run(True)
     assert np.isfinite(graphed).all() and len(set(graphed)) > 1
     np.testing.assert_allclose(graphed, eager, rtol=2e-6)
+
+
+# =============================================================================== round 5: the Linear layers of training on the matrix cores
+def _close_to_f64(got, want64, ref32, what, slack=1e-6):
+    """|hip - f64| <= |fp32 library - f64| + slack * scale, element-wise maxima (the bar of DESIGN 4)"""
+    scale = want64.abs().max().item()
+    err, ref = (got.double().cpu() - want64).abs().max().item(), (ref32.double().cpu() - want64).abs().max().item()
+    assert err <= ref + slack * scale, (what, err, ref, scale)
+
+
+@pytest.mark.parametrize("shape,out_f,bias", [((7, 50, 96), 64, True), ((5, 130, 256), 256, True), ((101, 256), 256, True), ((3, 64, 32), 48, False)])
+def test_linear_on_the_matrix_cores(mods, shape, out_f, bias):
+    """`ops.linear_mfma` (reference gnn.py:31, the Linear of a graph convolution, and gnn.py:98, fc): y and the three gradients
+    against float64, no further from it than the library's fp32 Linear; gradients of the size training sees (1e-4)."""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(sum(shape) + out_f)
+    x = torch.randn(*shape, generator=g)
+    w = torch.randn(out_f, shape[-1], generator=g) / shape[-1] ** 0.5
+    b = torch.randn(out_f, generator=g) if bias else None
+    dy = torch.randn(*shape[:-1], out_f, generator=g) * 1e-4
+
+    def run(dtype, dev, fn):
+        xd, wd = x.to(dev, dtype).requires_grad_(True), w.to(dev, dtype).requires_grad_(True)
+        bd = b.to(dev, dtype).requires_grad_(True) if bias else None
+        y = fn(xd, wd, bd)
+        y.backward(dy.to(dev, dtype))
+        return [y.detach(), xd.grad, wd.grad] + ([bd.grad] if bias else [])
+    want = [t.double().cpu() for t in run(torch.float64, "cpu", torch.nn.functional.linear)]
+    ref = run(torch.float32, DEV, torch.nn.functional.linear)
+    got = run(torch.float32, DEV, ops.linear_mfma)
+    for g_, w_, r_, what in zip(got, want, ref, ("y", "dx", "dw", "db")):
+        assert g_.shape == w_.shape
+        _close_to_f64(g_, w_, r_, what)
+
+
+def test_linear_routes_of_the_gcn(mods, monkeypatch):
+    """`gnn._linear`: under autograd on the GPU the matrix-core form (3-D and 2-D inputs); SN_LINEAR_MFMA=0: the library's GEMMs with
+    the per-graph weight gradient (3-D) / nn.Linear (2-D); without autograd nn.Linear"""
+    from schema_inference.graph import gnn as gnn_mod
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(96, 64).to(DEV)
+    x = torch.randn(7, 50, 96, device=DEV, requires_grad=True)
+    assert type(gnn_mod._linear(lin, x).grad_fn).__name__.startswith("_LinearMfma")
+    assert type(gnn_mod._linear(lin, x[0]).grad_fn).__name__.startswith("_LinearMfma")
+    with torch.no_grad():
+        assert gnn_mod._linear(lin, x).grad_fn is None
+    monkeypatch.setenv("SN_LINEAR_MFMA", "0")
+    assert type(gnn_mod._linear(lin, x).grad_fn).__name__.startswith("_LinearPerGraphWeightGrad")
+    assert not type(gnn_mod._linear(lin, x[0]).grad_fn).__name__.startswith(("_LinearPerGraphWeightGrad", "_LinearMfma"))
+
+
+@pytest.mark.parametrize("G,n,rows,F,cached", [(3, 196, 513, 256, False), (4, 128, 101, 64, True), (2, 300, 1025, 256, True)])
+def test_gather_adj_matmul_with_autograd(mods, G, n, rows, F, cached):
+    """`ops.gather_adj_matmul` = ((E + E^T)/2 + I) @ table[ids] + b (layer 1 of the GCN with its Linear folded into the table,
+    reference gnn.py:27-31 re-associated): the product and the gradients of the edges, the table and the bias against float64;
+    the padding row of the table gets no gradient; with and without a cached sort of the ids."""
+    ops = mods["ops"]
+    g = torch.Generator().manual_seed(G * 7 + n + rows)
+    e = torch.rand(G, n, n, generator=g) / n
+    tab = torch.randn(rows, F, generator=g)
+    b = torch.randn(F, generator=g)
+    ids = torch.randint(0, rows, (G, n), generator=g)
+    ids[:, -5:] = rows - 1                                           # padding positions
+    dy = torch.randn(G, n, F, generator=g) * 1e-4
+
+    def run64():
+        ed, td, bd = (t.double().requires_grad_(True) for t in (e, tab, b))
+        adj = (ed + ed.transpose(1, 2)) / 2 + torch.eye(n, dtype=torch.float64)
+        y = torch.bmm(adj, torch.nn.functional.embedding(ids, td, padding_idx=rows - 1)) + bd
+        y.backward(dy.double())
+        return y.detach(), ed.grad, td.grad, bd.grad
+
+    def run32(fn):
+        ed, td, bd = (t.to(DEV).requires_grad_(True) for t in (e, tab, b))
+        y = fn(ed, td, bd)
+        y.backward(dy.to(DEV))
+        return y.detach(), ed.grad, td.grad, bd.grad
+    ids_d = ids.to(DEV)
+
+    def lib(ed, td, bd):
+        adj = (ed + ed.transpose(1, 2)) / 2 + torch.eye(n, device=DEV)
+        return torch.bmm(adj, torch.nn.functional.embedding(ids_d, td, padding_idx=rows - 1)) + bd
+    sort = ops.sorted_ids_of(ids_d, rows) if cached else None
+    want, ref = run64(), run32(lib)
+    got = run32(lambda ed, td, bd: ops.gather_adj_matmul(ed, td, ids_d, bd, None, sort, rows - 1, sum_edge_grads=False))
+    for g_, w_, r_, what in zip(got, want, ref, ("y", "d edges", "d table", "d bias")):
+        _close_to_f64(g_, w_, r_, what, slack=2e-6)
+    assert float(got[2][rows - 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("G,n,M,E", [(3, 196, 512, 256), (5, 64, 100, 64)])
+def test_gnn_training_route_with_the_folded_first_layer(mods, monkeypatch, G, n, M, E):
+    """GNN.forward under autograd: layer 1 folded into the embedding table + every Linear on the matrix cores (default) against
+    the route of round 4 (SN_TRAIN_FOLD=0, SN_LINEAR_MFMA=0: fp32 embedding, library GEMMs) and against float64 on the host: the graph
+    features and the gradients of every parameter, of the edges and of the node weights."""
+    from schema_inference.graph import gnn as gnn_mod
+    torch.manual_seed(11)
+    net = gnn_mod.GNN(M, E, 2).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    nodes = torch.rand(G, n, generator=g)
+    edges = torch.rand(G, n, n, generator=g) / n
+    ids = torch.randint(0, M, (G, n), generator=g)
+    n_valid = torch.tensor([n, n - 7, n // 2, n - 1, 3][:G], dtype=torch.int32)
+    mask = torch.arange(n)[None, :] >= n_valid[:, None]
+    ids[mask] = M
+    nodes[mask] = 0
+    edges = edges * (~mask)[:, :, None] * (~mask)[:, None, :]
+    dout = torch.randn(G, E, generator=g) * 1e-3
+
+    def run(model, dev, dtype):
+        model.zero_grad()
+        nd, ed = nodes.to(dev, dtype).requires_grad_(True), edges.to(dev, dtype).requires_grad_(True)
+        out = model(nd, ed, ids.to(dev), feat_mask=mask.to(dev))
+        out.backward(dout.to(dev, dtype))
+        return [out.detach(), nd.grad, ed.grad] + [p.grad.clone() for p in model.parameters()]
+    import copy
+    net64 = copy.deepcopy(net).double().cpu()
+    want = [t.double() for t in run(net64, "cpu", torch.float64)]
+    got = run(net, DEV, torch.float32)
+    monkeypatch.setenv("SN_TRAIN_FOLD", "0")
+    monkeypatch.setenv("SN_LINEAR_MFMA", "0")
+    ref = run(net, DEV, torch.float32)
+    names = ["out", "d nodes", "d edges"] + [k for k, _ in net.named_parameters()]
+    for g_, w_, r_, what in zip(got, want, ref, names):
+        _close_to_f64(g_, w_, r_, what, slack=3e-6)
