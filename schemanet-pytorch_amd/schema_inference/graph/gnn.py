@@ -260,6 +260,19 @@ class GNN(nn.Module):
         self._prepared = (key, out)
         return out
 
+    def train_folds(self, device_is_cuda: bool = True) -> bool:
+        """True when `forward` under autograd takes the route with layer 1's Linear folded into the embedding table"""
+        first = self.layers[0] if len(self.layers) else None
+        return bool(device_is_cuda and first is not None and isinstance(first.g_conv.linear, nn.Linear) and self.embed_dim % 16 == 0
+                    and self.embedding.weight.is_cuda and self.embedding.weight.dtype == torch.float32
+                    and os.environ.get("SN_GCN_MFMA", "1") != "0" and os.environ.get("SN_TRAIN_FOLD", "1") != "0")
+
+    def train_table(self):
+        """embedding.weight @ W1^T with autograd (ops.linear_mfma): the folded table of the training route, for a caller that runs
+        several passes in one iteration (`forward(..., prepared={"train_table": t})`: Matcher embeds the instance graphs and the class
+        graphs with the same weights)"""
+        return ops.linear_mfma(self.embedding.weight, self.layers[0].g_conv.linear.weight)
+
     def invalidate_prepared(self):
         self._prepared = None
 
@@ -396,7 +409,9 @@ class GNN(nn.Module):
             # [E, E] product with autograd) and the graph product gathers its operand from that table as fp16 planes - no [G n, E] x [E, E]
             # GEMM in the forward or the backward pass, no fp32 embedding of the graphs
             lin = first.g_conv.linear
-            table = ops.linear_mfma(self.embedding.weight, lin.weight)
+            table = prepared.get("train_table") if isinstance(prepared, dict) else None     # (Matcher: one table for both passes of an iteration)
+            if table is None:
+                table = ops.linear_mfma(self.embedding.weight, lin.weight)
             srt = self._cached_sort(ingredients, table.shape[0])
             feat = ops.gather_adj_matmul(edges, table, ingredients.detach(), lin.bias, adj_planes, srt, self.embedding.padding_idx, sum_edge_grads=True)
             feat = first.post(feat, feat_mask, n_valid, fused)

@@ -156,11 +156,12 @@ class Matcher(nn.Module):
             # written without its zero padding, and this GNN route reads all of it: mask by the vertex counts here
             valid = torch.arange(edges.shape[-1], device=edges.device)[None, :] < graph["n"][:, None]
             edges = torch.where(valid[:, :, None] & valid[:, None, :], edges, torch.zeros((), dtype=edges.dtype, device=edges.device))
+        training = bool(feat_kg is None and edges.is_cuda and torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters()))
+        shared = {"train_table": self.gnn.train_table()} if training and self.gnn.train_folds() else None
         run_instance = lambda: self.gnn(nodes=graph["vertices"], edges=edges, ingredients=graph["ids"],     # noqa: E731
                                         n_valid=graph["n"], divisor=graph["n_max"],
-                                        prepared=feat_kg.prepared if isinstance(feat_kg, _AtlasHandle) else None)
-        if (feat_kg is None and edges.is_cuda and torch.is_grad_enabled() and any(p.requires_grad for p in self.gnn.parameters())
-                and os.environ.get("SN_TRAIN_SIDE_STREAM", "1") != "0"):
+                                        prepared=feat_kg.prepared if isinstance(feat_kg, _AtlasHandle) else shared)
+        if training and os.environ.get("SN_TRAIN_SIDE_STREAM", "1") != "0":
             # Training: the two GNN passes of an iteration meet at the similarity only.  The instance pass is a chain of ~25 small
             # launches forward and ~50 backward (64 graphs of <= 196 vertices: ~20 us each whatever their size), the class pass a chain
             # of large ones: the instance pass runs on a second stream, forward AND backward (autograd runs a node's backward on the
@@ -176,12 +177,12 @@ class Matcher(nn.Module):
                     quiet(False)
             main, side = torch.cuda.current_stream(dev), self._train_stream
             side.wait_stream(main)
-            for t in (graph["vertices"], edges, graph["ids"], graph["n"], graph["n_max"]):
+            for t in (graph["vertices"], edges, graph["ids"], graph["n"], graph["n_max"], shared["train_table"] if shared else None):
                 if torch.is_tensor(t):
                     t.record_stream(side)                    # allocated on the current stream, read on the side stream
             with torch.cuda.stream(side):
                 feat_instance = run_instance()
-            feat_kg = self.atlas_features(class_dict)
+            feat_kg = self.atlas_features(class_dict, shared)
             main.wait_stream(side)
             feat_instance.record_stream(main)
             return self.similarity(feat_instance, feat_kg, votes)
@@ -189,7 +190,7 @@ class Matcher(nn.Module):
         if isinstance(feat_kg, _AtlasHandle):
             feat_kg = feat_kg.join()
         elif feat_kg is None:
-            feat_kg = self.atlas_features(class_dict)
+            feat_kg = self.atlas_features(class_dict, shared)
         return self.similarity(feat_instance, feat_kg, votes)
 
     @staticmethod
