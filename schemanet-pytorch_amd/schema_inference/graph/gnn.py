@@ -314,10 +314,18 @@ class GNN(nn.Module):
             zt1, b_table = None, (t_hi, t_lo, ingredients.contiguous(), prepared["table_scale"])
         else:
             zt1, b_table = ops.gcn_gather_planes(prepared["table"], ingredients, extent=ext, scale=prepared["table_scale"]), None     # Bt [G, E, n]
+        # Extents of the products.  A batch of graphs with their own vertex counts (instance graphs: ~113 vertices each, the
+        # largest of a batch ~160) takes them PER GRAPH (round 5; the compacted class graphs always did): a graph of at most 128
+        # vertices costs one row tile and its own k-stages where the batch maximum made it two tiles - the rows and stages beyond a
+        # graph's count are pad rows (zeroed, gnn.py:43-45) times zero adjacency columns, and nothing downstream reads them.
+        gext = ext
+        if (compact is None and ext is not None and n_valid is not None and n_valid.numel() == G and G > 1 and "w2_next" in prepared
+                and os.environ.get("SN_GCN_GRAPH_EXTENTS", "1") != "0"):
+            gext = n_valid
         if "w2_next" in prepared:
             zt2 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                                layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
-                               rows_valid=n_valid, want_planes=n, m_extent=ext, k_extent=ext, b_table=b_table,
+                               rows_valid=n_valid, want_planes=n, m_extent=gext, k_extent=gext, b_table=b_table,
                                next_w=prepared["w2_next"], h_scale=prepared["h1_scale"],
                                out_scale=prepared["zt2_scale"])["planes"]            # W2 @ H1^T [G, E, n], H1 never stored
         else:
@@ -328,7 +336,7 @@ class GNN(nn.Module):
             zt2 = ops.gcn_gemm(prepared["w2"], h1, G, want_planes=n, out_scale=prepared["zt2_scale"])["planes"]      # A = W2 planes [1, E, E] -> [G, E, n]
         pooled = ops.gcn_gemm(adj, zt2, G, bias=l2.g_conv.linear.bias,
                               layernorm=(l2.norm.weight, l2.norm.bias, l2.norm.eps), relu=l2._is_relu,
-                              rows_valid=n_valid, pool_w=nodes, m_extent=ext, k_extent=ext,
+                              rows_valid=n_valid, pool_w=nodes, m_extent=gext, k_extent=gext,
                               pooled_out=pooled_buf)["pooled"]   # [G, row tiles (+ 1: the isolated vertices' share), E]
         return ops.pool_fc(pooled, divisor if divisor is not None else n, self.fc.weight, self.fc.bias, weight_t=prepared.get("fc_t"))
 
