@@ -425,6 +425,11 @@ int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, const int32
                                    float scale, void *adj_hi, void *adj_lo, void *stream);
 int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, float scale, void *adj_hi,
                             void *adj_lo, void *stream);
+/* sn_gcn_adjacency_planes_masked with every graph's OWN extent (round 5): only the blocks of graph g that hold a row or a k
+ * below n_valid[g] (rounded up to 32 / 16) are produced - for sn_gcn_gemm with one extent per graph (m_extent = k_extent =
+ * n_valid, extent_stride 1), which reads no other block's rows below the count and masks the rows above it (rows_valid). */
+int sn_gcn_adjacency_planes_per_graph(const float *edges, int G, int n, const int32_t *n_valid, float scale, void *adj_hi,
+                                      void *adj_lo, void *stream);
 
 /* Zt[g][f][j] = table[ids[g][j]][f] as blocked planes of an [E, n] operand per graph (ids outside
  * [0, rows_table) give zero): the transposed, gathered B operand of layer 1 (gnn.py:64-66 with the

@@ -687,17 +687,22 @@ def _alloc_planes(lib, dev, batches, rows, k):
     return Planes(hi, torch.empty_like(hi), batches, rows, k)
 
 
-def gcn_adjacency_planes(edges, extent=None, n_valid=None):
+def gcn_adjacency_planes(edges, extent=None, n_valid=None, per_graph=False):
     """(E + E^T)/2 + I of [G, n, n] edges as blocked fp16 hi/lo planes.  extent: optional int32 [1]
     device tensor (largest vertex count of the batch): blocks beyond it are not produced.  n_valid: optional int32 [G]
-    vertex counts: edges outside a graph's own corner count as zero and are not read."""
+    vertex counts: edges outside a graph's own corner count as zero and are not read.  per_graph (with n_valid): every graph's
+    own count is its extent - for gcn_gemm(..., m_extent=n_valid, k_extent=n_valid) only."""
     lib = N.require_gpu()
     dev = _check_dev(edges)
     e = _f32c(edges)
     G, n, _ = e.shape
     out = _alloc_planes(lib, dev, G, n, n)
     with torch.cuda.device(dev):
-        if n_valid is not None:
+        if n_valid is not None and per_graph:
+            assert n_valid.dtype == torch.int32 and n_valid.numel() == G and n_valid.device == dev and n_valid.is_contiguous()
+            N.check(lib.sn_gcn_adjacency_planes_per_graph(N.ptr(e), G, n, N.ptr(n_valid), ADJ_SCALE, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+                    "sn_gcn_adjacency_planes_per_graph")
+        elif n_valid is not None:
             assert n_valid.dtype == torch.int32 and n_valid.numel() == G and n_valid.device == dev
             N.check(lib.sn_gcn_adjacency_planes_masked(N.ptr(e), G, n, N.ptr(n_valid), N.ptr(extent), ADJ_SCALE, N.ptr(out.hi), N.ptr(out.lo),
                                                        N.stream_ptr(dev)), "sn_gcn_adjacency_planes_masked")

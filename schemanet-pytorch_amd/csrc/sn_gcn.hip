@@ -1207,6 +1207,28 @@ extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, 
     return SN_OK;
 }
 
+extern "C" int sn_gcn_adjacency_planes_per_graph(const float *edges, int G, int n, const int32_t *n_valid, float scale, void *adj_hi,
+                                                 void *adj_lo, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_per_graph: bad G=%d n=%d", G, n);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(edges && adj_hi && adj_lo && n_valid, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_per_graph: NULL pointer");
+    SN_REQUIRE(scale > 0.0f && scale <= 65536.0f, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_per_graph: scale %g (a power of two in (0, 65536])", (double)scale);
+    SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes_per_graph: G=%d > 65535", G);
+    const int kb = (n + 15) / 16;
+    unsigned tiles; int pair_tiles;
+    adjacency_grid(n, G, tiles, pair_tiles);
+    // (the vertex counts serve as the extents too: one per graph)
+    if (n % 4 == 0 && ((uintptr_t)edges & 15) == 0)
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_valid, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 1);
+    else
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_valid, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 1);
+    SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_per_graph");
+    return SN_OK;
+}
+
 extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, const float *row_sum, int K, int n, int remove_self_loop,
                                              float scale, void *adj_hi, void *adj_lo, float *class_edges_out, void *stream)
 {

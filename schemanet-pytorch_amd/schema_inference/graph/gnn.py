@@ -300,10 +300,13 @@ class GNN(nn.Module):
         # `divisor` (when given) is the largest vertex count of the batch, on the device: nothing beyond it
         # (rounded up to the block sizes) is produced or multiplied - no host synchronisation needed
         ext = divisor if (divisor is not None and torch.is_tensor(divisor)) else None
-        if adj is None:
-            adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid)                       # A  [G, n, n]
         if prepared is None:
             prepared = self.prepare()
+        # per-graph extents (see below): decided here because the adjacency operand is then produced per graph as well
+        graph_ext = bool(adj is None and compact is None and ext is not None and n_valid is not None and n_valid.numel() == G and G > 1
+                         and n_valid.dtype == torch.int32 and "w2_next" in prepared and os.environ.get("SN_GCN_GRAPH_EXTENTS", "1") != "0")
+        if adj is None:
+            adj = ops.gcn_adjacency_planes(edges, extent=ext, n_valid=n_valid.contiguous() if graph_ext else n_valid, per_graph=graph_ext)     # A  [G, n, n]
         pooled_buf = None
         if compact is not None:                          # (class graphs of a pruned atlas: per-graph extents)
             ingredients, nodes, ext, pooled_buf = self._compacted(nodes, ingredients, compact, prepared["iso"])
@@ -318,10 +321,7 @@ class GNN(nn.Module):
         # largest of a batch ~160) takes them PER GRAPH (round 5; the compacted class graphs always did): a graph of at most 128
         # vertices costs one row tile and its own k-stages where the batch maximum made it two tiles - the rows and stages beyond a
         # graph's count are pad rows (zeroed, gnn.py:43-45) times zero adjacency columns, and nothing downstream reads them.
-        gext = ext
-        if (compact is None and ext is not None and n_valid is not None and n_valid.numel() == G and G > 1 and "w2_next" in prepared
-                and os.environ.get("SN_GCN_GRAPH_EXTENTS", "1") != "0"):
-            gext = n_valid
+        gext = n_valid.contiguous() if graph_ext else ext
         if "w2_next" in prepared:
             zt2 = ops.gcn_gemm(adj, zt1, G, bias=l1.g_conv.linear.bias,
                                layernorm=(l1.norm.weight, l1.norm.bias, l1.norm.eps), relu=l1._is_relu,
