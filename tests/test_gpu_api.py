@@ -847,3 +847,53 @@ def test_atlas_pass_writes_class_edges_as_a_by_product(mods):
         assert torch.equal(adj1.hi, adj2.hi) and torch.equal(adj1.lo, adj2.lo)
         assert torch.isfinite(ce2).all() and torch.equal(ce0 == 0, ce2 == 0)
         np.testing.assert_allclose(ce2.cpu().numpy(), ce0.cpu().numpy(), rtol=4e-7, atol=0)             # (two roundings instead of one: <= 2 ulp)
+
+
+# =============================================================================== round 5: the instance side with one extent per graph
+def test_adjacency_planes_per_graph_equal_the_masked_ones_where_they_are_read(mods):
+    """`sn_gcn_adjacency_planes_per_graph` (reference operand: gnn.py:27-30 on the zero-padded batch, match.py:48-54): inside a graph's
+    own extent (rows rounded up to 32, k to 16) the planes are those of the masked producer bit for bit; what lies beyond is not
+    produced (the buffer keeps its poison)."""
+    ops = mods["ops"]
+    G, n = 9, 196
+    g = torch.Generator().manual_seed(12)
+    e = torch.rand(G, n, n, generator=g).to(DEV)
+    nv = torch.tensor([1, 15, 16, 33, 113, 128, 129, 160, 196], dtype=torch.int32, device=DEV)
+    ext = nv.max().reshape(1).to(torch.int32)
+    ref = ops.gcn_adjacency_planes(e, extent=ext, n_valid=nv)
+    got = ops.gcn_adjacency_planes(e, extent=ext, n_valid=nv, per_graph=True)
+    d_ref, d_got = ref.to_dense()[1], got.to_dense()[1]                  # [G, rows padded to 32, k padded to 16]
+    for i, c in enumerate(nv.tolist()):
+        rows, k = (c + 31) // 32 * 32, (c + 15) // 16 * 16
+        assert torch.equal(d_got[i, :rows, :k], d_ref[i, :rows, :k]), (i, c)
+
+
+@pytest.mark.parametrize("E", [256])
+def test_instance_gnn_with_per_graph_extents(mods, monkeypatch, E):
+    """GNN.forward without autograd on instance graphs with their own vertex counts (1 .. 196: below, at and above the 128-row
+    tile): extents per graph (the default since round 5) against the batch maximum for everybody (SN_GCN_GRAPH_EXTENTS=0) and
+    against the float64 forward on the host - the pooled graph features, element-wise."""
+    import copy
+    from schema_inference.graph import gnn as gnn_mod
+    M, n = 512, 196
+    torch.manual_seed(21)
+    net = gnn_mod.GNN(M, E, 2).to(DEV).eval()
+    g = torch.Generator().manual_seed(6)
+    counts = [1, 2, 15, 16, 17, 100, 113, 127, 128, 129, 130, 160, 196, 64, 31, 32]
+    G = len(counts)
+    nv = torch.tensor(counts, dtype=torch.int32)
+    mask = torch.arange(n)[None, :] >= nv[:, None]
+    nodes = torch.rand(G, n, generator=g); nodes[mask] = 0
+    edges = torch.rand(G, n, n, generator=g) / n
+    edges = edges * (~mask)[:, :, None] * (~mask)[:, None, :]
+    ids = torch.randint(0, M, (G, n), generator=g); ids[mask] = M
+    n_max = nv.max().reshape(1).to(torch.int32)
+    with torch.no_grad():
+        want = copy.deepcopy(net).double().cpu()(nodes.double(), edges.double(), ids, feat_mask=mask, divisor=n_max)
+        run = lambda: net(nodes.to(DEV), edges.to(DEV), ids.to(DEV), n_valid=nv.to(DEV), divisor=n_max.to(DEV)).double().cpu()      # noqa: E731
+        got = run()
+        monkeypatch.setenv("SN_GCN_GRAPH_EXTENTS", "0")
+        ref = run()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= float((ref - want).abs().max()) + 1e-6 * scale
+    assert float((got - ref).abs().max()) <= 2e-6 * scale
