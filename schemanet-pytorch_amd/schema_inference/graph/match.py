@@ -49,6 +49,15 @@ class Matcher(nn.Module):
         self.cache_atlas = False
         self._atlas_cache = None
 
+    def __getstate__(self):
+        """copies and pickles of the module (`copy.deepcopy` for an EMA model, `torch.save(model)`) leave the HIP streams and the
+        cached class-branch handle behind: they are per-process resources, re-created on first use"""
+        state = self.__dict__.copy()
+        for k in ("_side_stream", "_train_stream", "_atlas_cache"):
+            if k in state:
+                state[k] = None
+        return state
+
     # reference match.py:21-31
     def similarity(self, feat_inst: torch.Tensor, feat_kg: torch.Tensor, votes: torch.Tensor = None) -> torch.Tensor:
         """feat_inst [bs, E], feat_kg [K, E] -> [bs, K].  votes (f32 [K + 1], optional): the evaluation loop's per-class vote

@@ -897,3 +897,36 @@ def test_instance_gnn_with_per_graph_extents(mods, monkeypatch, E):
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= float((ref - want).abs().max()) + 1e-6 * scale
     assert float((got - ref).abs().max()) <= 2e-6 * scale
+
+
+def test_matcher_copies_and_pickles_after_it_has_run(mods):
+    """`copy.deepcopy` (an EMA copy of the model) and `pickle` of a Matcher that has already run - in inference (class branch on a
+    side stream, cached handle) and in training (instance pass on a second stream): the per-process stream objects and the cached
+    handle stay behind, the copy computes the same scores."""
+    import copy
+    import pickle
+    graph = mods["graph"]
+    M, K, E, B, L = 128, 5, 256, 4, 196
+    torch.manual_seed(2)
+    sn = make_schema_net(mods, M, K)
+    sn.register_class_vertices(torch.arange(M, device=DEV).repeat(K, 1))
+    m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu")).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    ing = torch.randint(0, M, (B, L), generator=g).to(DEV)
+    attn, acls = torch.randn(B, L, L, generator=g).to(DEV), torch.randn(B, L, generator=g).to(DEV)
+
+    def scores(matcher, train):
+        matcher.train(train); sn.train(train)
+        with torch.set_grad_enabled(train):
+            gr = sn.instance_graph_padded(ing, attn.clone(), acls.clone())
+            if train:
+                return matcher.forward_padded(gr, sn.get_atlas()).detach().clone()
+            h = matcher.atlas_features_async(lambda: sn.get_atlas(detach=True, fused_adjacency=True))
+            return matcher.forward_padded(gr, None, feat_kg=h).clone()
+    want_eval, want_train = scores(m, False), scores(m, True)
+    assert getattr(m, "_side_stream", None) is not None or getattr(m, "_train_stream", None) is not None
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert getattr(clone, "_side_stream", None) is None and getattr(clone, "_train_stream", None) is None
+        assert torch.equal(scores(clone, False), want_eval)
+        got = scores(clone, True)
+        assert float((got - want_train).abs().max()) <= 1e-6 * float(want_train.abs().max())
