@@ -224,7 +224,12 @@ struct NoTick {
 
 constexpr int kRowWaves = 15;           // the sixteen-wave kernel: waves 0 .. 14 bring rows in, wave 15 sorts
 constexpr int kOwnMax = 14;             // positions a row wave owns in the deferred S1 finish: ceil(L / 15) (L <= 210)
-constexpr int kFinishItems = 4;         // candidate pairs it has in flight at once (0.9 flagged tokens, ~1.1 pairs expected per wave)
+constexpr int kFinishItems = 4;         // candidate pairs a row wave has in flight at once (0.9 flagged tokens, ~1.1 pairs expected per wave)
+// ... at D = 384 (NT = 6: 18 registers per pair) two: with four the kernel's 128 registers did not hold them - 79 spilled registers,
+// 88 B of scratch per lane, and the parked rows came back from scratch right in front of their fp64 products.  Two in flight: 114
+// registers, no scratch, the kernel 38.0 us instead of 40.9 (tools/time_defer.py); a third / fourth pair of a wave (rare) is scored
+// one at a time behind them.
+template <int NT> constexpr int finish_items() { return NT >= 6 ? 2 : kFinishItems; }
 
 template <int NT>
 struct RerankWave {
@@ -247,7 +252,7 @@ struct RerankWave {
     unsigned cmv;               // lane j: candidate slots of token j not yet requested
     unsigned best_lo, best_hi;  // lane j: best fp64 score of token j so far (+inf)
     int best_i;                 // lane j: its word (0x7fffffff: none)
-    Item it[kFinishItems];
+    Item it[finish_items<NT>()];
     int cnt;
 
     __device__ __forceinline__ int64_t token_index(int pos) const { return (int64_t)b * rv.tsb + (int64_t)pos * rv.tsl; }
@@ -331,7 +336,7 @@ struct RerankWave {
         best_lo = 0u; best_hi = 0x7FF00000u; best_i = 0x7fffffff;    // +inf
         cnt = 0;
 #pragma unroll
-        for (int i = 0; i < kFinishItems; ++i) {
+        for (int i = 0; i < finish_items<NT>(); ++i) {
             if (!issue_item(it[i])) break;
             cnt = i + 1;
         }
@@ -343,7 +348,7 @@ struct RerankWave {
     __device__ __forceinline__ void complete()
     {
 #pragma unroll
-        for (int i = 0; i < kFinishItems; ++i) {
+        for (int i = 0; i < finish_items<NT>(); ++i) {
             if (i >= cnt) break;                                     // wave-uniform
             score_item(it[i]);
         }
