@@ -261,7 +261,7 @@ constexpr int kOverflowBlocks = 64;     // blocks reserved for the overflow list
 // FMT 0: records of assign_screen_kernel / assign_screen5_kernel (24 code bytes per token); FMT 2: 16-bit codes (M > 2048);
 
 template <int NT, int FMT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void assign_rerank_kernel(const AssignArgs p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT > 6 ? 4 : 6, 8))) void assign_rerank_kernel(const AssignArgs p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const PackLayout lay = pack_layout(p.M, p.D);
