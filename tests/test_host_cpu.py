@@ -487,3 +487,46 @@ def test_labelled_case_is_deterministic_and_learnable():
     block = 128 // 5
     own = ((ing // block) == label[:, None]).mean()
     assert own > 0.6 and ing.min() >= 0 and ing.max() < 128 and set(label.tolist()) <= set(range(5))
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
+    """Every gfx950 kernel of libschemanet_hip.so has a private segment of 0 bytes (no register spilled, no array in scratch): read
+    from the code objects' metadata (one offload bundle per translation unit in the .hip_fatbin section).  A spill reload waits for
+    `vmcnt(0)`, i.e. for every LDS-DMA copy in flight - the reason DESIGN insists on it."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    lib = os.path.join(ROOT, "schemanet-pytorch_amd", "lib", "libschemanet_hip.so")
+    if not all(os.path.exists(t) for t in tools) or not os.path.exists(lib):
+        pytest.skip("ROCm llvm tools or the built library not present")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert len(starts) >= 8                                           # one per .hip file of csrc/
+    n_kernels, spilled = 0, []
+    for i, a in enumerate(starts):
+        part = str(tmp_path / f"b{i}.bin")
+        with open(part, "wb") as fh:
+            fh.write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = str(tmp_path / f"co{i}.elf")
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part, "--output=" + co],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s*\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name is not None:
+                n_kernels += 1
+                if int(m.group(1)) != 0:
+                    spilled.append((name, int(m.group(1))))
+                name = None
+    assert n_kernels >= 60, n_kernels
+    assert not spilled, spilled
+    shutil.rmtree(str(tmp_path), ignore_errors=True)
