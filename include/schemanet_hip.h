@@ -168,7 +168,7 @@ int sn_head_mean_attention(const float *extracted, int B, int H, int L, float *a
  * inside its row phase - fp64, the oracle's summation order, the same ids bit for bit as mode 0 - and writes them back
  * to `out`: no stand-alone re-rank launch between S1 and the graph (reference op: discretization/discretization.py:65,
  * consumer schema_net.py:278-305).  Applies to the edges kernel (attn != NULL) in its prediction configuration and to
- * D in {192, 384}, M <= 2048, L <= 210 (sn_assign_defers); sn_instance_graph returns SN_ERR_UNSUPPORTED otherwise. */
+ * D in {192, 384, 768} (768: round 5), M <= 2048, L <= 210 (sn_assign_defers); sn_instance_graph returns SN_ERR_UNSUPPORTED otherwise. */
 typedef struct sn_rerank_args {
     uint32_t struct_size;         /* sizeof(sn_rerank_args) of the caller's header (checked: see sn_abi_version)     */
     const void *x;                /* the tokens sn_assign_words screened: token (b, l) is the row at element offset

@@ -1497,7 +1497,7 @@ extern "C" int sn_assign_defers(int M, int D)
 {
     const int v = screen_variant();
     const bool dflt = v == 0 || v == 5;                          // (form 5 writes the default form's records)
-    return (dflt && M > 0 && M <= 2048 && (D == 192 || D == 384)) ? 1 : 0;      // (D = 768: the finish's state - three 12-register rows - does not fit the graph kernel's 128 registers)
+    return (dflt && M > 0 && M <= 2048 && (D == 192 || D == 384 || D == 768)) ? 1 : 0;      // (D = 768, round 5: one candidate pair in flight per row wave - three 12-register rows - fits the graph kernel's 128 registers; four did not)
 }
 
 extern "C" int sn_assign_set_variant(int variant)
@@ -1580,6 +1580,7 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
         // (where mode 2 did not defer it has cleared the flag words and the overflow count: the kernels find nothing)
         if (D == 192) launch_rerank<3, 0>(a, st);
         else if (D == 384) launch_rerank<6, 0>(a, st);
+        else if (D == 768) launch_rerank<12, 0>(a, st);
         else SN_REQUIRE(false, SN_ERR_UNSUPPORTED, "sn_assign_words: mode 3 for D=%d", D);
         SN_CHECK_LAUNCH("sn_assign_words");
         return SN_OK;
@@ -1601,7 +1602,7 @@ static int assign_words_impl(const void *x_any, int x_bf16, int64_t n_outer, int
             else rc = launch_screen<48, 4, 3, 10>(a, st);
         } else if (D == 192) rc = launch_screen<12, 4, 3>(a, st, deferred = want_defer);
         else if (D == 384) rc = (assign_dual() ? launch_screen<24, 4, 3, 8, true>(a, st) : launch_screen<24, 4, 3>(a, st, deferred = want_defer));
-        else rc = launch_screen<48, 4, 3>(a, st);
+        else rc = launch_screen<48, 4, 3>(a, st, deferred = want_defer);
         if (rc) return rc;
     } else {
         const int nt = (D + 63) / 64;

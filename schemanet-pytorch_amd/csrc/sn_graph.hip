@@ -228,8 +228,8 @@ constexpr int kFinishItems = 4;         // candidate pairs a row wave has in fli
 // ... at D = 384 (NT = 6: 18 registers per pair) two: with four the kernel's 128 registers did not hold them - 79 spilled registers,
 // 88 B of scratch per lane, and the parked rows came back from scratch right in front of their fp64 products.  Two in flight: 114
 // registers, no scratch, the kernel 38.0 us instead of 40.9 (tools/time_defer.py); a third / fourth pair of a wave (rare) is scored
-// one at a time behind them.
-template <int NT> constexpr int finish_items() { return NT >= 6 ? 2 : kFinishItems; }
+// one at a time behind them.  D = 768 (NT = 12, round 5: config [3]'s DeiT-Base tokens): one pair in flight - 120 registers, no scratch.
+template <int NT> constexpr int finish_items() { return NT >= 12 ? 1 : (NT >= 6 ? 2 : kFinishItems); }
 
 template <int NT>
 struct RerankWave {
@@ -1922,16 +1922,18 @@ extern "C" int sn_instance_graph(const sn_graph_args *args, void *stream)
             rv.scal = (const unsigned *)(pk + lay.scal_off);
             rv.ids = r.ids; rv.isb = r.ids_stride_b; rv.isl = r.ids_stride_l;
             rv.M = r.M; rv.D = r.D; rv.n_tiles = lay.n_tiles;
-            rr = r.D / 64;                                        // (sn_assign_defers: D in {192, 384})
+            rr = r.D / 64;                                        // (sn_assign_defers: D in {192, 384, 768})
         }
         const void *fn = rr == 3 ? (const void *)instance_graph_kernel<true, true, 3>
                        : rr == 6 ? (const void *)instance_graph_kernel<true, true, 6>
+                       : rr == 12 ? (const void *)instance_graph_kernel<true, true, 12>
                        : fast ? (const void *)instance_graph_kernel<true, true> : (const void *)instance_graph_kernel<true>;
         int rc = ensure_lds(fn, lds, "sn_instance_graph");
         if (rc) return rc;
         sn_prof_start(2, st);
         if (rr == 3) hipLaunchKernelGGL((instance_graph_kernel<true, true, 3>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
         else if (rr == 6) hipLaunchKernelGGL((instance_graph_kernel<true, true, 6>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
+        else if (rr == 12) hipLaunchKernelGGL((instance_graph_kernel<true, true, 12>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
         else if (fast) hipLaunchKernelGGL((instance_graph_kernel<true, true>), dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
         else hipLaunchKernelGGL(instance_graph_kernel<true>, dim3(a.B), dim3(1024), lds, st, a, g_graph_stamps, signed_table, rv);
         sn_prof_stop(2, st);

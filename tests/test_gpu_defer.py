@@ -58,7 +58,7 @@ def screen_form(request, mods):
     lib.sn_assign_set_variant(old)
 
 
-@pytest.mark.parametrize("D,M", [(384, 512), (192, 128), (384, 1000), (192, 480)])
+@pytest.mark.parametrize("D,M", [(384, 512), (192, 128), (384, 1000), (192, 480), (768, 1000)])
 @pytest.mark.parametrize("layout", ["batch_first", "sequence_first"])
 def test_deferred_finish_equals_mode0_and_oracle(mods, D, M, layout, screen_form):
     ops, lib = mods["ops"], mods["cx"].load()
@@ -124,11 +124,11 @@ def test_deferred_finish_with_per_head_taps_and_fallbacks(mods):
     ids2, h2 = ops.assign_words(x, cbt, packed, defer=True)
     g2 = sn.instance_graph_padded(ids2, *args, mutate_inputs=False, zero_padding=True, rerank=h2)
     assert h2.done and torch.equal(ids2, want) and torch.equal(g2["ids"], g_ref["ids"])
-    # no deferred form: D = 768, codebooks of more than 2048 words, the other screen forms
-    assert lib.sn_assign_defers(1024, 768) == 0 and lib.sn_assign_defers(4096, 384) == 0
-    cb3 = T(datagen.bellish((256, 768), 5, 1.0))
+    # no deferred form: codebooks of more than 2048 words (16-bit word codes), widths other than 192 / 384 / 768
+    assert lib.sn_assign_defers(1024, 768) == 1 and lib.sn_assign_defers(4096, 384) == 0 and lib.sn_assign_defers(512, 256) == 0
+    cb3 = T(datagen.bellish((2304, 384), 5, 1.0))
     cbt3, packed3 = ops.PackedCodebook().get(cb3)
-    x3 = T(datagen.bellish((2, L, 768), 6, 1.0))
+    x3 = T(datagen.bellish((2, L, 384), 6, 1.0))
     ids3, h3 = ops.assign_words(x3, cbt3, packed3, defer=True)
     assert h3 is None and torch.equal(ids3, ops.assign_words(x3, cbt3, packed3))
     # the K-outer screen writes the default screen's records: the same deferred finish
