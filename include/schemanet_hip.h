@@ -431,6 +431,12 @@ int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *ext
 int sn_gcn_adjacency_planes_per_graph(const float *edges, int G, int n, const int32_t *n_valid, float scale, void *adj_hi,
                                       void *adj_lo, void *stream);
 
+/* sn_gcn_adjacency_planes_per_graph through a vertex permutation (round 5, training with compacted class graphs): vertex a of graph
+ * g's operand is vertex perm[g][a] of `edges` (sn_atlas_keep_perm: the kept vertices first), only the n_kept[g] x n_kept[g] corner
+ * (+ identity) is produced.  n <= 1024. */
+int sn_gcn_adjacency_planes_compact(const float *edges, int G, int n, const int32_t *perm, const int32_t *n_kept, float scale,
+                                    void *adj_hi, void *adj_lo, void *stream);
+
 /* Zt[g][f][j] = table[ids[g][j]][f] as blocked planes of an [E, n] operand per graph (ids outside
  * [0, rows_table) give zero): the transposed, gathered B operand of layer 1 (gnn.py:64-66 with the
  * Linear folded into the embedding table). */
@@ -516,6 +522,12 @@ int sn_pow2_scale(const float *x, int64_t n, float top, void *partial, float *sc
 /* s [G, n, n] <- (s + s^T) / 2 per graph, in place: the chain rule through the GCN operand (E + E^T)/2 + I
  * (reference schema_inference/graph/gnn.py:27-30), applied once to the sum of the layers' dY . X^T. */
 int sn_sym_half_inplace(float *s, int G, int n, void *stream);
+/* Training with compacted class graphs (round 5).  corner [G, n, n]: the sum of the layers' dY . X^T taken in the COMPACTED vertex
+ * order (vertex a of graph g = vertex perm[g][a] of the stored graph, the kept vertices first: sn_atlas_keep_perm), written for
+ * rows < n_kept[g] only.  out [G, n, n] <- the edge gradient in the stored order: out[g][i][j] = (corner[g][a][b] +
+ * corner[g][b][a]) / 2 with i = perm[g][a], j = perm[g][b] when both a, b < n_kept[g], 0 elsewhere (the chain rule through
+ * (E + E^T)/2 + I, reference gnn.py:27-30; a pruned vertex's row and column of E are constants).  n <= 1024. */
+int sn_sym_scatter_corner(const float *corner, const int32_t *perm, const int32_t *n_kept, int G, int n, float *out, void *stream);
 /* x [rows, n] <- nan_to_num(clamp_min(x, min_val) / sum(clamp_min(x, min_val), -1), 0), then x[r, r % diag_n] <- 0 when
  * diag_n > 0 (x = a [K, n, n] tensor viewed as [K n, n]): `SchemaNet.normalize()` on one parameter in one pass
  * (reference schema_net.py:133-142, graph/utils.py:7-13, :59-61).  The row sum is taken in fp32 in a fixed order

@@ -149,6 +149,8 @@ _SIGNATURES = {
     "sn_gcn_adjacency_planes": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_adjacency_planes_masked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_adjacency_planes_per_graph": (c_int, [c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "sn_gcn_adjacency_planes_compact": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "sn_sym_scatter_corner": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes_transposed": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),

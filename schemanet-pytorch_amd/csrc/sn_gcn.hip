@@ -1275,6 +1275,25 @@ extern "C" int sn_gcn_atlas_adjacency_planes_compact(const float *pruned_edge_we
     return SN_OK;
 }
 
+extern "C" int sn_gcn_adjacency_planes_compact(const float *edges, int G, int n, const int32_t *perm, const int32_t *n_kept, float scale,
+                                               void *adj_hi, void *adj_lo, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_compact: bad G=%d n=%d", G, n);
+    if (G == 0) return SN_OK;
+    SN_REQUIRE(edges && adj_hi && adj_lo && perm && n_kept, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_compact: NULL pointer");
+    SN_REQUIRE(n <= kMaxPerm, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes_compact: n=%d > %d", n, kMaxPerm);
+    SN_REQUIRE(scale > 0.0f && scale <= 65536.0f, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes_compact: scale %g (a power of two in (0, 65536])", (double)scale);
+    SN_REQUIRE(G <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_adjacency_planes_compact: G=%d > 65535", G);
+    const int kb = (n + 15) / 16;
+    unsigned tiles; int pair_tiles;
+    adjacency_grid(n, G, tiles, pair_tiles);
+    hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                       sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_kept, n_kept, pair_tiles,
+                       scale, (float *)nullptr, perm, 1);
+    SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_compact");
+    return SN_OK;
+}
+
 extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const int64_t *ids, int G, int n, int E,
                                     const int32_t *extent_dev, const float *scale_dev, void *out_hi, void *out_lo, void *stream)
 {
@@ -1384,7 +1403,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     SN_REQUIRE(!u->layernorm || (u->n == kTileN && u->gamma && u->beta), SN_ERR_UNSUPPORTED,
                "sn_gcn_gemm: the LayerNorm epilogue needs n == 256 (got %d) and gamma/beta", u->n);
     SN_REQUIRE(!u->pooled || u->pool_w, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooling without weights");
-    SN_REQUIRE(!u->accumulate || (u->c && !u->c_hi && !u->pooled && !u->bias && !u->layernorm && !u->relu && !u->rows_valid && !u->m_extent && !gathered), SN_ERR_UNSUPPORTED,
+    SN_REQUIRE(!u->accumulate || (u->c && !u->c_hi && !u->pooled && !u->bias && !u->layernorm && !u->relu && !u->rows_valid && !gathered), SN_ERR_UNSUPPORTED,
                "sn_gcn_gemm: accumulate is for the plain fp32 product only");
     SN_REQUIRE(u->batches <= 65535, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: batches=%d > 65535", u->batches);
     GemmArgs a;

@@ -428,6 +428,41 @@ extern "C" int sn_pow2_scale(const float *x, int64_t n, float top, void *partial
     return SN_OK;
 }
 
+// out[g][i][j] = (corner[g][a][b] + corner[g][b][a]) / 2 for i = perm[a], j = perm[b], a, b < n_kept[g]; 0 elsewhere.  One workgroup per
+// (64-row block of the STORED order, graph): the inverse permutation of the graph staged in LDS, a thread per column, rows in turn - the
+// writes are whole rows of `out`, the reads two gathers inside 4 KiB rows / columns of the corner (L2: a corner is at most 4 MiB).
+constexpr int kScatterMaxN = 1024;
+__global__ __launch_bounds__(256) void sym_scatter_corner_kernel(const float *corner, const int32_t *perm, const int32_t *n_kept, int n, float *out)
+{
+    __shared__ short inv[kScatterMaxN];
+    const int g = blockIdx.y, nk = min(max(n_kept[g], 0), n);
+    for (int a = threadIdx.x; a < n; a += 256) inv[perm[(int64_t)g * n + a]] = (short)(a < nk ? a : -1);
+    __syncthreads();
+    const float *c = corner + (int64_t)g * n * n;
+    float *o = out + (int64_t)g * n * n;
+    const int i0 = blockIdx.x * 64;
+    for (int i = i0; i < min(n, i0 + 64); ++i) {
+        const int a = inv[i];                                     // (block-uniform)
+        for (int j = threadIdx.x; j < n; j += 256) {
+            float v = 0.0f;
+            const int b = inv[j];
+            if (a >= 0 && b >= 0) v = (c[(int64_t)a * n + b] + c[(int64_t)b * n + a]) * 0.5f;
+            o[(int64_t)i * n + j] = v;
+        }
+    }
+}
+
+extern "C" int sn_sym_scatter_corner(const float *corner, const int32_t *perm, const int32_t *n_kept, int G, int n, float *out, void *stream)
+{
+    SN_REQUIRE(G >= 0 && n >= 0, SN_ERR_BAD_ARG, "sn_sym_scatter_corner: bad G=%d n=%d", G, n);
+    if (G == 0 || n == 0) return SN_OK;
+    SN_REQUIRE(corner && perm && n_kept && out, SN_ERR_BAD_ARG, "sn_sym_scatter_corner: NULL pointer");
+    SN_REQUIRE(n <= kScatterMaxN && G <= 65535, SN_ERR_UNSUPPORTED, "sn_sym_scatter_corner: n=%d > %d or G=%d > 65535", n, kScatterMaxN, G);
+    hipLaunchKernelGGL(sym_scatter_corner_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)G), dim3(256), 0, (hipStream_t)stream, corner, perm, n_kept, n, out);
+    SN_CHECK_LAUNCH("sn_sym_scatter_corner");
+    return SN_OK;
+}
+
 extern "C" int sn_sym_half_inplace(float *s, int G, int n, void *stream)
 {
     SN_REQUIRE(G >= 0 && n >= 0, SN_ERR_BAD_ARG, "sn_sym_half_inplace: bad G=%d n=%d", G, n);

@@ -72,7 +72,7 @@ def test_graph_args_struct_matches_header(lib):
     assert N.GraphArgs().struct_size == sizes[0] and N.RerankArgs().struct_size == sizes[1] and N.GemmArgs().struct_size == sizes[2]
     # the deferred S1 finish exists for the shipped DeiT-Tiny / DeiT-Small widths with byte word codes (host-side rule)
     assert lib.sn_assign_defers(512, 384) == 1 and lib.sn_assign_defers(128, 192) == 1
-    assert lib.sn_assign_defers(1024, 768) == 0 and lib.sn_assign_defers(4096, 384) == 0
+    assert lib.sn_assign_defers(1024, 768) == 1 and lib.sn_assign_defers(4096, 384) == 0 and lib.sn_assign_defers(512, 256) == 0
 
 
 def test_struct_of_another_abi_is_refused(lib):
