@@ -508,6 +508,9 @@ typedef struct sn_gemm_args {
                                      ReLU): the layers of a training pass sum their dY . X^T into one adjacency gradient */
     int pooled_parts;             /* 0, or the number of [n] partial sums per graph `pooled` is laid out with (>= ceil(m / 128): the
                                      caller keeps the further slots, e.g. sn_class_compact's pooled_iso) */
+    int zero_skipped;             /* 1 (with m_extent and c): the row tiles past a graph's extent, which are not multiplied, are
+                                     written as zeros by the workgroups that skip them - with rows_valid the whole fp32 result is
+                                     then defined without a clearing pass over it (round 5: training with compacted class graphs) */
 } sn_gemm_args;
 int sn_gcn_gemm(const sn_gemm_args *args, void *stream);
 
@@ -526,8 +529,9 @@ int sn_sym_half_inplace(float *s, int G, int n, void *stream);
  * order (vertex a of graph g = vertex perm[g][a] of the stored graph, the kept vertices first: sn_atlas_keep_perm), written for
  * rows < n_kept[g] only.  out [G, n, n] <- the edge gradient in the stored order: out[g][i][j] = (corner[g][a][b] +
  * corner[g][b][a]) / 2 with i = perm[g][a], j = perm[g][b] when both a, b < n_kept[g], 0 elsewhere (the chain rule through
- * (E + E^T)/2 + I, reference gnn.py:27-30; a pruned vertex's row and column of E are constants).  n <= 1024. */
-int sn_sym_scatter_corner(const float *corner, const int32_t *perm, const int32_t *n_kept, int G, int n, float *out, void *stream);
+ * (E + E^T)/2 + I, reference gnn.py:27-30; a pruned vertex's row and column of E are constants).  The corner is symmetrised IN
+ * PLACE on the way.  n <= 1024. */
+int sn_sym_scatter_corner(float *corner, const int32_t *perm, const int32_t *n_kept, int G, int n, float *out, void *stream);
 /* x [rows, n] <- nan_to_num(clamp_min(x, min_val) / sum(clamp_min(x, min_val), -1), 0), then x[r, r % diag_n] <- 0 when
  * diag_n > 0 (x = a [K, n, n] tensor viewed as [K n, n]): `SchemaNet.normalize()` on one parameter in one pass
  * (reference schema_net.py:133-142, graph/utils.py:7-13, :59-61).  The row sum is taken in fp32 in a fixed order

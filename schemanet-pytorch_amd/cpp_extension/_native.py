@@ -86,7 +86,7 @@ class GemmArgs(_SizedArgs):
         ("b_ids", c_void_p), ("b_ids_stride", c_int64), ("b_ids_n", c_int), ("b_table_rows", c_int),
         ("next_w_hi", c_void_p), ("next_w_lo", c_void_p),
         ("a_scale", c_void_p), ("b_scale", c_void_p), ("out_scale", c_void_p), ("next_w_scale", c_void_p), ("next_h_scale", c_void_p),
-        ("extent_stride", c_int), ("accumulate", c_int), ("pooled_parts", c_int),
+        ("extent_stride", c_int), ("accumulate", c_int), ("pooled_parts", c_int), ("zero_skipped", c_int),
     ]
 
 

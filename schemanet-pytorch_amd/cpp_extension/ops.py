@@ -456,26 +456,32 @@ class _ClassEdges(torch.autograd.Function):
     def forward(ctx, edge_weights, vertex_weights, prune_threshold, remove_self_loop, entropy_eps=None):
         ctx.save_for_backward(edge_weights, vertex_weights)
         ctx.opts = (prune_threshold, remove_self_loop, entropy_eps)
+        # (the third output: the normalised vertex weights AS THE KERNEL COMPUTED THEM - the values its pruning rule compared with the
+        # threshold; whoever partitions the vertices into kept and pruned ones afterwards uses these, not a second evaluation)
         if entropy_eps is None:
-            _, ce = atlas_normalize(vertex_weights, edge_weights.detach(), prune_threshold, remove_self_loop)
-            return ce
+            cv, ce = atlas_normalize(vertex_weights, edge_weights.detach(), prune_threshold, remove_self_loop)
+            ctx.mark_non_differentiable(cv)
+            return ce, cv
         lib = N.require_gpu()
         ew = edge_weights.detach()
         dev = _check_dev(vertex_weights, ew)
         K, n = vertex_weights.shape
         ce = torch.empty((K, n, n), dtype=torch.float32, device=dev)
         ent = torch.empty((K, n), dtype=torch.float32, device=dev)
+        cv = torch.empty((K, n), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             N.check(lib.sn_atlas_normalize_entropy(N.ptr(vertex_weights), N.ptr(ew), K, n, int(prune_threshold is not None),
-                                                   float(prune_threshold or 0.0), int(remove_self_loop), None, N.ptr(ce), N.ptr(ent),
+                                                   float(prune_threshold or 0.0), int(remove_self_loop), N.ptr(cv), N.ptr(ce), N.ptr(ent),
                                                    float(entropy_eps), N.stream_ptr(dev)), "sn_atlas_normalize_entropy")
-        return ce, ent
+        ctx.mark_non_differentiable(cv)
+        return ce, ent, cv
 
     @staticmethod
     @_amp_bwd
-    def backward(ctx, grad_ce, grad_ent=None):
+    def backward(ctx, grad_ce, *more):
         ew, vw = ctx.saved_tensors
         thr, rsl, eps = ctx.opts
+        grad_ent = more[0] if eps is not None and more else None          # (outputs: ce, [ent,] cv - cv is not differentiable)
         lib = N.require_gpu()
         dev = _check_dev(ew, vw)
         K, n = vw.shape
@@ -502,9 +508,12 @@ def class_edges_autograd(edge_weights, vertex_weights, prune_threshold=None, rem
     reading class_edges again (and their gradient is folded into this op's one backward pass)."""
     assert edge_weights.is_contiguous() and vertex_weights.is_contiguous()
     if not with_entropy:
-        return _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop)
-    ce, ent = _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop, ENTROPY_EPS)
+        ce, cv = _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop)
+        ce._sn_kernel_cv = cv
+        return ce
+    ce, ent, cv = _ClassEdges.apply(edge_weights, vertex_weights.detach(), prune_threshold, remove_self_loop, ENTROPY_EPS)
     ce._sn_row_entropy = (ENTROPY_EPS, ent)
+    ce._sn_kernel_cv = cv              # (the normalised vertex weights the pruning rule of this pass saw: SchemaNet.get_atlas, compacted training)
     return ce
 
 
@@ -657,11 +666,12 @@ class Planes:
     k of the blocks (multiple of 16); `scale`: None or a device scalar (fp32 [1], a power of two) - the planes hold
     x * scale."""
 
-    __slots__ = ("hi", "lo", "batches", "rows", "k", "kpad", "scale", "pending", "grad_sum")
+    __slots__ = ("hi", "lo", "batches", "rows", "k", "kpad", "scale", "pending", "grad_sum", "compact")
 
     def __init__(self, hi, lo, batches, rows, k, scale=None):
         self.hi, self.lo, self.batches, self.rows, self.k, self.scale = hi, lo, batches, rows, k, scale
         self.pending, self.grad_sum = 0, None       # training: products whose backward is still to come / the sum of their dY . X^T
+        self.compact = None                         # training with compacted class graphs: (perm int32 [G, n], n_kept int32 [G]) of an adjacency operand
         self.kpad = (k + 15) // 16 * 16
 
     @property
@@ -710,6 +720,51 @@ def gcn_adjacency_planes(edges, extent=None, n_valid=None, per_graph=False):
             N.check(lib.sn_gcn_adjacency_planes(N.ptr(e), G, n, N.ptr(extent), ADJ_SCALE, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                     "sn_gcn_adjacency_planes")
     out.scale = const_scale(ADJ_SCALE, dev)
+    return out
+
+
+def gcn_adjacency_planes_compact(edges, perm, n_kept):
+    """(E + E^T)/2 + I of [G, n, n] edges through a vertex permutation: vertex a of graph g's operand is vertex perm[g, a] of `edges`
+    (the kept vertices first: atlas_keep_perm), only the n_kept[g] x n_kept[g] corner (+ identity) is produced - the operand of the
+    training route with compacted class graphs (`planes.compact` = (perm, n_kept); products take n_kept as their extents)."""
+    lib = N.require_gpu()
+    dev = _check_dev(edges, perm, n_kept)
+    e = _f32c(edges)
+    G, n, _ = e.shape
+    assert perm.dtype == torch.int32 and perm.is_contiguous() and tuple(perm.shape) == (G, n) and n_kept.dtype == torch.int32 and n_kept.numel() == G
+    out = _alloc_planes(lib, dev, G, n, n)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_gcn_adjacency_planes_compact(N.ptr(e), G, n, N.ptr(perm), N.ptr(n_kept), ADJ_SCALE, N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
+                "sn_gcn_adjacency_planes_compact")
+    out.scale = const_scale(ADJ_SCALE, dev)
+    out.compact = (perm, n_kept.contiguous())
+    return out
+
+
+def atlas_keep_perm(class_vertices, prune_threshold):
+    """-> (perm int32 [K, n]: the vertices of every class with class_vertices > threshold first, in their own order, then the others;
+    n_kept int32 [K]).  No host synchronisation."""
+    lib = N.require_gpu()
+    dev = _check_dev(class_vertices)
+    cv = _f32c(class_vertices.detach())
+    K, n = cv.shape
+    perm = torch.empty((K, n), dtype=torch.int32, device=dev)
+    n_kept = torch.empty((K,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_atlas_keep_perm(N.ptr(cv), K, n, float(prune_threshold), N.ptr(perm), N.ptr(n_kept), N.stream_ptr(dev)), "sn_atlas_keep_perm")
+    return perm, n_kept
+
+
+def sym_scatter_corner(corner, perm, n_kept):
+    """corner [G, n, n] (rows < n_kept[g] written, compacted vertex order) -> the symmetrised edge gradient [G, n, n] in the stored vertex
+    order, zero where a pruned vertex is involved (sn_sym_scatter_corner)."""
+    lib = N.require_gpu()
+    dev = _check_dev(corner, perm, n_kept)
+    assert corner.dtype == torch.float32 and corner.is_contiguous() and corner.dim() == 3 and corner.shape[1] == corner.shape[2]
+    out = torch.empty_like(corner)
+    with torch.cuda.device(dev):
+        N.check(lib.sn_sym_scatter_corner(N.ptr(corner), N.ptr(perm), N.ptr(n_kept), corner.shape[0], corner.shape[1], N.ptr(out), N.stream_ptr(dev)),
+                "sn_sym_scatter_corner")
     return out
 
 
@@ -822,12 +877,16 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     if accumulate_into is not None:
         c = accumulate_into
         assert c.dtype == torch.float32 and c.is_contiguous() and tuple(c.shape) == (batches, m, n) and c.device == dev
-        assert not want_planes and pool_w is None and bias is None and layernorm is None and not relu and rows_valid is None and m_extent is None
+        assert not want_planes and pool_w is None and bias is None and layernorm is None and not relu and rows_valid is None
         args.c, args.c_batch_stride, args.ldc, args.accumulate = _dp(c), m * n, n, 1
         out["c"] = c
     elif want_c:
-        c = (torch.zeros if zero_c else torch.empty)((batches, m, n), dtype=torch.float32, device=dev)
+        # zero_c with a row mask: the kernel defines every element itself (rows_valid zeroes the pad rows of the tiles it multiplies, the
+        # workgroups of skipped tiles write their zeros) - no clearing pass over the result
+        in_kernel = bool(zero_c and m_extent is not None and rows_valid is not None and rows_valid is m_extent and m_extent.numel() == batches)
+        c = (torch.zeros if (zero_c and not in_kernel) else torch.empty)((batches, m, n), dtype=torch.float32, device=dev)
         args.c, args.c_batch_stride, args.ldc = _dp(c), m * n, n
+        args.zero_skipped = int(in_kernel)
         out["c"] = c
     if next_w is not None:
         assert want_planes and not want_c and pool_w is None and n == 256 and layernorm is not None and next_w.rows == 256 and next_w.kpad == 256
@@ -918,6 +977,14 @@ class _SymAdjMatmul(torch.autograd.Function):
         return d_adj, d_x, None
 
 
+def _edge_grad_of(s_, adj_planes):
+    """S = sum of the layers' dY . X^T -> dE = (S + S^T) / 2; for a compacted operand: its corner symmetrised and scattered back to
+    the stored vertex order (zero where a pruned vertex is involved)"""
+    if adj_planes.compact is not None:
+        return sym_scatter_corner(s_, *adj_planes.compact)
+    return sym_half_(s_)
+
+
 class _EdgesAdjMatmul(torch.autograd.Function):
     """Y = ((E + E^T)/2 + I) @ X straight from the edge tensor E [G, n, n] (reference gnn.py:27-31): the adjacency only ever
     exists as the fp16 planes `adj_planes` = gcn_adjacency_planes(E) (one pass over E; no dense adjacency, no identity
@@ -929,7 +996,8 @@ class _EdgesAdjMatmul(torch.autograd.Function):
     def forward(ctx, edges, x, adj_planes, sum_edge_grads=False):
         G = edges.shape[0]
         xt = split_planes(x.detach(), transpose=True)
-        y = gcn_gemm(adj_planes, xt, G, want_c=True)["c"]
+        ext = adj_planes.compact[1] if adj_planes.compact is not None else None      # compacted class graphs: one extent per graph
+        y = gcn_gemm(adj_planes, xt, G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext, rows_valid=ext)["c"]
         ctx.save_for_backward(x)
         ctx.adj_planes = adj_planes
         ctx.x_scale = xt.scale                               # (the backward's planes of x: no second reduction over it)
@@ -951,24 +1019,25 @@ class _EdgesAdjMatmul(torch.autograd.Function):
                     torch.zeros_like(x) if ctx.needs_input_grad[1] else None, None, None)
         d_e = d_x = None
         dy_scale = pow2_scale(dy)                            # one reduction over dy for both of its plane forms
+        ext = ap.compact[1] if ap.compact is not None else None
         if ctx.needs_input_grad[1]:
-            d_x = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True)["c"]
+            d_x = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext, rows_valid=ext)["c"]
         if ctx.needs_input_grad[0]:
             dyp, xp = split_planes(dy, scale=dy_scale), split_planes(x.detach(), scale=ctx.x_scale)
             if not ctx.counted:
-                s_ = gcn_gemm(dyp, xp, G, want_c=True)["c"]
-                return sym_half_(s_), d_x, None, None
+                s_ = gcn_gemm(dyp, xp, G, want_c=True, m_extent=ext)["c"]
+                return _edge_grad_of(s_, ap), d_x, None, None
             # The layers of one forward pass share `ap` and the edge tensor: their S = dY . X^T are summed in ONE buffer (the
             # product's epilogue adds) and symmetrised once, by the layer whose backward runs last; the others hand autograd
             # no gradient for the edges (= zero).  Per layer this was a strided add, a scale and autograd's accumulation:
             # three more passes over a [G, n, n] tensor (404 MB at config [4]'s real size).
             if ap.grad_sum is None:
-                ap.grad_sum = gcn_gemm(dyp, xp, G, want_c=True)["c"]
+                ap.grad_sum = gcn_gemm(dyp, xp, G, want_c=True, m_extent=ext)["c"]
             else:
-                gcn_gemm(dyp, xp, G, accumulate_into=ap.grad_sum)
+                gcn_gemm(dyp, xp, G, accumulate_into=ap.grad_sum, m_extent=ext)
             ap.pending -= 1
             if ap.pending == 0:
-                d_e, ap.grad_sum = sym_half_(ap.grad_sum), None
+                d_e, ap.grad_sum = _edge_grad_of(ap.grad_sum, ap), None
         return d_e, d_x, None, None
 
 
@@ -997,18 +1066,20 @@ def _plane_batches(p, g0, g1):
 _DW_TEMP_BYTES = 256 << 20     # largest [group, out, in] fp32 temporary of a per-graph weight gradient
 
 
-def _weight_grad_per_graph(dyt, xt):
+def _weight_grad_per_graph(dyt, xt, extents=None):
     """sum_g dY[g]^T X[g] from the planes of dY^T [G, out, n] and X^T [G, in, n]: G products of inner length n and one sum over G
     (one [out, in] product of inner length G n would be (out / 128) x (in / 256) workgroups walking 100 k rows each); graphs in
-    groups when the [G, out, in] temporary would pass _DW_TEMP_BYTES (config [3]: 1000 class graphs of width 1024 = 4.2 GB)."""
+    groups when the [G, out, in] temporary would pass _DW_TEMP_BYTES (config [3]: 1000 class graphs of width 1024 = 4.2 GB).
+    extents (int32 [G]): the inner length of graph g (rows beyond it are zero rows of dY)."""
     G, out_f, in_f = dyt.batches, dyt.rows, xt.rows
     group = max(1, min(G, _DW_TEMP_BYTES // max(1, 4 * out_f * in_f)))
     if group >= G:
-        return gcn_gemm(dyt, xt, G, want_c=True)["c"].sum(dim=0)
+        return gcn_gemm(dyt, xt, G, want_c=True, k_extent=extents)["c"].sum(dim=0)
     dw = None
     for g0 in range(0, G, group):
         g1 = min(G, g0 + group)
-        part = gcn_gemm(_plane_batches(dyt, g0, g1), _plane_batches(xt, g0, g1), g1 - g0, want_c=True)["c"].sum(dim=0)
+        part = gcn_gemm(_plane_batches(dyt, g0, g1), _plane_batches(xt, g0, g1), g1 - g0, want_c=True,
+                        k_extent=None if extents is None else extents[g0:g1].contiguous())["c"].sum(dim=0)
         dw = part if dw is None else dw.add_(part)
     return dw
 
@@ -1023,15 +1094,17 @@ class _LinearMfma(torch.autograd.Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, extents=None):
         x3 = _f32c(x.detach())
         x3 = x3[None] if x3.dim() == 2 else x3
         G = x3.shape[0]
         xp, wp = split_planes(x3), split_planes(weight.detach())
-        y = gcn_gemm(xp, wp, G, bias=bias, want_c=True)["c"]
+        # extents (int32 [G], graphs of [G, n, in] only): rows >= extents[g] of graph g are pad rows - neither multiplied nor written (zeros)
+        y = gcn_gemm(xp, wp, G, bias=bias, want_c=True, zero_c=extents is not None, m_extent=extents, rows_valid=extents)["c"]
         ctx.save_for_backward(x, weight)
         ctx.scales = (xp.scale, wp.scale)
         ctx.has_bias = bias is not None
+        ctx.extents = extents
         return y[0] if x.dim() == 2 else y
 
     @staticmethod
@@ -1046,22 +1119,26 @@ class _LinearMfma(torch.autograd.Function):
         G = x3.shape[0]
         if dy3.numel() == 0:
             return (torch.zeros_like(x) if ctx.needs_input_grad[0] else None, torch.zeros_like(weight) if ctx.needs_input_grad[1] else None,
-                    torch.zeros(weight.shape[0], dtype=weight.dtype, device=weight.device) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+                    torch.zeros(weight.shape[0], dtype=weight.dtype, device=weight.device) if ctx.has_bias and ctx.needs_input_grad[2] else None, None)
+        ext = ctx.extents
         dy_scale = pow2_scale(dy3)                              # one reduction over dY for both of its plane forms
         if ctx.needs_input_grad[0]:
-            dx = gcn_gemm(split_planes(dy3, scale=dy_scale), split_planes(weight.detach(), scale=w_scale, transpose=True), G, want_c=True)["c"]
+            dx = gcn_gemm(split_planes(dy3, scale=dy_scale), split_planes(weight.detach(), scale=w_scale, transpose=True), G, want_c=True,
+                          zero_c=ext is not None, m_extent=ext, rows_valid=ext)["c"]
             dx = dx[0] if x.dim() == 2 else dx
         if ctx.needs_input_grad[1]:
-            dw = _weight_grad_per_graph(split_planes(dy3, scale=dy_scale, transpose=True), split_planes(x3, scale=x_scale, transpose=True))
+            dw = _weight_grad_per_graph(split_planes(dy3, scale=dy_scale, transpose=True), split_planes(x3, scale=x_scale, transpose=True), ext)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy3.sum(dim=(0, 1))
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear_mfma(x, weight, bias=None):
+def linear_mfma(x, weight, bias=None, extents=None):
     """x [G, n, in] or [rows, in] fp32 (CUDA; in and out multiples of 16), weight [out, in], bias [out] or None -> x W^T + b,
-    differentiable in all three, every product on the matrix cores (no library GEMM)."""
-    return _LinearMfma.apply(x, weight, bias)
+    differentiable in all three, every product on the matrix cores (no library GEMM).  extents (int32 [G], 3-D x only): the rows
+    of graph g from extents[g] on are pad rows whose gradient is zero (compacted class graphs): they come back as zeros."""
+    assert extents is None or (x.dim() == 3 and extents.dtype == torch.int32 and extents.numel() == x.shape[0])
+    return _LinearMfma.apply(x, weight, bias, extents)
 
 
 class _GatherAdjMatmul(torch.autograd.Function):
@@ -1080,7 +1157,8 @@ class _GatherAdjMatmul(torch.autograd.Function):
         tab = _f32c(table.detach())
         t_scale = pow2_scale(tab)
         zt = gcn_gather_planes(tab, ids, scale=t_scale)
-        y = gcn_gemm(adj_planes, zt, G, bias=bias, want_c=True)["c"]
+        ext = adj_planes.compact[1] if adj_planes.compact is not None else None      # compacted class graphs (ids in the operand's vertex order)
+        y = gcn_gemm(adj_planes, zt, G, bias=bias, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext, rows_valid=ext)["c"]
         ctx.save_for_backward(tab, ids, *(sort if sort is not None else ()))
         ctx.adj_planes, ctx.t_scale, ctx.has_bias = adj_planes, t_scale, bias is not None
         ctx.pad = int(padding_idx) if padding_idx is not None else -1
@@ -1104,8 +1182,9 @@ class _GatherAdjMatmul(torch.autograd.Function):
                     torch.zeros_like(tab) if ctx.needs_input_grad[1] else None, None,
                     torch.zeros(F, dtype=tab.dtype, device=tab.device) if ctx.has_bias and ctx.needs_input_grad[3] else None, None, None, None, None)
         dy_scale = pow2_scale(dy)
+        ext = ap.compact[1] if ap.compact is not None else None
         if ctx.needs_input_grad[1]:
-            dz = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True)["c"].reshape(-1, F)
+            dz = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext, rows_valid=ext)["c"].reshape(-1, F)
             if sort:
                 lib = N.require_gpu()
                 d_tab = torch.empty((rows, F), dtype=torch.float32, device=dz.device)
@@ -1118,15 +1197,15 @@ class _GatherAdjMatmul(torch.autograd.Function):
             dyp = split_planes(dy, scale=dy_scale)
             zp = split_planes(torch.nn.functional.embedding(ids, tab), scale=ctx.t_scale)
             if not ctx.counted:
-                d_e = sym_half_(gcn_gemm(dyp, zp, G, want_c=True)["c"])
+                d_e = _edge_grad_of(gcn_gemm(dyp, zp, G, want_c=True, m_extent=ext)["c"], ap)
             else:
                 if ap.grad_sum is None:
-                    ap.grad_sum = gcn_gemm(dyp, zp, G, want_c=True)["c"]
+                    ap.grad_sum = gcn_gemm(dyp, zp, G, want_c=True, m_extent=ext)["c"]
                 else:
-                    gcn_gemm(dyp, zp, G, accumulate_into=ap.grad_sum)
+                    gcn_gemm(dyp, zp, G, accumulate_into=ap.grad_sum, m_extent=ext)
                 ap.pending -= 1
                 if ap.pending == 0:
-                    d_e, ap.grad_sum = sym_half_(ap.grad_sum), None
+                    d_e, ap.grad_sum = _edge_grad_of(ap.grad_sum, ap), None
         if ctx.has_bias and ctx.needs_input_grad[3]:
             d_b = dy.sum(dim=(0, 1))
         return d_e, d_tab, None, d_b, None, None, None, None

@@ -558,6 +558,7 @@ struct GemmArgs {
     const int32_t *m_extent, *k_extent;   // device scalars (or NULL): rows / k beyond them are never consumed downstream
     int ext_stride;                       // 0: one value for the batch; 1: per graph (m_extent[batch], k_extent[batch])
     int accumulate;                       // c += result (plain products only)
+    int zero_skipped;                     // row tiles past the extent are written as zeros
     int pooled_parts;                     // partial sums per graph in `pooled` (>= tiles_y: the caller may keep further slots)
     unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
     int nt_a, nt_b;                  // stream that operand past the caches (read once by one workgroup)
@@ -630,6 +631,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     const int tile_m = tile_m_, tile_n = (tile % p.tiles_x) * kTileN;
     if (p.m_extent && tile_m >= p.m_extent[(int64_t)batch * p.ext_stride]) {      // a row tile past the largest graph of the batch (ext_stride 1: past this graph)
         if (p.pooled && tid + tile_n < p.n) p.pooled[((int64_t)batch * p.pooled_parts + tile / p.tiles_x) * p.n + tile_n + tid] = 0.0f;
+        if (p.zero_skipped && p.c && !p.accumulate) {              // (its rows of the fp32 result: zeros, whole lines)
+            const int cols = min(kTileN, p.n - tile_n), rows = min(kTileM, p.m - tile_m);
+            float *c0 = p.c + (int64_t)batch * p.c_batch_stride + (int64_t)tile_m * p.ldc + tile_n;
+            if ((cols & 3) == 0 && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(c0) & 15) == 0) {
+                const int c4 = cols >> 2;
+                for (int i = tid; i < rows * c4; i += kGemmThreads) *reinterpret_cast<float4 *>(c0 + (int64_t)(i / c4) * p.ldc + 4 * (i % c4)) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            } else {
+                for (int i = tid; i < rows * cols; i += kGemmThreads) c0[(int64_t)(i / cols) * p.ldc + i % cols] = 0.0f;
+            }
+        }
         return;
     }
     const int kb_count = p.k / kStageK;
@@ -1417,6 +1428,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     a.stamps = g_gemm_stamps;
     a.m_extent = u->m_extent; a.k_extent = u->k_extent; a.ext_stride = u->extent_stride != 0 ? 1 : 0;
     a.accumulate = u->accumulate != 0 ? 1 : 0;
+    a.zero_skipped = u->zero_skipped != 0 ? 1 : 0;
     a.tab_hi = (const _Float16 *)u->b_table_hi; a.tab_lo = (const _Float16 *)u->b_table_lo;
     a.ids = u->b_ids; a.ids_stride = u->b_ids_stride; a.ids_n = u->b_ids_n; a.tab_rows = u->b_table_rows; a.tab_ld = u->n;
     a.w2_hi = (const _Float16 *)u->next_w_hi; a.w2_lo = (const _Float16 *)u->next_w_lo;

@@ -428,11 +428,38 @@ extern "C" int sn_pow2_scale(const float *x, int64_t n, float top, void *partial
     return SN_OK;
 }
 
-// out[g][i][j] = (corner[g][a][b] + corner[g][b][a]) / 2 for i = perm[a], j = perm[b], a, b < n_kept[g]; 0 elsewhere.  One workgroup per
-// (64-row block of the STORED order, graph): the inverse permutation of the graph staged in LDS, a thread per column, rows in turn - the
-// writes are whole rows of `out`, the reads two gathers inside 4 KiB rows / columns of the corner (L2: a corner is at most 4 MiB).
+// out[g][i][j] = (corner[g][a][b] + corner[g][b][a]) / 2 for i = perm[a], j = perm[b], a, b < n_kept[g]; 0 elsewhere.  Two launches: the
+// corner symmetrised in place, tile pairs through LDS as sym_half_kernel does (tiles past the graph's extent skipped); then one
+// workgroup per (64-row block of the STORED order, graph): the inverse permutation of the graph staged in LDS, a thread per column,
+// rows in turn - the writes are whole rows of `out`, the reads a gather inside ONE 4 KiB row of the corner per output row.
 constexpr int kScatterMaxN = 1024;
-__global__ __launch_bounds__(256) void sym_scatter_corner_kernel(const float *corner, const int32_t *perm, const int32_t *n_kept, int n, float *out)
+__global__ __launch_bounds__(256) void sym_corner_kernel(float *s, int n, int T, const int32_t *n_kept)
+{
+    int I = 0, rest = blockIdx.x;
+    while (rest >= T - I) { rest -= T - I; ++I; }
+    const int J = I + rest;
+    const int nk = min(max(n_kept[blockIdx.y], 0), n);
+    const int ri = I * kSymTile, cj = J * kSymTile;
+    if (ri >= nk || cj >= nk) return;                            // (whole workgroup, before any barrier; J >= I)
+    __shared__ float ta[kSymTile * kSymLd], tb[kSymTile * kSymLd];
+    float *g = s + (int64_t)blockIdx.y * n * n;
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = r0; r < kSymTile; r += 4) {
+        const bool in_a = ri + r < nk && cj + c < nk, in_b = cj + r < nk && ri + c < nk;
+        ta[r * kSymLd + c] = in_a ? g[(int64_t)(ri + r) * n + cj + c] : 0.0f;
+        if (I != J) tb[r * kSymLd + c] = in_b ? g[(int64_t)(cj + r) * n + ri + c] : 0.0f;
+    }
+    __syncthreads();
+    const float *tt = I != J ? tb : ta;
+#pragma unroll 4
+    for (int r = r0; r < kSymTile; r += 4) {
+        if (ri + r < nk && cj + c < nk) g[(int64_t)(ri + r) * n + cj + c] = (ta[r * kSymLd + c] + tt[c * kSymLd + r]) * 0.5f;
+        if (I != J && cj + r < nk && ri + c < nk) g[(int64_t)(cj + r) * n + ri + c] = (tb[r * kSymLd + c] + ta[c * kSymLd + r]) * 0.5f;
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_corner_kernel(const float *corner, const int32_t *perm, const int32_t *n_kept, int n, float *out)
 {
     __shared__ short inv[kScatterMaxN];
     const int g = blockIdx.y, nk = min(max(n_kept[g], 0), n);
@@ -444,21 +471,21 @@ __global__ __launch_bounds__(256) void sym_scatter_corner_kernel(const float *co
     for (int i = i0; i < min(n, i0 + 64); ++i) {
         const int a = inv[i];                                     // (block-uniform)
         for (int j = threadIdx.x; j < n; j += 256) {
-            float v = 0.0f;
             const int b = inv[j];
-            if (a >= 0 && b >= 0) v = (c[(int64_t)a * n + b] + c[(int64_t)b * n + a]) * 0.5f;
-            o[(int64_t)i * n + j] = v;
+            o[(int64_t)i * n + j] = (a >= 0 && b >= 0) ? c[(int64_t)a * n + b] : 0.0f;
         }
     }
 }
 
-extern "C" int sn_sym_scatter_corner(const float *corner, const int32_t *perm, const int32_t *n_kept, int G, int n, float *out, void *stream)
+extern "C" int sn_sym_scatter_corner(float *corner, const int32_t *perm, const int32_t *n_kept, int G, int n, float *out, void *stream)
 {
     SN_REQUIRE(G >= 0 && n >= 0, SN_ERR_BAD_ARG, "sn_sym_scatter_corner: bad G=%d n=%d", G, n);
     if (G == 0 || n == 0) return SN_OK;
     SN_REQUIRE(corner && perm && n_kept && out, SN_ERR_BAD_ARG, "sn_sym_scatter_corner: NULL pointer");
     SN_REQUIRE(n <= kScatterMaxN && G <= 65535, SN_ERR_UNSUPPORTED, "sn_sym_scatter_corner: n=%d > %d or G=%d > 65535", n, kScatterMaxN, G);
-    hipLaunchKernelGGL(sym_scatter_corner_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)G), dim3(256), 0, (hipStream_t)stream, corner, perm, n_kept, n, out);
+    const int T = (n + kSymTile - 1) / kSymTile;
+    hipLaunchKernelGGL(sym_corner_kernel, dim3((unsigned)(T * (T + 1) / 2), (unsigned)G), dim3(256), 0, (hipStream_t)stream, corner, n, T, n_kept);
+    hipLaunchKernelGGL(scatter_corner_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)G), dim3(256), 0, (hipStream_t)stream, corner, perm, n_kept, n, out);
     SN_CHECK_LAUNCH("sn_sym_scatter_corner");
     return SN_OK;
 }

@@ -76,14 +76,14 @@ class _LinearPerGraphWeightGrad(torch.autograd.Function):
 _DW_TEMP_BYTES = 256 << 20     # largest [group, out, in] fp32 temporary of _LinearPerGraphWeightGrad.backward
 
 
-def _linear(lin, x):
+def _linear(lin, x, extents=None):
     """`lin(x)`; for a batch of graphs on the GPU under autograd: on the matrix cores (ops.linear_mfma: forward and both gradients
     as split-fp16 MFMA GEMMs, no library GEMM in a training iteration), or - SN_LINEAR_MFMA=0 - the library's GEMMs with the
     per-graph weight gradient above."""
     if isinstance(lin, nn.Linear) and x.is_cuda and torch.is_grad_enabled() and lin.weight.requires_grad and x.dim() in (2, 3) and x.shape[0] > 0:
         if (x.dtype == torch.float32 and lin.in_features % 16 == 0 and lin.out_features % 16 == 0 and os.environ.get("SN_GCN_MFMA", "1") != "0"
                 and os.environ.get("SN_LINEAR_MFMA", "1") != "0"):
-            return ops.linear_mfma(x, lin.weight, lin.bias)
+            return ops.linear_mfma(x, lin.weight, lin.bias, extents if x.dim() == 3 else None)
         if x.dim() == 3 and x.shape[0] > 1 and os.environ.get("SN_LINEAR_PER_GRAPH_DW", "1") != "0":
             return _LinearPerGraphWeightGrad.apply(x, lin.weight, lin.bias)
     return lin(x)
@@ -109,7 +109,9 @@ class GraphConv(nn.Module):
             adj = self.adjacency(edges)
         if adj_planes is not None:      # training on the matrix cores: adj @ feat and both of its gradients as split-fp16 MFMA GEMMs
             if adj is None:             # ... with the adjacency built straight from the edges as fp16 planes (never dense)
-                return _linear(self.linear, ops.edges_adj_matmul(edges, feat, adj_planes, sum_edge_grads))
+                # (compacted class graphs: the operand holds the kept vertices only, every product takes their counts as extents)
+                ext = adj_planes.compact[1] if getattr(adj_planes, "compact", None) is not None else None
+                return _linear(self.linear, ops.edges_adj_matmul(edges, feat, adj_planes, sum_edge_grads), ext)
             return _linear(self.linear, ops.sym_adj_matmul(adj, feat, adj_planes))
         return _linear(self.linear, torch.bmm(adj, feat))
 
@@ -410,9 +412,46 @@ class GNN(nn.Module):
             feat = ops.mask_layernorm_act_(feat, first.norm.weight, first.norm.bias, first.norm.eps,
                                            n_valid=n_valid, relu=first._is_relu)
             layers = layers[1:]
-        adj_planes = ops.gcn_adjacency_planes(_contig(edges.detach())) if train_mfma else None      # shared by the layers (and by their backward passes)
-        if (feat is None and train_mfma and first is not None and isinstance(first.g_conv.linear, nn.Linear) and ingredients.dtype == torch.int64
-                and self.embedding.weight.dtype == torch.float32 and edges.dtype == torch.float32 and os.environ.get("SN_TRAIN_FOLD", "1") != "0"):
+        fold = bool(feat is None and train_mfma and first is not None and isinstance(first.g_conv.linear, nn.Linear) and ingredients.dtype == torch.int64
+                    and self.embedding.weight.dtype == torch.float32 and edges.dtype == torch.float32 and os.environ.get("SN_TRAIN_FOLD", "1") != "0")
+        pooled_iso, compact_sort = None, None
+        if fold and compact is not None and all(isinstance(l.g_conv.linear, nn.Linear) for l in layers):
+            # Training with COMPACTED class graphs (round 5): a vertex under the prune threshold has no edge (schema_net.py:152-166 zeroes its
+            # row and column), so its adjacency row is the identity and its feature a function of its word only.  The products run on the
+            # kept vertices of every class (perm: kept first; their counts are the extents of every product, pad rows masked as in the
+            # instance graphs), the pruned ones enter the pooled class feature through the per-word table `iso` - with autograd, so
+            # their share of the gradients of the GNN's weights and of the vertex weights is kept.
+            perm, n_kept = compact
+            perm_l = perm.long()
+            kept = torch.arange(nodes.shape[1], device=nodes.device)[None, :] < n_kept[:, None]
+            # (the cached sort of the stored ids carried over to the permuted order: position (g, i) of the stored order is row
+            # (g, inv[g, i]) of the compacted one - the table's gradient stays one gather-sum, no sort per iteration)
+            compact_sort = None
+            srt0 = self._cached_sort(ingredients, self.embedding.weight.shape[0])
+            if srt0 is not None:
+                n_ = ingredients.shape[1]
+                inv = torch.empty_like(perm_l).scatter_(1, perm_l, torch.arange(n_, device=perm.device).expand_as(perm_l))
+                order = srt0[0]
+                compact_sort = ((order // n_) * n_ + inv.reshape(-1)[order], srt0[1])
+            ingredients = ingredients.gather(1, perm_l)
+            w_all = nodes.gather(1, perm_l)
+            nodes = w_all * kept.to(w_all.dtype)
+            feat_mask, n_valid = ~kept, n_kept
+            adj_planes = ops.gcn_adjacency_planes_compact(_contig(edges.detach()), perm, n_kept)
+            table = prepared.get("train_table") if isinstance(prepared, dict) else None
+            if table is None:
+                table = ops.linear_mfma(self.embedding.weight, first.g_conv.linear.weight)
+            prepared = {"train_table": table}
+            h = first.post((table + first.g_conv.linear.bias)[None], None, None, False)[0]                   # an isolated vertex of word w, layer by layer
+            for l in layers[1:]:
+                h = l.post(_linear(l.g_conv.linear, h)[None], None, None, False)[0]
+            w_sum = torch.zeros((nodes.shape[0], table.shape[0]), dtype=w_all.dtype, device=nodes.device)
+            w_sum = w_sum.scatter_add(1, ingredients.clamp(0, table.shape[0] - 1), w_all * (~kept).to(w_all.dtype))   # [G, words]: pruned weight per word
+            pad = (-table.shape[0]) % 16
+            pooled_iso = ops.linear_mfma(torch.nn.functional.pad(w_sum, (0, pad)), torch.nn.functional.pad(h.t(), (0, pad)).contiguous())
+        else:
+            adj_planes = ops.gcn_adjacency_planes(_contig(edges.detach())) if train_mfma else None      # shared by the layers (and by their backward passes)
+        if fold:
             # training, layer 1 re-associated the same way: the Linear of the first convolution acts on the embedding TABLE (a [M + 1, E] x
             # [E, E] product with autograd) and the graph product gathers its operand from that table as fp16 planes - no [G n, E] x [E, E]
             # GEMM in the forward or the backward pass, no fp32 embedding of the graphs
@@ -420,7 +459,7 @@ class GNN(nn.Module):
             table = prepared.get("train_table") if isinstance(prepared, dict) else None     # (Matcher: one table for both passes of an iteration)
             if table is None:
                 table = ops.linear_mfma(self.embedding.weight, lin.weight)
-            srt = self._cached_sort(ingredients, table.shape[0])
+            srt = self._cached_sort(ingredients, table.shape[0]) if pooled_iso is None else compact_sort
             feat = ops.gather_adj_matmul(edges, table, ingredients.detach(), lin.bias, adj_planes, srt, self.embedding.padding_idx, sum_edge_grads=True)
             feat = first.post(feat, feat_mask, n_valid, fused)
             layers = layers[1:]
@@ -437,4 +476,6 @@ class GNN(nn.Module):
         else:
             pooled = (feat * nodes[..., None]).sum(dim=1)
             pooled = pooled / (divisor.to(pooled.dtype) if divisor is not None else feat.shape[1])
+        if pooled_iso is not None:                                           # (compacted class graphs: the pruned vertices' share)
+            pooled = pooled + pooled_iso / (divisor.to(pooled.dtype) if divisor is not None else float(feat.shape[1]))
         return _linear(self.fc, pooled)

@@ -81,8 +81,11 @@ class Matcher(nn.Module):
             compact = (class_dict["class_perm"], class_dict["class_n_kept"]) if "class_perm" in class_dict else None
             return self.gnn(nodes=class_dict["class_vertices"], edges=None, ingredients=class_dict["class_ingredients"],
                             adjacency=class_dict["class_adjacency"], prepared=prepared, compact=compact)
+        # (training with a pruned atlas: SchemaNet.get_atlas adds the partition of every class into kept and pruned vertices, and the
+        # GNN runs its products on the kept ones - GNN.forward, "compacted class graphs")
+        compact = (class_dict["class_perm"], class_dict["class_n_kept"]) if "class_perm" in class_dict and torch.is_grad_enabled() else None
         return self.gnn(nodes=class_dict["class_vertices"], edges=class_dict["class_edges"],
-                        ingredients=class_dict["class_ingredients"], prepared=prepared)
+                        ingredients=class_dict["class_ingredients"], prepared=prepared, compact=compact)
 
     # ---- atlas branch on its own HIP stream -------------------------------------------------
     # The class-graph branch (atlas normalisation -> GNN over K graphs) depends only on parameters,
@@ -170,7 +173,10 @@ class Matcher(nn.Module):
         run_instance = lambda: self.gnn(nodes=graph["vertices"], edges=edges, ingredients=graph["ids"],     # noqa: E731
                                         n_valid=graph["n"], divisor=graph["n_max"],
                                         prepared=feat_kg.prepared if isinstance(feat_kg, _AtlasHandle) else shared)
-        if training and os.environ.get("SN_TRAIN_SIDE_STREAM", "1") != "0":
+        # (not beside a COMPACTED class pass: that one is a chain of small launches as well, and the two chains were measured slower
+        # side by side - 5.55 ms - than one after the other - 5.23 ms - at config [4]'s real size)
+        side_env = os.environ.get("SN_TRAIN_SIDE_STREAM", "1")     # 0: never, 1: beside an uncompacted class pass, 2: always
+        if training and side_env != "0" and (side_env == "2" or "class_perm" not in class_dict):
             # Training: the two GNN passes of an iteration meet at the similarity only.  The instance pass is a chain of ~25 small
             # launches forward and ~50 backward (64 graphs of <= 196 vertices: ~20 us each whatever their size), the class pass a chain
             # of large ones: the instance pass runs on a second stream, forward AND backward (autograd runs a node's backward on the

@@ -211,7 +211,39 @@ class SchemaNet(nn.Module):
             cv, ce = ops.atlas_normalize(vw.detach(), ew.detach(), self.prune_node_threshold, self.remove_self_loop)
         else:
             cv, ce = self.get_class_vertices(detach), self.get_class_edges(detach)
-        return {"class_vertices": cv, "class_edges": ce, "class_ingredients": self.class_ingredients.tensor}
+        out = {"class_vertices": cv, "class_edges": ce, "class_ingredients": self.class_ingredients.tensor}
+        kcv = getattr(ce, "_sn_kernel_cv", None)
+        mode = os.environ.get("SN_TRAIN_COMPACT", "1")              # 0: never, 1: when it pays (below), 2: always (tests)
+        if (kcv is not None and self.prune_node_threshold is not None and vw.shape[1] <= 1024 and mode != "0"
+                and (mode == "2" or self._train_compaction_pays(kcv))):
+            # training with a pruned atlas (round 5): the partition of every class into kept vertices (first) and pruned ones, from the
+            # normalised weights the pruning pass itself compared with the threshold; `Matcher` runs the class GNN on the kept vertices
+            out["class_perm"], out["class_n_kept"] = ops.atlas_keep_perm(kcv, self.prune_node_threshold)
+        return out
+
+    def __getstate__(self):
+        """copies and pickles of the module start the bookkeeping of `_train_compaction_pays` afresh"""
+        state = self.__dict__.copy()
+        state.pop("_compaction_state", None)
+        return state
+
+    def _train_compaction_pays(self, kernel_cv: torch.Tensor) -> bool:
+        """Compacting the class graphs pays when enough vertices are pruned (the products cost row tiles x k stages per class; the
+        compacted route adds a permuted operand, the scatter of the edge gradient and the per-word pass of the pruned vertices):
+        below 3/4 of the vertices kept.  The kept fraction is read from the device at the first training forward and at every
+        256th from then on (one host synchronisation each: the vertex weights change with every optimizer step, so a per-version
+        look-up as in inference would synchronise every iteration); in between - and inside a stream capture - the last decision
+        holds.  Deterministic in the number of calls: two runs from the same state take the same route."""
+        st = getattr(self, "_compaction_state", None)
+        if st is None:
+            st = self._compaction_state = {"calls": 0, "decision": False}
+        if torch.cuda.is_current_stream_capturing():
+            return st["decision"]
+        if st["calls"] % 256 == 0:
+            with torch.no_grad():
+                st["decision"] = bool(float((kernel_cv > float(self.prune_node_threshold)).float().mean()) < 0.75)
+        st["calls"] += 1
+        return st["decision"]
 
     def _atlas_compaction_pays(self) -> bool:
         """Are enough class vertices under prune_node_threshold for the compacted route to pay (see below)?  One host

@@ -586,3 +586,55 @@ def test_gnn_training_route_with_the_folded_first_layer(mods, monkeypatch, G, n,
     names = ["out", "d nodes", "d edges"] + [k for k, _ in net.named_parameters()]
     for g_, w_, r_, what in zip(got, want, ref, names):
         _close_to_f64(g_, w_, r_, what, slack=3e-6)
+
+
+# =============================================================================== round 5: training with compacted class graphs
+def _pruned_atlas(mods, K, M, frac_pruned, seed):
+    """SchemaNet whose classes have `frac_pruned` of their vertex weights far under the prune threshold (and the atlas pruned accordingly
+    by the first forward pass, as in a trained model)"""
+    torch.manual_seed(seed)
+    sn = mods["graph"].SchemaNet(num_vertices=M, num_classes=K, clamp_vertex_attn=-1.0, clamp_edge_attn=-1.0, prune_node_threshold=0.001).to(DEV)
+    sn.register_class_vertices(torch.arange(M, device=DEV).repeat(K, 1))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        vw = torch.rand(K, M, generator=g) + 0.5
+        drop = torch.rand(K, M, generator=g) < frac_pruned
+        vw[drop] = 1.0e-7
+        sn.vertex_weights.tensor.copy_(vw.to(DEV))
+        sn.edge_weights.tensor.copy_(torch.rand(K, M, M, generator=g).to(DEV))
+    return sn
+
+
+@pytest.mark.parametrize("K,M,E,frac", [(5, 256, 256, 0.5), (3, 200, 64, 0.8), (4, 128, 256, 0.0)])
+def test_training_with_compacted_class_graphs(mods, monkeypatch, K, M, E, frac):
+    """Matcher.atlas_features under autograd on a pruned IR-Atlas: the class GNN on the kept vertices of every class + the per-word share of
+    the pruned ones (SN_TRAIN_COMPACT=2: always) against the uncompacted route (=0) - the class features and the gradients of every
+    GNN parameter, of the vertex weights and of the edge weights (NaN rows of pruned vertices at the same places, reference
+    schema_net.py:152-175) - and both against float64 where the reference is finite."""
+    graph = mods["graph"]
+    sn = _pruned_atlas(mods, K, M, frac, 31 + K)
+    torch.manual_seed(5)
+    m = graph.Matcher("inner_product", M, dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu")).to(DEV).train()
+    sn.train()
+    dout = torch.randn(K, E, generator=torch.Generator().manual_seed(9)).to(DEV) * 1e-2
+
+    def run(mode):
+        monkeypatch.setenv("SN_TRAIN_COMPACT", mode)
+        m.zero_grad(); sn.zero_grad()
+        atlas = sn.get_atlas()
+        assert ("class_perm" in atlas) == (mode == "2")
+        feat = m.atlas_features(atlas)
+        feat.backward(dout)
+        grads = [p.grad.detach().clone() for p in m.gnn.parameters()]
+        return feat.detach().clone(), grads, sn.vertex_weights.tensor.grad.detach().clone(), sn.edge_weights.tensor.grad.detach().clone()
+    f0, g0, gv0, ge0 = run("0")
+    f1, g1, gv1, ge1 = run("2")
+    scale = float(f0.abs().max())
+    assert float((f1 - f0).abs().max()) <= 3e-6 * scale, (float((f1 - f0).abs().max()), scale)
+    for a, b, (name, _) in zip(g1, g0, m.gnn.named_parameters()):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, (name, float((a - b).abs().max()), float(b.abs().max()))
+    assert float((gv1 - gv0).abs().max()) <= 2e-5 * float(gv0.abs().max()) + 1e-12
+    nan0, nan1 = torch.isnan(ge0), torch.isnan(ge1)
+    assert torch.equal(nan0, nan1)
+    fin = ~nan0
+    assert float((ge1[fin] - ge0[fin]).abs().max()) <= 2e-5 * float(ge0[fin].abs().max()) + 1e-12
