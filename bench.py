@@ -404,7 +404,9 @@ def train_leg(device, n_iter=10):
         del sn_t, m_t, opt, run
         torch.cuda.empty_cache()
     out["c5_train_note"] = ("config [4] at its real size, one training iteration (normalize, forward, loss, backward, fused AdamW): `train.GraphedTrainIter` "
-                            "(one hipGraph launch) / eager `train_iter` over the same padded route; r03: 13.4 ms")
+                            "(one hipGraph launch; the class GNN on the kept vertices of the atlas, half of which is pruned at this initialisation) / eager `train_iter` "
+                            "calls over the same padded batch (class graphs at full size, the instance pass on a second stream: the better route "
+                            "when every launch costs host time); r03: 13.4 ms, r04: 6.5 ms")
     return out
 
 

@@ -213,9 +213,12 @@ class SchemaNet(nn.Module):
             cv, ce = self.get_class_vertices(detach), self.get_class_edges(detach)
         out = {"class_vertices": cv, "class_edges": ce, "class_ingredients": self.class_ingredients.tensor}
         kcv = getattr(ce, "_sn_kernel_cv", None)
-        mode = os.environ.get("SN_TRAIN_COMPACT", "1")              # 0: never, 1: when it pays (below), 2: always (tests)
+        # SN_TRAIN_COMPACT: 0 never; 1 (default) where the caller has asked for it (`compact_training`: train.GraphedTrainIter does -
+        # the compacted route has ~90 launches more per iteration, which a captured iteration does not pay for and an eager one does:
+        # 6.5 ms against 5.3 ms eager, 5.0 against 5.4 ms captured at config [4]'s real size) and it pays (below); 2 always (tests)
+        mode = os.environ.get("SN_TRAIN_COMPACT", "1")
         if (kcv is not None and self.prune_node_threshold is not None and vw.shape[1] <= 1024 and mode != "0"
-                and (mode == "2" or self._train_compaction_pays(kcv))):
+                and (mode == "2" or (getattr(self, "compact_training", False) and self._train_compaction_pays(kcv)))):
             # training with a pruned atlas (round 5): the partition of every class into kept vertices (first) and pruned ones, from the
             # normalised weights the pruning pass itself compared with the threshold; `Matcher` runs the class GNN on the kept vertices
             out["class_perm"], out["class_n_kept"] = ops.atlas_keep_perm(kcv, self.prune_node_threshold)

@@ -83,7 +83,11 @@ class GraphedTrainIter:
 
     def __init__(self, forward: Callable[[Dict[str, torch.Tensor]], Dict[str, torch.Tensor]], schema_net, loss_fn,
                  loss_weights: Dict[str, float], optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor],
-                 targets: Dict[str, torch.Tensor], warmup: int = 2):
+                 targets: Dict[str, torch.Tensor], warmup: int = 2, compact: bool = True):
+        # compact: the class GNN of the captured iteration runs on the kept vertices of a pruned IR-Atlas where that pays
+        # (`schema_net.compact_training`, SchemaNet.get_atlas): the extra launches of that route cost a replay nothing
+        if compact and hasattr(schema_net, "get_atlas"):
+            schema_net.compact_training = True
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainIter needs an optimizer built with capturable=True")
         if warmup < 1 and not optimizer.state:

@@ -512,7 +512,8 @@ def test_c5_real_size_training_iterations(mods):
                     out = {"pred": m_.forward_padded(sn_.instance_graph_padded(b["ingredients"], b["attn"].clone(), b["attn_cls"].clone()), atlas)}
                     out.update(atlas)
                     return out
-                if graphed == "eager":                                   # the same 2 + 6 steps as plain `train_iter` calls
+                if graphed == "eager":                                   # the same 2 + 6 steps as plain `train_iter` calls (on the route GraphedTrainIter takes)
+                    sn_.compact_training = True
                     losses = [float(train_mod.train_iter(lambda: padded(batch), sn_, loss_fn, weights, opt, target)[0]) for _ in range(8)]
                     return losses[2:], None, None, None
                 step = train_mod.GraphedTrainIter(padded, sn_, loss_fn, weights, opt, batch, target, warmup=2)
