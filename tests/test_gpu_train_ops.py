@@ -598,14 +598,16 @@ def _pruned_atlas(mods, K, M, frac_pruned, seed):
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         vw = torch.rand(K, M, generator=g) + 0.5
-        drop = torch.rand(K, M, generator=g) < frac_pruned
+        drop = torch.rand(K, M, generator=g) < abs(frac_pruned)
         vw[drop] = 1.0e-7
+        if frac_pruned < 0:
+            vw[0] = 1.0                                              # M > 1000 equal weights: 1 / M < the threshold - a class with NO kept vertex
         sn.vertex_weights.tensor.copy_(vw.to(DEV))
         sn.edge_weights.tensor.copy_(torch.rand(K, M, M, generator=g).to(DEV))
     return sn
 
 
-@pytest.mark.parametrize("K,M,E,frac", [(5, 256, 256, 0.5), (3, 200, 64, 0.8), (4, 128, 256, 0.0)])
+@pytest.mark.parametrize("K,M,E,frac", [(5, 256, 256, 0.5), (3, 200, 64, 0.8), (4, 128, 256, 0.0), (2, 1024, 64, -0.5)])
 def test_training_with_compacted_class_graphs(mods, monkeypatch, K, M, E, frac):
     """Matcher.atlas_features under autograd on a pruned IR-Atlas: the class GNN on the kept vertices of every class + the per-word share of
     the pruned ones (SN_TRAIN_COMPACT=2: always) against the uncompacted route (=0) - the class features and the gradients of every
