@@ -453,6 +453,11 @@ int sn_split_planes(const float *x, int batches, int rows, int cols, int64_t ld,
 int sn_split_planes_transposed(const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
                                const float *scale_dev, void *out_hi, void *out_lo, void *stream);
 
+/* sn_split_planes / sn_split_planes_transposed of x [G, n, E] (contiguous: nodes x features per graph) with one node extent per graph
+ * (round 5, training with compacted class graphs): the blocks that hold no node below node_extent[g] - row blocks of the plain
+ * form, k chunks of the transposed one - are not produced; for consumers that skip them (sn_gcn_gemm with per-graph extents). */
+int sn_split_planes_nodes(const float *x, int G, int n, int E, const float *scale_dev, const int32_t *node_extent, int transposed,
+                          void *out_hi, void *out_lo, void *stream);
 /* sn_mask_layernorm_act(x [G, n, E]) followed by sn_split_planes of the result (times *scale_dev) as one pass that leaves x
  * untouched and never stores the normalised rows: blocked planes of an [n, E] operand per graph (gnn.py:43-46 feeding the
  * next layer's Linear).  E % 16 == 0, E <= 1024.  Bit-identical to the two calls. */

@@ -154,6 +154,7 @@ _SIGNATURES = {
     "sn_gcn_gather_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_split_planes_transposed": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sn_split_planes_nodes": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "sn_gcn_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     "sn_pow2_scale_blocks": (c_int, [c_int64]),
     "sn_pow2_scale": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -785,7 +785,7 @@ def gcn_gather_planes(table, ids, extent=None, scale=None):
     return out
 
 
-def split_planes(x, scale="auto", transpose=False):
+def split_planes(x, scale="auto", transpose=False, node_extents=None):
     """fp32 [rows, k] or [batches, rows, k] -> blocked hi/lo planes with hi + lo ~= x * scale (22 significant bits down to
     2^-17 of the largest magnitude).  scale: "auto" = pow2_scale(x) (one reduction over x, no host synchronisation), a
     device scalar from pow2_scale(bound) when a bound on |x| is known without reading x, or None (= 1: only for operands
@@ -800,6 +800,13 @@ def split_planes(x, scale="auto", transpose=False):
         scale = pow2_scale(xc) if xc.numel() else None
     out = _alloc_planes(lib, dev, B_, k, rows) if transpose else _alloc_planes(lib, dev, B_, rows, k)
     with torch.cuda.device(dev):
+        if node_extents is not None:
+            # x = [G, nodes, features] of graphs with their own node counts (compacted class graphs): blocks of pad nodes only are not produced
+            assert node_extents.dtype == torch.int32 and node_extents.numel() == B_ and node_extents.is_contiguous() and node_extents.device == dev
+            N.check(lib.sn_split_planes_nodes(N.ptr(xc), B_, rows, k, N.ptr(scale), N.ptr(node_extents), int(bool(transpose)), N.ptr(out.hi), N.ptr(out.lo),
+                                              N.stream_ptr(dev)), "sn_split_planes_nodes")
+            out.scale = scale
+            return out
         fn = lib.sn_split_planes_transposed if transpose else lib.sn_split_planes
         N.check(fn(N.ptr(xc), B_, rows, k, k, rows * k, N.ptr(scale), N.ptr(out.hi), N.ptr(out.lo), N.stream_ptr(dev)),
                 "sn_split_planes_transposed" if transpose else "sn_split_planes")
@@ -995,8 +1002,8 @@ class _EdgesAdjMatmul(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, edges, x, adj_planes, sum_edge_grads=False):
         G = edges.shape[0]
-        xt = split_planes(x.detach(), transpose=True)
         ext = adj_planes.compact[1] if adj_planes.compact is not None else None      # compacted class graphs: one extent per graph
+        xt = split_planes(x.detach(), transpose=True, node_extents=ext)
         y = gcn_gemm(adj_planes, xt, G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext, rows_valid=ext)["c"]
         ctx.save_for_backward(x)
         ctx.adj_planes = adj_planes
@@ -1021,9 +1028,10 @@ class _EdgesAdjMatmul(torch.autograd.Function):
         dy_scale = pow2_scale(dy)                            # one reduction over dy for both of its plane forms
         ext = ap.compact[1] if ap.compact is not None else None
         if ctx.needs_input_grad[1]:
-            d_x = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext, rows_valid=ext)["c"]
+            d_x = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True, node_extents=ext), G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext,
+                           rows_valid=ext)["c"]
         if ctx.needs_input_grad[0]:
-            dyp, xp = split_planes(dy, scale=dy_scale), split_planes(x.detach(), scale=ctx.x_scale)
+            dyp, xp = split_planes(dy, scale=dy_scale, node_extents=ext), split_planes(x.detach(), scale=ctx.x_scale, node_extents=ext)
             if not ctx.counted:
                 s_ = gcn_gemm(dyp, xp, G, want_c=True, m_extent=ext)["c"]
                 return _edge_grad_of(s_, ap), d_x, None, None
@@ -1098,7 +1106,7 @@ class _LinearMfma(torch.autograd.Function):
         x3 = _f32c(x.detach())
         x3 = x3[None] if x3.dim() == 2 else x3
         G = x3.shape[0]
-        xp, wp = split_planes(x3), split_planes(weight.detach())
+        xp, wp = split_planes(x3, node_extents=extents), split_planes(weight.detach())
         # extents (int32 [G], graphs of [G, n, in] only): rows >= extents[g] of graph g are pad rows - neither multiplied nor written (zeros)
         y = gcn_gemm(xp, wp, G, bias=bias, want_c=True, zero_c=extents is not None, m_extent=extents, rows_valid=extents)["c"]
         ctx.save_for_backward(x, weight)
@@ -1123,11 +1131,12 @@ class _LinearMfma(torch.autograd.Function):
         ext = ctx.extents
         dy_scale = pow2_scale(dy3)                              # one reduction over dY for both of its plane forms
         if ctx.needs_input_grad[0]:
-            dx = gcn_gemm(split_planes(dy3, scale=dy_scale), split_planes(weight.detach(), scale=w_scale, transpose=True), G, want_c=True,
+            dx = gcn_gemm(split_planes(dy3, scale=dy_scale, node_extents=ext), split_planes(weight.detach(), scale=w_scale, transpose=True), G, want_c=True,
                           zero_c=ext is not None, m_extent=ext, rows_valid=ext)["c"]
             dx = dx[0] if x.dim() == 2 else dx
         if ctx.needs_input_grad[1]:
-            dw = _weight_grad_per_graph(split_planes(dy3, scale=dy_scale, transpose=True), split_planes(x3, scale=x_scale, transpose=True), ext)
+            dw = _weight_grad_per_graph(split_planes(dy3, scale=dy_scale, transpose=True, node_extents=ext),
+                                        split_planes(x3, scale=x_scale, transpose=True, node_extents=ext), ext)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy3.sum(dim=(0, 1))
         return dx, dw, db, None
@@ -1184,7 +1193,8 @@ class _GatherAdjMatmul(torch.autograd.Function):
         dy_scale = pow2_scale(dy)
         ext = ap.compact[1] if ap.compact is not None else None
         if ctx.needs_input_grad[1]:
-            dz = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True), G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext, rows_valid=ext)["c"].reshape(-1, F)
+            dz = gcn_gemm(ap, split_planes(dy, scale=dy_scale, transpose=True, node_extents=ext), G, want_c=True, zero_c=ext is not None, m_extent=ext, k_extent=ext,
+                          rows_valid=ext)["c"].reshape(-1, F)
             if sort:
                 lib = N.require_gpu()
                 d_tab = torch.empty((rows, F), dtype=torch.float32, device=dz.device)
@@ -1194,8 +1204,8 @@ class _GatherAdjMatmul(torch.autograd.Function):
             else:
                 d_tab = torch.ops.aten.embedding_dense_backward(dz, ids, rows, ctx.pad, False)
         if ctx.needs_input_grad[0]:
-            dyp = split_planes(dy, scale=dy_scale)
-            zp = split_planes(torch.nn.functional.embedding(ids, tab), scale=ctx.t_scale)
+            dyp = split_planes(dy, scale=dy_scale, node_extents=ext)
+            zp = split_planes(torch.nn.functional.embedding(ids, tab), scale=ctx.t_scale, node_extents=ext)
             if not ctx.counted:
                 d_e = _edge_grad_of(gcn_gemm(dyp, zp, G, want_c=True, m_extent=ext)["c"], ap)
             else:

@@ -406,7 +406,8 @@ constexpr int kSplitThreads = 512, kSplitKc = 512, kSplitPad = 4;
 template <bool TR>
 __global__ __launch_bounds__(kSplitThreads) void split_planes_kernel(const float *x, int rows_x, int cols_x, int64_t ld, int64_t x_batch_stride,
                                                                      int kb_count, int64_t batch_stride, _Float16 *out_h, _Float16 *out_l,
-                                                                     const float *scale_dev, int kc, int row_blocks, int k_chunks, int64_t tiles)
+                                                                     const float *scale_dev, int kc, int row_blocks, int k_chunks, int64_t tiles,
+                                                                     const int32_t *node_extent)
 {
     extern __shared__ __attribute__((aligned(16))) float sp_tile[];      // [32][kc + kSplitPad]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -416,6 +417,9 @@ __global__ __launch_bounds__(kSplitThreads) void split_planes_kernel(const float
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int kci = (int)(t % k_chunks), rb = (int)((t / k_chunks) % row_blocks), g = (int)(t / ((int64_t)k_chunks * row_blocks));
         const int k0 = kci * kc, r0 = rb * 32;
+        // node_extent (training with compacted class graphs: x = [G, nodes, features]): the nodes of graph g from node_extent[g] on are
+        // pad rows that every consumer skips (per-graph extents of sn_gcn_gemm) - tiles that hold nothing else are not produced
+        if (node_extent && (TR ? k0 : r0) >= node_extent[g]) continue;     // (whole workgroup, in front of the tile's barriers)
         const int kn = min(kc, kb_count * 16 - k0);                         // k of this tile (a multiple of 16), zero beyond op_k
         const float *xg = x + (int64_t)g * x_batch_stride;
         if (!TR) {
@@ -1320,7 +1324,7 @@ extern "C" int sn_gcn_gather_planes(const float *table, int rows_table, const in
 }
 
 static int split_planes_launch(bool transposed, const float *x, int batches, int rows, int cols, int64_t ld, int64_t batch_stride,
-                               const float *scale_dev, void *out_hi, void *out_lo, void *stream, const char *name)
+                               const float *scale_dev, void *out_hi, void *out_lo, void *stream, const char *name, const int32_t *node_extent = nullptr)
 {
     SN_REQUIRE(batches >= 0 && rows > 0 && cols > 0 && ld >= cols, SN_ERR_BAD_ARG, "%s: bad shape", name);
     if (batches == 0) return SN_OK;
@@ -1336,10 +1340,19 @@ static int split_planes_launch(bool transposed, const float *x, int batches, int
     const dim3 grid((unsigned)(tiles < slots ? tiles : slots));
     if (transposed)
         hipLaunchKernelGGL(split_planes_kernel<true>, grid, dim3(kSplitThreads), lds, (hipStream_t)stream, x, rows, cols, ld, batch_stride, kb,
-                           sn_gcn_plane_elems(op_rows, op_k), (_Float16 *)out_hi, (_Float16 *)out_lo, scale_dev, kc, row_blocks, k_chunks, tiles);
+                           sn_gcn_plane_elems(op_rows, op_k), (_Float16 *)out_hi, (_Float16 *)out_lo, scale_dev, kc, row_blocks, k_chunks, tiles, node_extent);
     else
         hipLaunchKernelGGL(split_planes_kernel<false>, grid, dim3(kSplitThreads), lds, (hipStream_t)stream, x, rows, cols, ld, batch_stride, kb,
-                           sn_gcn_plane_elems(op_rows, op_k), (_Float16 *)out_hi, (_Float16 *)out_lo, scale_dev, kc, row_blocks, k_chunks, tiles);
+                           sn_gcn_plane_elems(op_rows, op_k), (_Float16 *)out_hi, (_Float16 *)out_lo, scale_dev, kc, row_blocks, k_chunks, tiles, node_extent);
+    return SN_OK;
+}
+
+extern "C" int sn_split_planes_nodes(const float *x, int G, int n, int E, const float *scale_dev, const int32_t *node_extent, int transposed,
+                                     void *out_hi, void *out_lo, void *stream)
+{
+    SN_REQUIRE(node_extent, SN_ERR_BAD_ARG, "sn_split_planes_nodes: NULL extents");
+    if (int rc = split_planes_launch(transposed != 0, x, G, n, E, E, (int64_t)n * E, scale_dev, out_hi, out_lo, stream, "sn_split_planes_nodes", node_extent)) return rc;
+    SN_CHECK_LAUNCH("sn_split_planes_nodes");
     return SN_OK;
 }
 
