@@ -557,6 +557,10 @@ int sn_mask_layernorm_act_backward(const float *x, const float *dy, int G, int n
  * graphs' words - constant between training iterations.) */
 int sn_embedding_grad_sorted(const float *dy, const int64_t *order, const int64_t *seg, int rows, int E, int padding_idx, float *grad,
                              void *stream);
+/* The same gradient without a sort, for ids that are new in every iteration (round 5): grad[w][:] = sum over the positions p (in
+ * position order) with ids[p] == w of dy[p][:]; row padding_idx = 0; ids outside [0, rows) contribute nothing.  Meant for short index
+ * tensors (every word's workgroup scans all n_ids: the instance graphs' 12 544 ids); E <= 1024. */
+int sn_embedding_grad_scan(const float *dy, const int64_t *ids, int64_t n_ids, int rows, int E, int padding_idx, float *grad, void *stream);
 /* Backward of sn_weighted_pool (pooled[g] = sum_i nodes[g][i] feat[g][i] / divisor, reference gnn.py:96) in one pass over feat:
  * grad_feat [G, n, E], grad_nodes [G, n] from grad_pooled [G, E].  E % 4 == 0. */
 int sn_weighted_pool_backward(const float *feat, const float *nodes, const float *grad_pooled, int G, int n, int E,

@@ -165,6 +165,7 @@ _SIGNATURES = {
     "sn_mask_layernorm_act_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,
                                                c_void_p, c_void_p, c_void_p]),
     "sn_embedding_grad_sorted": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sn_embedding_grad_scan": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sn_weighted_pool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_graph_replace_memsets": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     # diagnostics (include/schemanet_hip.h, last section)

@@ -1201,6 +1201,13 @@ class _GatherAdjMatmul(torch.autograd.Function):
                 with torch.cuda.device(dz.device):
                     N.check(lib.sn_embedding_grad_sorted(N.ptr(dz), N.ptr(sort[0]), N.ptr(sort[1]), rows, F, ctx.pad, N.ptr(d_tab), N.stream_ptr(dz.device)),
                             "sn_embedding_grad_sorted")
+            elif ids.numel() <= 32768 and F <= 1024 and os.environ.get("SN_EMBED_SCAN", "1") != "0":
+                # ids that are new in every iteration (the instance graphs' words): one launch, no sort (sn_embedding_grad_scan)
+                lib = N.require_gpu()
+                d_tab = torch.empty((rows, F), dtype=torch.float32, device=dz.device)
+                with torch.cuda.device(dz.device):
+                    N.check(lib.sn_embedding_grad_scan(N.ptr(dz), N.ptr(ids), ids.numel(), rows, F, ctx.pad, N.ptr(d_tab), N.stream_ptr(dz.device)),
+                            "sn_embedding_grad_scan")
             else:
                 d_tab = torch.ops.aten.embedding_dense_backward(dz, ids, rows, ctx.pad, False)
         if ctx.needs_input_grad[0]:

@@ -384,6 +384,50 @@ __global__ __launch_bounds__(256) void embedding_grad_sorted_kernel(const float 
     }
 }
 
+// The same gradient for an index tensor that is new in every iteration (the instance graphs' words: 64 x 196 ids): no sort at all.
+// One workgroup per word scans the ids 256 at a time (they stay in L2: 100 KB), keeps the positions that hold its word - in
+// position order, through a ballot prefix - and adds their rows of dy, a feature (or four, E <= 1024) per thread: a fixed order,
+// bit-reproducible.  (The library's embedding backward: radix sort, segment offsets, sum-and-scatter - 0.17 ms of an iteration,
+// most of it launch latency of six small kernels.)
+constexpr int kScanMaxE = 1024;
+__global__ __launch_bounds__(256) void embedding_grad_scan_kernel(const float *dy, const int64_t *ids, int64_t n_ids, int E, int padding_idx, float *grad)
+{
+    __shared__ int hits[256];
+    __shared__ int wave_cnt[4];
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float acc[kScanMaxE / 256];
+#pragma unroll
+    for (int k = 0; k < kScanMaxE / 256; ++k) acc[k] = 0.0f;
+    if (w != padding_idx) {
+        for (int64_t c0 = 0; c0 < n_ids; c0 += 256) {
+            const int64_t i = c0 + tid;
+            const bool hit = i < n_ids && ids[i] == (int64_t)w;
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wave_cnt[wid] = __popcll(m);
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { if (v < wid) base += wave_cnt[v]; total += wave_cnt[v]; }
+            if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = tid;
+            __syncthreads();
+            for (int h = 0; h < total; ++h) {                      // (block-uniform trip count; usually 0)
+                const float *row = dy + (c0 + hits[h]) * E;
+#pragma unroll
+                for (int k = 0; k < kScanMaxE / 256; ++k) {
+                    const int f = tid + 256 * k;
+                    if (f < E) acc[k] += row[f];
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kScanMaxE / 256; ++k) {
+        const int f = tid + 256 * k;
+        if (f < E) grad[(int64_t)w * E + f] = acc[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Backward of the node-weighted mean pooling pooled[g] = sum_i nodes[g][i] feat[g][i] / div (reference gnn.py:96), one pass over
 // feat: d_feat[g][i] = nodes[g][i] g[g] / div, d_nodes[g][i] = feat[g][i] . g[g] / div.  One wave per row, 16-byte accesses.
@@ -572,6 +616,17 @@ extern "C" int sn_embedding_grad_sorted(const float *dy, const int64_t *order, c
     SN_REQUIRE((((uintptr_t)dy | (uintptr_t)grad) & 15) == 0, SN_ERR_BAD_ARG, "sn_embedding_grad_sorted: dy / grad must be 16-byte aligned");
     hipLaunchKernelGGL(embedding_grad_sorted_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, order, seg, E, padding_idx, grad);
     SN_CHECK_LAUNCH("sn_embedding_grad_sorted");
+    return SN_OK;
+}
+
+extern "C" int sn_embedding_grad_scan(const float *dy, const int64_t *ids, int64_t n_ids, int rows, int E, int padding_idx, float *grad, void *stream)
+{
+    SN_REQUIRE(rows >= 0 && E > 0 && n_ids >= 0, SN_ERR_BAD_ARG, "sn_embedding_grad_scan: bad rows=%d E=%d n_ids=%lld", rows, E, (long long)n_ids);
+    if (rows == 0) return SN_OK;
+    SN_REQUIRE(grad && (n_ids == 0 || (dy && ids)), SN_ERR_BAD_ARG, "sn_embedding_grad_scan: NULL pointer");
+    SN_REQUIRE(E <= kScanMaxE, SN_ERR_UNSUPPORTED, "sn_embedding_grad_scan: E=%d > %d", E, kScanMaxE);
+    hipLaunchKernelGGL(embedding_grad_scan_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, dy, ids, n_ids, E, padding_idx, grad);
+    SN_CHECK_LAUNCH("sn_embedding_grad_scan");
     return SN_OK;
 }
 

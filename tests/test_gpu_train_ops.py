@@ -640,3 +640,32 @@ def test_training_with_compacted_class_graphs(mods, monkeypatch, K, M, E, frac):
     assert torch.equal(nan0, nan1)
     fin = ~nan0
     assert float((ge1[fin] - ge0[fin]).abs().max()) <= 2e-5 * float(ge0[fin].abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("rows,E,n_ids", [(1025, 256, 64 * 196), (101, 64, 1000), (513, 1024, 300), (7, 16, 0)])
+def test_embedding_backward_without_a_sort(mods, rows, E, n_ids):
+    """`sn_embedding_grad_scan` (reference gnn.py:83, the gradient of nn.Embedding for ids that change with every batch): every row of
+    the table's gradient against float64, no further from it than the library's embedding backward; the padding row zero; twice the
+    same bits (a fixed summation order)."""
+    from cpp_extension import _native as N
+    lib = mods["cx"].load()
+    g = torch.Generator().manual_seed(rows + E)
+    ids = torch.randint(0, rows, (n_ids,), generator=g)
+    if n_ids > 10:
+        ids[:7] = rows - 1                                           # the padding row
+        ids[7:40] = 3                                                # a word with many occurrences
+    dy = torch.randn(n_ids, E, generator=g) * 1e-3
+    ids_d, dy_d = ids.to(DEV), dy.to(DEV)
+
+    def run():
+        out = torch.full((rows, E), float("nan"), device=DEV)
+        N.check(lib.sn_embedding_grad_scan(N.ptr(dy_d), N.ptr(ids_d), n_ids, rows, E, rows - 1, N.ptr(out), N.stream_ptr(torch.device(DEV, 0))), "scan")
+        return out
+    got = run()
+    assert torch.equal(got, run())
+    want = torch.zeros(rows, E, dtype=torch.float64).index_add_(0, ids, dy.double())
+    want[rows - 1] = 0
+    ref = torch.ops.aten.embedding_dense_backward(dy_d, ids_d, rows, rows - 1, False) if n_ids else torch.zeros(rows, E, device=DEV)
+    scale = float(want.abs().max()) if n_ids else 1.0
+    assert float((got.double().cpu() - want).abs().max()) <= float((ref.double().cpu() - want).abs().max()) + 1e-6 * scale
+    assert float(got[rows - 1].abs().max()) == 0.0
