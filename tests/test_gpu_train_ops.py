@@ -669,3 +669,46 @@ def test_embedding_backward_without_a_sort(mods, rows, E, n_ids):
     scale = float(want.abs().max()) if n_ids else 1.0
     assert float((got.double().cpu() - want).abs().max()) <= float((ref.double().cpu() - want).abs().max()) + 1e-6 * scale
     assert float(got[rows - 1].abs().max()) == 0.0
+
+
+def test_operand_splits_with_node_extents_and_corner_scatter(mods):
+    """The helpers of the compacted training route against plain torch: `split_planes(..., node_extents=)` equals the plain split
+    inside every graph's extent (rows rounded up to 32 in the plain form, nodes to the k chunk in the transposed one) bit for bit;
+    `sym_scatter_corner` = the symmetrised corner scattered through the permutation, zero where a pruned vertex is involved
+    (reference gnn.py:27-30: the chain rule through (E + E^T)/2 + I); a product with `zero_c`, `rows_valid` and `m_extent` leaves no
+    element of its fp32 result undefined."""
+    ops = mods["ops"]
+    G, n, E = 5, 200, 64
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(G, n, E, generator=g).to(DEV)
+    ext = torch.tensor([0, 1, 33, 128, 200], dtype=torch.int32, device=DEV)
+    full, part = ops.split_planes(x, scale=None), ops.split_planes(x, scale=None, node_extents=ext)
+    d_full, d_part = full.to_dense()[1], part.to_dense()[1]
+    for i, c in enumerate(ext.tolist()):
+        r = (c + 31) // 32 * 32
+        assert torch.equal(d_part[i, :r], d_full[i, :r]), i
+    full_t, part_t = ops.split_planes(x, scale=None, transpose=True), ops.split_planes(x, scale=None, transpose=True, node_extents=ext)
+    dt_full, dt_part = full_t.to_dense()[1], part_t.to_dense()[1]                       # [G, E, nodes padded to 16]
+    for i, c in enumerate(ext.tolist()):
+        assert torch.equal(dt_part[i, :, :c], dt_full[i, :, :c]), i
+    # ---- the corner gradient
+    perm = torch.stack([torch.randperm(n, generator=g) for _ in range(G)]).to(torch.int32).to(DEV)
+    corner = torch.randn(G, n, n, generator=g).to(DEV)
+    want = torch.zeros(G, n, n, dtype=torch.float64)
+    c64, p = corner.double().cpu(), perm.long().cpu()
+    for i, k in enumerate(ext.tolist()):
+        sym = (c64[i, :k, :k] + c64[i, :k, :k].t()) / 2
+        want[i][p[i, :k][:, None], p[i, :k][None, :]] = sym
+    got = ops.sym_scatter_corner(corner.clone(), perm, ext)
+    assert float((got.double().cpu() - want).abs().max()) <= 1.2e-7 * float(want.abs().max())       # (one fp32 rounding of the half sum)
+    assert torch.equal(got == 0, (want == 0).to(DEV))
+    # ---- no undefined element behind the extents
+    a, b = ops.split_planes(x, scale=None, node_extents=ext), ops.split_planes(torch.randn(96, E, generator=g).to(DEV), scale=None)
+    bias = torch.randn(96, generator=g).to(DEV)
+    c = ops.gcn_gemm(a, b, G, bias=bias, want_c=True, zero_c=True, m_extent=ext, rows_valid=ext)["c"]
+    assert bool(torch.isfinite(c).all())
+    ref = torch.matmul(x, b.to_dense()[0][0].t()) + bias
+    for i, k in enumerate(ext.tolist()):
+        assert float(c[i, k:].abs().max()) == 0.0 if k < n else True
+        if k:
+            assert float((c[i, :k] - ref[i, :k]).abs().max()) <= 2e-5 * float(ref.abs().max())
