@@ -34,7 +34,9 @@ extern "C" {
 
 #define SN_MAX_TOKENS 196        /* L: 14x14 patch tokens; the graph kernels keep one image in LDS */
 
-/* ABI version, bumped on any change of a signature or of a by-pointer struct (10: round 5, struct_size members).
+/* ABI version, bumped on any change of a signature or of a by-pointer struct (10: round 5, struct_size members; 11: round 6 -
+ * sn_gemm_args.zero_skipped and the entry points added after 10, sn_debug_set_gemm_tile; tests/test_host_cpu.py holds a hash of
+ * this header's declarations next to the version, so that a change of either without the other fails the CPU suite).
  * The three by-pointer argument structs below start with `struct_size`: the caller stores sizeof(the struct it was compiled
  * against) there; a call whose struct_size differs from the library's own sizeof is rejected with SN_ERR_BAD_ARG before any
  * member is read, so a caller built against an older header can never have the library read past the end of its struct. */
@@ -585,6 +587,11 @@ int sn_debug_screen_occupancy(int lds);
 void sn_debug_set_stamps(void *device_buffer);
 void sn_debug_set_graph_stamps(void *device_buffer);
 void sn_debug_set_gemm_stamps(void *device_buffer);
+/* sn_gcn_gemm's tile form (round 6): tile_rows 0 = chosen per call (256-row tiles, one 8-wave workgroup per CU, for m >= 256 with
+ * one extent per batch; 128-row tiles, two 4-wave workgroups per CU, otherwise), 128 / 256 = forced; stagger 1 / 0 = waves 4-7 of a
+ * 256-row workgroup half a stage behind waves 0-3 or in step with them; -1 leaves a setting as it is.  Initial values: environment
+ * SN_GEMM_TM (0) and SN_GEMM_STAGGER (1).  Both forms give the same bits. */
+void sn_debug_set_gemm_tile(int tile_rows, int stagger);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,11 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SN_LIB_PATH") or os.path.join(_PKG, "lib", "libschemanet_hip.so")     # (override: kernel experiments of tools/)
-ABI_VERSION = 10
+ABI_VERSION = 11
+# sha256[:16] of include/schemanet_hip.h with comments removed and whitespace collapsed: the declarations this binding (and
+# ABI_VERSION) were written against.  tests/test_host_cpu.py::test_abi_version_names_the_header recomputes it, so a change to a
+# signature or a struct without a new hash here - and, by the rule in the header, a new ABI_VERSION - fails the CPU suite.
+ABI_HEADER_SHA = "bbdaa31ffe5ba687"
 SN_MAX_TOKENS = 196
 _lib = None
 
@@ -174,6 +178,7 @@ _SIGNATURES = {
     "sn_debug_set_stamps": (None, [c_void_p]),
     "sn_debug_set_graph_stamps": (None, [c_void_p]),
     "sn_debug_set_gemm_stamps": (None, [c_void_p]),
+    "sn_debug_set_gemm_tile": (None, [c_int, c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1452,7 +1452,15 @@ int launch_screen5(const AssignArgs &a, hipStream_t st, bool defer)
 int g_variant = -1;
 int screen_variant()
 {
-    if (g_variant < 0) { const char *e = getenv("SN_ASSIGN_VARIANT"); g_variant = e ? atoi(e) : 0; }
+    if (g_variant < 0) {
+        // the environment and sn_assign_set_variant() agree on what exists: 0 and 5.  The lab forms 1-4 of rounds 1-4 left the library
+        // (an old script that still exports one of them gets the default, with one note - not a form that sn_assign_variant() would
+        // report and no kernel implements, which silently dropped the deferred S1 finish: ADVICE r05)
+        const char *e = getenv("SN_ASSIGN_VARIANT");
+        const int v = e ? atoi(e) : 0;
+        if (v != 0 && v != 5) fprintf(stderr, "libschemanet_hip: SN_ASSIGN_VARIANT=%d is not a screen form of this library (0 or 5): using 0\n", v);
+        g_variant = v == 5 ? 5 : 0;
+    }
     return g_variant;
 }
 

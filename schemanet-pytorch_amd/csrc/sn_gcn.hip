@@ -42,11 +42,18 @@
 // 12 ds_read_b128 per wave per stage.
 #include "sn_common.h"
 
+#ifndef SN_GEMM_SADDR
+#define SN_GEMM_SADDR 1        // ring copies addressed by SGPR base + 32-bit lane offset (0: a 64-bit address per lane, rounds 1-5)
+#endif
+#ifndef SN_GEMM_ABLATE
+#define SN_GEMM_ABLATE 0       // lab builds only (results are garbage): 1 no MFMAs, 2 no fragment reads, 4 no ring copies, 8 no copies of A, 16 no copies of B
+#endif
 #ifndef SN_GEMM_ISSUE_AT
 #define SN_GEMM_ISSUE_AT 1     // where in a stage the ring copies of stage t + 2 are issued: 0 in front of the MFMAs, 1 behind the first 8, 2 behind 16 (fewer loop cycles, the same launch time)
 #endif
 
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 namespace {
 
@@ -54,13 +61,29 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTileM = 128, kTileN = 256;   // output tile of a workgroup
+constexpr int kTileN = 256;             // output columns of a workgroup
 constexpr int kStageK = 16;             // k per stage (one MFMA k-step)
-constexpr int kChunksA = (kTileM / 32) * 2, kChunksB = (kTileN / 32) * 2;   // 1 KiB blocks per stage: [row block][plane]
-constexpr int kStageBytes = (kChunksA + kChunksB) * 1024;                    // 24 KiB
-constexpr int kRing = 3;                // LDS stages: two in flight behind the one being multiplied (72 KiB -> 2 workgroups / CU)
-constexpr int kGemmThreads = 256;
-constexpr int kDmaPerWave = (kChunksA + kChunksB) / (kGemmThreads / 64);     // 6
+constexpr int kChunksB = (kTileN / 32) * 2;          // 1 KiB blocks of B per stage: [column block][plane]
+// Two tile heights (round 6).  TM = 128: 4 waves, 24 KiB stages, a 3-slot ring, two workgroups per CU (small graphs: the instance
+// side, compacted class graphs).  TM = 256: 8 waves (wave (wm, wn) still owns 64 x 128), 32 KiB stages, a 4-slot ring, ONE workgroup
+// per CU: a k-stage of a CU's 256 rows moves 32 KiB through the vector memory path where two 128-row workgroups move 48 -
+// the ring of the 128-row form delivers ~27 B per cycle and CU where its MFMAs need 31, this one needs 21.
+// The second wave of every SIMD (waves 4-7) runs half a stage behind the first, so that one of a SIMD's two waves always has
+// MFMAs to issue while the other sits in the barrier, the copy issue or the fragment reads.
+template <int TM> struct Geom {
+    static constexpr int kTileM = TM;
+    static constexpr int kWavesM = TM / 64, kWaves = 2 * kWavesM, kThreads = 64 * kWaves;
+    static constexpr int kChunksA = (TM / 32) * 2;                              // 1 KiB blocks of A per stage: [row block][plane]
+    static constexpr int kStageBytes = (kChunksA + kChunksB) * 1024;            // 24 / 32 KiB
+    static constexpr int kRing = TM == 128 ? 3 : 4;                             // LDS stages: kRing - 1 in flight
+    static constexpr int kDmaPerWave = (kChunksA + kChunksB) / kWaves;          // 6 / 4
+    // epilogue scratch: LayerNorm row statistics [5][TM] floats at 0; pooled partials [kWavesM][256] floats; the per-wave staging
+    // of the plane stores (16 x kC8Stride dwords per wave) - TM = 128 keeps the offsets it always had
+    static constexpr int kPoolOff = TM == 128 ? 2048 : 5 * TM * 4;
+    static constexpr int kStgOff = TM == 128 ? 4096 : kPoolOff + kWavesM * 256 * 4;
+    static constexpr int kStgBytes = kWaves * 16 * (32 * 8 + 8) * 4;
+    static constexpr int kLdsBytes = kRing * kStageBytes > kStgOff + kStgBytes ? kRing * kStageBytes : kStgOff + kStgBytes;
+};
 constexpr int kBlockElems = 512;        // fp16 elements of one 32-row x 16-k block (1 KiB)
 constexpr int kMaxPerm = 1024;          // vertices per class graph the compacted atlas producer stages a permutation for
 
@@ -575,6 +598,7 @@ struct GemmArgs {
     // fused second product (FL kernels): planes of W2 [256, 256] with its columns in the order the epilogue holds them
     const _Float16 *w2_hi, *w2_lo;
     int fl_twin;                     // idle row tiles take the second half of the fused epilogue (SN_GEMM_FL_TWIN=0: off)
+    int stagger;                     // 256-row tiles: waves 4-7 half a stage behind waves 0-3 (SN_GEMM_STAGGER=0: off)
     // power-of-two operand scales (device scalars, NULL = 1; see the header comment): the planes of A / B hold x * scale;
     // output planes are written as result * out_scale; FL: the W2 planes hold W * w2_scale, the H fragments H * h_scale
     const float *a_scale, *b_scale, *out_scale, *w2_scale, *h_scale;
@@ -602,9 +626,12 @@ static unsigned long long *g_gemm_stamps = nullptr;
 // 8-byte piece per (node, plane), and the host permutes the columns of W2 the same way once (GNN.prepare).  Wave w then
 // owns the output features [64 w, 64 w + 64) for the 64 nodes of the half: 2 x 2 accumulators, 16 k-steps of 12 MFMAs,
 // A fragments (W2, 256 KB, L2-resident) straight from global memory three k-steps ahead, B fragments from the LDS image.
-template <bool LN, bool GB = false, bool FL = false>
-__global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArgs p)
+template <bool LN, bool GB = false, bool FL = false, int TM = 128>
+__global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const GemmArgs p)
 {
+    using GG = Geom<TM>;
+    constexpr int kTileM = GG::kTileM, kGemmThreads = GG::kThreads, kChunksA = GG::kChunksA, kStageBytes = GG::kStageBytes, kRing = GG::kRing,
+                  kDmaPerWave = GG::kDmaPerWave, kWaves = GG::kWaves;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -624,7 +651,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     // (each graph otherwise leaves half of it idle) and the serial epilogue of a tile is halved.
     int fl_first = 0, fl_last = 2;
     if constexpr (FL) {
-        if (p.m_extent && p.tiles_x == 1 && p.fl_twin) {
+        if (TM == 128 && p.m_extent && p.tiles_x == 1 && p.fl_twin) {
             const int t_real = (p.m_extent[(int64_t)batch * p.ext_stride] + kTileM - 1) / kTileM, ty = tile;
             if (t_real > 0 && p.tiles_y >= 2 * t_real) {
                 if (ty < t_real) fl_last = 1;
@@ -634,7 +661,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     }
     const int tile_m = tile_m_, tile_n = (tile % p.tiles_x) * kTileN;
     if (p.m_extent && tile_m >= p.m_extent[(int64_t)batch * p.ext_stride]) {      // a row tile past the largest graph of the batch (ext_stride 1: past this graph)
-        if (p.pooled && tid + tile_n < p.n) p.pooled[((int64_t)batch * p.pooled_parts + tile / p.tiles_x) * p.n + tile_n + tid] = 0.0f;
+        // (the pooled partial sums are kept per 128 rows whatever the tile height: a 256-row tile owns two of them)
+        if (p.pooled) {
+            const int part = (tile / p.tiles_x) * (kTileM / 128) + (tid >> 8), col = tile_n + (tid & 255);
+            if (part * 128 < p.m && col < p.n) p.pooled[((int64_t)batch * p.pooled_parts + part) * p.n + col] = 0.0f;
+        }
         if (p.zero_skipped && p.c && !p.accumulate) {              // (its rows of the fp32 result: zeros, whole lines)
             const int cols = min(kTileN, p.n - tile_n), rows = min(kTileM, p.m - tile_m);
             float *c0 = p.c + (int64_t)batch * p.c_batch_stride + (int64_t)tile_m * p.ldc + tile_n;
@@ -660,6 +691,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     // ---- LDS-DMA sources: wave w copies chunks 6w .. 6w+5 of a stage.  chunk c < 8: A row block c>>1,
     // plane c&1; c >= 8: the same for B.  A chunk is one contiguous 1 KiB block of the blocked plane.
     const _Float16 *src[kDmaPerWave];
+#if SN_GEMM_SADDR
+    const unsigned char *sbase[kDmaPerWave];
+    unsigned voff[kDmaPerWave];
+    auto plane_of_gather = [](int pb) { return pb >> 3; };
+#endif
     unsigned nt_mask = 0;
 #pragma unroll
     for (int j = 0; j < kDmaPerWave; ++j) {
@@ -673,6 +709,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         const _Float16 *base = is_b ? (plane ? p.b_lo : p.b_hi) + (int64_t)batch * p.b_batch_stride
                                     : (plane ? p.a_lo : p.a_hi) + (int64_t)batch * p.a_batch_stride;
         src[j] = base + (int64_t)rb * kb_count * kBlockElems + lane * 8;
+#if SN_GEMM_SADDR
+        // (round 6) the copies take their address as a wave-uniform base in SGPRs + a 32-bit per-lane byte offset: the form with a
+        // 64-bit address per lane kept the CU's address unit busy for ~37 cycles per 1 KiB copy - the 27 B per cycle and CU every
+        // ring of this kernel ran at, whatever its depth -, this one about half of that (the S1 screens' rings use it)
+        sbase[j] = reinterpret_cast<const unsigned char *>(GB && is_b ? (plane_of_gather(c - kChunksA) ? p.tab_lo : p.tab_hi) : base);
+        voff[j] = (unsigned)((int64_t)rb * kb_count * kBlockElems * 2) + (unsigned)lane * 16u;
+#endif
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     // GB: the table row (id) of this lane's node for each of the wave's B pieces of the NEXT stage to be issued, read from
@@ -695,15 +738,36 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
         for (int j = 0; j < kDmaPerWave; ++j) {
             unsigned keep;
+            if (SN_GEMM_ABLATE & 4) continue;
+            if ((SN_GEMM_ABLATE & 8) && wid * kDmaPerWave + j < kChunksA) continue;
+            if ((SN_GEMM_ABLATE & 16) && wid * kDmaPerWave + j >= kChunksA) continue;
             if (GB && wid * kDmaPerWave + j >= kChunksA) {            // (wave-uniform) piece = plane, node pair; lane = (node, 16-byte chunk)
                 const int pb = wid * kDmaPerWave + j - kChunksA, row = 2 * (pb & 7) + h;
                 const int id = next_id[j];
+#if SN_GEMM_SADDR
+                const unsigned goff = (unsigned)(id * p.tab_ld + tile_n + ((r ^ ((row & 3) << 2)) << 3)) * 2u;       // (bytes into the table plane: < 4 GiB)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, %2\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(goff), "s"(sbase[j]), "s"(dst + j * 1024) : "memory");
+#else
                 const _Float16 *gsrc = ((pb >> 3) ? p.tab_lo : p.tab_hi) + (int64_t)id * p.tab_ld + tile_n + ((r ^ ((row & 3) << 2)) << 3);
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %1, off\n\t"
                              "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst + j * 1024) : "memory");
+#endif
                 continue;
             }
+#if SN_GEMM_SADDR
+            if ((nt_mask >> j) & 1u)                                  // wave-uniform
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff[j] + (unsigned)t * 1024u), "s"(sbase[j]), "s"(dst + j * 1024) : "memory");
+            else
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %1, %2\n\t"
+                             "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff[j] + (unsigned)t * 1024u), "s"(sbase[j]), "s"(dst + j * 1024) : "memory");
+            continue;
+#endif
             if ((nt_mask >> j) & 1u)                                  // wave-uniform
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %1, off nt\n\t"
@@ -731,20 +795,27 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
     for (int t = 0; t < kRing - 1; ++t)
         if (t < n_stages) issue_stage(t);
-    for (int t = 0; t < n_stages; ++t) {
-        unsigned long long ta = 0, tb = 0;
-        if (p.stamps) ta = __builtin_amdgcn_s_memtime();
-        // this wave's part of stage t has landed: at most the younger stage is outstanding
-        if (t + 1 < n_stages) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
+    half8 ah[2], al[2], bh[4], bl[4];
+    // this wave's part of stage t has landed: at most the kRing - 2 younger stages are outstanding; then everybody's, and the
+    // slot of stage t - 1 is free (every wave consumed its fragments of it in front of this barrier)
+    auto wait_stage = [&](int t) {
+        const int younger = n_stages - 1 - t;
+        if (kRing >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaPerWave) : "memory");
+        else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // ... everybody's; the slot of stage t-1 is free
-        if (p.stamps) tb = __builtin_amdgcn_s_memtime();
-#if SN_GEMM_ISSUE_AT == 0
-        if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
-#endif
-        if (p.stamps) { t_wait += tb - ta; t_issue += __builtin_amdgcn_s_memtime() - tb; }
+        __builtin_amdgcn_s_barrier();
+    };
+    auto read_fragments = [&](int t) {
+        if (SN_GEMM_ABLATE & 2) {
+            if (t == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { ah[i] = half8{1, 2, 3, 4, 5, 6, 7, 8}; al[i] = ah[i]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bh[j] = half8{1, 2, 3, 4, 5, 6, 7, 8}; bl[j] = bh[j]; }
+            }
+            return;
+        }
         const unsigned char *sa = smem + (t % kRing) * kStageBytes, *sb = sa + kChunksA * 1024;
-        half8 ah[2], al[2], bh[4], bl[4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int mt = 2 * wm + i;
@@ -771,28 +842,73 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 bl[j] = *reinterpret_cast<const half8 *>(sb + (nt * 2 + 1) * 1024 + lane * 16);
             }
         }
+    };
+    // The 24 MFMAs of a stage in the order every form of this loop keeps per accumulator: lo.hi, hi.lo, hi.hi
+    auto mfma_lo_hi = [&]() {
+        if (SN_GEMM_ABLATE & 1) { asm volatile("" :: "v"(al[0]), "v"(al[1]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3])); return; }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#if SN_GEMM_ISSUE_AT == 1
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+    };
+    auto mfma_hi_lo = [&](int i) {
+        if (SN_GEMM_ABLATE & 1) { asm volatile("" :: "v"(ah[i]), "v"(bl[0]), "v"(bl[1]), "v"(bl[2]), "v"(bl[3])); return; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#if SN_GEMM_ISSUE_AT == 2
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+    };
+    auto mfma_hi_hi = [&]() {
+        if (SN_GEMM_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    };
+    // TM = 256: waves 4-7 - the second wave of every SIMD - run HALF A STAGE BEHIND (MI355X_MICROARCH "Two waves per SIMD", item 9):
+    // behind the barrier of stage t they still hold the fragments of stage t - 1 and issue its last 12 MFMAs while waves 0-3 wait
+    // for their fragment reads of stage t; they read their own fragments of stage t under waves 0-3's MFMAs.  The order of the
+    // three products per accumulator is the same in both halves of the workgroup: results bit for bit those of the 128-row form.
+    const bool late = TM == 256 && wid >= kWaves / 2 && p.stagger;
+    if (!late) {
+        for (int t = 0; t < n_stages; ++t) {
+            unsigned long long ta = 0, tb = 0;
+            if (p.stamps) ta = __builtin_amdgcn_s_memtime();
+            wait_stage(t);
+            if (p.stamps) tb = __builtin_amdgcn_s_memtime();
+#if SN_GEMM_ISSUE_AT == 0
+            if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+#endif
+            if (p.stamps) { t_wait += tb - ta; t_issue += __builtin_amdgcn_s_memtime() - tb; }
+            read_fragments(t);
+            mfma_lo_hi();
+#if SN_GEMM_ISSUE_AT == 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            mfma_hi_lo(0);
+            mfma_hi_lo(1);
+#if SN_GEMM_ISSUE_AT == 2
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            mfma_hi_hi();
+        }
+    } else {
+        for (int t = 0; t < n_stages; ++t) {
+            unsigned long long ta = 0, tb = 0;
+            if (p.stamps) ta = __builtin_amdgcn_s_memtime();
+            wait_stage(t);
+            if (p.stamps) { tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; }
+            if (t > 0) { mfma_hi_lo(1); mfma_hi_hi(); }                       // (stage t - 1, from registers)
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + kRing - 1 < n_stages) issue_stage(t + kRing - 1);
+            read_fragments(t);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_lo_hi();
+            mfma_hi_lo(0);
+        }
+        if (n_stages > 0) { mfma_hi_lo(1); mfma_hi_hi(); }
     }
     __builtin_amdgcn_s_barrier();                              // LDS is reused by the epilogue
     if (p.stamps) t_loop_end = __builtin_amdgcn_s_memtime();
@@ -911,12 +1027,15 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
         constexpr int kC8Stride = 32 * 8 + 8;                   // dwords (output staging, as in the plane stores below)
         constexpr int kPF = 2;                                  // k-steps of W2 fragments in flight (16 % kPF == 0)
         unsigned char *frag = smem;
-        unsigned *stg = reinterpret_cast<unsigned *>(smem + 4096) + wid * (16 * kC8Stride);
+        unsigned *stg = reinterpret_cast<unsigned *>(smem + GG::kStgOff) + wid * (16 * kC8Stride);
         const int kb_out = p.cp_cols / kStageK;
-        auto load_w2 = [&](int s2, half8 (&dst)[4]) {            // [2 ob + plane]: rows 64 wid + 32 ob .., slots 16 s2 ..
+        // wave -> (fg: its 64 output features, np: its pair of 32-node blocks of the half).  128-row tiles: four waves x all 64 nodes
+        // of a half; 256-row tiles: a half is 128 nodes, waves 4-7 take the second pair of node blocks for the same features.
+        const int fg = TM == 128 ? wid : (wid & 3), np = TM == 128 ? 0 : (wid >> 2);
+        auto load_w2 = [&](int s2, half8 (&dst)[4]) {            // [2 ob + plane]: rows 64 fg + 32 ob .., slots 16 s2 ..
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob) {
-                const int64_t idx = ((int64_t)(wid * 2 + ob) * (kTileN / kStageK) + s2) * kBlockElems + lane * 8;
+                const int64_t idx = ((int64_t)(fg * 2 + ob) * (kTileN / kStageK) + s2) * kBlockElems + lane * 8;
                 dst[2 * ob] = *reinterpret_cast<const half8 *>(p.w2_hi + idx);
                 dst[2 * ob + 1] = *reinterpret_cast<const half8 *>(p.w2_lo + idx);
             }
@@ -965,7 +1084,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                     half8 bh[2], bl[2];
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
-                        const unsigned char *src = frag + (size_t)((nb * 16 + s2) * 2) * kFragBlock + h * kFragHalf + r * 16;
+                        const unsigned char *src = frag + (size_t)(((2 * np + nb) * 16 + s2) * 2) * kFragBlock + h * kFragHalf + r * 16;
                         bh[nb] = *reinterpret_cast<const half8 *>(src);
                         bl[nb] = *reinterpret_cast<const half8 *>(src + kFragBlock);
                     }
@@ -988,12 +1107,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
             if (p.stamps && i == 0) t_fl2 = __builtin_amdgcn_s_memtime();
             __syncthreads();                                     // every wave is done with the fragment image: the staging overlaps it
             if (p.stamps && i == 0) t_fl3 = __builtin_amdgcn_s_memtime();
-            // u[ob][nb]: lane (r, h) = node (2 nb + i) * 32 + r of the tile, registers = output features 64 wid + 32 ob + row(q, h).
+            // u[ob][nb]: lane (r, h) = node (2 (2 np + nb) + i) * 32 + r of the tile, registers = output features 64 fg + 32 ob + row(q, h).
             // Planes want eight consecutive nodes per 16-byte piece: transposed through the wave's own staging as packed
             // (hi | lo << 16) dwords, [8-node group][row][node % 8] (the scheme of the plane stores below).
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob) {
-                const int rb = wid * 2 + ob;                     // 32-row block of the [256, cp_cols] result
+                const int rb = fg * 2 + ob;                      // 32-row block of the [256, cp_cols] result
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -1009,7 +1128,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
                 for (int it = 0; it < 4; ++it) {                 // (node block nb, 16-node k-block pi inside it); lane half h = 8-node half of the k-block
                     const int nb = it >> 1, pi = it & 1;
                     const int c8 = nb * 4 + 2 * pi + h;
-                    const int kb = (tile_m >> 4) + (2 * nb + i) * 2 + pi;
+                    const int kb = (tile_m >> 4) + (2 * (2 * np + nb) + i) * 2 + pi;
                     const uint4 lo4 = *reinterpret_cast<const uint4 *>(stg + c8 * kC8Stride + r * 8);
                     const uint4 hi4 = *reinterpret_cast<const uint4 *>(stg + c8 * kC8Stride + r * 8 + 4);
                     if (kb < kb_out) {
@@ -1026,7 +1145,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
             }
         }
         if (p.stamps && lane == 0) {
-            unsigned long long *st = p.stamps + ((size_t)blockIdx.x * 4 + wid) * 8;
+            unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 8;
             st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_fl0; st[4] = t_fl1; st[5] = t_fl2; st[6] = t_fl3;
         }
         return;
@@ -1082,7 +1201,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
     // (conflict-free writes), and writes whole 1 KiB blocks: lanes 0-31 = rows of the k-half 0, 32-63 of half 1.
     if (p.c_hi) {
         constexpr int kC8Stride = 32 * 8 + 8;                                  // dwords
-        unsigned *stg = reinterpret_cast<unsigned *>(smem + 4096) + wid * (16 * kC8Stride);
+        unsigned *stg = reinterpret_cast<unsigned *>(smem + GG::kStgOff) + wid * (16 * kC8Stride);
         const int kb_out = p.cp_cols / kStageK;
         const int rb_count = (p.m + 31) >> 5;
 #pragma unroll
@@ -1135,20 +1254,21 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gcn_gemm_kernel(const GemmArg
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[j] = fmaf(w, acc[i][j][q], part[j]);
             }
-        float *pr = reinterpret_cast<float *>(smem) + 512;     // [2 (wm)][256 cols], bytes 2048..4095
+        float *pr = reinterpret_cast<float *>(smem + GG::kPoolOff);     // [kWavesM (wm)][256 cols]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             part[j] += __shfl_xor(part[j], 32, SN_WAVE);
             if (h == 0) pr[wm * 256 + (4 * wn + j) * 32 + r] = part[j];
         }
         __syncthreads();
-        {   // one partial row per row tile: pooled[batch][tile_y][n] (summed in a fixed order by sn_pool_fc: deterministic)
-            const int n = tile_n + tid;
-            if (n < p.n) p.pooled[((int64_t)batch * p.pooled_parts + tile / p.tiles_x) * p.n + n] = pr[tid] + pr[256 + tid];
+        {   // one partial row per 128 rows: pooled[batch][part][n] (summed in a fixed order by sn_pool_fc: deterministic; a 256-row
+            // tile writes the two partial rows its rows would have given as two 128-row tiles - the same sums in the same order)
+            const int half = tid >> 8, n = tile_n + (tid & 255), part = (tile / p.tiles_x) * (kTileM / 128) + half;
+            if (n < p.n && part * 128 < p.m) p.pooled[((int64_t)batch * p.pooled_parts + part) * p.n + n] = pr[(2 * half) * 256 + (tid & 255)] + pr[(2 * half + 1) * 256 + (tid & 255)];
         }
     }
     if (p.stamps && lane == 0) {
-        unsigned long long *st = p.stamps + ((size_t)blockIdx.x * 4 + wid) * 8;
+        unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 8;
         st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_wait; st[4] = t_issue;
     }
 }
@@ -1392,6 +1512,24 @@ extern "C" int sn_layernorm_split_planes(const float *x, int G, int n, int E, co
     return SN_OK;
 }
 
+/* tile form of sn_gcn_gemm: see sn_debug_set_gemm_tile */
+static int g_gemm_tile = -1, g_gemm_stagger = -1;
+static int gemm_tile_setting()
+{
+    if (g_gemm_tile < 0) { const char *e = getenv("SN_GEMM_TM"); const int v = e ? atoi(e) : 0; g_gemm_tile = (v == 128 || v == 256) ? v : 0; }
+    return g_gemm_tile;
+}
+static int gemm_stagger_setting()
+{
+    if (g_gemm_stagger < 0) { const char *e = getenv("SN_GEMM_STAGGER"); g_gemm_stagger = (e && atoi(e) == 0) ? 0 : 1; }
+    return g_gemm_stagger;
+}
+extern "C" void sn_debug_set_gemm_tile(int tile_rows, int stagger)
+{
+    if (tile_rows >= 0) g_gemm_tile = (tile_rows == 128 || tile_rows == 256) ? tile_rows : 0;
+    if (stagger >= 0) g_gemm_stagger = stagger ? 1 : 0;
+}
+
 /* diagnostics: device buffer of 8 x u64 per wave of the GEMM kernel (NULL = off) */
 extern "C" void sn_debug_set_gemm_stamps(void *device_buffer) { g_gemm_stamps = (unsigned long long *)device_buffer; }
 
@@ -1459,28 +1597,42 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
         a.nt_b = (nt & 2) && u->a_batch_stride == 0;
     }
     const int cols = (u->c_hi && !fused2 && u->cp_cols > u->n) ? u->cp_cols : u->n;       // zero-filled plane columns need a tile too
-    a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + kTileM - 1) / kTileM;
-    SN_REQUIRE(u->pooled_parts == 0 || u->pooled_parts >= a.tiles_y, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooled_parts=%d < %d row tiles", u->pooled_parts, a.tiles_y);
-    a.pooled_parts = u->pooled_parts > 0 ? u->pooled_parts : a.tiles_y;
+    // Tile height (round 6): 256 rows - one 8-wave workgroup per CU - for graphs of at least 256 rows that share one extent (the class
+    // graphs of the IR-Atlas, config [3]'s 500-vertex classes); 128 rows - two 4-wave workgroups per CU - for small graphs and for
+    // batches with per-graph extents (instance graphs of ~110 vertices, compacted classes: a graph then costs whole tiles of its own
+    // height).  SN_GEMM_TM=128 / 256 forces one form (256 needs m >= 129 to make sense; any m is correct).
+    const int tm_set = gemm_tile_setting(), tile_m = (tm_set == 256 || (tm_set != 128 && u->m >= 256 && !(u->m_extent && u->extent_stride != 0))) ? 256 : 128;
+    const bool tall = tile_m == 256;
+    a.stagger = gemm_stagger_setting();
+    a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + tile_m - 1) / tile_m;
+    const int parts = (u->m + 127) / 128;                                                  // pooled partial rows: one per 128 rows, whatever the tile
+    SN_REQUIRE(u->pooled_parts == 0 || u->pooled_parts >= parts, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooled_parts=%d < %d row tiles", u->pooled_parts, parts);
+    a.pooled_parts = u->pooled_parts > 0 ? u->pooled_parts : parts;
     const int64_t n_blocks = (int64_t)8 * ((u->batches + 7) / 8) * a.tiles_x * a.tiles_y;
     SN_REQUIRE(n_blocks <= 0x7fffffff, SN_ERR_UNSUPPORTED, "sn_gcn_gemm: grid too large");
     const dim3 grid((unsigned)n_blocks);
-    const size_t lds = (size_t)kRing * kStageBytes;
-    {
-        const void *fn = fused2 ? (gathered ? (const void *)gcn_gemm_kernel<true, true, true> : (const void *)gcn_gemm_kernel<true, false, true>)
-                                : gathered ? (u->layernorm ? (const void *)gcn_gemm_kernel<true, true> : (const void *)gcn_gemm_kernel<false, true>)
-                                           : (u->layernorm ? (const void *)gcn_gemm_kernel<true> : (const void *)gcn_gemm_kernel<false>);
-        if (int rc = sn_ensure_dynamic_lds(fn, lds, "sn_gcn_gemm")) return rc;
-    }
     hipStream_t st = (hipStream_t)stream;
-    sn_prof_start(4, st);
-    if (fused2 && gathered) hipLaunchKernelGGL((gcn_gemm_kernel<true, true, true>), grid, dim3(kGemmThreads), lds, st, a);
-    else if (fused2) hipLaunchKernelGGL((gcn_gemm_kernel<true, false, true>), grid, dim3(kGemmThreads), lds, st, a);
-    else if (gathered && u->layernorm) hipLaunchKernelGGL((gcn_gemm_kernel<true, true>), grid, dim3(kGemmThreads), lds, st, a);
-    else if (gathered) hipLaunchKernelGGL((gcn_gemm_kernel<false, true>), grid, dim3(kGemmThreads), lds, st, a);      // (wide GNNs: E = 512, 1024 - each column tile gathers its slice of the table rows)
-    else if (u->layernorm) hipLaunchKernelGGL(gcn_gemm_kernel<true>, grid, dim3(kGemmThreads), lds, st, a);
-    else hipLaunchKernelGGL(gcn_gemm_kernel<false>, grid, dim3(kGemmThreads), lds, st, a);
-    sn_prof_stop(4, st);
+    int rc = SN_OK;
+    auto launch = [&](auto kernel, int threads, size_t lds) {
+        if ((rc = sn_ensure_dynamic_lds((const void *)kernel, lds, "sn_gcn_gemm"))) return;
+        sn_prof_start(4, st);
+        hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, st, a);
+        sn_prof_stop(4, st);
+    };
+    auto pick = [&](auto tm) {
+        constexpr int TMv = decltype(tm)::value;
+        const int threads = Geom<TMv>::kThreads;
+        const size_t lds = Geom<TMv>::kLdsBytes;
+        if (fused2 && gathered) launch(gcn_gemm_kernel<true, true, true, TMv>, threads, lds);
+        else if (fused2) launch(gcn_gemm_kernel<true, false, true, TMv>, threads, lds);
+        else if (gathered && u->layernorm) launch(gcn_gemm_kernel<true, true, false, TMv>, threads, lds);
+        else if (gathered) launch(gcn_gemm_kernel<false, true, false, TMv>, threads, lds);      // (wide GNNs: E = 512, 1024 - each column tile gathers its slice of the table rows)
+        else if (u->layernorm) launch(gcn_gemm_kernel<true, false, false, TMv>, threads, lds);
+        else launch(gcn_gemm_kernel<false, false, false, TMv>, threads, lds);
+    };
+    if (tall) pick(std::integral_constant<int, 256>{});
+    else pick(std::integral_constant<int, 128>{});
+    if (rc) return rc;
     SN_CHECK_LAUNCH("sn_gcn_gemm");
     return SN_OK;
 }

@@ -133,6 +133,21 @@ class SchemaNetPredictor(nn.Module):
     # ---- the path behind the backbone -----------------------------------------------------------------------
     def _after_backbone(self, output, requires_graph: bool, side_stream=None):
         ret = LazyOutputs()
+        if self._trains():
+            # Training (round 6: the reference's own call sequence is the fast path - worker_schema_net.py:121-147 calls
+            # `self.predictor(x)` between `normalize()` and the loss): the route `train.GraphedTrainIter` captures and the bench's
+            # eager leg times - the differentiable atlas (`class_edges` with its gradient: what the loss's entropy terms read), the
+            # padded instance batch without a host synchronisation, `Matcher.forward_padded` with ONE folded embedding table for
+            # both GNN passes and the instance pass on a second stream beside the class pass.  (Until round 5 a training forward
+            # went through the inference fork - class branch on the side stream, the table folded once per pass.)
+            atlas = self.schema_net.get_atlas()
+            graph = self.schema_net.instance_graph_padded(output["ingredients"], output["attn"], output["attn_cls"],
+                                                          zero_padding=requires_graph, return_attn_cls=requires_graph,
+                                                          rerank=output.get("rerank"))
+            ret["pred"] = self.matcher.forward_padded(graph, atlas)
+            for k in ("class_vertices", "class_edges", "class_ingredients"):
+                ret[k] = atlas[k]
+            return self._with_graphs(ret, graph, output) if requires_graph else ret
         # class branch (atlas normalisation + GNN over the K class graphs) on the side stream,
         # instance branch on the current one; joined inside forward_padded
         get_atlas = self.schema_net.get_atlas
@@ -160,14 +175,27 @@ class SchemaNetPredictor(nn.Module):
                 ret.set_lazy(k, self._class_edges_now)
             else:
                 ret[k] = atlas.class_dict[k]
-        if requires_graph:
-            n = int(graph["n_max"].item())
-            bs = graph["ids"].shape[0]
-            ret["instance_ingredients"] = [graph["ids"][b, :n] for b in range(bs)]
-            ret["instance_vertices"] = [graph["vertices"][b, :n] for b in range(bs)]
-            ret["instance_edges"] = [graph["edges"][b, :n, :n] for b in range(bs)]
-            ret["ingredients"] = output["ingredients"]
-            ret["attn_cls"] = graph["attn_cls"]          # [bs, L] head mean, clamp-masked (reference schema_net.py:296)
+        return self._with_graphs(ret, graph, output) if requires_graph else ret
+
+    def _trains(self) -> bool:
+        """autograd is on and some parameter behind the backbone wants a gradient: `forward` is a training forward"""
+        if not torch.is_grad_enabled():
+            return False
+        sn = self.schema_net
+        if not sn.vertex_weights.tensor.is_cuda:
+            return False
+        return any(p.requires_grad for p in sn.parameters()) or any(p.requires_grad for p in self.matcher.parameters())
+
+    @staticmethod
+    def _with_graphs(ret, graph, output):
+        """requires_graph: the instance graphs as the reference returns them after Matcher's in-place padding (one host read)"""
+        n = int(graph["n_max"].item())
+        bs = graph["ids"].shape[0]
+        ret["instance_ingredients"] = [graph["ids"][b, :n] for b in range(bs)]
+        ret["instance_vertices"] = [graph["vertices"][b, :n] for b in range(bs)]
+        ret["instance_edges"] = [graph["edges"][b, :n, :n] for b in range(bs)]
+        ret["ingredients"] = output["ingredients"]
+        ret["attn_cls"] = graph["attn_cls"]          # [bs, L] head mean, clamp-masked (reference schema_net.py:296)
         return ret
 
     def _class_edges_now(self):

@@ -442,7 +442,15 @@ class GNN(nn.Module):
             if table is None:
                 table = ops.linear_mfma(self.embedding.weight, first.g_conv.linear.weight)
             prepared = {"train_table": table}
-            h = first.post((table + first.g_conv.linear.bias)[None], None, None, False)[0]                   # an isolated vertex of word w, layer by layer
+            # (the padding word's row of the table takes no gradient on this path either: nn.Embedding keeps embedding.weight[padding_idx].grad
+            # at 0 - reference gnn.py:63-67 - and the uncompacted route does so through gather_adj_matmul's `pad`; a class vertex whose
+            # word IS the padding index reaches this table only here: ADVICE r05)
+            pad = self.embedding.padding_idx
+            table_iso = table
+            if pad is not None and 0 <= pad < table.shape[0]:
+                table_iso = table.clone()
+                table_iso[pad] = table[pad].detach()
+            h = first.post((table_iso + first.g_conv.linear.bias)[None], None, None, False)[0]               # an isolated vertex of word w, layer by layer
             for l in layers[1:]:
                 h = l.post(_linear(l.g_conv.linear, h)[None], None, None, False)[0]
             w_sum = torch.zeros((nodes.shape[0], table.shape[0]), dtype=w_all.dtype, device=nodes.device)

@@ -29,6 +29,26 @@ class _AtlasHandle:
         return self.feat
 
 
+def _quiet_stream_mismatch_in_backward(out: torch.Tensor) -> torch.Tensor:
+    """The GNN's parameters of a side-stream iteration receive gradients from two streams; the engine orders them, and its warning
+    about the mismatch is about an unintended one.  The process-wide switch is turned off for THIS backward pass only (it
+    used to stay off for the rest of the process): a hook on the scores - the first gradient of the pass - saves and clears it, a
+    callback queued on the engine restores it when the pass is over."""
+    setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    getter = getattr(torch._C, "_warn_on_accumulate_grad_stream_mismatch", None)
+    if setter is None or getter is None or not out.requires_grad:
+        return out
+
+    def at_backward_start(grad):
+        before = bool(getter())
+        if before:
+            setter(False)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: setter(True))
+        return grad
+    out.register_hook(at_backward_start)
+    return out
+
+
 class Matcher(nn.Module):
     """Same constructor and state-dict (`gnn.*`) as the reference.  `forward` keeps the
     reference's list-based contract; `forward_padded` consumes the padded batch produced by
@@ -185,11 +205,6 @@ class Matcher(nn.Module):
             dev = edges.device
             if getattr(self, "_train_stream", None) is None or self._train_stream.device != dev:
                 self._train_stream = torch.cuda.Stream(device=dev)
-                # (the GNN's parameters receive gradients from both streams: the engine orders them; its warning about the
-                # mismatch is about an unintended one)
-                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-                if quiet is not None:
-                    quiet(False)
             main, side = torch.cuda.current_stream(dev), self._train_stream
             side.wait_stream(main)
             for t in (graph["vertices"], edges, graph["ids"], graph["n"], graph["n_max"], shared["train_table"] if shared else None):
@@ -200,7 +215,7 @@ class Matcher(nn.Module):
             feat_kg = self.atlas_features(class_dict, shared)
             main.wait_stream(side)
             feat_instance.record_stream(main)
-            return self.similarity(feat_instance, feat_kg, votes)
+            return _quiet_stream_mismatch_in_backward(self.similarity(feat_instance, feat_kg, votes))
         feat_instance = run_instance()
         if isinstance(feat_kg, _AtlasHandle):
             feat_kg = feat_kg.join()

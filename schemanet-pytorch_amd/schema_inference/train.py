@@ -86,12 +86,17 @@ class GraphedTrainIter:
                  targets: Dict[str, torch.Tensor], warmup: int = 2, compact: bool = True):
         # compact: the class GNN of the captured iteration runs on the kept vertices of a pruned IR-Atlas where that pays
         # (`schema_net.compact_training`, SchemaNet.get_atlas): the extra launches of that route cost a replay nothing
-        if compact and hasattr(schema_net, "get_atlas"):
-            schema_net.compact_training = True
+        # The switch is a property of THIS captured iteration: it is set for the warm-up and the capture and put back
+        # afterwards, so that eager `train_iter` calls on the same SchemaNet keep their own (uncompacted, faster eagerly) route.
+        # `self.compacted` says which route the graph holds: the decision is taken at the warm-up (kept fraction under 3/4) and is
+        # baked into the replay - build a new GraphedTrainIter when the atlas has changed enough for the other route to pay.
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainIter needs an optimizer built with capturable=True")
         if warmup < 1 and not optimizer.state:
             raise ValueError("GraphedTrainIter: the optimizer has no state yet - at least one warm-up iteration is needed")
+        had_switch = getattr(schema_net, "compact_training", False)
+        if compact and hasattr(schema_net, "get_atlas"):
+            schema_net.compact_training = True
         self.batch = {k: v.clone() for k, v in batch.items()}
         self.targets = {k: v.clone() for k, v in targets.items()}
         self.optimizer, self.schema_net = optimizer, schema_net
@@ -131,6 +136,10 @@ class GraphedTrainIter:
                           "memsets): on ROCm 7.2 a captured memset node may not clear on replay - compare a replay with an eager call")
         self.graph.instantiate()
         self.warmup_steps = warmup
+        state = getattr(schema_net, "_compaction_state", None)
+        self.compacted = bool(compact and state is not None and state.get("decision", False))
+        if compact and hasattr(schema_net, "get_atlas"):
+            schema_net.compact_training = had_switch
 
     def __call__(self, batch: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor]):
         for mine, theirs in ((self.batch, batch), (self.targets, targets)):

@@ -40,6 +40,24 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.sn_assign_variant() in (0, 5)
 
 
+def test_abi_version_names_the_header(lib):
+    """The rule of include/schemanet_hip.h - `sn_abi_version()` is bumped on any change of a signature or of a by-pointer struct - made
+    mechanical: the header's declarations (comments removed, whitespace collapsed) are hashed against the value
+    committed next to ABI_VERSION in the binding; whoever changes a declaration has to touch that pair, and the version with it.
+    The table of (version, hash) pairs keeps an old version from being reused for new declarations."""
+    import hashlib
+    import cpp_extension._native as N
+    header = open(os.path.join(ROOT, "include", "schemanet_hip.h")).read()
+    text = re.sub(r"\s+", " ", re.sub(r"/\*.*?\*/", "", header, flags=re.S)).strip()
+    sha = hashlib.sha256(text.encode()).hexdigest()[:16]
+    assert sha == N.ABI_HEADER_SHA, (f"include/schemanet_hip.h changed (declarations hash {sha}, binding has {N.ABI_HEADER_SHA}): bump sn_abi_version() / "
+                                     f"ABI_VERSION and store the new hash in cpp_extension/_native.py and in KNOWN_ABIS below")
+    assert lib.sn_abi_version() == N.ABI_VERSION
+    KNOWN_ABIS = {11: "bbdaa31ffe5ba687"}                       # one line per ABI from 11 on; a version never names two headers
+    assert KNOWN_ABIS.get(N.ABI_VERSION) == sha, "a new header needs a new ABI version (and its line here)"
+    assert re.search(r"ABI version.*?\b" + str(N.ABI_VERSION) + r":", header, flags=re.S), "the header's version comment does not name this version"
+
+
 def _struct_field_names(header, name):
     body = header[header.index("typedef struct %s {" % name):header.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
