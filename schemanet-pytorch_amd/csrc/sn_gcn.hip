@@ -45,6 +45,9 @@
 #ifndef SN_GEMM_SADDR
 #define SN_GEMM_SADDR 1        // ring copies addressed by SGPR base + 32-bit lane offset (0: a 64-bit address per lane, rounds 1-5)
 #endif
+#ifndef SN_GEMM_FL_TRANSPOSED
+#define SN_GEMM_FL_TRANSPOSED 1   // fused next-layer product: output tile as [node][feature] (plane pieces straight from registers); 0: rounds 3-5 (through LDS)
+#endif
 #ifndef SN_GEMM_ABLATE
 #define SN_GEMM_ABLATE 0       // lab builds only (results are garbage): 1 no MFMAs, 2 no fragment reads, 4 no ring copies, 8 no copies of A, 16 no copies of B
 #endif
@@ -1024,10 +1027,14 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
     if constexpr (FL) {
         constexpr int kFragHalf = 528, kFragBlock = 1056;       // bytes: a 32-node x 8-slot half / a (node block, k-step, plane) block;
                                                                 // the 16- and 32-byte paddings spread a wave's 8-byte stores over all banks
+#if !SN_GEMM_FL_TRANSPOSED
         constexpr int kC8Stride = 32 * 8 + 8;                   // dwords (output staging, as in the plane stores below)
+#endif
         constexpr int kPF = 2;                                  // k-steps of W2 fragments in flight (16 % kPF == 0)
         unsigned char *frag = smem;
+#if !SN_GEMM_FL_TRANSPOSED
         unsigned *stg = reinterpret_cast<unsigned *>(smem + GG::kStgOff) + wid * (16 * kC8Stride);
+#endif
         const int kb_out = p.cp_cols / kStageK;
         // wave -> (fg: its 64 output features, np: its pair of 32-node blocks of the half).  128-row tiles: four waves x all 64 nodes
         // of a half; 256-row tiles: a half is 128 nodes, waves 4-7 take the second pair of node blocks for the same features.
@@ -1089,6 +1096,23 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
                         bl[nb] = *reinterpret_cast<const half8 *>(src + kFragBlock);
                     }
                     half8 (&w)[4] = wq[t];
+#if SN_GEMM_FL_TRANSPOSED
+                    // (round 6) the SAME three products with the operands' roles exchanged: rows = nodes (the H fragments), columns = output
+                    // features (the W2 fragments) - u[ob][nb] then holds a feature per lane and nodes along its registers, which is
+                    // how the planes of Zt2 want them (below): no transposition through LDS
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) u[ob][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nb], w[2 * ob + 1], u[ob][nb], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) u[ob][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nb], w[2 * ob], u[ob][nb], 0, 0, 0);
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) u[ob][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nb], w[2 * ob], u[ob][nb], 0, 0, 0);
+#else
 #pragma unroll
                     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -1101,10 +1125,56 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
                     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb) u[ob][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * ob], bh[nb], u[ob][nb], 0, 0, 0);
+#endif
                     if (s2 + kPF < kTileN / kStageK) load_w2(s2 + kPF, wq[t]);
                 }
             }
             if (p.stamps && i == 0) t_fl2 = __builtin_amdgcn_s_memtime();
+#if SN_GEMM_FL_TRANSPOSED
+            if (p.stamps && i == 0) t_fl3 = t_fl2;
+            // u[ob][nb]: lane (r, h) = output feature 64 fg + 32 ob + r, register q = node (2 (2 np + nb) + i) * 32 + (q & 3) + 8 (q >> 2) + 4 h
+            // of the tile.  A plane piece is eight consecutive nodes of one feature: a lane holds four (q & 3) of each group of eight and
+            // its partner lane ^ 32 the other four - one v_permlane32_swap per register pair (q, q + 4) hands each lane a whole piece:
+            // lane (r, 0) the nodes 0-7 and 16-23 of the 32-node block, lane (r, 1) the nodes 8-15 and 24-31, i.e. k-half h of the
+            // 16-node k-blocks 0 and 1 - and the wave's 64 pieces of a k-block are its 1 KiB in order (byte lane * 16).
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const int rb = fg * 2 + ob;                      // 32-row block of the [256, cp_cols] result
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    unsigned pk[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        _Float16 hi, lo;
+                        split2(u[ob][nb][q] * u_mul, hi, lo);
+                        pk[q] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                    }
+#pragma unroll
+                    for (int g8 = 0; g8 < 2; ++g8)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(pk[8 * g8 + qq], pk[8 * g8 + 4 + qq], false, false);
+                            pk[8 * g8 + qq] = sw[0];
+                            pk[8 * g8 + 4 + qq] = sw[1];
+                        }
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi) {             // 16-node k-block pi of the node block; this lane's k-half = h
+                        const int kb = (tile_m >> 4) + (2 * (2 * np + nb) + i) * 2 + pi;
+                        if (kb < kb_out) {
+                            const unsigned *q8 = pk + 8 * pi;
+                            uint4 ph, pl;
+                            ph.x = __builtin_amdgcn_perm(q8[1], q8[0], 0x05040100u); pl.x = __builtin_amdgcn_perm(q8[1], q8[0], 0x07060302u);
+                            ph.y = __builtin_amdgcn_perm(q8[3], q8[2], 0x05040100u); pl.y = __builtin_amdgcn_perm(q8[3], q8[2], 0x07060302u);
+                            ph.z = __builtin_amdgcn_perm(q8[5], q8[4], 0x05040100u); pl.z = __builtin_amdgcn_perm(q8[5], q8[4], 0x07060302u);
+                            ph.w = __builtin_amdgcn_perm(q8[7], q8[6], 0x05040100u); pl.w = __builtin_amdgcn_perm(q8[7], q8[6], 0x07060302u);
+                            const int64_t o = (int64_t)batch * p.cp_batch_stride + ((int64_t)rb * kb_out + kb) * kBlockElems + lane * 8;
+                            *reinterpret_cast<uint4 *>(p.c_hi + o) = ph;
+                            *reinterpret_cast<uint4 *>(p.c_lo + o) = pl;
+                        }
+                    }
+                }
+            }
+#else
             __syncthreads();                                     // every wave is done with the fragment image: the staging overlaps it
             if (p.stamps && i == 0) t_fl3 = __builtin_amdgcn_s_memtime();
             // u[ob][nb]: lane (r, h) = node (2 (2 np + nb) + i) * 32 + r of the tile, registers = output features 64 fg + 32 ob + row(q, h).
@@ -1143,6 +1213,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
                     }
                 }
             }
+#endif
         }
         if (p.stamps && lane == 0) {
             unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 8;
