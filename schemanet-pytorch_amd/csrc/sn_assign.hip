@@ -30,6 +30,9 @@
 #ifndef SN_S1_TOKENS_NT
 #define SN_S1_TOKENS_NT 1   // token rows with the non-temporal hint: read once by the screen (the re-rank re-reads the 6.6 % it flags: +0.4 us there, -1.8 us here, +1.1 % on the replayed bench; round 1, with 13 % flagged, it lost)
 #endif
+#ifndef SN_S1_SADDR
+#define SN_S1_SADDR 1       // codebook ring copies addressed by an SGPR base + 32-bit lane offset (0: a 64-bit address per lane, rounds 1-5)
+#endif
 #ifndef SN_S1_STAGE
 #define SN_S1_STAGE 1       // token rows through LDS in whole cache lines (0: fragment loads straight from global memory)
 #endif
@@ -391,6 +394,35 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
     // offset of global_load_lds moves the LDS address together with the global one, so up to four pieces
     // (offsets 0, 1, 2, 3 KiB) share one address register pair and one M0 value: one asm statement per group.
     const int dma_c0 = wid * kDmaMin + (wid < kDmaExtra ? wid : kDmaExtra);
+#if SN_S1_SADDR
+    // (round 6) wave-uniform source base in SGPRs + a 32-bit lane offset: with a 64-bit address per lane the CU's address unit took
+    // ~37 cycles per 1 KiB copy (the "28 B per cycle and CU" of this ring; measured on the GCN product's rings, 8d)
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto issue_tile = [&](int w, int slot) {
+        const unsigned char *sbase = tiles + (size_t)w * kTileBytes + dma_c0 * 1024;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + dma_c0 * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+#pragma unroll
+        for (int j = 0; j < kDmaMin; j += 4) {
+            const unsigned char *sj = sbase + (size_t)j * 1024;
+            const unsigned dj = dst + j * 1024;
+            if (kDmaMin - j >= 4)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, %2 offset:2048\n\tglobal_load_lds_dwordx4 %0, %2 offset:3072" :: "v"(lane16), "s"(dj), "s"(sj) : "memory");
+            else if (kDmaMin - j == 3)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, %2 offset:2048" :: "v"(lane16), "s"(dj), "s"(sj) : "memory");
+            else if (kDmaMin - j == 2)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024" :: "v"(lane16), "s"(dj), "s"(sj) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(lane16), "s"(dj), "s"(sj) : "memory");
+        }
+        if (kDmaExtra != 0 && wid < kDmaExtra)                                    // wave-uniform
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(lane16), "s"(dst + kDmaMin * 1024), "s"(sbase + (size_t)kDmaMin * 1024) : "memory");
+        asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
+    };
+#else
     auto issue_tile = [&](int w, int slot) {
         const unsigned char *src = tiles + (size_t)w * kTileBytes + dma_c0 * 1024 + lane * 16;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot * kTileBytes + dma_c0 * 1024);
@@ -415,6 +447,7 @@ __global__ __launch_bounds__(64 * NW, (NSTEPS <= 24 ? 2 : 1)) void assign_screen
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src + (size_t)kDmaMin * 1024), "s"(dst + kDmaMin * 1024) : "memory");
         asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
     };
+#endif
     // wait until this wave's copies of all but the newest `ahead` tiles have landed (the first
     // kDmaExtra waves over-wait by up to `ahead` chunks: the immediate must be a constant)
     auto wait_tiles = [&](int ahead) {

@@ -49,7 +49,7 @@
 #define SN_GEMM_FL_TRANSPOSED 1   // fused next-layer product: output tile as [node][feature] (plane pieces straight from registers); 0: rounds 3-5 (through LDS)
 #endif
 #ifndef SN_GEMM_ABLATE
-#define SN_GEMM_ABLATE 0       // lab builds only (results are garbage): 1 no MFMAs, 2 no fragment reads, 4 no ring copies, 8 no copies of A, 16 no copies of B
+#define SN_GEMM_ABLATE 0       // lab builds only (results are garbage): 1 no MFMAs, 2 no fragment reads, 4 no ring copies, 8 no copies of A, 16 no copies of B, 32 no stage barrier
 #endif
 #ifndef SN_GEMM_ISSUE_AT
 #define SN_GEMM_ISSUE_AT 1     // where in a stage the ring copies of stage t + 2 are issued: 0 in front of the MFMAs, 1 behind the first 8, 2 behind 16 (fewer loop cycles, the same launch time)
@@ -636,6 +636,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
     constexpr int kTileM = GG::kTileM, kGemmThreads = GG::kThreads, kChunksA = GG::kChunksA, kStageBytes = GG::kStageBytes, kRing = GG::kRing,
                   kDmaPerWave = GG::kDmaPerWave, kWaves = GG::kWaves;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long rt_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;      // (diagnostics: the 100 MHz clock all XCDs share)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
         if (kRing >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaPerWave) : "memory");
         else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaPerWave) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(SN_GEMM_ABLATE & 32)) __builtin_amdgcn_s_barrier();
     };
     auto read_fragments = [&](int t) {
         if (SN_GEMM_ABLATE & 2) {
@@ -1251,6 +1252,9 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
                     }
             }
         }
+        // (round 6, measured and not kept: 16-byte stores behind a 4 x 4 in-quad DPP transpose - 32 global_store_dwordx4 per wave instead
+        // of 128 global_store_dword - left the store tail where it was: 28.3 k against 28.5 k cycles on a 256-row tile, 600 against
+        // 570 us for 1000 graphs x 512 x 256; the tail is not bound by the number of store instructions.  DESIGN 8)
         if (!added) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1341,6 +1345,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
     if (p.stamps && lane == 0) {
         unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 8;
         st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_wait; st[4] = t_issue;
+        st[5] = rt_entry; st[6] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

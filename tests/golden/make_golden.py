@@ -362,6 +362,15 @@ def _trajectory_run(perturb=0.0, c=None):
     m = ref.graph.Matcher(similarity="inner_product", num_codes=M,
                           gnn_cfg=dict(embed_dim=E, num_layers=2, identity_proj=False, activation="relu"))
 
+    if c.get("prune_frac"):
+        # a TRAINED atlas is sparse (the loss's entropy terms push most vertices of a class under prune_node_threshold, reference
+        # schema_net.py:152-166); the freshly initialised one prunes nothing.  A seeded share of the vertex weights is scaled under the
+        # threshold, so that the trajectory starts where the package's compacted training route applies
+        gen = torch.Generator().manual_seed(c["prune_seed"])
+        low = torch.rand(K, n_max, generator=gen) < c["prune_frac"]
+        with torch.no_grad():
+            sn.vertex_weights.tensor.mul_(torch.where(low, torch.tensor(1.0e-4), torch.tensor(1.0)))
+
     class _Wrapper(torch.nn.Module):             # stands for IngredientModelWrapper: x already is its output dict
         def forward(self, x):
             return {k: v.clone() for k, v in x.items()}
@@ -448,12 +457,14 @@ def trajectory():
 TRAJ2 = dict(B=8, L=196, M=512, K=10, n_max=128, E=256, iters=10, seed0=700, eval_seed=1990, lr=1.0e-3, wd=0.05, wd_schema_net=5.0e-4)
 
 
-def trajectory_mfma():
-    c = TRAJ2
+def trajectory_mfma(c=None, fname="trajectory_mfma.npz"):
+    c = c or TRAJ2
     B, L, M, K, n_max, E = c["B"], c["L"], c["M"], c["K"], c["n_max"], c["E"]
     predictor, sn, init, losses, cls_losses = _trajectory_run(c=c)
     rec = dict(case=np.asarray([B, L, M, K, n_max, E, c["iters"], c["seed0"], c["eval_seed"]]),
                hyper=np.asarray([c["lr"], c["wd"], c["wd_schema_net"]]), seeds=np.asarray([21, 22, 23]))
+    if c.get("prune_frac"):
+        rec["prune"] = np.asarray([c["prune_frac"], c["prune_seed"]], np.float64)
     # (the initial state is re-created by the test from the seeds; these checksums pin it)
     for k, v in init.items():
         rec["init_sum:" + k] = np.float64(v.double().sum()) if v.dtype.is_floating_point else np.float64(v.sum())
@@ -481,8 +492,18 @@ def trajectory_mfma():
     rec["eval_pred"] = pred.numpy()
     rec["eval_top1"] = pred.argmax(1).numpy()
     rec["eval_label"] = label
-    print("trajectory_mfma: loss", " ".join(f"{x:.5f}" for x in losses), "| eval top-1", rec["eval_top1"].tolist(), "labels", label.tolist())
-    save("trajectory_mfma.npz", **rec)
+    print(fname, "loss", " ".join(f"{x:.5f}" for x in losses), "| eval top-1", rec["eval_top1"].tolist(), "labels", label.tolist())
+    save(fname, **rec)
+
+
+# --------------------------------------------------------------------------- the same trajectory from a PRUNED atlas:
+# 60 % of every class's vertex weights start under prune_node_threshold, so the package's training route with the class graphs
+# compacted to their kept vertices (train.GraphedTrainIter, SchemaNet.compact_training) is what reproduces these losses
+TRAJ3 = dict(TRAJ2, prune_frac=0.6, prune_seed=24, seed0=900, eval_seed=2990)
+
+
+def trajectory_mfma_pruned():
+    trajectory_mfma(TRAJ3, "trajectory_mfma_pruned.npz")
 
 
 if __name__ == "__main__":
@@ -499,3 +520,4 @@ if __name__ == "__main__":
     predictor_graph()
     trajectory()
     trajectory_mfma()
+    trajectory_mfma_pruned()

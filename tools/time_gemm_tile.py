@@ -89,6 +89,10 @@ def run(G, n, label, which=("fused", "pooled", "plain")):
                 t0 = s8[:, 0].min()
                 msg = (f"span {s8[:, 2].max() - t0:.0f} cycles, loop median {(s8[:, 1] - s8[:, 0]).median():.0f}, epilogue median "
                        f"{(s8[:, 2] - s8[:, 1]).median():.0f} max {(s8[:, 2] - s8[:, 1]).max():.0f}, waves {len(s8)}")
+                if name != "fused" and s8[:, 5].min() > 0:      # (the 100 MHz clock all XCDs share: entry of the first workgroup .. end of the last)
+                    r0 = s8[:, 5].min()
+                    msg += (f"; wall (100 MHz clock) first entry -> last end {(s8[:, 6].max() - r0) / 100:.1f} us, entries spread over "
+                            f"{(s8[:, 5].max() - r0) / 100:.1f} us, median workgroup {((s8[:, 6] - s8[:, 5]).median()) / 100:.1f} us")
             print(f"{label} {name:10s} tile {fl:14s} {us:7.1f} us per launch; {same}; {msg}", flush=True)
     lib.sn_debug_set_gemm_tile(0, 1)
 
