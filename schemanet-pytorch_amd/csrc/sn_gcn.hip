@@ -73,19 +73,26 @@ constexpr int kChunksB = (kTileN / 32) * 2;          // 1 KiB blocks of B per st
 // the ring of the 128-row form delivers ~27 B per cycle and CU where its MFMAs need 31, this one needs 21.
 // The second wave of every SIMD (waves 4-7) runs half a stage behind the first, so that one of a SIMD's two waves always has
 // MFMAs to issue while the other sits in the barrier, the copy issue or the fragment reads.
+// TM = 64 (round 6, the FUSED product of small graphs only: instance graphs of ~110 vertices, compacted classes): 4 waves side by side,
+// each 64 rows x 64 columns (2 x 2 accumulators), 20 KiB stages; a tile's 64 nodes are exactly one pass of the fused next-layer
+// product, so a graph of <= 128 vertices is two workgroups that share nothing - where the 128-row form ran the main product and the
+// LayerNorm TWICE (tile + twin) to split its two passes over two workgroups.
 template <int TM> struct Geom {
     static constexpr int kTileM = TM;
-    static constexpr int kWavesM = TM / 64, kWaves = 2 * kWavesM, kThreads = 64 * kWaves;
+    static constexpr int kWavesM = TM >= 128 ? TM / 64 : 1, kWavesN = TM >= 128 ? 2 : 4, kWaves = kWavesM * kWavesN, kThreads = 64 * kWaves;
+    static constexpr int NJ = kTileN / 32 / kWavesN;                            // 32-column accumulators per wave and row block: 4 / 2
     static constexpr int kChunksA = (TM / 32) * 2;                              // 1 KiB blocks of A per stage: [row block][plane]
     static constexpr int kStageBytes = (kChunksA + kChunksB) * 1024;            // 24 / 32 KiB
-    static constexpr int kRing = TM == 128 ? 3 : 4;                             // LDS stages: kRing - 1 in flight
+    static constexpr int kRing = TM <= 128 ? 3 : 4;                             // LDS stages: kRing - 1 in flight
     static constexpr int kDmaPerWave = (kChunksA + kChunksB) / kWaves;          // 6 / 4
     // epilogue scratch: LayerNorm row statistics [5][TM] floats at 0; pooled partials [kWavesM][256] floats; the per-wave staging
     // of the plane stores (16 x kC8Stride dwords per wave) - TM = 128 keeps the offsets it always had
     static constexpr int kPoolOff = TM == 128 ? 2048 : 5 * TM * 4;
     static constexpr int kStgOff = TM == 128 ? 4096 : kPoolOff + kWavesM * 256 * 4;
     static constexpr int kStgBytes = kWaves * 16 * (32 * 8 + 8) * 4;
-    static constexpr int kLdsBytes = kRing * kStageBytes > kStgOff + kStgBytes ? kRing * kStageBytes : kStgOff + kStgBytes;
+    static constexpr int kFragImage = 2 * 16 * 2 * 1056;                        // TM = 64: the fragment image of the fused product (64 nodes)
+    static constexpr int kLdsBytes = TM < 128 ? (kRing * kStageBytes > kFragImage ? kRing * kStageBytes : kFragImage)
+                                              : (kRing * kStageBytes > kStgOff + kStgBytes ? kRing * kStageBytes : kStgOff + kStgBytes);
 };
 constexpr int kBlockElems = 512;        // fp16 elements of one 32-row x 16-k block (1 KiB)
 constexpr int kMaxPerm = 1024;          // vertices per class graph the compacted atlas producer stages a permutation for
@@ -590,7 +597,7 @@ struct GemmArgs {
     int accumulate;                       // c += result (plain products only)
     int zero_skipped;                     // row tiles past the extent are written as zeros
     int pooled_parts;                     // partial sums per graph in `pooled` (>= tiles_y: the caller may keep further slots)
-    unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 8 u64 per wave
+    unsigned long long *stamps;      // diagnostics (sn_debug_set_gemm_stamps): 16 u64 per wave ([8], [9]: the 100 MHz clock at entry / end)
     int nt_a, nt_b;                  // stream that operand past the caches (read once by one workgroup)
     // gathered B (GB kernels): Bt[g][f][j] = table[ids[g][j]][f] from row-major fp16 hi/lo tables [tab_rows + 1][256]
     // (row tab_rows is zero: it stands for j >= ids_n and for ids outside the table)
@@ -601,6 +608,7 @@ struct GemmArgs {
     // fused second product (FL kernels): planes of W2 [256, 256] with its columns in the order the epilogue holds them
     const _Float16 *w2_hi, *w2_lo;
     int fl_twin;                     // idle row tiles take the second half of the fused epilogue (SN_GEMM_FL_TWIN=0: off)
+    int tile_major;                  // block order inside an XCD: all graphs' tile 0, then tile 1, ... (per-graph extents)
     int stagger;                     // 256-row tiles: waves 4-7 half a stage behind waves 0-3 (SN_GEMM_STAGGER=0: off)
     // power-of-two operand scales (device scalars, NULL = 1; see the header comment): the planes of A / B hold x * scale;
     // output planes are written as result * out_scale; FL: the W2 planes hold W * w2_scale, the H fragments H * h_scale
@@ -634,19 +642,28 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
 {
     using GG = Geom<TM>;
     constexpr int kTileM = GG::kTileM, kGemmThreads = GG::kThreads, kChunksA = GG::kChunksA, kStageBytes = GG::kStageBytes, kRing = GG::kRing,
-                  kDmaPerWave = GG::kDmaPerWave, kWaves = GG::kWaves;
+                  kDmaPerWave = GG::kDmaPerWave, kWaves = GG::kWaves, NJ = GG::NJ, kWavesN = GG::kWavesN;
+    static_assert(TM >= 128 || FL, "64-row tiles are built for the fused next-layer product only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned long long rt_entry = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;      // (diagnostics: the 100 MHz clock all XCDs share)
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / kWavesN, wn = wid % kWavesN;
     // XCD-aware block -> tile map.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with
     // its own L2; the row tiles of one graph all stream the same Bt operand, so they must be neighbours
     // on ONE XCD (then Bt comes from HBM once, not once per row tile): id % 8 labels the XCD, id / 8 walks
     // that XCD's graphs (xcd, xcd + 8, ...) tile by tile.
     const int per_graph = p.tiles_x * p.tiles_y;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int batch = (slot / per_graph) * 8 + xcd, tile = slot % per_graph;
+    // Per-graph extents (instance graphs, compacted classes): most graphs leave their LAST row tiles idle, and with the tiles of a
+    // graph on consecutive ids the idle ones fell at a fixed period of the dispatch order - measured with 64-row tiles of ~110-vertex
+    // graphs (tiles 2 and 3 of every four idle): half of the active workgroups started a whole workgroup time late, the idle
+    // workgroups having taken their turn of the shader engines.  Tile-major order inside the XCD: every graph's tile 0, then every
+    // graph's tile 1, ... - the idle workgroups come last and the active ones are dealt over all CUs at once; a graph's tiles are still
+    // on one XCD and still run at the same time (they share Bt through its L2).
+    const int graphs_per_xcd = (p.batches + 7) >> 3;
+    const int batch = p.tile_major ? (slot % graphs_per_xcd) * 8 + xcd : (slot / per_graph) * 8 + xcd;
+    const int tile = p.tile_major ? slot / graphs_per_xcd : slot % per_graph;
     if (batch >= p.batches) return;                            // (whole workgroup, before any barrier)
     int tile_m_ = (tile / p.tiles_x) * kTileM;
     // FL, small graphs: when the batch's extent leaves row tiles idle (instance graphs: padded to 196 rows = 2 tiles, the
@@ -784,11 +801,11 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
         if constexpr (GB) load_ids(t + 1);                          // (stages are issued in order)
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
@@ -799,7 +816,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
 #pragma unroll
     for (int t = 0; t < kRing - 1; ++t)
         if (t < n_stages) issue_stage(t);
-    half8 ah[2], al[2], bh[4], bl[4];
+    half8 ah[2], al[2], bh[NJ], bl[NJ];
     // this wave's part of stage t has landed: at most the kRing - 2 younger stages are outstanding; then everybody's, and the
     // slot of stage t - 1 is free (every wave consumed its fragments of it in front of this barrier)
     auto wait_stage = [&](int t) {
@@ -815,7 +832,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
 #pragma unroll
                 for (int i = 0; i < 2; ++i) { ah[i] = half8{1, 2, 3, 4, 5, 6, 7, 8}; al[i] = ah[i]; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { bh[j] = half8{1, 2, 3, 4, 5, 6, 7, 8}; bl[j] = bh[j]; }
+                for (int j = 0; j < NJ; ++j) { bh[j] = half8{1, 2, 3, 4, 5, 6, 7, 8}; bl[j] = bh[j]; }
             }
             return;
         }
@@ -827,8 +844,8 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
             al[i] = *reinterpret_cast<const half8 *>(sa + (mt * 2 + 1) * 1024 + lane * 16);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nt = 4 * wn + j;
+        for (int j = 0; j < NJ; ++j) {
+            const int nt = NJ * wn + j;
             if constexpr (GB) {
                 // lane 4q + p of its 16-lane group addresses row (node) 8h + 4 half + q, features 32 nt + 16 rh + 4p .. + 3
                 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -849,23 +866,23 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
     };
     // The 24 MFMAs of a stage in the order every form of this loop keeps per accumulator: lo.hi, hi.lo, hi.hi
     auto mfma_lo_hi = [&]() {
-        if (SN_GEMM_ABLATE & 1) { asm volatile("" :: "v"(al[0]), "v"(al[1]), "v"(bh[0]), "v"(bh[1]), "v"(bh[2]), "v"(bh[3])); return; }
+        if (SN_GEMM_ABLATE & 1) { asm volatile("" :: "v"(al[0]), "v"(al[1]), "v"(bh[0]), "v"(bh[1]), "v"(bh[NJ - 2]), "v"(bh[NJ - 1])); return; }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
     };
     auto mfma_hi_lo = [&](int i) {
-        if (SN_GEMM_ABLATE & 1) { asm volatile("" :: "v"(ah[i]), "v"(bl[0]), "v"(bl[1]), "v"(bl[2]), "v"(bl[3])); return; }
+        if (SN_GEMM_ABLATE & 1) { asm volatile("" :: "v"(ah[i]), "v"(bl[0]), "v"(bl[1]), "v"(bl[NJ - 2]), "v"(bl[NJ - 1])); return; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
     };
     auto mfma_hi_hi = [&]() {
         if (SN_GEMM_ABLATE & 1) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     };
     // TM = 256: waves 4-7 - the second wave of every SIMD - run HALF A STAGE BEHIND (MI355X_MICROARCH "Two waves per SIMD", item 9):
     // behind the barrier of stage t they still hold the fragments of stage t - 1 and issue its last 12 MFMAs while waves 0-3 wait
@@ -924,10 +941,10 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
     // (powers of two: the reciprocal and the products are exact; 1.0f when no scale is given - results bit-identical)
     const float acc_mul = 1.0f / ((p.a_scale ? *p.a_scale : 1.0f) * (p.b_scale ? *p.b_scale : 1.0f));
     const float out_mul = p.out_scale ? *p.out_scale : 1.0f;
-    float bias[4], gam[4], bet[4];
+    float bias[NJ], gam[NJ], bet[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = tile_n + (4 * wn + j) * 32 + r;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = tile_n + (NJ * wn + j) * 32 + r;
         bias[j] = (p.bias && n < p.n) ? p.bias[n] : 0.0f;
         gam[j] = (LN && n < p.n) ? p.gamma[n] : 1.0f;
         bet[j] = (LN && n < p.n) ? p.beta[n] : 0.0f;
@@ -939,12 +956,17 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
             const int m = tile_m + (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
             const bool live = m < nv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j][q] = live ? acc[i][j][q] * acc_mul + bias[j] : 0.0f;     // pad rows -> 0 (gnn.py:43-45)
+            for (int j = 0; j < NJ; ++j) acc[i][j][q] = live ? acc[i][j][q] * acc_mul + bias[j] : 0.0f;     // pad rows -> 0 (gnn.py:43-45)
         }
     if (LN) {
         // LayerNorm over the 256 columns of a row: 4 lane-local values x 32 lanes x the two wn waves.
         // Two passes (mean, then centred sum of squares); the row statistics live in LDS, not registers.
-        float *red2 = red + 2 * kTileM;
+        float *red2 = red + kWavesN * kTileM;
+        // (the row totals of the wn waves, added in a fixed order: two waves, or four - 64-row tiles - as two pairs)
+        auto across_waves = [&](const float *part, int row) {
+            if constexpr (kWavesN == 2) return part[row] + part[kTileM + row];
+            else return (part[row] + part[kTileM + row]) + (part[2 * kTileM + row] + part[3 * kTileM + row]);
+        };
         auto row_of = [&](int i, int q) { return (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h; };
         // Row totals over the 32 lanes of a half by recursive halving: at every level a lane keeps half of
         // its values and hands the other half to its partner (xor 16 via v_permlane16_swap, then the DPP
@@ -981,7 +1003,10 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v[i * 16 + q] = (acc[i][0][q] + acc[i][1][q]) + (acc[i][2][q] + acc[i][3][q]);
+                for (int q = 0; q < 16; ++q) {
+                    if constexpr (NJ == 4) v[i * 16 + q] = (acc[i][0][q] + acc[i][1][q]) + (acc[i][2][q] + acc[i][3][q]);
+                    else v[i * 16 + q] = acc[i][0][q] + acc[i][NJ - 1][q];
+                }
             red[wn * kTileM + my_row] = reduce32(v);
         }
         __syncthreads();
@@ -992,10 +1017,10 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int row = row_of(i, q);
-                    const float mean = (red[row] + red[kTileM + row]) * (1.0f / 256.0f);      // n == 256: exact
+                    const float mean = across_waves(red, row) * (1.0f / 256.0f);      // n == 256: exact
                     float s2 = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         acc[i][j][q] -= mean;
                         s2 = fmaf(acc[i][j][q], acc[i][j][q], s2);
                     }
@@ -1004,8 +1029,8 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
             red2[wn * kTileM + my_row] = reduce32(v);
         }
         __syncthreads();
-        float *rstd_row = red2 + 2 * kTileM;                    // one correctly rounded 1/sqrt per row, not per lane
-        if (tid < kTileM) rstd_row[tid] = 1.0f / sqrtf((red2[tid] + red2[kTileM + tid]) * (1.0f / 256.0f) + p.eps);
+        float *rstd_row = red2 + kWavesN * kTileM;              // one correctly rounded 1/sqrt per row, not per lane
+        if (tid < kTileM) rstd_row[tid] = 1.0f / sqrtf(across_waves(red2, tid) * (1.0f / 256.0f) + p.eps);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1013,7 +1038,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
             for (int q = 0; q < 16; ++q) {
                 const float rstd = rstd_row[row_of(i, q)];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][q] = acc[i][j][q] * rstd * gam[j] + bet[j];
+                for (int j = 0; j < NJ; ++j) acc[i][j][q] = acc[i][j][q] * rstd * gam[j] + bet[j];
             }
         __syncthreads();
     }
@@ -1021,7 +1046,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = fmaxf(acc[i][j][q], 0.0f);
     }
@@ -1039,7 +1064,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
         const int kb_out = p.cp_cols / kStageK;
         // wave -> (fg: its 64 output features, np: its pair of 32-node blocks of the half).  128-row tiles: four waves x all 64 nodes
         // of a half; 256-row tiles: a half is 128 nodes, waves 4-7 take the second pair of node blocks for the same features.
-        const int fg = TM == 128 ? wid : (wid & 3), np = TM == 128 ? 0 : (wid >> 2);
+        const int fg = TM <= 128 ? wid : (wid & 3), np = TM <= 128 ? 0 : (wid >> 2);
         auto load_w2 = [&](int s2, half8 (&dst)[4]) {            // [2 ob + plane]: rows 64 fg + 32 ob .., slots 16 s2 ..
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob) {
@@ -1053,12 +1078,13 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
         unsigned long long t_fl0 = 0, t_fl1 = 0, t_fl2 = 0, t_fl3 = 0;
         if (p.stamps) t_fl0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < (TM >= 128 ? 2 : 1); ++i) {           // passes of 64 (128: 256-row tiles) nodes; a 64-row tile is one pass
             if (i < fl_first || i >= fl_last) continue;          // (workgroup-uniform: the other half belongs to the twin workgroup)
             half8 wq[kPF][4];
 #pragma unroll
             for (int s2 = 0; s2 < kPF; ++s2) load_w2(s2, wq[s2]);       // in flight under the fragment stores and the barriers
             __syncthreads();                                     // LDS free: LayerNorm scratch / the staging of the half before
+            if constexpr (TM >= 128) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int nd = (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -1074,6 +1100,29 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
                 unsigned char *dst = frag + (size_t)((wm * 16 + wn * 8 + (r >> 2)) * 2) * kFragBlock + ((r >> 1) & 1) * kFragHalf + nd * 16 + (r & 1) * 8;
                 *reinterpret_cast<uint2 *>(dst) = uint2{hw[0] | (hw[1] << 16), hw[2] | (hw[3] << 16)};
                 *reinterpret_cast<uint2 *>(dst + kFragBlock) = uint2{lw[0] | (lw[1] << 16), lw[2] | (lw[3] << 16)};
+            }
+            } else {
+                // 64-row tile: both row blocks (ib) of the wave in this one pass; the wave holds TWO features per lane and block (j = 0, 1:
+                // features (2 wn + j) * 32 + r) = the slots 2 (wn & 1) + j of the four-slot group the 128-row form's wave wn >> 1 would hold,
+                // so the image - and the column order of W2 (GNN.prepare) - are those of the other forms: one 4-byte piece per (node, plane)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int nd = (q & 3) + 8 * (q >> 2) + 4 * h;
+                        const bool keep = tile_m + ib * 32 + nd < p.m;
+                        unsigned hw[2], lw[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            _Float16 hi, lo;
+                            split2(keep ? acc[ib][j][q] * h_mul : 0.0f, hi, lo);
+                            hw[j] = (unsigned)__builtin_bit_cast(unsigned short, hi);
+                            lw[j] = (unsigned)__builtin_bit_cast(unsigned short, lo);
+                        }
+                        unsigned char *dst = frag + (size_t)((ib * 16 + (wn >> 1) * 8 + (r >> 2)) * 2) * kFragBlock + ((r >> 1) & 1) * kFragHalf + nd * 16 + (r & 1) * 8 + (wn & 1) * 4;
+                        *reinterpret_cast<unsigned *>(dst) = hw[0] | (hw[1] << 16);
+                        *reinterpret_cast<unsigned *>(dst + kFragBlock) = lw[0] | (lw[1] << 16);
+                    }
             }
             __syncthreads();
             if (p.stamps && i == 0) t_fl1 = __builtin_amdgcn_s_memtime();
@@ -1160,7 +1209,7 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
                         }
 #pragma unroll
                     for (int pi = 0; pi < 2; ++pi) {             // 16-node k-block pi of the node block; this lane's k-half = h
-                        const int kb = (tile_m >> 4) + (2 * (2 * np + nb) + i) * 2 + pi;
+                        const int kb = TM >= 128 ? (tile_m >> 4) + (2 * (2 * np + nb) + i) * 2 + pi : (tile_m >> 4) + nb * 2 + pi;
                         if (kb < kb_out) {
                             const unsigned *q8 = pk + 8 * pi;
                             uint4 ph, pl;
@@ -1217,11 +1266,13 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
 #endif
         }
         if (p.stamps && lane == 0) {
-            unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 8;
+            unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 16;
             st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_fl0; st[4] = t_fl1; st[5] = t_fl2; st[6] = t_fl3;
+            st[8] = rt_entry; st[9] = __builtin_amdgcn_s_memrealtime();
         }
         return;
     }
+    if constexpr (!FL) {      // (the fused-product kernels returned above; 64-row tiles exist as such only)
     // ---- stores
     if (p.c) {
         bool added = false;
@@ -1342,10 +1393,11 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
             if (n < p.n && part * 128 < p.m) p.pooled[((int64_t)batch * p.pooled_parts + part) * p.n + n] = pr[(2 * half) * 256 + (tid & 255)] + pr[(2 * half + 1) * 256 + (tid & 255)];
         }
     }
+    }
     if (p.stamps && lane == 0) {
-        unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 8;
+        unsigned long long *st = p.stamps + ((size_t)blockIdx.x * kWaves + wid) * 16;
         st[0] = t_begin; st[1] = t_loop_end; st[2] = __builtin_amdgcn_s_memtime(); st[3] = t_wait; st[4] = t_issue;
-        st[5] = rt_entry; st[6] = __builtin_amdgcn_s_memrealtime();
+        st[8] = rt_entry; st[9] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1592,7 +1644,7 @@ extern "C" int sn_layernorm_split_planes(const float *x, int G, int n, int E, co
 static int g_gemm_tile = -1, g_gemm_stagger = -1;
 static int gemm_tile_setting()
 {
-    if (g_gemm_tile < 0) { const char *e = getenv("SN_GEMM_TM"); const int v = e ? atoi(e) : 0; g_gemm_tile = (v == 128 || v == 256) ? v : 0; }
+    if (g_gemm_tile < 0) { const char *e = getenv("SN_GEMM_TM"); const int v = e ? atoi(e) : 0; g_gemm_tile = (v == 64 || v == 128 || v == 256) ? v : 0; }
     return g_gemm_tile;
 }
 static int gemm_stagger_setting()
@@ -1602,11 +1654,11 @@ static int gemm_stagger_setting()
 }
 extern "C" void sn_debug_set_gemm_tile(int tile_rows, int stagger)
 {
-    if (tile_rows >= 0) g_gemm_tile = (tile_rows == 128 || tile_rows == 256) ? tile_rows : 0;
+    if (tile_rows >= 0) g_gemm_tile = (tile_rows == 64 || tile_rows == 128 || tile_rows == 256) ? tile_rows : 0;
     if (stagger >= 0) g_gemm_stagger = stagger ? 1 : 0;
 }
 
-/* diagnostics: device buffer of 8 x u64 per wave of the GEMM kernel (NULL = off) */
+/* diagnostics: device buffer of 16 x u64 per wave of the GEMM kernel (NULL = off) */
 extern "C" void sn_debug_set_gemm_stamps(void *device_buffer) { g_gemm_stamps = (unsigned long long *)device_buffer; }
 
 extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
@@ -1677,9 +1729,17 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     // graphs of the IR-Atlas, config [3]'s 500-vertex classes); 128 rows - two 4-wave workgroups per CU - for small graphs and for
     // batches with per-graph extents (instance graphs of ~110 vertices, compacted classes: a graph then costs whole tiles of its own
     // height).  SN_GEMM_TM=128 / 256 forces one form (256 needs m >= 129 to make sense; any m is correct).
-    const int tm_set = gemm_tile_setting(), tile_m = (tm_set == 256 || (tm_set != 128 && u->m >= 256 && !(u->m_extent && u->extent_stride != 0))) ? 256 : 128;
+    // 64-row tiles: the fused product (layer 1 + the next layer's Linear) of graphs with their own extents - the instance graphs of a
+    // batch, the compacted classes of a pruned atlas; SN_GEMM_TM=64 forces it for every fused product, 128 / 256 switch it off.
+    const int tm_set = gemm_tile_setting();
+    const bool small = fused2 && (tm_set == 64 || (tm_set == 0 && u->m_extent && u->extent_stride != 0));
+    const int tile_m = small ? 64 : (tm_set == 256 || (tm_set != 128 && tm_set != 64 && u->m >= 256 && !(u->m_extent && u->extent_stride != 0))) ? 256 : 128;
     const bool tall = tile_m == 256;
     a.stagger = gemm_stagger_setting();
+    {
+        static const int tmaj = getenv("SN_GEMM_TILE_MAJOR") ? atoi(getenv("SN_GEMM_TILE_MAJOR")) : 1;
+        a.tile_major = (tmaj && u->m_extent && u->extent_stride != 0) ? 1 : 0;
+    }
     a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + tile_m - 1) / tile_m;
     const int parts = (u->m + 127) / 128;                                                  // pooled partial rows: one per 128 rows, whatever the tile
     SN_REQUIRE(u->pooled_parts == 0 || u->pooled_parts >= parts, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooled_parts=%d < %d row tiles", u->pooled_parts, parts);
@@ -1691,6 +1751,12 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     int rc = SN_OK;
     auto launch = [&](auto kernel, int threads, size_t lds) {
         if ((rc = sn_ensure_dynamic_lds((const void *)kernel, lds, "sn_gcn_gemm"))) return;
+        if (getenv("SN_GEMM_OCC")) {
+            int nb = -1; hipFuncAttributes fa{};
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds);
+            (void)hipFuncGetAttributes(&fa, (const void *)kernel);
+            fprintf(stderr, "sn_gcn_gemm: tile %d threads %d dynamic LDS %zu static LDS %zu regs %d -> %d workgroups per CU (runtime)\n", tile_m, threads, lds, fa.sharedSizeBytes, fa.numRegs, nb);
+        }
         sn_prof_start(4, st);
         hipLaunchKernelGGL(kernel, grid, dim3((unsigned)threads), lds, st, a);
         sn_prof_stop(4, st);
@@ -1706,7 +1772,10 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
         else if (u->layernorm) launch(gcn_gemm_kernel<true, false, false, TMv>, threads, lds);
         else launch(gcn_gemm_kernel<false, false, false, TMv>, threads, lds);
     };
-    if (tall) pick(std::integral_constant<int, 256>{});
+    if (small) {
+        if (gathered) launch(gcn_gemm_kernel<true, true, true, 64>, Geom<64>::kThreads, Geom<64>::kLdsBytes);
+        else launch(gcn_gemm_kernel<true, false, true, 64>, Geom<64>::kThreads, Geom<64>::kLdsBytes);
+    } else if (tall) pick(std::integral_constant<int, 256>{});
     else pick(std::integral_constant<int, 128>{});
     if (rc) return rc;
     SN_CHECK_LAUNCH("sn_gcn_gemm");

@@ -42,14 +42,14 @@ for (m, n, k, batches) in ((512, 256, 512, 128), (512, 256, 512, 64), (196, 256,
     a, b = ops.split_planes(A), ops.split_planes(Bt)
     g, be = torch.ones(n, device=dev), torch.zeros(n, device=dev)
     blocks = 8 * ((batches + 7) // 8) * ((m + 127) // 128)
-    st = torch.zeros(blocks * 4 * 8, dtype=torch.int64, device=dev)
+    st = torch.zeros(blocks * 4 * 16, dtype=torch.int64, device=dev)
     for _ in range(2):
         ops.gcn_gemm(a, b, batches, want_planes=n, layernorm=(g, be, 1e-5), relu=True)
     lib.sn_debug_set_gemm_stamps(st.data_ptr())
     ops.gcn_gemm(a, b, batches, want_planes=n, layernorm=(g, be, 1e-5), relu=True)
     torch.cuda.synchronize()
     lib.sn_debug_set_gemm_stamps(None)
-    s8 = st.view(-1, 8).cpu().double()
+    s8 = st.view(-1, 16).cpu().double()
     s8 = s8[s8[:, 0] > 0]
     t0 = s8[:, 0].min()
     print(f"m={m} k={k} batches={batches}: span {s8[:,2].max()-t0:.0f} cycles; start skew {s8[:,0].max()-t0:.0f}; "

@@ -21,7 +21,11 @@ for (G, n, nv_hi) in ((100, 512, 512), (256, 196, 125)):
     W2 = (torch.randn(256, 256, generator=g) / 16).to(dev)
     w2n, w2p = ops.next_layer_weight_planes(W2), ops.split_planes(W2)
     gam, bet, bias = torch.ones(256, device=dev), torch.zeros(256, device=dev), torch.zeros(256, device=dev)
-    kw = dict(bias=bias, layernorm=(gam, bet, 1e-5), relu=True, rows_valid=nv, m_extent=ext, k_extent=ext, b_table=(t_hi, t_lo, ids))
+    per_graph = os.environ.get("SN_TIME_PER_GRAPH", "1") == "1" and n < 256          # (instance graphs take their extents per graph: GNN._forward_mfma)
+    if per_graph:
+        adj = ops.gcn_adjacency_planes(e, extent=ext, n_valid=nv.contiguous(), per_graph=True)
+    gext = nv.contiguous() if per_graph else ext
+    kw = dict(bias=bias, layernorm=(gam, bet, 1e-5), relu=True, rows_valid=nv, m_extent=gext, k_extent=gext, b_table=(t_hi, t_lo, ids))
     forms = {"fused": lambda: ops.gcn_gemm(adj, None, G, want_planes=n, next_w=w2n, **kw),
              "H1 planes": lambda: ops.gcn_gemm(adj, None, G, want_planes=256, **kw)}
     h1 = forms["H1 planes"]()["planes"]
@@ -36,11 +40,11 @@ for (G, n, nv_hi) in ((100, 512, 512), (256, 196, 125)):
             fn()
         e1.record(); torch.cuda.synchronize()
         blocks = 8 * ((G + 7) // 8) * 4
-        st = torch.zeros(blocks * 4 * 8, dtype=torch.int64, device=dev)
+        st = torch.zeros(blocks * 4 * 16 * 2, dtype=torch.int64, device=dev)
         lib.sn_debug_set_gemm_stamps(st.data_ptr())
         fn(); torch.cuda.synchronize()
         lib.sn_debug_set_gemm_stamps(None)
-        s8 = st.view(-1, 8).cpu().double(); s8 = s8[s8[:, 0] > 0]
+        s8 = st.view(-1, 16).cpu().double(); s8 = s8[s8[:, 0] > 0]
         msg = ""
         if len(s8):
             t0 = s8[:, 0].min()
@@ -52,4 +56,12 @@ for (G, n, nv_hi) in ((100, 512, 512), (256, 196, 125)):
                     f"stores of half 0 + all of half 1 {d(2, 6):.0f}")
         if name != "fused" and len(s8):
             msg += f"; in the loop: wait + barrier median {s8[:, 3].median():.0f}, copy issue median {s8[:, 4].median():.0f} (cycles per wave)"
+        if len(s8) and s8[:, 8].min() > 0:
+            r0 = s8[:, 8].min()
+            msg += (f"; wall: first entry -> last end {(s8[:, 9].max() - r0) / 100:.1f} us, entries spread over {(s8[:, 8].max() - r0) / 100:.1f} us, median "
+                    f"workgroup {((s8[:, 9] - s8[:, 8]).median()) / 100:.1f} us, workgroups {len(s8) // 4}")
+        if len(s8) and s8[:, 8].min() > 0 and os.environ.get("SN_TIME_HIST") == "1":
+            ent = ((s8[:, 8] - s8[:, 8].min()) / 100)[::4]
+            hist = torch.histc(ent.float(), bins=12, min=0, max=float(ent.max()) + 1e-3)
+            msg += "; entries per " + f"{float(ent.max()) / 12:.1f}" + " us bin: " + " ".join(str(int(v)) for v in hist.tolist())
         print(f"G={G} n={n} {name:20s} {e0.elapsed_time(e1) * 1e3 / 20:7.1f} us per launch (launch-to-launch); {msg}", flush=True)

@@ -26,11 +26,11 @@ def timed(fn, reps=20):
 
 
 def stamps(fn, waves_total):
-    st = torch.zeros(waves_total * 8, dtype=torch.int64, device=dev)
+    st = torch.zeros(waves_total * 16, dtype=torch.int64, device=dev)
     lib.sn_debug_set_gemm_stamps(st.data_ptr())
     fn(); torch.cuda.synchronize()
     lib.sn_debug_set_gemm_stamps(None)
-    s8 = st.view(-1, 8).cpu().double()
+    s8 = st.view(-1, 16).cpu().double()
     return s8[s8[:, 0] > 0]
 
 
@@ -89,10 +89,10 @@ def run(G, n, label, which=("fused", "pooled", "plain")):
                 t0 = s8[:, 0].min()
                 msg = (f"span {s8[:, 2].max() - t0:.0f} cycles, loop median {(s8[:, 1] - s8[:, 0]).median():.0f}, epilogue median "
                        f"{(s8[:, 2] - s8[:, 1]).median():.0f} max {(s8[:, 2] - s8[:, 1]).max():.0f}, waves {len(s8)}")
-                if name != "fused" and s8[:, 5].min() > 0:      # (the 100 MHz clock all XCDs share: entry of the first workgroup .. end of the last)
-                    r0 = s8[:, 5].min()
-                    msg += (f"; wall (100 MHz clock) first entry -> last end {(s8[:, 6].max() - r0) / 100:.1f} us, entries spread over "
-                            f"{(s8[:, 5].max() - r0) / 100:.1f} us, median workgroup {((s8[:, 6] - s8[:, 5]).median()) / 100:.1f} us")
+                if s8[:, 8].min() > 0:      # (the 100 MHz clock all XCDs share: entry of the first workgroup .. end of the last)
+                    r0 = s8[:, 8].min()
+                    msg += (f"; wall (100 MHz clock) first entry -> last end {(s8[:, 9].max() - r0) / 100:.1f} us, entries spread over "
+                            f"{(s8[:, 8].max() - r0) / 100:.1f} us, median workgroup {((s8[:, 9] - s8[:, 8]).median()) / 100:.1f} us")
             print(f"{label} {name:10s} tile {fl:14s} {us:7.1f} us per launch; {same}; {msg}", flush=True)
     lib.sn_debug_set_gemm_tile(0, 1)
 
