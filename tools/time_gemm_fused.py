@@ -30,6 +30,10 @@ for (G, n, nv_hi) in ((100, 512, 512), (256, 196, 125)):
              "H1 planes": lambda: ops.gcn_gemm(adj, None, G, want_planes=256, **kw)}
     h1 = forms["H1 planes"]()["planes"]
     forms["stand-alone Linear"] = lambda: ops.gcn_gemm(w2p, h1, G, want_planes=n)
+    zt2 = forms["fused"]()["planes"]
+    nodes = torch.rand(G, n, generator=g).to(dev)
+    kw_pool = {k_: v for k_, v in kw.items() if k_ != "b_table"}
+    forms["pooled"] = lambda: ops.gcn_gemm(adj, zt2, G, pool_w=nodes, **kw_pool)
     for name, fn in forms.items():
         for _ in range(3):
             fn()
