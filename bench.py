@@ -377,7 +377,7 @@ def shape_leg(device, name, Bc, Dc, Mc, Kc, n_max, Ec, token_dtype, n_steps):
             "gcn_frac_issued": 3.0 * gcn_flops / (gemm_ms * 1e-3) / PEAK if gemm_ms else None,
             "note": "eager steps in line, HIP event pair per launch; gcn_frac_useful = the reference's fp32-GEMM flops of the class side over the time of "
                     "ALL GCN product launches of a step / 2.5 PF; gcn_frac_issued = x 3 (split-f16: hi.hi + hi.lo + lo.hi MFMAs per product, what keeps "
-                    "the scores within 1e-5); rocprofv3 kernel tables of the same steps: profiles/r04_c4_kernel_stats.csv, r04_c5_kernel_stats.csv"}
+                    "the scores within 1e-5); rocprofv3 kernel tables of the same steps: profiles/r06_c4_kernel_stats.csv, r06_c5_kernel_stats.csv"}
     return {"value": Bc * n_steps / dt, "ms_per_step": 1e3 * dt / n_steps, "steps": n_steps, "launch": how, "roofline": roof,
             "shape": {"batch": Bc, "D": Dc, "words": Mc, "classes": Kc, "vertices_per_class": n_max, "gnn_width": Ec,
                       "tokens": str(token_dtype).replace("torch.", "")}}
@@ -788,7 +788,7 @@ def main():
         copy_gbps = stream_copy_GBps(device)
         ev_floor = event_pair_floor_ms()
         traffic, traffic_s3, traffic_src = None, None, None      # HBM bytes per launch from the committed rocprofv3 PMC passes (not measurable live)
-        for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     for row in json.load(fh)["kernels"]:

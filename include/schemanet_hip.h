@@ -35,8 +35,7 @@ extern "C" {
 #define SN_MAX_TOKENS 196        /* L: 14x14 patch tokens; the graph kernels keep one image in LDS */
 
 /* ABI version, bumped on any change of a signature or of a by-pointer struct (10: round 5, struct_size members; 11: round 6 -
- * sn_gemm_args.zero_skipped and the entry points added after 10, sn_debug_set_gemm_tile; 12: round 6 - the pooled partial sums of
- * sn_gcn_gemm per 64 rows, sn_debug_set_gemm_tile takes 64; tests/test_host_cpu.py holds a hash of
+ * sn_gemm_args.zero_skipped and the entry points added after 10, sn_debug_set_gemm_tile; tests/test_host_cpu.py holds a hash of
  * this header's declarations next to the version, so that a change of either without the other fails the CPU suite).
  * The three by-pointer argument structs below start with `struct_size`: the caller stores sizeof(the struct it was compiled
  * against) there; a call whose struct_size differs from the library's own sizeof is rejected with SN_ERR_BAD_ARG before any
@@ -473,10 +472,10 @@ int sn_layernorm_split_planes(const float *x, int G, int n, int E, const int32_t
  * operand.  Epilogue, in this order: + bias[n]; rows >= rows_valid[b] set to 0 (gnn.py:43-45);
  * LayerNorm over the n == 256 columns with gamma/beta/eps (gnn.py:46); ReLU; then any of: fp32 C
  * [m][ldc]; blocked hi/lo planes of C as an [m, cp_cols] operand (columns [n, cp_cols) zero);
- * pooled[b][t][n] = sum over the 64 rows m of row group t of pool_w[b][m] * C[m][n], t <
- * ceil(m / 64): partial sums of the node-weighted pooling (gnn.py:96), added up in a fixed order
- * by sn_pool_fc (no atomics: results are bit-reproducible; ABI 12: per 64 rows whatever the tile
- * height the library picks - 64, 128 or 256 rows -, ABI <= 11: per 128 rows). */
+ * pooled[b][t][n] = sum over the rows m of row group t (128 rows, whatever the tile height the
+ * library picks) of pool_w[b][m] * C[m][n], t < ceil(m / 128): partial sums of the node-weighted
+ * pooling (gnn.py:96), added up in a fixed order by sn_pool_fc (no atomics: results are
+ * bit-reproducible). */
 typedef struct sn_gemm_args {
     uint32_t struct_size;                 /* sizeof(sn_gemm_args) of the caller's header (checked: see sn_abi_version) */
     const void *a_hi, *a_lo; int64_t a_batch_stride;
@@ -515,7 +514,7 @@ typedef struct sn_gemm_args {
     int extent_stride;            /* 0: m_extent / k_extent are one value for the batch; 1: one per graph ([batches]) */
     int accumulate;               /* 1: the fp32 result is ADDED to what c holds (c += A . Bt^T; plain product only: no bias / LayerNorm /
                                      ReLU): the layers of a training pass sum their dY . X^T into one adjacency gradient */
-    int pooled_parts;             /* 0, or the number of [n] partial sums per graph `pooled` is laid out with (>= ceil(m / 64): the
+    int pooled_parts;             /* 0, or the number of [n] partial sums per graph `pooled` is laid out with (>= ceil(m / 128): the
                                      caller keeps the further slots, e.g. sn_class_compact's pooled_iso) */
     int zero_skipped;             /* 1 (with m_extent and c): the row tiles past a graph's extent, which are not multiplied, are
                                      written as zeros by the workgroups that skip them - with rows_valid the whole fp32 result is

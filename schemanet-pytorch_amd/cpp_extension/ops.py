@@ -841,7 +841,7 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     """C[g] = A[g] . Bt[g]^T on split-fp16 planes (sn_gcn_gemm): A = Planes [*, m, k], Bt = Planes [*, n, k].
 
     layernorm: (gamma, beta, eps) or None.  want_planes: 0, or the k extent of the result planes
-    (>= n; the extra columns are zero).  pool_w [batches, m] -> "pooled" [batches, ceil(m/64), n]:
+    (>= n; the extra columns are zero).  pool_w [batches, m] -> "pooled" [batches, ceil(m/128), n]:
     per-row-tile partial sums of sum_m pool_w[m] C[m, :] (add them up, or hand them to pool_fc).
     zero_c: the fp32 result starts as zeros (row tiles beyond m_extent are never written).
     b_table = (hi, lo, ids): B is gathered inside the kernel, Bt[g, f, j] = table[ids[g, j], f] (hi, lo = table_planes(table),
@@ -852,7 +852,7 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
     (device scalar from pow2_scale(bound on the result)) is what the output planes are multiplied by and carry as their
     `.scale`; h_scale (with next_w): the bound-derived scale of the epilogue's H fragments.
     accumulate_into: fp32 [batches, m, n] contiguous - the plain product is ADDED to it (and it is returned as "c").
-    pooled_out: fp32 [batches, parts >= ceil(m / 64), n] contiguous that receives the partial sums in its first slots (the
+    pooled_out: fp32 [batches, parts >= ceil(m / 128), n] contiguous that receives the partial sums in its first slots (the
     further ones are the caller's: class_compact's pooled_iso) and is returned as "pooled".
     Returns dict(c=fp32 [batches, m, n], planes=Planes, pooled=...)."""
     lib = N.require_gpu()
@@ -923,11 +923,11 @@ def gcn_gemm(a, b, batches, bias=None, layernorm=None, relu=False, rows_valid=No
         pw = _f32c(pool_w); keep.append(pw)
         assert pw.shape == (batches, m)
         if pooled_out is None:
-            pooled = torch.empty((batches, (m + 63) // 64, n), dtype=torch.float32, device=dev)
+            pooled = torch.empty((batches, (m + 127) // 128, n), dtype=torch.float32, device=dev)
         else:
             pooled = pooled_out
             assert pooled.dtype == torch.float32 and pooled.is_contiguous() and pooled.device == dev and pooled.dim() == 3
-            assert pooled.shape[0] == batches and pooled.shape[1] >= (m + 63) // 64 and pooled.shape[2] == n
+            assert pooled.shape[0] == batches and pooled.shape[1] >= (m + 127) // 128 and pooled.shape[2] == n
             args.pooled_parts = pooled.shape[1]
         args.pool_w, args.pool_w_stride, args.pooled = _dp(pw), m, _dp(pooled)
         out["pooled"] = pooled

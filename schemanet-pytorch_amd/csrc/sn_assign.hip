@@ -1481,7 +1481,7 @@ int launch_screen5(const AssignArgs &a, hipStream_t st, bool defer)
 // {192, 384}, fp32 tokens, at most 208 tokens per CU; other shapes take form 0).  Both write the same records.
 // Initialised from SN_ASSIGN_VARIANT, changed with sn_assign_set_variant().
 // (The lab forms of rounds 1-4 - 8-wave workgroups, codebook-stationary, K-outer in rounds, K-outer on four 512-register waves - are
-// in the history and in NOTES.md / DESIGN.md section 8.)
+// in the history and in profiles/NOTES_r01-r05.md / DESIGN.md section 8.)
 int g_variant = -1;
 int screen_variant()
 {

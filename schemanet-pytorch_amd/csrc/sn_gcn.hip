@@ -682,12 +682,10 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
     }
     const int tile_m = tile_m_, tile_n = (tile % p.tiles_x) * kTileN;
     if (p.m_extent && tile_m >= p.m_extent[(int64_t)batch * p.ext_stride]) {      // a row tile past the largest graph of the batch (ext_stride 1: past this graph)
-        // (the pooled partial sums are kept per 64 rows whatever the tile height: a 256-row tile owns four of them)
-        if (p.pooled) {
-            for (int idx = tid; idx < (kTileM / 64) * 256; idx += kGemmThreads) {
-                const int part = (tile / p.tiles_x) * (kTileM / 64) + (idx >> 8), col = tile_n + (idx & 255);
-                if (part * 64 < p.m && col < p.n) p.pooled[((int64_t)batch * p.pooled_parts + part) * p.n + col] = 0.0f;
-            }
+        // (the pooled partial sums are kept per 128 rows whatever the tile height: a 256-row tile owns two of them)
+        if (p.pooled && TM >= 128) {
+            const int part = (tile / p.tiles_x) * (kTileM / 128) + (tid >> 8), col = tile_n + (tid & 255);
+            if (part * 128 < p.m && col < p.n) p.pooled[((int64_t)batch * p.pooled_parts + part) * p.n + col] = 0.0f;
         }
         if (p.zero_skipped && p.c && !p.accumulate) {              // (its rows of the fp32 result: zeros, whole lines)
             const int cols = min(kTileN, p.n - tile_n), rows = min(kTileM, p.m - tile_m);
@@ -1371,12 +1369,9 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
             }
         }
     }
-    }
     // ---- node-weighted pooling of the tile's rows (gnn.py:96: sum_i w_i H[i, :], the caller divides)
     if (p.pooled) {
-        float part[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) part[j] = 0.0f;
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1384,18 +1379,23 @@ __global__ __launch_bounds__(Geom<TM>::kThreads, 2) void gcn_gemm_kernel(const G
                 const int m = tile_m + (2 * wm + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                 const float w = m < p.m ? p.pool_w[(int64_t)batch * p.pool_w_stride + m] : 0.0f;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) part[j] = fmaf(w, acc[i][j][q], part[j]);
+                for (int j = 0; j < 4; ++j) part[j] = fmaf(w, acc[i][j][q], part[j]);
             }
-        // one partial row per 64 rows - the rows of one wave (row group wm) -: pooled[batch][part][n], part = 64-row group of the graph
-        // (summed in a fixed order by sn_pool_fc: deterministic, and the same sums whatever the tile height; round 6: per 64 rows,
-        // rounds 1-5: per 128)
-        const int part_idx = (tile / p.tiles_x) * (kTileM / 64) + wm;
+        float *pr = reinterpret_cast<float *>(smem + GG::kPoolOff);     // [kWavesM (wm)][256 cols]
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < 4; ++j) {
             part[j] += __shfl_xor(part[j], 32, SN_WAVE);
-            const int n = tile_n + (NJ * wn + j) * 32 + r;
-            if (h == 0 && n < p.n && part_idx * 64 < p.m) p.pooled[((int64_t)batch * p.pooled_parts + part_idx) * p.n + n] = part[j];
+            if (h == 0) pr[wm * 256 + (4 * wn + j) * 32 + r] = part[j];
         }
+        __syncthreads();
+        {   // one partial row per 128 rows: pooled[batch][part][n] (summed in a fixed order by sn_pool_fc: deterministic; a 256-row
+            // tile writes the two partial rows its rows would have given as two 128-row tiles - the same sums in the same order).
+            // (Round 6, measured and not kept: one partial row per 64 rows - no LDS round here, and a layout a 64-row pooled product
+            // could share - made sn_pool_fc read twice the rows: 12.3 against 8.5 us on the class side, 8.6 against 6.7 on the instance side.)
+            const int half = tid >> 8, n = tile_n + (tid & 255), part = (tile / p.tiles_x) * (kTileM / 128) + half;
+            if (n < p.n && part * 128 < p.m) p.pooled[((int64_t)batch * p.pooled_parts + part) * p.n + n] = pr[(2 * half) * 256 + (tid & 255)] + pr[(2 * half + 1) * 256 + (tid & 255)];
+        }
+    }
     }
     }
     if (p.stamps && lane == 0) {
@@ -1747,7 +1747,7 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
         a.tile_major = (tmaj && u->m_extent && u->extent_stride != 0) ? 1 : 0;
     }
     a.batches = u->batches; a.tiles_x = (cols + kTileN - 1) / kTileN; a.tiles_y = (u->m + tile_m - 1) / tile_m;
-    const int parts = (u->m + 63) / 64;                                                    // pooled partial rows: one per 64 rows, whatever the tile
+    const int parts = (u->m + 127) / 128;                                                  // pooled partial rows: one per 128 rows, whatever the tile
     SN_REQUIRE(u->pooled_parts == 0 || u->pooled_parts >= parts, SN_ERR_BAD_ARG, "sn_gcn_gemm: pooled_parts=%d < %d row tiles", u->pooled_parts, parts);
     a.pooled_parts = u->pooled_parts > 0 ? u->pooled_parts : parts;
     const int64_t n_blocks = (int64_t)8 * ((u->batches + 7) / 8) * a.tiles_x * a.tiles_y;

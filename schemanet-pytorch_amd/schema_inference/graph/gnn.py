@@ -285,7 +285,7 @@ class GNN(nn.Module):
         and the buffer of the pooled partial sums [G, row tiles + 1, E] whose LAST slot already holds the isolated vertices' share)"""
         perm, n_kept = compact
         G, n = ingredients.shape
-        pooled = torch.empty((G, (n + 63) // 64 + 1, iso.shape[1]), dtype=torch.float32, device=iso.device)
+        pooled = torch.empty((G, (n + 127) // 128 + 1, iso.shape[1]), dtype=torch.float32, device=iso.device)
         ids_c, w_c, _ = ops.class_compact(perm, n_kept, nodes, ingredients, iso, pooled_slot=pooled[:, -1, :])
         return ids_c, w_c, n_kept, pooled
 

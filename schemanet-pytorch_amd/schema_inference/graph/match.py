@@ -196,6 +196,13 @@ class Matcher(nn.Module):
         # (not beside a COMPACTED class pass: that one is a chain of small launches as well, and the two chains were measured slower
         # side by side - 5.55 ms - than one after the other - 5.23 ms - at config [4]'s real size)
         side_env = os.environ.get("SN_TRAIN_SIDE_STREAM", "1")     # 0: never, 1: beside an uncompacted class pass, 2: always
+        # (gradients of the GNN's parameters then arrive from two streams.  The plain engine orders them; a hook that launches
+        # work from the hook's current stream - a gradient all-reduce - has not been exercised with it, so parameters that carry hooks
+        # keep both passes on one stream; DistributedDataParallel hooks the accumulation nodes, which cannot be seen from here:
+        # INTEGRATION.md says to set SN_TRAIN_SIDE_STREAM=0 under it)
+        if training and side_env == "1" and any(getattr(p_, "_backward_hooks", None) or getattr(p_, "_post_accumulate_grad_hooks", None)
+                                                for p_ in self.gnn.parameters()):
+            side_env = "0"
         if training and side_env != "0" and (side_env == "2" or "class_perm" not in class_dict):
             # Training: the two GNN passes of an iteration meet at the similarity only.  The instance pass is a chain of ~25 small
             # launches forward and ~50 backward (64 graphs of <= 196 vertices: ~20 us each whatever their size), the class pass a chain

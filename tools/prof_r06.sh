@@ -29,14 +29,9 @@ python3 tools/pmc_to_json.py $O/r06_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_
 python3 tools/pmc_to_json.py $O/r06_pmc_step_instructions.json "rocprofv3 --pmc SQ_* (two passes), eager bench; per launch" $O/r06_pmc_p3 $O/r06_pmc_p4
 python3 tools/pmc_to_json.py $O/r06_pmc_pruned_atlas_compacted.json "pruned atlas (70 % of the class vertices under the threshold), compacted class branch: FETCH_SIZE / WRITE_SIZE per launch, eager steps" $O/r06_pmc_pruned_c1_FETCH_SIZE $O/r06_pmc_pruned_c1_WRITE_SIZE
 python3 tools/pmc_to_json.py $O/r06_pmc_pruned_atlas_uncompacted.json "the same atlas through the plain fused route (SN_ATLAS_COMPACT=0)" $O/r06_pmc_pruned_c0_FETCH_SIZE $O/r06_pmc_pruned_c0_WRITE_SIZE
-# the two screen forms of S1 side by side in one process (kernel trace, split by kernel name) and the opt-in form's HBM bytes
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/r06_s1_forms -o s --output-format csv -- python3 $R/tools/time_s1.py 30 0,5 > $O/r06_s1_forms.txt 2>&1 && echo "s1 forms done"
-for g in FETCH_SIZE WRITE_SIZE; do
-  SN_ASSIGN_VARIANT=5 rocprofv3 --kernel-trace --output-format csv --pmc $g -d $O/r06_pmc_s5_$g -o p -- python3 $R/tools/time_s1.py 10 5 > $O/r06_pmc_s5_$g.log 2>&1 && echo "s5 $g done"
-done
 cd $R
-python3 tools/pmc_to_json.py $O/r06_pmc_s1_screen5.json "the opt-in K-outer screen (SN_ASSIGN_VARIANT=5) alone, tools/time_s1.py: FETCH_SIZE / WRITE_SIZE per launch (randn and k-means-like tokens mixed)" $O/r06_pmc_s5_FETCH_SIZE $O/r06_pmc_s5_WRITE_SIZE
 python3 tools/trace_split.py $O/r06_eager > $O/r06_bench_eager_split_by_grid.txt
-python3 tools/trace_split.py $O/r06_s1_forms assign_ > $O/r06_s1_forms_trace.txt
 echo all done
+python3 tools/pmc_by_grid.py $O/r06_pmc_p1 $O/r06_pmc_p2 > $O/r06_pmc_hbm_traffic_by_grid.txt 2>/dev/null
+bash tools/prof_train_r06.sh
+echo profiles done
