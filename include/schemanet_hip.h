@@ -35,7 +35,7 @@ extern "C" {
 #define SN_MAX_TOKENS 196        /* L: 14x14 patch tokens; the graph kernels keep one image in LDS */
 
 /* ABI version, bumped on any change of a signature or of a by-pointer struct (10: round 5, struct_size members; 11: round 6 -
- * sn_gemm_args.zero_skipped and the entry points added after 10, sn_debug_set_gemm_tile; tests/test_host_cpu.py holds a hash of
+ * sn_gemm_args.zero_skipped and the entry points added after 10, sn_debug_set_gemm_tile; 12: round 6 - sn_weigh_attributes(_backward), sn_weigh_blocks; tests/test_host_cpu.py holds a hash of
  * this header's declarations next to the version, so that a change of either without the other fails the CPU suite).
  * The three by-pointer argument structs below start with `struct_size`: the caller stores sizeof(the struct it was compiled
  * against) there; a call whose struct_size differs from the library's own sizeof is rejected with SN_ERR_BAD_ARG before any
@@ -568,6 +568,13 @@ int sn_embedding_grad_scan(const float *dy, const int64_t *ids, int64_t n_ids, i
  * grad_feat [G, n, E], grad_nodes [G, n] from grad_pooled [G, E].  E % 4 == 0. */
 int sn_weighted_pool_backward(const float *feat, const float *nodes, const float *grad_pooled, int G, int n, int E,
                               const int32_t *divisor_dev, float *grad_feat, float *grad_nodes, void *stream);
+/* out[i] = attr2[i][0] * w[0] + attr2[i][1] * w[1], i < n: the reference's `attr2 @ w` behind its instance vertices / edges
+ * (cpp_extension/src/large_scale_feat_to_v.cpp, large_scale_feat_to_e.cpp:141-147; squeezed) as one pass under autograd (round 6),
+ * and its gradient with respect to the two weights: dw[k] = sum_i g[i] * attr2[i][k], reduced in a fixed order through `partial`
+ * (sn_weigh_blocks(n) * 2 doubles of scratch, 8-byte aligned). */
+int sn_weigh_blocks(int64_t n);
+int sn_weigh_attributes(const float *attr2, int64_t n, const float *w, float *out, void *stream);
+int sn_weigh_attributes_backward(const float *attr2, const float *g, int64_t n, void *partial, float *dw, void *stream);
 /* `graph`: a captured, not yet instantiated hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Every
  * one-dimensional memset node is replaced by a kernel node with the same predecessors and successors (a captured memset
  * node was seen not to clear on replay on ROCm 7.2; a graph PyTorch captured holds the library's own: semaphores of

@@ -1437,11 +1437,51 @@ def layernorm_split_planes(x, gamma, beta, eps, n_valid=None, relu=True, scale=N
     return out
 
 
+class _WeighAttributes(torch.autograd.Function):
+    """attr2 [..., 2] x w [2, 1] -> [...] with the gradient of the two weights (attr2 itself carries none: the attributes are counts,
+    geometry and attention values of the HIP forward): sn_weigh_attributes / _backward, one launch forward and two backward (round 6;
+    as torch ops - two products, an add, four selects of the weights and their backward nodes - it was ~30 launches of an iteration)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, attr2, w):
+        lib = N.require_gpu()
+        dev = _check_dev(attr2, w)
+        a = _f32c(attr2.detach())
+        wc = _f32c(w.detach()).reshape(2)
+        out = torch.empty(a.shape[:-1], dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_weigh_attributes(N.ptr(a), out.numel(), N.ptr(wc), N.ptr(out), N.stream_ptr(dev)), "sn_weigh_attributes")
+        ctx.save_for_backward(a)
+        ctx.w_shape, ctx.w_dtype = tuple(w.shape), w.dtype
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None
+        lib = N.require_gpu()
+        dev = a.device
+        gc = _f32c(g)
+        dw = torch.zeros(2, dtype=torch.float32, device=dev) if gc.numel() == 0 else torch.empty(2, dtype=torch.float32, device=dev)
+        if gc.numel():
+            partial = torch.empty(lib.sn_weigh_blocks(gc.numel()) * 2, dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                N.check(lib.sn_weigh_attributes_backward(N.ptr(a), N.ptr(gc), gc.numel(), N.ptr(partial), N.ptr(dw), N.stream_ptr(dev)),
+                        "sn_weigh_attributes_backward")
+        return None, dw.reshape(ctx.w_shape).to(ctx.w_dtype)
+
+
 def weigh_attributes(attr2, w):
     """attr2 [..., 2] (count / geometry, attention) and the attribute weights w [2, 1] -> attr2 @ w, squeezed, visible to autograd
-    (the reference runs this matmul inside its C++, large_scale_feat_to_e.cpp:141-147).  On the GPU as two multiplies and an
-    add: the library runs a [B n n, 2] x [2, 1] product on 16 x 16 tiles - 2.9 ms for the 2.4 M edge cells of a 64-image batch,
-    a fifth of a training iteration's GPU time - and its weight gradient as a second such product."""
+    (the reference runs this matmul inside its C++, large_scale_feat_to_e.cpp:141-147).  The library runs a [B n n, 2] x [2, 1]
+    product on 16 x 16 tiles - 2.9 ms for the 2.4 M edge cells of a 64-image batch - and its weight gradient as a second such product;
+    here one HIP pass each way (`SN_WEIGH_FUSED=0`: two multiplies and an add as torch ops, rounds 3-5: the same values forward)."""
+    if attr2.is_cuda and not attr2.requires_grad and attr2.dtype == torch.float32 and w.numel() == 2 and attr2.shape[-1] == 2 \
+            and os.environ.get("SN_WEIGH_FUSED", "1") != "0":
+        return _WeighAttributes.apply(attr2, w)
     if attr2.is_cuda:
         return attr2[..., 0] * w[0, 0] + attr2[..., 1] * w[1, 0]
     return (attr2 @ w).squeeze(-1)

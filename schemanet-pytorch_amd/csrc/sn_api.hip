@@ -16,7 +16,7 @@ void sn_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-extern "C" int sn_abi_version(void) { return 11; }
+extern "C" int sn_abi_version(void) { return 12; }
 
 extern "C" const char *sn_last_error(void) { return g_err; }
 

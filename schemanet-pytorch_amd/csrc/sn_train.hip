@@ -452,6 +452,58 @@ __global__ __launch_bounds__(256) void weighted_pool_backward_kernel(const float
     }
 }
 
+// out[i] = attr2[i][0] w[0] + attr2[i][1] w[1]: the reference's `attr2 @ w` behind its instance graphs (large_scale_feat_to_v.cpp /
+// large_scale_feat_to_e.cpp:141-147, squeezed) under autograd - round 6: one launch forward and two backward where the two products, the
+// add, the selects of the weights and their backward nodes were ~30 library launches of an iteration.  The products are rounded one by
+// one and then added (-ffp-contract=off): the values of `a0 * w0 + a1 * w1` in torch.
+__global__ __launch_bounds__(256) void weigh_attributes_kernel(const float *attr2, int64_t n, const float *w, float *out)
+{
+    const float w0 = w[0], w1 = w[1];
+    const int64_t n2 = ((reinterpret_cast<uintptr_t>(attr2) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) ? n / 2 : 0;
+    const float4 *a4 = reinterpret_cast<const float4 *>(attr2);
+    float2 *o2 = reinterpret_cast<float2 *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const float4 a = a4[i];
+        o2[i] = float2{a.x * w0 + a.y * w1, a.z * w0 + a.w * w1};
+    }
+    for (int64_t i = n2 * 2 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = attr2[2 * i] * w0 + attr2[2 * i + 1] * w1;
+}
+
+// dw[k] = sum_i g[i] attr2[i][k]: per-block partial sums (fp32 per thread over its strided elements, fp64 from there on), summed in
+// block order by the finishing launch - deterministic
+__global__ __launch_bounds__(256) void weigh_attributes_backward_kernel(const float *attr2, const float *g, int64_t n, double *partial)
+{
+    __shared__ double red[2][4];
+    float s0 = 0.0f, s1 = 0.0f;
+    const int64_t n2 = ((reinterpret_cast<uintptr_t>(attr2) & 15) == 0 && (reinterpret_cast<uintptr_t>(g) & 7) == 0) ? n / 2 : 0;
+    const float4 *a4 = reinterpret_cast<const float4 *>(attr2);
+    const float2 *g2 = reinterpret_cast<const float2 *>(g);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const float4 a = a4[i];
+        const float2 gg = g2[i];
+        s0 += gg.x * a.x; s1 += gg.x * a.y;
+        s0 += gg.y * a.z; s1 += gg.y * a.w;
+    }
+    for (int64_t i = n2 * 2 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        s0 += g[i] * attr2[2 * i];
+        s1 += g[i] * attr2[2 * i + 1];
+    }
+    double d0 = sn_wave_sum_f64((double)s0), d1 = sn_wave_sum_f64((double)s1);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d0; red[1][threadIdx.x >> 6] = d1; }
+    __syncthreads();
+    if (threadIdx.x < 2) partial[(int64_t)blockIdx.x * 2 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(64) void weigh_attributes_finish_kernel(const double *partial, int blocks, float *dw)
+{
+    const int lane = threadIdx.x, k = blockIdx.x;
+    double t = 0.0;
+    for (int b = lane; b < blocks; b += 64) t += partial[(int64_t)b * 2 + k];
+    t = sn_wave_sum_f64(t);
+    if (lane == 0) dw[k] = (float)t;
+}
+
 }  // namespace
 
 extern "C" int sn_pow2_scale_blocks(int64_t n)
@@ -641,5 +693,34 @@ extern "C" int sn_weighted_pool_backward(const float *feat, const float *nodes, 
     hipLaunchKernelGGL(weighted_pool_backward_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, (hipStream_t)stream, feat, nodes,
                        grad_pooled, rows, n, E, divisor_dev, grad_feat, grad_nodes);
     SN_CHECK_LAUNCH("sn_weighted_pool_backward");
+    return SN_OK;
+}
+
+extern "C" int sn_weigh_blocks(int64_t n)
+{
+    const int64_t b = (n + 256 * 16 - 1) / (256 * 16);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int sn_weigh_attributes(const float *attr2, int64_t n, const float *w, float *out, void *stream)
+{
+    SN_REQUIRE(n >= 0, SN_ERR_BAD_ARG, "sn_weigh_attributes: bad n=%lld", (long long)n);
+    if (n == 0) return SN_OK;
+    SN_REQUIRE(attr2 && w && out, SN_ERR_BAD_ARG, "sn_weigh_attributes: NULL pointer");
+    hipLaunchKernelGGL(weigh_attributes_kernel, dim3((unsigned)sn_weigh_blocks(n)), dim3(256), 0, (hipStream_t)stream, attr2, n, w, out);
+    SN_CHECK_LAUNCH("sn_weigh_attributes");
+    return SN_OK;
+}
+
+extern "C" int sn_weigh_attributes_backward(const float *attr2, const float *g, int64_t n, void *partial, float *dw, void *stream)
+{
+    SN_REQUIRE(n > 0, SN_ERR_BAD_ARG, "sn_weigh_attributes_backward: bad n=%lld", (long long)n);
+    SN_REQUIRE(attr2 && g && partial && dw, SN_ERR_BAD_ARG, "sn_weigh_attributes_backward: NULL pointer");
+    SN_REQUIRE(((uintptr_t)partial & 7) == 0, SN_ERR_BAD_ARG, "sn_weigh_attributes_backward: partial must be 8-byte aligned");
+    const int blocks = sn_weigh_blocks(n);
+    hipLaunchKernelGGL(weigh_attributes_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, attr2, g, n, (double *)partial);
+    SN_CHECK_LAUNCH("sn_weigh_attributes_backward");
+    hipLaunchKernelGGL(weigh_attributes_finish_kernel, dim3(2), dim3(64), 0, (hipStream_t)stream, (const double *)partial, blocks, dw);
+    SN_CHECK_LAUNCH("sn_weigh_attributes_backward");
     return SN_OK;
 }

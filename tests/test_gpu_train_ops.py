@@ -712,3 +712,32 @@ def test_operand_splits_with_node_extents_and_corner_scatter(mods):
         assert float(c[i, k:].abs().max()) == 0.0 if k < n else True
         if k:
             assert float((c[i, :k] - ref[i, :k]).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 196, 196), (8, 196), (3, 5, 7), (1,), (0, 4)])
+def test_weigh_attributes_fused(mods, shape, monkeypatch):
+    """`attr2 @ w` behind the instance graphs under autograd (reference large_scale_feat_to_e.cpp:141-147, schema_net.py:302-305) as one
+    HIP pass each way (round 6): the forward values are those of the torch form `a0 * w0 + a1 * w1` bit for bit, the gradient of the two
+    weights is the float64 sum to fp32 rounding and no further from it than the torch form's."""
+    from cpp_extension import ops
+    g = torch.Generator().manual_seed(len(shape) * 100 + sum(shape))
+    attr2 = torch.rand(*shape, 2, generator=g).to(DEV)
+    w0 = torch.tensor([[0.35], [0.65]])
+    grad = torch.randn(*shape, generator=g).to(DEV)
+
+    def run(fused):
+        monkeypatch.setenv("SN_WEIGH_FUSED", "1" if fused else "0")
+        w = w0.clone().to(DEV).requires_grad_(True)
+        out = ops.weigh_attributes(attr2, w)
+        out.backward(grad)
+        return out.detach(), w.grad.detach()
+    out_f, dw_f = run(True)
+    out_t, dw_t = run(False)
+    assert tuple(out_f.shape) == tuple(shape) and tuple(dw_f.shape) == (2, 1)
+    assert torch.equal(out_f, out_t)
+    want = (grad.double().unsqueeze(-1) * attr2.double()).reshape(-1, 2).sum(0).reshape(2, 1)
+    scale = (grad.double().abs().unsqueeze(-1) * attr2.double()).reshape(-1, 2).sum(0).reshape(2, 1) + 1e-30
+    err_f = ((dw_f.double() - want).abs() / scale).max().item() if attr2.numel() else 0.0
+    err_t = ((dw_t.double() - want).abs() / scale).max().item() if attr2.numel() else 0.0
+    assert err_f <= 1e-6 and err_f <= err_t + 2e-7, (err_f, err_t)
