@@ -154,7 +154,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edges, int n, int kb_count, int64_t batch_stride,
                                                                _Float16 *out_h, _Float16 *out_l, const float *rowsum, int remove_self_loop,
                                                                const int32_t *extent, const int32_t *n_valid, int pair_tiles, float scale,
-                                                               float *edges_out, const int32_t *perm, int ext_stride)
+                                                               float *edges_out, const int32_t *perm, int ext_stride, int graph_fast_flag)
 {
     __shared__ float te[64][65], tt[64][65];
     __shared__ float rs_i[64], rs_j[64];
@@ -163,7 +163,12 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
     // (ext_stride 1): the operand is the n_kept x n_kept corner + identity, rows and k beyond the class's own extent are
     // neither produced nor read by sn_gcn_gemm.  Staged once per workgroup.
     __shared__ int perm_s[kMaxPerm];
-    const int g = blockIdx.y;
+    // Pair mode (small graphs, pair_tiles > 0): the grid is (graphs, pairs) - graph fastest.  With (pairs, graphs) the few pairs a small
+    // graph really has (3 of 10 for <= 128 vertices of a graph padded to 4 tiles a side) sat at a fixed period of the dispatch order, and
+    // the active workgroups fell on the even XCDs twice as often as on the odd ones (round 6; `SN_ADJ_GRAPH_MAJOR=0`: the old order).
+    const bool graph_fast = pair_tiles > 0 && gridDim.y == (unsigned)(pair_tiles * (pair_tiles + 1) / 2) && graph_fast_flag;
+    const int g = graph_fast ? blockIdx.x : blockIdx.y;
+    const int bx = graph_fast ? blockIdx.y : blockIdx.x;
     if (perm) {
         for (int i = threadIdx.x; i < n; i += 256) perm_s[i] = perm[(int64_t)g * n + i];
         __syncthreads();
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
     // 53 us beside other kernels for 34 MB (the instance side of the bench); pairs beyond the batch's extent exit at once.
     int pair_I = -1, pair_J = -1;
     if (pair_tiles > 0) {
-        int x = (int)blockIdx.x;
+        int x = bx;
         for (int i = 0; i < pair_tiles && pair_I < 0; ++i) {
             if (x < pair_tiles - i) { pair_I = i; pair_J = i + x; }
             x -= pair_tiles - i;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void adjacency_planes_kernel(const float *edge
     // I1 > x (odd T: the middle tile once); pair mode: the one pair.  The NEXT pair's tiles are requested as soon as the
     // current pair's are in LDS, so its loads are in flight under the conversion and the plane stores (a walk used to be
     // T + 1 rounds of load latency + store latency, one after the other, with 1.5 workgroups per CU to hide them).
-    const int x0 = (int)blockIdx.x;
+    const int x0 = bx;
     int cI, cJ, chalf = 0;
     bool have;
     // pair_tiles < 0 (large graphs, round 4): the T (T + 1) / 2 tile pairs of the graph are dealt round-robin over the graph's
@@ -1431,6 +1436,16 @@ static void adjacency_grid(int n, int G, unsigned &wgs, int &pair_tiles)
     else { pair_tiles = -1; wgs = (unsigned)w; }
 }
 
+static int adjacency_graph_fast()
+{
+    static const int v = getenv("SN_ADJ_GRAPH_MAJOR") ? atoi(getenv("SN_ADJ_GRAPH_MAJOR")) : 1;
+    return v;
+}
+static dim3 adjacency_dim(unsigned wgs, int G, int pair_tiles)
+{
+    return (pair_tiles > 0 && adjacency_graph_fast()) ? dim3((unsigned)G, wgs) : dim3(wgs, (unsigned)G);
+}
+
 extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const int32_t *extent_dev, float scale, void *adj_hi, void *adj_lo, void *stream)
 {
     SN_REQUIRE(G >= 0 && n > 0, SN_ERR_BAD_ARG, "sn_gcn_adjacency_planes: bad G=%d n=%d", G, n);
@@ -1442,13 +1457,13 @@ extern "C" int sn_gcn_adjacency_planes(const float *edges, int G, int n, const i
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, G, tiles, pair_tiles);
     if (n % 4 == 0 && ((uintptr_t)edges & 15) == 0)
-        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, adjacency_dim(tiles, G, pair_tiles), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                            sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
-                           (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+                           (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0, adjacency_graph_fast());
     else
-        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, adjacency_dim(tiles, G, pair_tiles), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                            sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev,
-                           (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+                           (const int32_t *)nullptr, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0, adjacency_graph_fast());
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes");
     return SN_OK;
 }
@@ -1465,11 +1480,11 @@ extern "C" int sn_gcn_adjacency_planes_masked(const float *edges, int G, int n, 
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, G, tiles, pair_tiles);
     if (n % 4 == 0 && ((uintptr_t)edges & 15) == 0)
-        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, adjacency_dim(tiles, G, pair_tiles), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0, adjacency_graph_fast());
     else
-        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0);
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, adjacency_dim(tiles, G, pair_tiles), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, extent_dev, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 0, adjacency_graph_fast());
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_masked");
     return SN_OK;
 }
@@ -1487,11 +1502,11 @@ extern "C" int sn_gcn_adjacency_planes_per_graph(const float *edges, int G, int 
     adjacency_grid(n, G, tiles, pair_tiles);
     // (the vertex counts serve as the extents too: one per graph)
     if (n % 4 == 0 && ((uintptr_t)edges & 15) == 0)
-        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_valid, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 1);
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, adjacency_dim(tiles, G, pair_tiles), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_valid, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 1, adjacency_graph_fast());
     else
-        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
-                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_valid, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 1);
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, adjacency_dim(tiles, G, pair_tiles), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+                           sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_valid, n_valid, pair_tiles, scale, (float *)nullptr, (const int32_t *)nullptr, 1, adjacency_graph_fast());
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_per_graph");
     return SN_OK;
 }
@@ -1508,13 +1523,13 @@ extern "C" int sn_gcn_atlas_adjacency_planes(const float *pruned_edge_weights, c
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, K, tiles, pair_tiles);
     if (n % 4 == 0 && (((uintptr_t)pruned_edge_weights | (uintptr_t)class_edges_out) & 15) == 0)
-        hipLaunchKernelGGL(adjacency_planes_kernel<true>, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+        hipLaunchKernelGGL(adjacency_planes_kernel<true>, adjacency_dim(tiles, K, pair_tiles), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                            kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0);
+                           (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0, adjacency_graph_fast());
     else
-        hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+        hipLaunchKernelGGL(adjacency_planes_kernel<false>, adjacency_dim(tiles, K, pair_tiles), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                            kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0);
+                           (const int32_t *)nullptr, pair_tiles, scale, class_edges_out, (const int32_t *)nullptr, 0, adjacency_graph_fast());
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes");
     return SN_OK;
 }
@@ -1535,9 +1550,9 @@ extern "C" int sn_gcn_atlas_adjacency_planes_compact(const float *pruned_edge_we
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, K, tiles, pair_tiles);
-    hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)K), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
+    hipLaunchKernelGGL(adjacency_planes_kernel<false>, adjacency_dim(tiles, K, pair_tiles), dim3(256), 0, (hipStream_t)stream, pruned_edge_weights, n,
                        kb, sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, row_sum, remove_self_loop, n_kept,
-                       n_kept, pair_tiles, scale, (float *)nullptr, perm, 1);
+                       n_kept, pair_tiles, scale, (float *)nullptr, perm, 1, adjacency_graph_fast());
     SN_CHECK_LAUNCH("sn_gcn_atlas_adjacency_planes_compact");
     return SN_OK;
 }
@@ -1554,9 +1569,9 @@ extern "C" int sn_gcn_adjacency_planes_compact(const float *edges, int G, int n,
     const int kb = (n + 15) / 16;
     unsigned tiles; int pair_tiles;
     adjacency_grid(n, G, tiles, pair_tiles);
-    hipLaunchKernelGGL(adjacency_planes_kernel<false>, dim3(tiles, (unsigned)G), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
+    hipLaunchKernelGGL(adjacency_planes_kernel<false>, adjacency_dim(tiles, G, pair_tiles), dim3(256), 0, (hipStream_t)stream, edges, n, kb,
                        sn_gcn_plane_elems(n, n), (_Float16 *)adj_hi, (_Float16 *)adj_lo, (const float *)nullptr, 0, n_kept, n_kept, pair_tiles,
-                       scale, (float *)nullptr, perm, 1);
+                       scale, (float *)nullptr, perm, 1, adjacency_graph_fast());
     SN_CHECK_LAUNCH("sn_gcn_adjacency_planes_compact");
     return SN_OK;
 }
