@@ -1772,7 +1772,8 @@ extern "C" int sn_gcn_gemm(const sn_gemm_args *u, void *stream)
     int rc = SN_OK;
     auto launch = [&](auto kernel, int threads, size_t lds) {
         if ((rc = sn_ensure_dynamic_lds((const void *)kernel, lds, "sn_gcn_gemm"))) return;
-        if (getenv("SN_GEMM_OCC")) {
+        static const bool print_occupancy = getenv("SN_GEMM_OCC") != nullptr;          // (diagnostics: tools/time_gemm_fused.py)
+        if (print_occupancy) {
             int nb = -1; hipFuncAttributes fa{};
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds);
             (void)hipFuncGetAttributes(&fa, (const void *)kernel);
