@@ -35,7 +35,7 @@ extern "C" {
 #define SN_MAX_TOKENS 196        /* L: 14x14 patch tokens; the graph kernels keep one image in LDS */
 
 /* ABI version, bumped on any change of a signature or of a by-pointer struct (10: round 5, struct_size members; 11: round 6 -
- * sn_gemm_args.zero_skipped and the entry points added after 10, sn_debug_set_gemm_tile; 12: round 6 - sn_weigh_attributes(_backward), sn_weigh_blocks; tests/test_host_cpu.py holds a hash of
+ * sn_gemm_args.zero_skipped and the entry points added after 10, sn_debug_set_gemm_tile; 12: round 6 - sn_weigh_attributes(_backward), sn_weigh_blocks, sn_rectify_linear; tests/test_host_cpu.py holds a hash of
  * this header's declarations next to the version, so that a change of either without the other fails the CPU suite).
  * The three by-pointer argument structs below start with `struct_size`: the caller stores sizeof(the struct it was compiled
  * against) there; a call whose struct_size differs from the library's own sizeof is rejected with SN_ERR_BAD_ARG before any
@@ -575,6 +575,9 @@ int sn_weighted_pool_backward(const float *feat, const float *nodes, const float
 int sn_weigh_blocks(int64_t n);
 int sn_weigh_attributes(const float *attr2, int64_t n, const float *w, float *out, void *stream);
 int sn_weigh_attributes_backward(const float *attr2, const float *g, int64_t n, void *partial, float *dw, void *stream);
+/* out[i] = x[i] if x[i] > a else a - 1 + 1 / (1 + a - x[i]); deriv[i] = d out / d x (1, or 1 / (1 + a - x[i])^2): the rectified sparsity
+ * terms of the reference's loss (schema_inference/loss/schema_inference_loss.py:61-67) without its python branch on a device scalar. */
+int sn_rectify_linear(const float *x, int n, float a, float *out, float *deriv, void *stream);
 /* `graph`: a captured, not yet instantiated hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()).  Every
  * one-dimensional memset node is replaced by a kernel node with the same predecessors and successors (a captured memset
  * node was seen not to clear on replay on ROCm 7.2; a graph PyTorch captured holds the library's own: semaphores of

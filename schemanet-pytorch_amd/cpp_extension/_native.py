@@ -20,7 +20,7 @@ ABI_VERSION = 12
 # sha256[:16] of include/schemanet_hip.h with comments removed and whitespace collapsed: the declarations this binding (and
 # ABI_VERSION) were written against.  tests/test_host_cpu.py::test_abi_version_names_the_header recomputes it, so a change to a
 # signature or a struct without a new hash here - and, by the rule in the header, a new ABI_VERSION - fails the CPU suite.
-ABI_HEADER_SHA = "7560a36b96b26487"
+ABI_HEADER_SHA = "cfb9f51fec2f16d9"
 SN_MAX_TOKENS = 196
 _lib = None
 
@@ -172,6 +172,7 @@ _SIGNATURES = {
     "sn_embedding_grad_scan": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sn_weighted_pool_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sn_graph_replace_memsets": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "sn_rectify_linear": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "sn_weigh_blocks": (c_int, [c_int64]),
     "sn_weigh_attributes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "sn_weigh_attributes_backward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

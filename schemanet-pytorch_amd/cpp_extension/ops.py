@@ -1487,6 +1487,34 @@ def weigh_attributes(attr2, w):
     return (attr2 @ w).squeeze(-1)
 
 
+class _RectifyLinear(torch.autograd.Function):
+    """x if x > a else a - 1 + 1 / (1 + a - x) on a CUDA tensor (the loss's rectified sparsity terms: scalars) as one launch, its
+    derivative kept from the forward: one multiply back."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, a):
+        lib = N.require_gpu()
+        dev = _check_dev(x)
+        xc = _f32c(x.detach())
+        out, deriv = torch.empty_like(xc), torch.empty_like(xc)
+        with torch.cuda.device(dev):
+            N.check(lib.sn_rectify_linear(N.ptr(xc), xc.numel(), float(a), N.ptr(out), N.ptr(deriv), N.stream_ptr(dev)), "sn_rectify_linear")
+        ctx.save_for_backward(deriv)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        (deriv,) = ctx.saved_tensors
+        return g * deriv, None
+
+
+def rectify_linear(x, a):
+    """the select form of the reference's rectify_linear (schema_inference_loss.py:61-67) for a CUDA fp32 tensor"""
+    return _RectifyLinear.apply(x, a)
+
+
 SIMILARITY = {"inner_product": 0, "cosine": 1, "euclidean": 2}
 
 

@@ -504,6 +504,21 @@ __global__ __launch_bounds__(64) void weigh_attributes_finish_kernel(const doubl
     if (lane == 0) dw[k] = (float)t;
 }
 
+// r(x) = x if x > a else a - 1 + 1 / (1 + a - x) and its derivative (1, or 1 / (1 + a - x)^2), elementwise: the "rectified" sparsity terms
+// of the reference's loss (schema_inference_loss.py:61-67) - a handful of scalars, which as a select built from torch ops was seven launches
+// forward and five back per term (round 6: one each way; the same operations in the same order: same values).
+__global__ __launch_bounds__(64) void rectify_linear_kernel(const float *x, int n, float a, float *out, float *deriv)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const bool above = v > a;
+    const float den = above ? 1.0f : (1.0f + a) - v;         // (the unselected branch's denominator replaced by 1, as in the torch form)
+    const float q = 1.0f / den;
+    out[i] = above ? v : (a - 1.0f) + q;
+    deriv[i] = above ? 1.0f : q * q;
+}
+
 }  // namespace
 
 extern "C" int sn_pow2_scale_blocks(int64_t n)
@@ -722,5 +737,15 @@ extern "C" int sn_weigh_attributes_backward(const float *attr2, const float *g, 
     SN_CHECK_LAUNCH("sn_weigh_attributes_backward");
     hipLaunchKernelGGL(weigh_attributes_finish_kernel, dim3(2), dim3(64), 0, (hipStream_t)stream, (const double *)partial, blocks, dw);
     SN_CHECK_LAUNCH("sn_weigh_attributes_backward");
+    return SN_OK;
+}
+
+extern "C" int sn_rectify_linear(const float *x, int n, float a, float *out, float *deriv, void *stream)
+{
+    SN_REQUIRE(n >= 0, SN_ERR_BAD_ARG, "sn_rectify_linear: bad n=%d", n);
+    if (n == 0) return SN_OK;
+    SN_REQUIRE(x && out && deriv, SN_ERR_BAD_ARG, "sn_rectify_linear: NULL pointer");
+    hipLaunchKernelGGL(rectify_linear_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x, n, a, out, deriv);
+    SN_CHECK_LAUNCH("sn_rectify_linear");
     return SN_OK;
 }

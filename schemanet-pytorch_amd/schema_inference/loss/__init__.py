@@ -10,6 +10,7 @@ each also "rectified": x if x > a else a - 1 + 1 / (1 + a - x).  On the GPU the 
 K = 100, n = 512) come from `cpp_extension.ops.row_entropy` (one HIP pass forward, a recomputing backward that
 skips the rows the max did not select); CPU tensors use the plain torch expression (the loss itself is not part of
 the inference hot path and the reference trains on the device)."""
+import os
 from collections import OrderedDict
 from pkgutil import extend_path
 from typing import Any, Dict
@@ -44,6 +45,9 @@ def rectify_linear(x: torch.Tensor, a: float = 0) -> torch.Tensor:
     asynchronous and can be captured into a hipGraph (train.GraphedTrainIter); the unselected branch's denominator is
     replaced by 1 before the division (at x = 1 + a it would be 0 and its - masked - gradient 0 * inf)."""
     if torch.is_tensor(x) and x.is_cuda:
+        if x.dtype == torch.float32 and x.numel() < (1 << 30) and os.environ.get("SN_RECTIFY_FUSED", "1") != "0":
+            from cpp_extension import ops
+            return ops.rectify_linear(x, a)          # (round 6: one launch forward, one multiply back; the torch form below: seven and five)
         above = x > a
         return torch.where(above, x, a - 1 + 1.0 / torch.where(above, torch.ones_like(x), 1 + a - x))
     return x if x > a else a - 1 + 1.0 / (1 + a - x)
